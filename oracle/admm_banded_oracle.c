@@ -1,0 +1,277 @@
+/*
+ * ORACLE - TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ *
+ * CPU restatement (plain C, FP64, one instance per call, runtime dimensions) of the ADMM solver
+ * the reference generates for the laxMPC and equMPC formulations:
+ *
+ *   formulations/+laxMPC/code_laxMPC_ADMM_C.c:21-695   (terminal block present, `terminal = 1`)
+ *   formulations/+equMPC/code_equMPC_ADMM_C.c:21-616   (no terminal block,      `terminal = 0`)
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.  The
+ * floating-point operation order of every accumulation follows the reference loop nests (cited per
+ * function) so that, fed the same constants, it reproduces the generated C bit for bit when built
+ * without FMA contraction (the Makefile passes -ffp-contract=off).
+ *
+ * Parity pin: tests/test_oracle_golden.py checks this file against the reference tests' hard-coded
+ * optimum (tests/test_laxMPC_ADMM.m:35, tests/test_equMPC_ADMM.m:33; tolerance 1e-4 as
+ * tests/spcies_tester.m:261) and against tests/golden/ vectors.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    int n, m, N;          /* states, inputs, horizon                                      */
+    int k_max;            /* iteration cap                                                 */
+    int terminal;         /* 1 = laxMPC (x_N is a variable, cost T), 0 = equMPC (x_N = xr) */
+    double tol, rho, rho_i;
+    const double *AB;     /* [n][n+m] row-major, [A B]                                     */
+    const double *Alpha;  /* [N-1][n][n]                                                   */
+    const double *Beta;   /* [N][n][n], upper triangle, diagonal holds 1/diag              */
+    const double *Hi;     /* [N-1][n+m] inverse diagonal of H+rho*I, middle stages         */
+    const double *Hi_0;   /* [m]                                                           */
+    const double *Hi_N;   /* [n][n] dense inverse of T+rho*I (terminal only)               */
+    const double *Q, *R;  /* NEGATED diagonals of Q, R ([n], [m])                          */
+    const double *T;      /* [n][n] NEGATED terminal cost (terminal only)                  */
+    const double *LB, *UB;/* [n+m] state bounds first, then input bounds                   */
+} admm_banded_data;
+
+/* Workspace layout mirrors the reference's split of every vector into a `_0` head (m inputs of
+ * stage 0), N-1 middle rows of n+m and a `_N` tail (n terminal states).                     */
+typedef struct {
+    double *h;   /* [m]          */
+    double *mid; /* [N-1][n+m]   */
+    double *t;   /* [n]          */
+} split_vec;
+
+static void split_alloc(split_vec *s, int n, int m, int N) {
+    s->h = (double *)calloc((size_t)m, sizeof(double));
+    s->mid = (double *)calloc((size_t)(N - 1) * (size_t)(n + m), sizeof(double));
+    s->t = (double *)calloc((size_t)n, sizeof(double));
+}
+static void split_free(split_vec *s) { free(s->h); free(s->mid); free(s->t); }
+
+#define ABij(i, j) (d->AB[(size_t)(i) * nm + (j)])
+#define ALPHA(l, i, j) (d->Alpha[((size_t)(l) * n + (i)) * n + (j)])
+#define BETA(l, i, j) (d->Beta[((size_t)(l) * n + (i)) * n + (j)])
+#define HI(l, j) (d->Hi[(size_t)(l) * nm + (j)])
+#define MID(s, l, j) ((s).mid[(size_t)(l) * nm + (j)])
+#define MU(l, j) (mu[(size_t)(l) * n + (j)])
+
+/* q_hat = q + lambda - rho*v, written into z (code_laxMPC_ADMM_C.c:323-349). */
+static void form_qhat(const admm_banded_data *d, const double *q, const double *qT,
+                      const split_vec *lam, const split_vec *v, split_vec *z) {
+    const int n = d->n, m = d->m, nm = n + m, N = d->N;
+    for (int j = 0; j < m; j++) z->h[j] = q[n + j] + lam->h[j] - d->rho * v->h[j];
+    for (int l = 0; l < N - 1; l++)
+        for (int j = 0; j < nm; j++) MID(*z, l, j) = q[j] + MID(*lam, l, j) - d->rho * MID(*v, l, j);
+    if (d->terminal)
+        for (int j = 0; j < n; j++) z->t[j] = qT[j] + lam->t[j] - d->rho * v->t[j];
+}
+
+/* Right-hand side  -G*Hhat^{-1}*q_hat - b  of the W system, stored in mu
+ * (code_laxMPC_ADMM_C.c:355-381; equMPC: code_equMPC_ADMM_C.c:337-352 with the `- xr` line). */
+static void form_rhs(const admm_banded_data *d, const double *b, const double *xr,
+                     const split_vec *z, double *mu) {
+    const int n = d->n, m = d->m, nm = n + m, N = d->N;
+    for (int j = 0; j < n; j++) {
+        double acc = HI(0, j) * MID(*z, 0, j) - b[j];
+        for (int i = 0; i < m; i++) acc = acc - ABij(j, n + i) * d->Hi_0[i] * z->h[i];
+        MU(0, j) = acc;
+    }
+    for (int l = 1; l < N - 1; l++)
+        for (int j = 0; j < n; j++) {
+            double acc = HI(l, j) * MID(*z, l, j);
+            for (int i = 0; i < nm; i++) acc = acc - ABij(j, i) * HI(l - 1, i) * MID(*z, l - 1, i);
+            MU(l, j) = acc;
+        }
+    for (int j = 0; j < n; j++) {
+        double acc = 0.0;
+        if (d->terminal)
+            for (int i = 0; i < n; i++) acc = acc + d->Hi_N[(size_t)j * n + i] * z->t[i];
+        for (int i = 0; i < nm; i++) acc = acc - ABij(j, i) * HI(N - 2, i) * MID(*z, N - 2, i);
+        if (!d->terminal) acc = acc - xr[j];
+        MU(N - 1, j) = acc;
+    }
+}
+
+/* mu <- W^{-1} mu through the block-bidiagonal Cholesky factor (Alpha / Beta):
+ * forward substitution code_laxMPC_ADMM_C.c:388-417, backward :422-451. */
+static void solve_W(const admm_banded_data *d, double *mu) {
+    const int n = d->n, N = d->N;
+    for (int l = 0; l < N; l++)
+        for (int j = 0; j < n; j++) {
+            double acc = MU(l, j);
+            if (l > 0)
+                for (int i = 0; i < n; i++) acc = acc - ALPHA(l - 1, i, j) * MU(l - 1, i);
+            for (int i = 0; i < j; i++) acc = acc - BETA(l, i, j) * MU(l, i);
+            MU(l, j) = BETA(l, j, j) * acc;
+        }
+    for (int l = N - 1; l >= 0; l--)
+        for (int j = n - 1; j >= 0; j--) {
+            double acc = MU(l, j);
+            if (l < N - 1)
+                for (int i = n - 1; i >= 0; i--) acc = acc - ALPHA(l, j, i) * MU(l + 1, i);
+            for (int i = n - 1; i > j; i--) acc = acc - BETA(l, j, i) * MU(l, i);
+            MU(l, j) = BETA(l, j, j) * acc;
+        }
+}
+
+/* z = -Hhat^{-1} (q_hat + G' mu)   (code_laxMPC_ADMM_C.c:456-485). */
+static void form_z(const admm_banded_data *d, const double *mu, split_vec *z, double *aux) {
+    const int n = d->n, m = d->m, nm = n + m, N = d->N;
+    for (int j = 0; j < m; j++) {
+        double acc = z->h[j];
+        for (int i = 0; i < n; i++) acc = acc + ABij(i, n + j) * MU(0, i);
+        z->h[j] = -d->Hi_0[j] * acc;
+    }
+    for (int l = 0; l < N - 1; l++) {
+        for (int j = 0; j < n; j++) MID(*z, l, j) = MID(*z, l, j) - MU(l, j);
+        for (int j = 0; j < nm; j++) {
+            double acc = MID(*z, l, j);
+            for (int i = 0; i < n; i++) acc = acc + ABij(i, j) * MU(l + 1, i);
+            MID(*z, l, j) = -HI(l, j) * acc;
+        }
+    }
+    if (d->terminal) {
+        for (int j = 0; j < n; j++) aux[j] = z->t[j] - MU(N - 1, j);
+        for (int j = 0; j < n; j++) {
+            double acc = 0.0;
+            for (int i = 0; i < n; i++) acc = acc - d->Hi_N[(size_t)j * n + i] * aux[i];
+            z->t[j] = acc;
+        }
+    }
+}
+
+static inline double clampd(double x, double lo, double hi) {
+    x = (x > lo) ? x : lo; /* same comparison sense as the reference (:500-501) */
+    x = (x > hi) ? hi : x;
+    return x;
+}
+
+/* v = clamp(z + lambda/rho), lambda += rho (z - v)   (code_laxMPC_ADMM_C.c:490-568). */
+static void update_v_lambda(const admm_banded_data *d, const split_vec *z, split_vec *v, split_vec *lam) {
+    const int n = d->n, m = d->m, nm = n + m, N = d->N;
+    for (int j = 0; j < m; j++)
+        v->h[j] = clampd(z->h[j] + d->rho_i * lam->h[j], d->LB[n + j], d->UB[n + j]);
+    for (int l = 0; l < N - 1; l++)
+        for (int j = 0; j < nm; j++)
+            MID(*v, l, j) = clampd(MID(*z, l, j) + d->rho_i * MID(*lam, l, j), d->LB[j], d->UB[j]);
+    if (d->terminal)
+        for (int j = 0; j < n; j++) v->t[j] = clampd(z->t[j] + d->rho_i * lam->t[j], d->LB[j], d->UB[j]);
+
+    for (int j = 0; j < m; j++) lam->h[j] = lam->h[j] + d->rho * (z->h[j] - v->h[j]);
+    for (int l = 0; l < N - 1; l++)
+        for (int j = 0; j < nm; j++)
+            MID(*lam, l, j) = MID(*lam, l, j) + d->rho * (MID(*z, l, j) - MID(*v, l, j));
+    if (d->terminal)
+        for (int j = 0; j < n; j++) lam->t[j] = lam->t[j] + d->rho * (z->t[j] - v->t[j]);
+}
+
+static inline int exceeds(double a, double b, double tol) {
+    double r1 = a - b;
+    r1 = (r1 > 0.0) ? r1 : -r1;
+    return r1 > tol;
+}
+
+/* 1 if any |v1 - v| or |z - v| component is above tol (code_laxMPC_ADMM_C.c:572-620). */
+static int residual_flag(const admm_banded_data *d, const split_vec *z, const split_vec *v, const split_vec *v1) {
+    const int n = d->n, m = d->m, nm = n + m, N = d->N;
+    for (int j = 0; j < m; j++)
+        if (exceeds(v1->h[j], v->h[j], d->tol) || exceeds(z->h[j], v->h[j], d->tol)) return 1;
+    if (d->terminal)
+        for (int j = 0; j < n; j++)
+            if (exceeds(v1->t[j], v->t[j], d->tol) || exceeds(z->t[j], v->t[j], d->tol)) return 1;
+    for (int l = 0; l < N - 1; l++)
+        for (int j = 0; j < nm; j++)
+            if (exceeds(MID(*v1, l, j), MID(*v, l, j), d->tol) || exceeds(MID(*z, l, j), MID(*v, l, j), d->tol))
+                return 1;
+    return 0;
+}
+
+static void flatten(const admm_banded_data *d, const split_vec *s, double *out) {
+    const int n = d->n, m = d->m, nm = n + m, N = d->N;
+    size_t c = 0;
+    for (int j = 0; j < m; j++) out[c++] = s->h[j];
+    for (size_t i = 0; i < (size_t)(N - 1) * nm; i++) out[c++] = s->mid[i];
+    if (d->terminal)
+        for (int j = 0; j < n; j++) out[c++] = s->t[j];
+}
+
+/* One solve.  z_out / v_out / lam_out (each N*(n+m) [- n for equMPC] doubles) may be NULL. */
+int oracle_admm_banded_solve(const admm_banded_data *d, const double *x0, const double *xr, const double *ur,
+                             double *u_opt, int *k_out, int *e_flag, double *z_out, double *v_out,
+                             double *lam_out) {
+    const int n = d->n, m = d->m, nm = n + m, N = d->N;
+    if (n <= 0 || m <= 0 || N < 2) return -1;
+    split_vec z, v, v1, lam;
+    split_alloc(&z, n, m, N);
+    split_alloc(&v, n, m, N);
+    split_alloc(&v1, n, m, N);
+    split_alloc(&lam, n, m, N);
+    double *mu = (double *)calloc((size_t)N * n, sizeof(double));
+    double *b = (double *)calloc((size_t)n, sizeof(double));
+    double *q = (double *)calloc((size_t)nm, sizeof(double));
+    double *qT = (double *)calloc((size_t)n, sizeof(double));
+    double *aux = (double *)calloc((size_t)n, sizeof(double));
+
+    /* per-instance setup (code_laxMPC_ADMM_C.c:282-299) */
+    for (int j = 0; j < n; j++) {
+        b[j] = 0.0;
+        for (int i = 0; i < n; i++) b[j] = b[j] - ABij(j, i) * x0[i];
+    }
+    for (int j = 0; j < n; j++) {
+        q[j] = d->Q[j] * xr[j];
+        qT[j] = 0.0;
+        if (d->terminal)
+            for (int i = 0; i < n; i++) qT[j] = qT[j] + d->T[(size_t)j * n + i] * xr[i];
+    }
+    for (int j = 0; j < m; j++) q[n + j] = d->R[j] * ur[j];
+
+    int k = 0, done = 0, flag = -1;
+    while (!done) {
+        k += 1;
+        memcpy(v1.h, v.h, sizeof(double) * (size_t)m);
+        memcpy(v1.mid, v.mid, sizeof(double) * (size_t)(N - 1) * nm);
+        memcpy(v1.t, v.t, sizeof(double) * (size_t)n);
+        form_qhat(d, q, qT, &lam, &v, &z);
+        form_rhs(d, b, xr, &z, mu);
+        solve_W(d, mu);
+        form_z(d, mu, &z, aux);
+        update_v_lambda(d, &z, &v, &lam);
+        if (!residual_flag(d, &z, &v, &v1)) {
+            done = 1;
+            flag = 1;
+        } else if (k >= d->k_max) {
+            done = 1;
+            flag = -1;
+        }
+    }
+    for (int j = 0; j < m; j++) u_opt[j] = v.h[j];
+    *k_out = k;
+    *e_flag = flag;
+    if (z_out) flatten(d, &z, z_out);
+    if (v_out) flatten(d, &v, v_out);
+    if (lam_out) flatten(d, &lam, lam_out);
+
+    split_free(&z); split_free(&v); split_free(&v1); split_free(&lam);
+    free(mu); free(b); free(q); free(qT); free(aux);
+    return 0;
+}
+
+/* Batch driver (instances are independent; used for fixtures and for the timed CPU baseline).
+ * x0 is [B][n]; xr/ur are [B][n]/[B][m] when ref_stride != 0, else a single shared reference.
+ * Outputs u [B][m], k [B], e_flag [B]; z/v/lam [B][dim] or NULL. */
+int oracle_admm_banded_batch(const admm_banded_data *d, long B, const double *x0, const double *xr,
+                             const double *ur, int ref_stride, double *u, int *k, int *e_flag, double *z,
+                             double *v, double *lam) {
+    const size_t dim = (size_t)d->N * (size_t)(d->n + d->m) - (d->terminal ? 0 : (size_t)d->n);
+    for (long i = 0; i < B; i++) {
+        const double *xri = ref_stride ? xr + (size_t)i * d->n : xr;
+        const double *uri = ref_stride ? ur + (size_t)i * d->m : ur;
+        int rc = oracle_admm_banded_solve(d, x0 + (size_t)i * d->n, xri, uri, u + (size_t)i * d->m, k + i,
+                                          e_flag + i, z ? z + (size_t)i * dim : NULL,
+                                          v ? v + (size_t)i * dim : NULL, lam ? lam + (size_t)i * dim : NULL);
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,85 @@
+"""ctypes front-end of the C oracle (``oracle/admm_banded_oracle.c``).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "admm_banded_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return so
+
+
+class _Data(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("N", C.c_int), ("k_max", C.c_int), ("terminal", C.c_int),
+                ("tol", C.c_double), ("rho", C.c_double), ("rho_i", C.c_double)] + [
+        (name, C.POINTER(C.c_double))
+        for name in ("AB", "Alpha", "Beta", "Hi", "Hi_0", "Hi_N", "Q", "R", "T", "LB", "UB")]
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.oracle_admm_banded_batch.restype = C.c_int
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def quantize_like_reference(a):
+    """Round-trip through ``%1.15f`` as ``platforms/+C_code/dec_var.m:262`` prints constants."""
+    a = np.asarray(a, dtype=float)
+    return np.array([float("%1.15f" % x) for x in a.ravel()]).reshape(a.shape)
+
+
+def admm_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False):
+    """Run the C oracle on a batch.  ``v`` is the ingredients dict of
+    ``spcies_amd.formulations.laxMPC.compute_*_ADMM_ingredients``.  Returns ``u, k, e_flag, z, v, lam``."""
+    n, m, N = int(v["n"]), int(v["m"]), int(v["N"])
+    terminal = bool(v.get("terminal", True))
+    qz = quantize_like_reference if quantize else (lambda a: a)
+    keep = {name: np.ascontiguousarray(qz(np.asarray(v[name], dtype=float)))
+            for name in ("AB", "Alpha", "Beta", "Hi", "Hi_0", "Hi_N", "Q", "R", "T", "LB", "UB")}
+    if quantize:  # +-inf -> +-1e20 as dec_var.m:245-248
+        for nm_ in ("LB", "UB"):
+            keep[nm_] = np.clip(keep[nm_], -1e20, 1e20)
+    d = _Data(n=n, m=m, N=N, k_max=int(v["k_max"]), terminal=int(terminal),
+              tol=float(qz(v["tol"])) if quantize else float(v["tol"]),
+              rho=float(v["rho"]), rho_i=float(qz(v["rho_i"])) if quantize else float(v["rho_i"]),
+              **{k_: _dp(a) for k_, a in keep.items()})
+    x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
+    B = x0.shape[0]
+    assert x0.shape[1] == n
+    xr = np.ascontiguousarray(np.asarray(xr, dtype=float))
+    ur = np.ascontiguousarray(np.asarray(ur, dtype=float))
+    stride = 1 if xr.ndim == 2 else 0
+    if stride:
+        assert xr.shape == (B, n) and ur.shape == (B, m)
+    else:
+        assert xr.shape == (n,) and ur.shape == (m,)
+    dim = N * (n + m) - (0 if terminal else n)
+    u = np.zeros((B, m))
+    k = np.zeros(B, dtype=np.int32)
+    e = np.zeros(B, dtype=np.int32)
+    z = np.zeros((B, dim)) if want_sol else None
+    vv = np.zeros((B, dim)) if want_sol else None
+    lam = np.zeros((B, dim)) if want_sol else None
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    rc = _lib().oracle_admm_banded_batch(C.byref(d), C.c_long(B), _dp(x0), _dp(xr), _dp(ur), C.c_int(stride),
+                                         _dp(u), ip(k), ip(e), _dp(z) if want_sol else None,
+                                         _dp(vv) if want_sol else None, _dp(lam) if want_sol else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle_admm_banded_batch failed rc={rc}")
+    return u, k, e, z, vv, lam

@@ -1,0 +1,138 @@
+"""ORACLE cross-check (test infrastructure, THIS CONTAINER ONLY - needs /root/reference).
+
+Instantiates the reference's own C solver template in a temporary directory, compiles it with
+gcc -O3 (as ``+sp_utils/get_generic_mex_exec.m:27`` does for the mex) into ``oracle/_ref/*.so`` and
+calls it through ctypes, so that ``oracle/admm_banded_oracle.c`` can be compared with the
+reference's hot loop itself.
+
+What is the reference's and what is ours - stated precisely because it limits the claim:
+
+* the solver text (``formulations/+X/code_X_ADMM_C.c``, ``header_X_ADMM_C.h``,
+  ``platforms/+C_code/generic_solver_struct.c``, ``snippets/*.c|h``) is read where it lies under
+  ``/root/reference`` and never copied into this repository (only the compiled ``.so`` is kept,
+  under the git-ignored ``oracle/_ref/``);
+* the ``$INSERT_DEFINES$`` / ``$INSERT_CONSTANTS$`` blocks, which the reference's MATLAB generator
+  would print (``classes/Spcies_constructor.m:95-271``, ``platforms/+C_code/dec_var.m``), are printed
+  HERE from our numpy ingredients with the reference's format rules (``%1.15f``, ``[k][i][j]``
+  3-D order, +-inf -> +-1e20).  MATLAB is not available, so this is a stand-in for generated
+  code: the result is NOT claimed as a "reference build" (bench.py's cpu_baseline stays
+  ``kind: "port"``) and the oracle's formal pin is the reference tests' golden optimum.  It is
+  recorded as additional evidence that the restated loop nests match the reference's.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+_HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(_HERE, "_ref")
+
+
+def available():
+    return os.path.isdir(os.path.join(REF, "formulations"))
+
+
+def _fmt(x):
+    x = float(x)
+    if x == np.inf:
+        x = 1e20
+    if x == -np.inf:
+        x = -1e20
+    return "%1.15f" % x
+
+
+def _decl(name, a):
+    """``const static double`` declaration as dec_var.m prints it ('array' option: scalars -> [1])."""
+    a = np.asarray(a, dtype=float)
+    if a.ndim == 0:
+        a = a.reshape(1)
+    if a.ndim == 1:
+        body = "{ " + ", ".join(_fmt(x) for x in a) + " }"
+        dims = f"[{a.size}]"
+    elif a.ndim == 2:
+        body = "{ " + ", ".join("{" + ", ".join(_fmt(x) for x in r) + "}" for r in a) + " }"
+        dims = f"[{a.shape[0]}][{a.shape[1]}]"
+    else:  # our 3-D arrays are already [k][i][j]
+        body = "{ " + ", ".join("{" + ", ".join("{" + ", ".join(_fmt(x) for x in r) + "}" for r in blk) + "}"
+                                for blk in a) + " }"
+        dims = f"[{a.shape[0]}][{a.shape[1]}][{a.shape[2]}]"
+    return f"const static double {name}{dims} = {body};\n"
+
+
+def _unescape(text):
+    """``fprintf(fid, text)`` semantics of Spcies_constructor.m:222."""
+    return text.replace("%%", "%").replace("\\\\", "\\")
+
+
+def _snippets(text, ext):
+    for name in set(re.findall(r"spcies_snippet_(\w+)\(\);", text)):
+        with open(os.path.join(REF, "snippets", f"{name}.{ext}")) as f:
+            text = text.replace(f"spcies_snippet_{name}();", f.read())
+    return text
+
+
+def build_admm(v, name):
+    """Instantiate + compile the lax/equ ADMM template for ingredients ``v``; returns the .so path."""
+    form = v["formulation"]
+    fdir = os.path.join(REF, "formulations", f"+{form}")
+    n, m, N = v["n"], v["m"], v["N"]
+    defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
+            "#define IS_DIAG 1", f"#define nn_ {n}", f"#define mm_ {m}", f"#define nm_ {n + m}", f"#define NN_ {N}",
+            f"#define k_max {int(v['k_max'])}", f"#define tol {_fmt(v['tol'])}", "#define SCALAR_RHO",
+            f"#define rho {_fmt(v['rho'])}", f"#define rho_i {_fmt(v['rho_i'])}"]
+    order = ["LB", "UB", "Hi", "Hi_0"] + (["Hi_N"] if v["terminal"] else []) + ["Q", "R", "AB", "Alpha", "Beta"] \
+        + (["T"] if v["terminal"] else [])
+    consts = "".join(_decl(k, v[k]) for k in order)
+    with open(os.path.join(REF, "platforms", "+C_code", "generic_solver_struct.c")) as f:
+        code = f.read()
+    with open(os.path.join(fdir, f"code_{form}_ADMM_C.c")) as f:
+        code = code.replace("$INSERT_SOLVER$", f.read())
+    with open(os.path.join(fdir, f"header_{form}_ADMM_C.h")) as f:
+        header = f.read()
+    code = code.replace("$INSERT_CONSTANTS$", consts)
+    header = header.replace("$INSERT_DEFINES$", "\n".join(defs))
+    code, header = _snippets(code, "c"), _snippets(header, "h")
+    code = _unescape(code.replace("$INSERT_NAME$", name))
+    header = _unescape(header.replace("$INSERT_NAME$", name))
+    os.makedirs(OUT, exist_ok=True)
+    so = os.path.join(OUT, f"lib{name}.so")
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, f"{name}.c"), "w") as f:
+            f.write(code)
+        with open(os.path.join(td, f"{name}.h"), "w") as f:
+            f.write(header)
+        subprocess.check_call(["gcc", "-O3", "-fPIC", "-shared", "-w", "-o", so, os.path.join(td, f"{name}.c"), "-lm"])
+    return so
+
+
+def run_admm(so, v, x0, xr, ur):
+    """Call ``laxMPC_ADMM`` / ``equMPC_ADMM`` of the compiled template once per instance."""
+    n, m, N = v["n"], v["m"], v["N"]
+    dim = N * (n + m) - (0 if v["terminal"] else n)
+    lib = C.CDLL(so)
+    fn = getattr(lib, f"{v['formulation']}_ADMM")
+
+    class Sol(C.Structure):
+        _fields_ = [("z", C.c_double * dim), ("v", C.c_double * dim), ("lam", C.c_double * dim),
+                    ("t", C.c_double * 4)]
+    x0 = np.atleast_2d(np.asarray(x0, float))
+    B = x0.shape[0]
+    per = np.ndim(xr) == 2
+    u = np.zeros((B, m)); k = np.zeros(B, np.int32); e = np.zeros(B, np.int32)
+    z = np.zeros((B, dim)); vv = np.zeros((B, dim)); lam = np.zeros((B, dim))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for i in range(B):
+        sol = Sol()
+        xi = np.ascontiguousarray(x0[i]); xri = np.ascontiguousarray(xr[i] if per else xr)
+        uri = np.ascontiguousarray(ur[i] if per else ur)
+        ui = np.zeros(m); ki = C.c_int(0); ei = C.c_int(0)
+        fn(dp(xi), dp(xri), dp(uri), dp(ui), C.byref(ki), C.byref(ei), C.byref(sol))
+        u[i] = ui; k[i] = ki.value; e[i] = ei.value
+        z[i] = np.frombuffer(sol.z); vv[i] = np.frombuffer(sol.v); lam[i] = np.frombuffer(sol.lam)
+    return u, k, e, z, vv, lam

@@ -1,0 +1,126 @@
+"""laxMPC / equMPC ADMM ingredients - host-side (offline) restatement.
+
+Reference: ``formulations/+laxMPC/compute_laxMPC_ADMM_ingredients.m:22-186`` and
+``formulations/+equMPC/compute_equMPC_ADMM_ingredients.m`` (same structure without the terminal
+block).  Decision vector order ``(u0, x1, u1, ..., x_{N-1}, u_{N-1}, x_N)`` (``:69``); equality
+constraint ``G z = b`` with ``b = [-A x0; 0]``; ``W = G Hhat^{-1} G'`` is block tridiagonal and its
+upper Cholesky factor block bidiagonal: ``Beta_l`` (diagonal blocks, diagonal entries stored
+inverted) and ``Alpha_l`` (super-diagonal blocks) (``:170-183``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _get(obj, name, default=None):
+    if isinstance(obj, dict):
+        return obj.get(name, default)
+    return getattr(obj, name, default)
+
+
+def _is_diag(M):
+    return np.count_nonzero(M - np.diag(np.diag(M))) == 0
+
+
+def build_G(A, B, N, terminal=True):
+    """Equality-constraint matrix of the lax (``terminal=True``) / equ (``False``) formulation.
+
+    lax: ``N*n`` rows, ``N*(n+m)`` columns (``compute_laxMPC_ADMM_ingredients.m:78-86``; the
+    reference relies on MATLAB growing ``Aeq`` when the last ``-I`` is written past its edge).
+    equ: same rows, but ``x_N`` is not a variable (it is fixed to ``xr`` through ``b``), so the last
+    ``n`` columns are absent.
+    """
+    n, m = B.shape
+    nm = n + m
+    ncol = N * nm if terminal else N * nm - n
+    G = np.zeros((N * n, ncol))
+    G[:n, :m] = B
+    G[:n, m:m + n] = -np.eye(n)
+    for l in range(1, N):
+        r = slice(l * n, (l + 1) * n)
+        c0 = m + (l - 1) * nm
+        G[r, c0:c0 + n] = A
+        G[r, c0 + n:c0 + nm] = B
+        if terminal or l < N - 1:
+            G[r, c0 + nm:c0 + nm + n] = -np.eye(n)
+    return G
+
+
+def compute_laxMPC_ADMM_ingredients(controller, opt, terminal=True):
+    """Returns the ``vars`` dict the reference's ``cons_laxMPC_ADMM_C.m:72-130`` prints as C constants.
+
+    ``controller`` needs ``.sys`` (A, B, LBx, UBx, LBu, UBu) and ``.param`` (Q, R, T, N);
+    ``opt`` is a :class:`SpciesOptions`.  Scalar ``rho`` only on the HIP platform for now (the
+    vector-``rho`` variant is SURVEY section 8f rank 3).
+    """
+    sys, param = _get(controller, "sys"), _get(controller, "param")
+    A = np.asarray(_get(sys, "A"), dtype=float)
+    B = np.asarray(_get(sys, "B"), dtype=float)
+    n, m = B.shape
+    N = int(_get(param, "N"))
+    Q = np.asarray(_get(param, "Q"), dtype=float)
+    R = np.asarray(_get(param, "R"), dtype=float)
+    T = np.asarray(_get(param, "T"), dtype=float)
+    if not (_is_diag(Q) and _is_diag(R)):
+        raise ValueError("Spcies:laxMPC:ADMM:non_diagonal - matrices Q and R must be diagonal")
+    rho = opt.solver["rho"]
+    if np.ndim(rho) != 0 or opt.solver.get("force_vector_rho", False):
+        raise NotImplementedError("HIP platform: vector rho is not built yet (scalar rho only)")
+    if opt.time_varying:
+        raise NotImplementedError("HIP platform: time_varying solvers are not built yet")
+    rho = float(rho)
+    nm = n + m
+    dim = N * nm if terminal else N * nm - n
+
+    H = np.zeros((dim, dim))
+    H[:m, :m] = R
+    for l in range(N - 1):
+        o = m + l * nm
+        H[o:o + n, o:o + n] = Q
+        H[o + n:o + nm, o + n:o + nm] = R
+    if terminal:
+        H[dim - n:, dim - n:] = T
+    Hhat = H + rho * np.eye(dim)
+    G = build_G(A, B, N, terminal=terminal)
+    Hinv = np.linalg.inv(Hhat)
+    W = G @ Hinv @ G.T
+    Wc = np.linalg.cholesky(W).T  # upper, as MATLAB chol()
+
+    v = dict(n=n, m=m, N=N, formulation="laxMPC" if terminal else "equMPC", method="ADMM",
+             terminal=bool(terminal))
+    v["Hi_0"] = np.diag(Hinv)[:m].copy()
+    v["Hi"] = np.diag(Hinv)[m:m + (N - 1) * nm].reshape(N - 1, nm).copy()
+    if terminal:
+        v["T"] = -T
+        v["Hi_N"] = Hinv[dim - n:, dim - n:].copy()
+    else:  # arrays the equMPC solver never reads; kept zero so the packed layout is uniform
+        v["T"] = np.zeros((n, n))
+        v["Hi_N"] = np.zeros((n, n))
+    v["AB"] = np.hstack([A, B])
+    v["Q"] = -np.diag(Q).copy()
+    v["R"] = -np.diag(R).copy()
+    v["LB"] = np.concatenate([np.ravel(_get(sys, "LBx")), np.ravel(_get(sys, "LBu"))]).astype(float)
+    v["UB"] = np.concatenate([np.ravel(_get(sys, "UBx")), np.ravel(_get(sys, "UBu"))]).astype(float)
+    v["rho"] = rho
+    v["rho_i"] = 1.0 / rho
+    v["rho_is_scalar"] = True
+    Beta = np.zeros((N, n, n))
+    Alpha = np.zeros((N - 1, n, n))
+    for i in range(N):
+        Beta[i] = Wc[i * n:(i + 1) * n, i * n:(i + 1) * n]
+        Beta[i][np.diag_indices(n)] = 1.0 / np.diag(Beta[i])
+    for i in range(N - 1):
+        Alpha[i] = Wc[i * n:(i + 1) * n, (i + 1) * n:(i + 2) * n]
+    v["Alpha"], v["Beta"] = Alpha, Beta
+    v["k_max"] = int(opt.solver["k_max"])
+    v["tol"] = float(opt.solver["tol"])
+    v["dim"] = dim
+    return v
+
+
+def compute_equMPC_ADMM_ingredients(controller, opt):
+    """equMPC-ADMM: the lax ingredients without the terminal block
+    (``formulations/+equMPC/compute_equMPC_ADMM_ingredients.m:66-93``: ``H`` has no ``T`` block and
+    ``Aeq = Aeq(:, 1:end-n)``); the solver then imposes ``x_N = xr`` through ``mu[N-1] -= xr``
+    (``code_equMPC_ADMM_C.c:351``)."""
+    return compute_laxMPC_ADMM_ingredients(controller, opt, terminal=False)
