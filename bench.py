@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py - headline metric of BASELINE.json: MPC solves/sec (whole node), laxMPC-ADMM,
+12-state oscillating masses, N=15, 200 iterations (config C2), B = 65 536 instances per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of B synthetic instances that are already
+resident in HBM (x0, xr, ur in; u, k, e_flag out).  The batch shards trivially: every rank solves its
+own B instances (weak scaling), the only collective is a one-time RCCL broadcast of the problem blob.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SOLVE = 27498 * 200          # 27 498 flop/iteration x 200 iterations
+IO_BYTES_PER_SOLVE = 232              # compulsory HBM bytes per solve (per-instance reference)
+PEAK_FP64_MFMA_TFLOPS = 78.6          # MI355X dense FP64 matrix peak = 256 CU x 128 flop/clk x 2.4 GHz (spec)
+PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(cfg, v, n_sample):
+    """Oracle (the C port of the reference's loop nests) on ONE host core, bounded sample of the same workload."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    x0, xr, ur = benchmarks.sample_batch(cfg, n_sample, seed=cfg.seed + 1)
+    oracle.admm_banded_batch(v, x0[:8], xr[:8], ur[:8], want_sol=False)  # warm
+    t = time.perf_counter()
+    oracle.admm_banded_batch(v, x0, xr, ur, want_sol=False)
+    dt = time.perf_counter() - t
+    return {"value": n_sample / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"{n_sample} seeded C2 instances, 200 iterations each, oracle/admm_banded_oracle.c "
+                      f"(gcc -O3 -ffp-contract=off), 1 thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--variant", default="auto", choices=["auto", "stream", "mfma"])
+    ap.add_argument("--cpu-sample", type=int, default=12288)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from spcies_amd import benchmarks, blob as blobmod, distributed as spdist
+    from spcies_amd.solver import HipSolver
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = benchmarks.config("C2")
+    # rank 0 factorises the controller once; the blob travels by one RCCL broadcast (xGMI)
+    v = benchmarks.ingredients(cfg) if rank == 0 else None
+    blob = blobmod.pack(v) if rank == 0 else None
+    blob = spdist.broadcast_blob(blob, dev)
+    solver = HipSolver(blob, device=local_rank)
+    solver.set_variant(args.variant)
+    variant = solver.variant
+
+    B = args.batch
+    # weak scaling: rank r owns global instances [r*B, (r+1)*B) of the seeded stream
+    x0, xr, ur = spdist.shard_inputs(cfg, B, rank)
+    tx0 = torch.from_numpy(x0).to(dev)
+    txr = torch.from_numpy(xr).to(dev)
+    tur = torch.from_numpy(ur).to(dev)
+    tu = torch.empty((B, cfg.sys.m), dtype=torch.float64, device=dev)
+    tk = torch.empty(B, dtype=torch.int32, device=dev)
+    te = torch.empty(B, dtype=torch.int32, device=dev)
+    solver.reserve(B)
+    stream = torch.cuda.current_stream(dev).cuda_stream  # the stream the kernel is launched on
+
+    def step():
+        solver.solve_device(tx0, txr, tur, tu, tk, te, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    fence()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream, over the timed region
+    tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+    dt = float(tdt.item())
+
+    # sanity on what was computed inside the timed region
+    k_ok = bool((tk == 200).all().item()) and bool((te == -1).all().item())
+    u_host = tu[:64].cpu().numpy()
+
+    if rank == 0:
+        out = {
+            "metric": "MPC solves/sec (whole node), laxMPC-ADMM 12-state N=15, 200 iters",
+            "value": world * B * args.steps / dt,
+            "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: laxMPC-ADMM, 12-state osc-masses (n=12, m=2), N=15, rho=15, tol=0, "
+                                   "k_max=200, batch=65536 random x0 / per-instance (xr, ur) per GPU",
+                       "batch_per_gpu": B, "variant": variant, "all_k_200_eflag_-1": k_ok},
+        }
+        secs = kernel_ms * 1e-3
+        if variant == "mfma":
+            ach = FLOP_PER_SOLVE * B / secs / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                               "kernel_ms": kernel_ms, "flop_per_solve": FLOP_PER_SOLVE}
+        else:
+            # STREAM variant: state is streamed through HBM by design; algorithmic bytes are only the I/O
+            ach = IO_BYTES_PER_SOLVE * B / secs / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": ach / PEAK_HBM_GBS, "traffic": None, "kernel_ms": kernel_ms,
+                               "algorithmic_bytes_per_solve": IO_BYTES_PER_SOLVE}
+        if world == 1 and not args.no_cpu_baseline:
+            if v is None:
+                v = benchmarks.ingredients(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, v, args.cpu_sample)
+            # the same run also re-checks the GPU result against the oracle on the first 64 instances
+            from oracle import oracle
+            uo, *_ = oracle.admm_banded_batch(v, x0[:64], xr[:64], ur[:64], want_sol=False)
+            out["config"]["max_abs_du_vs_oracle_first64"] = float(np.abs(u_host - uo).max())
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

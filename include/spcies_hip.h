@@ -1,0 +1,161 @@
+/*
+ * spcies_hip.h - C-ABI of the MI355X (gfx950) batched MPC solve engine.
+ *
+ * This is the drop-in boundary for the hot path of the Spcies solver family: it replaces the call
+ * a generated solver's gateway makes into the generated C function,
+ *
+ *     void laxMPC_ADMM(double *x0_in, double *xr_in, double *ur_in,
+ *                      double *u_opt, int *k_in, int *e_flag, sol_<name> *sol);
+ *         reference: formulations/+laxMPC/header_laxMPC_ADMM_C.h:27
+ *                    (called from formulations/+laxMPC/struct_laxMPC_ADMM_C_Matlab.c:149 and
+ *                     examples/cl_in_C/main_cl_in_C.c:103)
+ *     void equMPC_ADMM(...same signature...)
+ *         reference: formulations/+equMPC/header_equMPC_ADMM_C.h
+ *
+ * with a batched equivalent: B independent (x0, xr, ur) instances per call.  The reference bakes the
+ * controller's constants into the generated C file (`$INSERT_CONSTANTS$`,
+ * formulations/+laxMPC/cons_laxMPC_ADMM_C.m:72-130); here they travel in a "problem blob"
+ * (layout below) that the host generator packs once per controller design.
+ *
+ * Conventions
+ *  - every entry point returns 0 on success, a negative SPCIES_HIP_E* code otherwise;
+ *    spcies_hip_last_error() gives the text (thread-local).
+ *  - the caller owns every buffer; the handle owns device constants and scratch
+ *    (reference: caller-owned buffers, solver allocates nothing, struct_laxMPC_ADMM_C_Matlab.c:26).
+ *  - per-instance results keep the reference semantics: k = iterations run,
+ *    e_flag = 1 converged / -1 hit k_max (code_laxMPC_ADMM_C.c:624-631), u = first input move
+ *    (:642-651), z / v / lambda = the DEBUG copy-out (:657-686), laid out [B][dim] (instance
+ *    contiguous == MATLAB dim x B column-major).
+ *  - x0 is [B][n]; xr is [B][n] and ur is [B][m] when ref_stride != 0, else one shared reference
+ *    ([n], [m]) for the whole batch.
+ *  - no CPU fallback exists: without a usable HIP device the calls fail with SPCIES_HIP_ENODEV.
+ */
+#ifndef SPCIES_HIP_H
+#define SPCIES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPCIES_HIP_ABI_VERSION 1
+
+/* error codes */
+#define SPCIES_HIP_OK 0
+#define SPCIES_HIP_EINVAL (-1)   /* bad argument / malformed blob           */
+#define SPCIES_HIP_ENODEV (-2)   /* no usable HIP device                    */
+#define SPCIES_HIP_EHIP (-3)     /* a HIP runtime call failed               */
+#define SPCIES_HIP_ENOSUP (-4)   /* formulation / shape / variant not built */
+#define SPCIES_HIP_ENOMEM (-5)
+
+/* ---- problem blob ------------------------------------------------------------------------------
+ * little-endian; header, then n_arrays directory entries, then 64-byte aligned payloads.        */
+#define SPCIES_BLOB_MAGIC "SPCSBLB1"
+#define SPCIES_BLOB_VERSION 1u
+
+enum spcies_formulation { SPCIES_LAXMPC = 1, SPCIES_EQUMPC = 2, SPCIES_MPCT = 3, SPCIES_ELLIPMPC = 4, SPCIES_HMPC = 5 };
+enum spcies_method { SPCIES_ADMM = 1, SPCIES_FISTA = 2, SPCIES_EADMM = 3, SPCIES_SADMM = 4 };
+
+/* array ids: names are the reference's constant names (cons_laxMPC_ADMM_C.m:82-118) */
+enum spcies_array_id {
+    SPCIES_A_AB = 1,    /* [n][n+m]       row-major [A B]                                  */
+    SPCIES_A_ALPHA = 2, /* [N-1][n][n]    super-diagonal blocks of chol(W)                 */
+    SPCIES_A_BETA = 3,  /* [N][n][n]      diagonal blocks, upper triangle, inverted diag   */
+    SPCIES_A_HI = 4,    /* [N-1][n+m]                                                      */
+    SPCIES_A_HI_0 = 5,  /* [m]                                                             */
+    SPCIES_A_HI_N = 6,  /* [n][n]                                                          */
+    SPCIES_A_Q = 7,     /* [n]   negated diag(Q)                                           */
+    SPCIES_A_R = 8,     /* [m]   negated diag(R)                                           */
+    SPCIES_A_T = 9,     /* [n][n] negated T                                                */
+    SPCIES_A_LB = 10,   /* [n+m]                                                           */
+    SPCIES_A_UB = 11    /* [n+m]                                                           */
+};
+
+typedef struct {
+    char magic[8];         /* SPCIES_BLOB_MAGIC                              */
+    uint32_t version;      /* SPCIES_BLOB_VERSION                            */
+    uint32_t header_bytes; /* sizeof(spcies_blob_header) = 128               */
+    uint32_t formulation;  /* enum spcies_formulation                        */
+    uint32_t method;       /* enum spcies_method                             */
+    uint32_t submethod;    /* 0 = none                                       */
+    uint32_t flags;        /* bit0: scalar rho                               */
+    uint32_t n, m, N, k_max;
+    uint32_t n_arrays;
+    uint32_t reserved0;
+    uint64_t total_bytes;
+    double tol, rho, rho_i;
+    double reserved[5];
+} spcies_blob_header;
+
+typedef struct {
+    uint32_t id;     /* enum spcies_array_id      */
+    uint32_t dtype;  /* 0 = f64, 1 = i32          */
+    uint64_t offset; /* from blob start, 64-B aligned */
+    uint64_t count;  /* elements                  */
+    uint32_t dims[4];
+    uint32_t pad[2];
+} spcies_blob_entry; /* 48 bytes */
+
+/* ---- engine ------------------------------------------------------------------------------------ */
+typedef struct spcies_hip_solver_s *spcies_hip_handle;
+
+/* kernel variants (spcies_hip_set_variant) */
+#define SPCIES_VARIANT_AUTO 0
+#define SPCIES_VARIANT_STREAM 1 /* one lane per instance, reference operation order, state streamed through HBM */
+#define SPCIES_VARIANT_MFMA 2   /* 16 instances per wavefront on v_mfma_f64_16x16x4, state in registers          */
+
+typedef struct {
+    int formulation, method, submethod;
+    int n, m, N, dim; /* dim = length of z / v / lambda per instance */
+    int k_max;
+    double tol, rho;
+    int variant;      /* variant a solve would use now   */
+    int device;
+} spcies_hip_info;
+
+/* Batch-level mirror of the reference's four timers (docs/timing.md:9-22, sol_<name> fields of
+ * header_laxMPC_ADMM_C.h:18-21), in milliseconds: update = H2D of inputs, solve = kernel,
+ * polish = D2H of outputs, run = whole call. */
+typedef struct {
+    double update_time, solve_time, polish_time, run_time;
+} spcies_hip_timing;
+
+int spcies_hip_abi_version(void);
+const char *spcies_hip_last_error(void);
+int spcies_hip_device_count(int *count);
+
+/* Parse + validate the blob, upload constants to `device`, derive the kernel-side packing. */
+int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_handle *out);
+int spcies_hip_destroy(spcies_hip_handle h);
+int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info);
+int spcies_hip_set_variant(spcies_hip_handle h, int variant);
+/* Override the blob's exit settings (the reference bakes them in as #defines k_max / tol,
+ * cons_laxMPC_ADMM_C.m:76-77).  tol < 0 keeps the current value; k_max <= 0 keeps the current value. */
+int spcies_hip_set_exit(spcies_hip_handle h, int k_max, double tol);
+/* Pre-size device scratch for batches up to B instances (otherwise grown on demand). */
+int spcies_hip_reserve(spcies_hip_handle h, long B);
+
+/* Host-buffer entry point (what a mex / cgo / ctypes gateway binds).  z, v, lambda, timing may be NULL. */
+int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
+                           int ref_stride, long B, double *u, int *k, int *e_flag, double *z, double *v,
+                           double *lambda, spcies_hip_timing *timing);
+
+/* Device-buffer entry point: all pointers are device memory on the handle's device; the launch is
+ * asynchronous on `stream` (a hipStream_t, NULL = default stream).  Scratch must already be large
+ * enough (spcies_hip_reserve) if the call is to be captured in a hipGraph. */
+int spcies_hip_solve_batch_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
+                                  int ref_stride, long B, double *u, int *k, int *e_flag, double *z,
+                                  double *v, double *lambda, void *stream);
+
+/* Time `reps` back-to-back device solves with hipEvents recorded on `stream` (the stream the
+ * kernel is launched on); returns the mean milliseconds per launch in *ms_per_launch. */
+int spcies_hip_time_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
+                           int ref_stride, long B, double *u, int *k, int *e_flag, void *stream, int reps,
+                           double *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPCIES_HIP_H */

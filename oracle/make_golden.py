@@ -1,0 +1,68 @@
+"""Generate ``tests/golden/`` fixtures (run in THIS container; needs /root/reference).  TEST INFRASTRUCTURE.
+
+1. ``reference_z_opt.json`` - the hard-coded optimum vectors the reference's own tests hold
+   (``tests/test_<form>_<method>.m``, variable ``z_opt``) and the discretised 3-mass ``[A B]`` matrix
+   embedded in ``examples/cl_in_C/main_cl_in_C.c:96``.  Pure data, extracted verbatim.
+2. ``template_<cfg>.npz`` - inputs and outputs of the reference's C solver template instantiated by
+   ``oracle/ref_template.py`` (see its header for exactly what is the reference's and what is ours) on
+   seeded instances, plus the C oracle's outputs on the same inputs.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def extract_z_opt():
+    out = {}
+    for fn in sorted(os.listdir(os.path.join(REF, "tests"))):
+        if not fn.startswith("test_"):
+            continue
+        s = open(os.path.join(REF, "tests", fn)).read()
+        mm = re.search(r"z_opt\s*=\s*\[([^\]]*)\]", s)
+        if mm:
+            out[fn[:-2]] = [float(x) for x in mm.group(1).replace(";", " ").split()]
+    s = open(os.path.join(REF, "examples", "cl_in_C", "main_cl_in_C.c")).read()
+    mm = re.search(r"double AB\[6\]\[8\]\s*=\s*\{(.*?)\};", s, re.S)
+    rows = re.findall(r"\{([^{}]*)\}", mm.group(1))
+    out["main_cl_in_C_AB"] = [[float(x) for x in r.split(",")] for r in rows]
+    return out
+
+
+def main():
+    from oracle import oracle, ref_template
+    from spcies_amd import benchmarks
+
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "reference_z_opt.json"), "w") as f:
+        json.dump(extract_z_opt(), f, indent=0)
+    for name, B, overrides in (("C1_lax", 16, {}), ("C1_lax_denseT", 16, {}), ("C1_equ", 16, {}),
+                               ("C2_lax", 32, {}), ("C2_lax", 32, dict(tol=1e-6, k_max=3000)),
+                               ("C2_equ", 32, dict(tol=1e-6, k_max=3000))):
+        cfg = benchmarks.config(name)
+        v = benchmarks.ingredients(cfg, **overrides)
+        x0, xr, ur = benchmarks.sample_batch(cfg, B)
+        if name.startswith("C1"):  # first instance = the reference tester's own status
+            st = benchmarks.tester_status(cfg.sys)
+            x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
+        tag = name + ("_conv" if overrides else "")
+        so = ref_template.build_admm(v, "golden_" + tag)
+        ut, kt, et, zt, vt, lt = ref_template.run_admm(so, v, x0, xr, ur)
+        uo, ko, eo, zo, vo, lo = oracle.admm_banded_batch(v, x0, xr, ur)
+        print(tag, "template-vs-oracle(full doubles): z %.2e v %.2e lam %.2e  dk %d" % (
+            np.abs(zt - zo).max(), np.abs(vt - vo).max(), np.abs(lt - lo).max(), np.abs(kt - ko).max()))
+        np.savez_compressed(os.path.join(OUT, f"template_{tag}.npz"), x0=x0, xr=xr, ur=ur, u=ut, k=kt, e_flag=et,
+                            z=zt, v=vt, lam=lt, solver_overrides=json.dumps(overrides))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""Benchmark / test configurations (BASELINE.json ``configs``).
+
+C1 is the reference's own test instance (``tests/spcies_tester.m:90-116`` with the solver settings
+of ``tests/test_laxMPC_ADMM.m:6-16``); C2 is the headline shape the metric is quoted on.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import sp_utils
+
+
+def _weights(sys, terminal="dlqr"):
+    p = sys.p
+    Q = np.diag(np.concatenate([15.0 * np.ones(p), np.ones(p)]))
+    R = 0.1 * np.eye(sys.m)
+    _, P = sp_utils.dlqr(sys.A, sys.B, Q, R)
+    T = np.diag(P.sum(axis=1)) if terminal == "diag" else P
+    return Q, R, T
+
+
+def tester_status(sys):
+    """``status`` of ``tests/spcies_tester.m:114-116``: x = 0.02, ur = 0.5, xr the matching steady state."""
+    x = 0.02 * np.ones(sys.n)
+    ur = 0.5 * np.ones(sys.m)
+    xr = np.linalg.solve(sys.A - np.eye(sys.n), -sys.B @ ur)
+    return SimpleNamespace(x=x, xr=xr, ur=ur)
+
+
+def config(name):
+    """Returns ``SimpleNamespace(sys, param, formulation, method, solver_options, B, seed)``."""
+    if name in ("C1", "C1_lax"):  # reference test instance, laxMPC-ADMM (diag T as tests/test_laxMPC_ADMM.m:15)
+        sys = sp_utils.oscillating_masses_sys(3)
+        Q, R, T = _weights(sys, "diag")
+        return SimpleNamespace(name=name, sys=sys, param=SimpleNamespace(Q=Q, R=R, T=T, N=10), formulation="laxMPC",
+                               method="ADMM", solver_options=dict(rho=15, k_max=5000, tol=1e-7), B=1, seed=1201)
+    if name == "C1_lax_denseT":  # example_OscMass.m:50-53 (dense T = P_dlqr)
+        c = config("C1")
+        c.name = name
+        c.param.T = _weights(c.sys, "dlqr")[2]
+        return c
+    if name == "C1_equ":  # tests/test_equMPC_ADMM.m:6-14
+        c = config("C1")
+        c.name, c.formulation = name, "equMPC"
+        return c
+    if name in ("C2", "C2_lax"):  # headline: 12-state, N=15, 200 fixed iterations, B=65536
+        sys = sp_utils.oscillating_masses_sys(6)
+        Q, R, T = _weights(sys, "dlqr")
+        return SimpleNamespace(name=name, sys=sys, param=SimpleNamespace(Q=Q, R=R, T=T, N=15), formulation="laxMPC",
+                               method="ADMM", solver_options=dict(rho=15, k_max=200, tol=0.0), B=65536, seed=1202)
+    if name == "C2_equ":
+        c = config("C2")
+        c.name, c.formulation = name, "equMPC"
+        return c
+    raise KeyError(name)
+
+
+def sample_batch(cfg, B=None, seed=None):
+    """Seeded instances: ``x0 ~ U(-0.1, 0.1)^n``, ``ur = 0.5 + 0.1 U(-1, 1)^m``, ``xr`` the steady state of ``ur``."""
+    B = cfg.B if B is None else B
+    rng = np.random.default_rng(cfg.seed if seed is None else seed)
+    sys = cfg.sys
+    x0 = rng.uniform(-0.1, 0.1, size=(B, sys.n))
+    ur = 0.5 + 0.1 * rng.uniform(-1.0, 1.0, size=(B, sys.m))
+    xr = np.linalg.solve(sys.A - np.eye(sys.n), -(sys.B @ ur.T)).T.copy()
+    return x0, xr, ur
+
+
+def ingredients(cfg, **solver_overrides):
+    from .formulations import laxMPC
+    from .options import SpciesOptions
+    so = dict(cfg.solver_options)
+    so.update(solver_overrides)
+    opt = SpciesOptions(formulation=cfg.formulation, method=cfg.method, options=so)
+    ctrl = SimpleNamespace(sys=cfg.sys, param=cfg.param)
+    fn = {"laxMPC": laxMPC.compute_laxMPC_ADMM_ingredients, "equMPC": laxMPC.compute_equMPC_ADMM_ingredients}
+    return fn[cfg.formulation](ctrl, opt)

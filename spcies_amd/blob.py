@@ -1,0 +1,81 @@
+"""Problem blob: the controller's constants in the layout ``include/spcies_hip.h`` documents.
+
+The reference prints these arrays as ``const static double`` initialisers into the generated C file
+(``formulations/+laxMPC/cons_laxMPC_ADMM_C.m:82-118`` through ``platforms/+C_code/dec_var.m``);
+the HIP platform ships them as one little-endian blob instead (full doubles, no ``%1.15f``
+quantisation).
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+MAGIC = b"SPCSBLB1"
+VERSION = 1
+HEADER_BYTES = 128
+ENTRY_BYTES = 48
+
+FORMULATION = {"laxMPC": 1, "equMPC": 2, "MPCT": 3, "ellipMPC": 4, "HMPC": 5}
+METHOD = {"ADMM": 1, "FISTA": 2, "EADMM": 3, "SADMM": 4}
+ARRAY_ID = {"AB": 1, "Alpha": 2, "Beta": 3, "Hi": 4, "Hi_0": 5, "Hi_N": 6, "Q": 7, "R": 8, "T": 9, "LB": 10, "UB": 11}
+_ID_NAME = {v: k for k, v in ARRAY_ID.items()}
+_HDR = "<8sIIIIIIIIIIIIQddd5d"
+assert struct.calcsize(_HDR) == HEADER_BYTES
+_ENT = "<IIQQ4I2I"
+assert struct.calcsize(_ENT) == ENTRY_BYTES
+
+INF_VALUE = 1e20  # +-inf bounds are stored as +-1e20, as dec_var.m:245-248 prints them
+
+
+def _align(x, a=64):
+    return (x + a - 1) // a * a
+
+
+def pack(v):
+    """Pack an ingredients dict (``compute_*_ingredients``) into blob bytes."""
+    names = [k for k in ARRAY_ID if k in v]
+    arrays = []
+    for k in names:
+        a = np.ascontiguousarray(np.asarray(v[k], dtype="<f8"))
+        if k in ("LB", "UB"):
+            a = np.clip(a, -INF_VALUE, INF_VALUE)
+        arrays.append((k, a))
+    off = _align(HEADER_BYTES + ENTRY_BYTES * len(arrays))
+    entries, payload = [], []
+    for k, a in arrays:
+        dims = list(a.shape)[:4] + [0] * (4 - min(a.ndim, 4))
+        entries.append(struct.pack(_ENT, ARRAY_ID[k], 0, off, a.size, *dims, 0, 0))
+        payload.append((off, a.tobytes()))
+        off = _align(off + a.nbytes)
+    total = off
+    flags = 1 if v.get("rho_is_scalar", True) else 0
+    hdr = struct.pack(_HDR, MAGIC, VERSION, HEADER_BYTES, FORMULATION[v["formulation"]], METHOD[v["method"]],
+                      0, flags, int(v["n"]), int(v["m"]), int(v["N"]), int(v["k_max"]), len(arrays), 0, total,
+                      float(v["tol"]), float(v["rho"]), float(v["rho_i"]), 0.0, 0.0, 0.0, 0.0, 0.0)
+    buf = bytearray(total)
+    buf[:HEADER_BYTES] = hdr
+    p = HEADER_BYTES
+    for e in entries:
+        buf[p:p + ENTRY_BYTES] = e
+        p += ENTRY_BYTES
+    for o, b in payload:
+        buf[o:o + len(b)] = b
+    return bytes(buf)
+
+
+def unpack(blob):
+    """Inverse of :func:`pack` (used by tests and by the multi-GPU broadcast receiver)."""
+    (magic, version, hb, form, meth, sub, flags, n, m, N, k_max, n_arr, _r0, total, tol, rho, rho_i,
+     *_res) = struct.unpack_from(_HDR, blob, 0)
+    if magic != MAGIC or version != VERSION or hb != HEADER_BYTES or total != len(blob):
+        raise ValueError("not a spcies problem blob")
+    inv = lambda d, x: next(k for k, val in d.items() if val == x)
+    v = dict(formulation=inv(FORMULATION, form), method=inv(METHOD, meth), n=n, m=m, N=N, k_max=k_max, tol=tol,
+             rho=rho, rho_i=rho_i, rho_is_scalar=bool(flags & 1))
+    v["terminal"] = v["formulation"] != "equMPC"
+    for i in range(n_arr):
+        aid, dtype, off, count, d0, d1, d2, d3, _p0, _p1 = struct.unpack_from(_ENT, blob, HEADER_BYTES + i * ENTRY_BYTES)
+        shape = tuple(d for d in (d0, d1, d2, d3) if d) or (count,)
+        v[_ID_NAME[aid]] = np.frombuffer(blob, dtype="<f8", count=count, offset=off).reshape(shape).copy()
+    return v

@@ -1,0 +1,317 @@
+// Variant STREAM of the banded-Cholesky ADMM solver (laxMPC / equMPC): ONE LANE PER INSTANCE.
+//
+// 64 independent instances per wavefront run the reference's iteration in lock step; every
+// floating-point accumulation is performed in the reference's own order
+// (formulations/+laxMPC/code_laxMPC_ADMM_C.c:308-633, equMPC: code_equMPC_ADMM_C.c), so with
+// EXACT = true (no FMA contraction) the results are bit-identical to the generated C built by
+// gcc -O3 on x86-64.  Controller constants are wave-uniform: they are fetched with scalar loads
+// (s_load) and fed to v_fma_f64 / v_mul_f64 as SGPR operands - no LDS, no lane idles.
+//
+// State that has to survive between iterations (v, lambda) and between the two sweeps of one
+// iteration (the forward-substituted y) does not fit on chip at 64 instances per wave
+// (600 doubles per instance), so it is streamed through HBM in a structure-of-arrays scratch
+// [element][instance]: every access is a fully coalesced 512-byte wave transaction.
+//
+// Per iteration and instance (n=12, m=2, N=15): reads 2 x (v, lambda) + y, writes y + (v, lambda)
+// = (4*420 + 2*180) * 8 B = 16.3 KB  ->  HBM-bound kernel.
+#pragma once
+#include "common.hpp"
+
+namespace spcies {
+
+#pragma clang fp contract(off)
+
+template <bool EXACT>
+__device__ __forceinline__ double msub(double acc, double a, double b) {  // acc - a*b
+    if constexpr (EXACT)
+        return acc - a * b;
+    else
+        return __builtin_fma(-a, b, acc);
+}
+template <bool EXACT>
+__device__ __forceinline__ double madd(double acc, double a, double b) {  // acc + a*b
+    if constexpr (EXACT)
+        return acc + a * b;
+    else
+        return __builtin_fma(a, b, acc);
+}
+
+__device__ __forceinline__ double clamp_ref(double x, double lo, double hi) {
+    x = (x > lo) ? x : lo;  // comparison sense of code_laxMPC_ADMM_C.c:500-501
+    x = (x > hi) ? hi : x;
+    return x;
+}
+
+__device__ __forceinline__ bool above(double a, double b, double tol) {
+    double r = a - b;
+    r = (r > 0.0) ? r : -r;
+    return r > tol;
+}
+
+// Scratch: V, LAM are [dim][Bp], Y is [N*n][Bp], ZS (optional, only when the caller wants
+// z / v / lambda back) is [dim][Bp].  Element order inside dim = the reference's flattened order
+// (code_laxMPC_ADMM_C.c:659-684): m head entries, N-1 rows of n+m, n tail entries.
+template <int n, int m, bool TERMINAL, bool EXACT>
+__global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double *__restrict__ C,
+                                                         const double *__restrict__ x0g,
+                                                         const double *__restrict__ xrg,
+                                                         const double *__restrict__ urg, int ref_stride, long B,
+                                                         long Bp, double *__restrict__ V,
+                                                         double *__restrict__ LAM, double *__restrict__ Y,
+                                                         double *__restrict__ ZS, double *__restrict__ u_out,
+                                                         int *__restrict__ k_out, int *__restrict__ e_out) {
+    constexpr int nm = n + m;
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    if (t >= B) return;
+    const int N = c.N;
+    const double rho = c.rho, rho_i = c.rho_i, tol = c.tol;
+    const double *cAB = C + c.AB, *cAlpha = C + c.Alpha, *cBeta = C + c.Beta, *cHi = C + c.Hi, *cHi_0 = C + c.Hi_0,
+                 *cHi_N = C + c.Hi_N, *cQ = C + c.Q, *cR = C + c.R, *cT = C + c.T, *cLB = C + c.LB, *cUB = C + c.UB;
+
+    // ---- per-instance setup (code_laxMPC_ADMM_C.c:282-299)
+    double xr[n], b[n], q[nm], qT[n];
+    {
+        double x0[n];
+#pragma unroll
+        for (int i = 0; i < n; i++) x0[i] = x0g[t * n + i];
+        const double *xrp = ref_stride ? xrg + t * n : xrg;
+        const double *urp = ref_stride ? urg + t * m : urg;
+#pragma unroll
+        for (int i = 0; i < n; i++) xr[i] = xrp[i];
+#pragma unroll
+        for (int j = 0; j < n; j++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < n; i++) acc = msub<EXACT>(acc, cAB[j * nm + i], x0[i]);
+            b[j] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < n; j++) {
+            q[j] = cQ[j] * xr[j];
+            double acc = 0.0;
+            if constexpr (TERMINAL) {
+#pragma unroll
+                for (int i = 0; i < n; i++) acc = madd<EXACT>(acc, cT[j * n + i], xr[i]);
+            }
+            qT[j] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < m; j++) q[n + j] = cR[j] * urp[j];
+    }
+
+    const long off_mid = (long)m;                       // element offset of the middle rows
+    const long off_tail = (long)m + (long)(N - 1) * nm; // element offset of the tail
+    double *Vt = V + t, *Lt = LAM + t, *Yt = Y + t;
+    double *Zt = ZS ? ZS + t : nullptr;
+
+    int k = 0, flag = -1;
+    double u0[m];
+    while (true) {
+        k += 1;
+        const bool first = (k == 1);  // v = lambda = 0: skip the scratch reads (scratch is never pre-zeroed)
+
+        // ================= forward sweep: q_hat, rhs, forward substitution (:323-417) =========
+        double qp[nm];  // q_hat of the previous reference block
+        double yp[n];
+        // stage 0 head (m entries)
+        double h0[m];
+#pragma unroll
+        for (int j = 0; j < m; j++) {
+            double lam = first ? 0.0 : Lt[(long)j * Bp];
+            double vv = first ? 0.0 : Vt[(long)j * Bp];
+            h0[j] = q[n + j] + lam - rho * vv;
+        }
+        for (int l = 0; l < N; l++) {
+            // q_hat of reference block l  (= z[l][.] for l < N-1, z_N[.] for l = N-1)
+            double qc[nm];
+            const bool last = (l == N - 1);
+            if (!last) {
+#pragma unroll
+                for (int j = 0; j < nm; j++) {
+                    long e = off_mid + (long)l * nm + j;
+                    double lam = first ? 0.0 : Lt[e * Bp];
+                    double vv = first ? 0.0 : Vt[e * Bp];
+                    qc[j] = q[j] + lam - rho * vv;
+                }
+            } else if constexpr (TERMINAL) {
+#pragma unroll
+                for (int j = 0; j < n; j++) {
+                    long e = off_tail + j;
+                    double lam = first ? 0.0 : Lt[e * Bp];
+                    double vv = first ? 0.0 : Vt[e * Bp];
+                    qc[j] = qT[j] + lam - rho * vv;
+                }
+            }
+            // right-hand side (:355-381)
+            double y[n];
+#pragma unroll
+            for (int j = 0; j < n; j++) {
+                double acc;
+                if (l == 0) {
+                    acc = cHi[j] * qc[j] - b[j];
+#pragma unroll
+                    for (int i = 0; i < m; i++) acc = acc - cAB[j * nm + n + i] * cHi_0[i] * h0[i];
+                } else {
+                    if (!last) {
+                        acc = cHi[l * nm + j] * qc[j];
+                    } else {
+                        acc = 0.0;
+                        if constexpr (TERMINAL) {
+#pragma unroll
+                            for (int i = 0; i < n; i++) acc = madd<EXACT>(acc, cHi_N[j * n + i], qc[i]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < nm; i++) acc = acc - cAB[j * nm + i] * cHi[(l - 1) * nm + i] * qp[i];
+                    if (last) {
+                        if constexpr (!TERMINAL) acc = acc - xr[j];
+                    }
+                }
+                y[j] = acc;
+            }
+            // forward substitution (:388-417)
+            const double *Bl = cBeta + (long)l * n * n;
+            const double *Al = cAlpha + (long)(l - 1) * n * n;
+#pragma unroll
+            for (int j = 0; j < n; j++) {
+                double acc = y[j];
+                if (l > 0) {
+#pragma unroll
+                    for (int i = 0; i < n; i++) acc = msub<EXACT>(acc, Al[i * n + j], yp[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < j; i++) acc = msub<EXACT>(acc, Bl[i * n + j], y[i]);
+                y[j] = Bl[j * n + j] * acc;
+            }
+#pragma unroll
+            for (int j = 0; j < n; j++) {
+                Yt[((long)l * n + j) * Bp] = y[j];
+                yp[j] = y[j];
+            }
+#pragma unroll
+            for (int j = 0; j < nm; j++) qp[j] = qc[j];
+        }
+
+        // ================= backward sweep + z, v, lambda, residual (:422-620) ==================
+        bool res = false;
+        double mun[n];  // mu of block l+1
+        for (int l = N - 1; l >= 0; l--) {
+            const double *Bl = cBeta + (long)l * n * n;
+            const double *Al = cAlpha + (long)l * n * n;
+            double mu[n];
+#pragma unroll
+            for (int j = 0; j < n; j++) mu[j] = (l == N - 1) ? yp[j] : Yt[((long)l * n + j) * Bp];
+#pragma unroll
+            for (int j = n - 1; j >= 0; j--) {
+                double acc = mu[j];
+                if (l < N - 1) {
+#pragma unroll
+                    for (int i = n - 1; i >= 0; i--) acc = msub<EXACT>(acc, Al[j * n + i], mun[i]);
+                }
+#pragma unroll
+                for (int i = n - 1; i > j; i--) acc = msub<EXACT>(acc, Bl[j * n + i], mu[i]);
+                mu[j] = Bl[j * n + j] * acc;
+            }
+            if (l == N - 1) {
+                if constexpr (TERMINAL) {
+                    // z_N = -Hi_N (q_hat_N - mu_{N-1})  (:477-485)
+                    double aux[n], lamv[n], vold[n];
+#pragma unroll
+                    for (int j = 0; j < n; j++) {
+                        long e = off_tail + j;
+                        lamv[j] = first ? 0.0 : Lt[e * Bp];
+                        vold[j] = first ? 0.0 : Vt[e * Bp];
+                        aux[j] = (qT[j] + lamv[j] - rho * vold[j]) - mu[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < n; j++) {
+                        double zz = 0.0;
+#pragma unroll
+                        for (int i = 0; i < n; i++) zz = msub<EXACT>(zz, cHi_N[j * n + i], aux[i]);
+                        double vn = clamp_ref(zz + rho_i * lamv[j], cLB[j], cUB[j]);
+                        double ln = lamv[j] + rho * (zz - vn);
+                        res = res || above(vold[j], vn, tol) || above(zz, vn, tol);
+                        long e = off_tail + j;
+                        Vt[e * Bp] = vn;
+                        Lt[e * Bp] = ln;
+                        if (Zt) Zt[e * Bp] = zz;
+                    }
+                }
+            } else {
+                // reference block l: z[l] = -Hi[l] (q_hat - [mu_l; 0] + AB' mu_{l+1})  (:464-474)
+#pragma unroll
+                for (int j = 0; j < nm; j++) {
+                    long e = off_mid + (long)l * nm + j;
+                    double lam = first ? 0.0 : Lt[e * Bp];
+                    double vold = first ? 0.0 : Vt[e * Bp];
+                    double zz = q[j] + lam - rho * vold;
+                    if (j < n) zz = zz - mu[j];
+#pragma unroll
+                    for (int i = 0; i < n; i++) zz = madd<EXACT>(zz, cAB[i * nm + j], mun[i]);
+                    zz = -cHi[l * nm + j] * zz;
+                    double vn = clamp_ref(zz + rho_i * lam, cLB[j], cUB[j]);
+                    double ln = lam + rho * (zz - vn);
+                    res = res || above(vold, vn, tol) || above(zz, vn, tol);
+                    Vt[e * Bp] = vn;
+                    Lt[e * Bp] = ln;
+                    if (Zt) Zt[e * Bp] = zz;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < n; j++) mun[j] = mu[j];
+        }
+        // head: z_0 = -Hi_0 (q_hat_0 + B' mu_0)  (:456-461)
+#pragma unroll
+        for (int j = 0; j < m; j++) {
+            double lam = first ? 0.0 : Lt[(long)j * Bp];
+            double vold = first ? 0.0 : Vt[(long)j * Bp];
+            double zz = q[n + j] + lam - rho * vold;
+#pragma unroll
+            for (int i = 0; i < n; i++) zz = madd<EXACT>(zz, cAB[i * nm + n + j], mun[i]);
+            zz = -cHi_0[j] * zz;
+            double vn = clamp_ref(zz + rho_i * lam, cLB[n + j], cUB[n + j]);
+            double ln = lam + rho * (zz - vn);
+            res = res || above(vold, vn, tol) || above(zz, vn, tol);
+            Vt[(long)j * Bp] = vn;
+            Lt[(long)j * Bp] = ln;
+            if (Zt) Zt[(long)j * Bp] = zz;
+            u0[j] = vn;
+        }
+        // exit condition (:624-631)
+        if (!res) {
+            flag = 1;
+            break;
+        }
+        if (k >= c.k_max) {
+            flag = -1;
+            break;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < m; j++) u_out[t * m + j] = u0[j];
+    k_out[t] = k;
+    e_out[t] = flag;
+}
+
+// [rows][Bp] structure-of-arrays scratch -> [B][rows] instance-contiguous output (the layout the
+// reference's DEBUG copy-out produces per instance, code_laxMPC_ADMM_C.c:657-686).
+__global__ __launch_bounds__(256) void soa_to_aos_kernel(const double *__restrict__ S, long Bp, long B, int rows,
+                                                          double *__restrict__ out) {
+    __shared__ double tile[64][65];
+    const long b0 = (long)blockIdx.x * 64;
+    const int r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    for (int rr = ty; rr < 64; rr += 4) {
+        int r = r0 + rr;
+        long bb = b0 + tx;
+        tile[rr][tx] = (r < rows && bb < B) ? S[(long)r * Bp + bb] : 0.0;
+    }
+    __syncthreads();
+    for (int bbi = ty; bbi < 64; bbi += 4) {
+        long bb = b0 + bbi;
+        int r = r0 + tx;
+        if (bb < B && r < rows) out[bb * rows + r] = tile[tx][bbi];
+    }
+}
+
+}  // namespace spcies

@@ -1,0 +1,53 @@
+// Shared host-side declarations of libspcies_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spcies_hip.h"
+
+namespace spcies {
+
+extern thread_local std::string g_last_error;
+
+inline int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define SPCIES_HIP_CHECK(expr)                                                                          \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return ::spcies::fail(SPCIES_HIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                                  __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// Reference-style ingredients of a banded-Cholesky ADMM controller (laxMPC / equMPC), host copy.
+struct AdmmHost {
+    int n = 0, m = 0, N = 0, k_max = 0;
+    bool terminal = true;
+    double tol = 0, rho = 0, rho_i = 0;
+    std::vector<double> AB, Alpha, Beta, Hi, Hi_0, Hi_N, Q, R, T, LB, UB;
+    int dim() const { return N * (n + m) - (terminal ? 0 : n); }
+};
+
+// Offsets (in doubles) of the same arrays inside ONE device allocation.  Kernels take the base as a
+// `const double *__restrict__` kernel argument: that is what lets hipcc prove the constants are
+// never written by the kernel and fetch them with scalar loads (s_load) into SGPRs.
+struct AdmmDev {
+    int AB, Alpha, Beta, Hi, Hi_0, Hi_N, Q, R, T, LB, UB;
+    int N, k_max;
+    double tol, rho, rho_i;
+};
+
+}  // namespace spcies

@@ -1,0 +1,382 @@
+// libspcies_hip.so - C-ABI implementation (include/spcies_hip.h).  gfx950 only; no CPU fallback.
+#include <chrono>
+#include <memory>
+#include <mutex>
+
+#include "admm_mfma.hpp"
+#include "admm_stream.hpp"
+#include "common.hpp"
+
+namespace spcies {
+
+thread_local std::string g_last_error;
+
+struct Solver {
+    int device = 0;
+    int formulation = 0, method = 0, submethod = 0;
+    int variant = SPCIES_VARIANT_AUTO;
+    AdmmHost host;
+    // device constants (one allocation) + pointers
+    double *d_consts = nullptr;
+    AdmmDev dev{};
+    // MFMA-variant packing
+    MfmaPlan mfma;
+    // scratch of the STREAM variant (grown on demand)
+    double *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // staging buffers of the host entry point
+    double *d_io = nullptr;
+    size_t io_bytes = 0;
+    hipStream_t stream = nullptr;  // owned; used by the host entry point
+    std::mutex mu;
+};
+
+static const double *find_array(const uint8_t *blob, size_t bytes, const spcies_blob_header &h, uint32_t id,
+                                uint64_t expect) {
+    for (uint32_t i = 0; i < h.n_arrays; i++) {
+        spcies_blob_entry e;
+        memcpy(&e, blob + h.header_bytes + (size_t)i * sizeof(e), sizeof(e));
+        if (e.id != id) continue;
+        if (e.dtype != 0 || e.count != expect || e.offset % 8 != 0 || e.offset + e.count * 8 > bytes) return nullptr;
+        return reinterpret_cast<const double *>(blob + e.offset);
+    }
+    return nullptr;
+}
+
+static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
+    const uint8_t *blob = static_cast<const uint8_t *>(blobv);
+    if (!blob || bytes < sizeof(spcies_blob_header)) return fail(SPCIES_HIP_EINVAL, "blob too small");
+    spcies_blob_header h;
+    memcpy(&h, blob, sizeof(h));
+    if (memcmp(h.magic, SPCIES_BLOB_MAGIC, 8) != 0) return fail(SPCIES_HIP_EINVAL, "bad blob magic");
+    if (h.version != SPCIES_BLOB_VERSION || h.header_bytes != sizeof(h) || h.total_bytes != bytes)
+        return fail(SPCIES_HIP_EINVAL, "blob version/size mismatch");
+    if ((size_t)h.header_bytes + (size_t)h.n_arrays * sizeof(spcies_blob_entry) > bytes)
+        return fail(SPCIES_HIP_EINVAL, "blob directory out of range");
+    if (h.method != SPCIES_ADMM || (h.formulation != SPCIES_LAXMPC && h.formulation != SPCIES_EQUMPC))
+        return fail(SPCIES_HIP_ENOSUP, "formulation %u / method %u not built in this library", h.formulation, h.method);
+    if (!(h.flags & 1u)) return fail(SPCIES_HIP_ENOSUP, "vector rho not built");
+    if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.N > 100000) return fail(SPCIES_HIP_EINVAL, "bad n/m/N");
+    s.formulation = (int)h.formulation;
+    s.method = (int)h.method;
+    s.submethod = (int)h.submethod;
+    AdmmHost &a = s.host;
+    a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max;
+    a.terminal = (h.formulation == SPCIES_LAXMPC);
+    a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
+    if (!(a.rho > 0) || a.k_max <= 0) return fail(SPCIES_HIP_EINVAL, "bad rho / k_max");
+    const uint64_t n = h.n, m = h.m, N = h.N, nm = n + m;
+    struct Want { uint32_t id; uint64_t count; std::vector<double> *dst; };
+    Want want[] = {{SPCIES_A_AB, n * nm, &a.AB},       {SPCIES_A_ALPHA, (N - 1) * n * n, &a.Alpha},
+                   {SPCIES_A_BETA, N * n * n, &a.Beta}, {SPCIES_A_HI, (N - 1) * nm, &a.Hi},
+                   {SPCIES_A_HI_0, m, &a.Hi_0},         {SPCIES_A_HI_N, n * n, &a.Hi_N},
+                   {SPCIES_A_Q, n, &a.Q},               {SPCIES_A_R, m, &a.R},
+                   {SPCIES_A_T, n * n, &a.T},           {SPCIES_A_LB, nm, &a.LB},
+                   {SPCIES_A_UB, nm, &a.UB}};
+    for (auto &w : want) {
+        const double *p = find_array(blob, bytes, h, w.id, w.count);
+        if (!p) return fail(SPCIES_HIP_EINVAL, "blob array id %u missing or mis-sized", w.id);
+        w.dst->assign(p, p + w.count);
+    }
+    return 0;
+}
+
+static int upload_consts(Solver &s) {
+    AdmmHost &a = s.host;
+    std::vector<const std::vector<double> *> arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Hi, &a.Hi_0, &a.Hi_N,
+                                                     &a.Q,  &a.R,     &a.T,    &a.LB, &a.UB};
+    std::vector<double> flat;
+    std::vector<size_t> offs;
+    for (auto *v : arrs) {
+        offs.push_back(flat.size());
+        flat.insert(flat.end(), v->begin(), v->end());
+        while (flat.size() % 8) flat.push_back(0.0);  // 64-byte aligned sub-arrays
+    }
+    SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_consts, flat.size() * sizeof(double)));
+    SPCIES_HIP_CHECK(hipMemcpy(s.d_consts, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
+    s.dev = AdmmDev{(int)offs[0], (int)offs[1], (int)offs[2], (int)offs[3], (int)offs[4], (int)offs[5],
+                    (int)offs[6], (int)offs[7], (int)offs[8], (int)offs[9], (int)offs[10],
+                    a.N,          a.k_max,      a.tol,        a.rho,        a.rho_i};
+    return 0;
+}
+
+static bool stream_shape_built(int n, int m) {
+    return (m == 2 && (n == 6 || n == 12 || n == 20)) || (n == 4 && m == 1) || (n == 8 && m == 2) ||
+           (n == 2 && m == 1);
+}
+
+static int resolve_variant(const Solver &s) {
+    if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
+    if (s.mfma.ok) return SPCIES_VARIANT_MFMA;
+    return SPCIES_VARIANT_STREAM;
+}
+
+static size_t stream_scratch_bytes(const Solver &s, long B, bool want_sol) {
+    long Bp = (B + 63) / 64 * 64;
+    size_t rows = 2 * (size_t)s.host.dim() + (size_t)s.host.N * s.host.n + (want_sol ? (size_t)s.host.dim() : 0);
+    return rows * (size_t)Bp * sizeof(double);
+}
+
+static int ensure_scratch(Solver &s, size_t need) {
+    if (need <= s.scratch_bytes) return 0;
+    if (s.d_scratch) SPCIES_HIP_CHECK(hipFree(s.d_scratch));
+    s.d_scratch = nullptr;
+    s.scratch_bytes = 0;
+    SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_scratch, need));
+    s.scratch_bytes = need;
+    return 0;
+}
+
+template <int n, int m>
+static int launch_stream_nm(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
+                            double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
+    const bool want_sol = (z || v || lam);
+    const long Bp = (B + 63) / 64 * 64;
+    const size_t dim = (size_t)s.host.dim();
+    double *V = s.d_scratch;
+    double *LAM = V + dim * Bp;
+    double *Y = LAM + dim * Bp;
+    double *ZS = want_sol ? Y + (size_t)s.host.N * n * Bp : nullptr;
+    dim3 grid((unsigned)(Bp / 64)), block(64);
+    if (s.host.terminal)
+        hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true>), grid, block, 0, st, s.dev, s.d_consts, x0, xr, ur,
+                           ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e);
+    else
+        hipLaunchKernelGGL((admm_stream_kernel<n, m, false, true>), grid, block, 0, st, s.dev, s.d_consts, x0, xr, ur,
+                           ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    if (want_sol) {
+        dim3 tg((unsigned)(Bp / 64), (unsigned)((dim + 63) / 64));
+        if (z) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, ZS, Bp, B, (int)dim, z);
+        if (v) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, V, Bp, B, (int)dim, v);
+        if (lam) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, LAM, Bp, B, (int)dim, lam);
+        SPCIES_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+static int launch_stream(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
+                         double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
+    const int n = s.host.n, m = s.host.m;
+#define SPCIES_CASE(NN, MM) \
+    if (n == NN && m == MM) return launch_stream_nm<NN, MM>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
+    SPCIES_CASE(6, 2)
+    SPCIES_CASE(12, 2)
+    SPCIES_CASE(20, 2)
+    SPCIES_CASE(8, 2)
+    SPCIES_CASE(4, 1)
+    SPCIES_CASE(2, 1)
+#undef SPCIES_CASE
+    return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", n, m);
+}
+
+static int solve_device(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
+                        double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
+    if (B <= 0) return 0;
+    const int variant = resolve_variant(s);
+    if (variant == SPCIES_VARIANT_MFMA) {
+        if (!s.mfma.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA variant not available for this shape: %s", s.mfma.why.c_str());
+        return launch_mfma(s.mfma, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
+    }
+    if (!stream_shape_built(s.host.n, s.host.m))
+        return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
+    int rc = ensure_scratch(s, stream_scratch_bytes(s, B, z || v || lam));
+    if (rc) return rc;
+    return launch_stream(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
+}
+
+}  // namespace spcies
+
+using namespace spcies;
+
+extern "C" {
+
+int spcies_hip_abi_version(void) { return SPCIES_HIP_ABI_VERSION; }
+
+const char *spcies_hip_last_error(void) { return g_last_error.c_str(); }
+
+int spcies_hip_device_count(int *count) {
+    if (!count) return fail(SPCIES_HIP_EINVAL, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(SPCIES_HIP_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = c;
+    return 0;
+}
+
+int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_handle *out) {
+    if (!out) return fail(SPCIES_HIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    std::unique_ptr<Solver> s(new Solver);
+    int rc = parse_blob(blob, bytes, *s);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SPCIES_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SPCIES_HIP_EINVAL, "device %d out of range (0..%d)", device, ndev - 1);
+    s->device = device;
+    SPCIES_HIP_CHECK(hipSetDevice(device));
+    SPCIES_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    rc = upload_consts(*s);
+    if (rc) return rc;
+    rc = mfma_plan_build(s->mfma, s->host);
+    if (rc) return rc;
+    *out = reinterpret_cast<spcies_hip_handle>(s.release());
+    return 0;
+}
+
+int spcies_hip_destroy(spcies_hip_handle h) {
+    if (!h) return 0;
+    Solver *s = reinterpret_cast<Solver *>(h);
+    hipSetDevice(s->device);
+    if (s->d_consts) hipFree(s->d_consts);
+    if (s->d_scratch) hipFree(s->d_scratch);
+    if (s->d_io) hipFree(s->d_io);
+    mfma_plan_free(s->mfma);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return 0;
+}
+
+int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
+    if (!h || !info) return fail(SPCIES_HIP_EINVAL, "NULL argument");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    info->formulation = s->formulation;
+    info->method = s->method;
+    info->submethod = s->submethod;
+    info->n = s->host.n; info->m = s->host.m; info->N = s->host.N; info->dim = s->host.dim();
+    info->k_max = s->host.k_max; info->tol = s->host.tol; info->rho = s->host.rho;
+    info->variant = resolve_variant(*s);
+    info->device = s->device;
+    return 0;
+}
+
+int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
+    if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_MFMA) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant == SPCIES_VARIANT_MFMA && !s->mfma.ok)
+        return fail(SPCIES_HIP_ENOSUP, "MFMA variant not available for this shape: %s", s->mfma.why.c_str());
+    if (variant == SPCIES_VARIANT_STREAM && !stream_shape_built(s->host.n, s->host.m))
+        return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s->host.n, s->host.m);
+    s->variant = variant;
+    return 0;
+}
+
+int spcies_hip_set_exit(spcies_hip_handle h, int k_max, double tol) {
+    if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    if (k_max > 0) s->host.k_max = s->dev.k_max = k_max;
+    if (tol >= 0) s->host.tol = s->dev.tol = tol;
+    return 0;
+}
+
+int spcies_hip_reserve(spcies_hip_handle h, long B) {
+    if (!h || B < 0) return fail(SPCIES_HIP_EINVAL, "bad argument");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    std::lock_guard<std::mutex> lk(s->mu);
+    SPCIES_HIP_CHECK(hipSetDevice(s->device));
+    return ensure_scratch(*s, stream_scratch_bytes(*s, B, true));
+}
+
+int spcies_hip_solve_batch_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
+                                  int ref_stride, long B, double *u, int *k, int *e_flag, double *z, double *v,
+                                  double *lambda, void *stream) {
+    if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
+    if (B < 0) return fail(SPCIES_HIP_EINVAL, "negative batch");
+    if (B == 0) return 0;
+    if (!x0 || !xr || !ur || !u || !k || !e_flag) return fail(SPCIES_HIP_EINVAL, "NULL buffer");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    std::lock_guard<std::mutex> lk(s->mu);
+    SPCIES_HIP_CHECK(hipSetDevice(s->device));
+    return solve_device(*s, x0, xr, ur, ref_stride, B, u, k, e_flag, z, v, lambda, (hipStream_t)stream);
+}
+
+int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride,
+                           long B, double *u, int *k, int *e_flag, double *z, double *v, double *lambda,
+                           spcies_hip_timing *timing) {
+    if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
+    if (B < 0) return fail(SPCIES_HIP_EINVAL, "negative batch");
+    if (timing) *timing = spcies_hip_timing{0, 0, 0, 0};
+    if (B == 0) return 0;
+    if (!x0 || !xr || !ur || !u || !k || !e_flag) return fail(SPCIES_HIP_EINVAL, "NULL buffer");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    std::lock_guard<std::mutex> lk(s->mu);
+    SPCIES_HIP_CHECK(hipSetDevice(s->device));
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    const size_t n = s->host.n, m = s->host.m, dim = s->host.dim();
+    const size_t nref = ref_stride ? (size_t)B : 1;
+    // device staging: x0 | xr | ur | u | z | v | lam | k | e   (doubles first, ints last)
+    size_t nd = (size_t)B * n + nref * n + nref * m + (size_t)B * m;
+    size_t o_x0 = 0, o_xr = (size_t)B * n, o_ur = o_xr + nref * n, o_u = o_ur + nref * m;
+    size_t o_z = nd, o_v = 0, o_l = 0;
+    if (z) { o_z = nd; nd += (size_t)B * dim; }
+    if (v) { o_v = nd; nd += (size_t)B * dim; }
+    if (lambda) { o_l = nd; nd += (size_t)B * dim; }
+    size_t need = nd * sizeof(double) + 2 * (size_t)B * sizeof(int);
+    if (need > s->io_bytes) {
+        if (s->d_io) SPCIES_HIP_CHECK(hipFree(s->d_io));
+        s->d_io = nullptr; s->io_bytes = 0;
+        SPCIES_HIP_CHECK(hipMalloc((void **)&s->d_io, need));
+        s->io_bytes = need;
+    }
+    double *d = s->d_io;
+    int *dk = reinterpret_cast<int *>(d + nd), *de = dk + B;
+    hipStream_t st = s->stream;
+    SPCIES_HIP_CHECK(hipMemcpyAsync(d + o_x0, x0, (size_t)B * n * 8, hipMemcpyHostToDevice, st));
+    SPCIES_HIP_CHECK(hipMemcpyAsync(d + o_xr, xr, nref * n * 8, hipMemcpyHostToDevice, st));
+    SPCIES_HIP_CHECK(hipMemcpyAsync(d + o_ur, ur, nref * m * 8, hipMemcpyHostToDevice, st));
+    SPCIES_HIP_CHECK(hipStreamSynchronize(st));
+    auto t1 = clk::now();
+    int rc = solve_device(*s, d + o_x0, d + o_xr, d + o_ur, ref_stride, B, d + o_u, dk, de, z ? d + o_z : nullptr,
+                          v ? d + o_v : nullptr, lambda ? d + o_l : nullptr, st);
+    if (rc) return rc;
+    SPCIES_HIP_CHECK(hipStreamSynchronize(st));
+    auto t2 = clk::now();
+    SPCIES_HIP_CHECK(hipMemcpyAsync(u, d + o_u, (size_t)B * m * 8, hipMemcpyDeviceToHost, st));
+    SPCIES_HIP_CHECK(hipMemcpyAsync(k, dk, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    SPCIES_HIP_CHECK(hipMemcpyAsync(e_flag, de, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (z) SPCIES_HIP_CHECK(hipMemcpyAsync(z, d + o_z, (size_t)B * dim * 8, hipMemcpyDeviceToHost, st));
+    if (v) SPCIES_HIP_CHECK(hipMemcpyAsync(v, d + o_v, (size_t)B * dim * 8, hipMemcpyDeviceToHost, st));
+    if (lambda) SPCIES_HIP_CHECK(hipMemcpyAsync(lambda, d + o_l, (size_t)B * dim * 8, hipMemcpyDeviceToHost, st));
+    SPCIES_HIP_CHECK(hipStreamSynchronize(st));
+    auto t3 = clk::now();
+    if (timing) {
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        timing->update_time = ms(t0, t1);
+        timing->solve_time = ms(t1, t2);
+        timing->polish_time = ms(t2, t3);
+        timing->run_time = ms(t0, t3);
+    }
+    return 0;
+}
+
+int spcies_hip_time_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride,
+                           long B, double *u, int *k, int *e_flag, void *stream, int reps, double *ms_per_launch) {
+    if (!h || !ms_per_launch || reps <= 0) return fail(SPCIES_HIP_EINVAL, "bad argument");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    SPCIES_HIP_CHECK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t a, b;
+    SPCIES_HIP_CHECK(hipEventCreate(&a));
+    SPCIES_HIP_CHECK(hipEventCreate(&b));
+    SPCIES_HIP_CHECK(hipEventRecord(a, st));
+    for (int i = 0; i < reps; i++) {
+        int rc = spcies_hip_solve_batch_device(h, x0, xr, ur, ref_stride, B, u, k, e_flag, nullptr, nullptr, nullptr, stream);
+        if (rc) { hipEventDestroy(a); hipEventDestroy(b); return rc; }
+    }
+    SPCIES_HIP_CHECK(hipEventRecord(b, st));
+    SPCIES_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    SPCIES_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    *ms_per_launch = (double)ms / reps;
+    return 0;
+}
+
+}  // extern "C"

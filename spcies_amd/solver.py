@@ -1,0 +1,147 @@
+"""Generated-solver object of the HIP platform.
+
+The reference's generated MATLAB function is called ``[u, k, e_flag, sol] = <name>(x0, xr, ur)``
+(``formulations/+laxMPC/struct_laxMPC_ADMM_C_Matlab.c:8-166``).  :class:`HipSolver` keeps that call
+and extends it to a batch: ``x0`` may be ``(n,)`` or ``(B, n)``; ``xr``/``ur`` one shared reference or
+one per instance.  Argument checks raise with the reference's message ids
+(``Spcies:<formulation>:nrhs:<arg>``, ``struct_laxMPC_ADMM_C_Matlab.c:34-55``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib, blob as _blob
+
+
+class SpciesArgError(ValueError):
+    """Mirror of ``mexErrMsgIdAndTxt("Spcies:...")`` argument errors; ``.identifier`` holds the id."""
+
+    def __init__(self, identifier, msg):
+        super().__init__(f"{identifier}: {msg}")
+        self.identifier = identifier
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class HipSolver:
+    """Handle on one controller (one problem blob) living on one GPU."""
+
+    def __init__(self, vars_or_blob, device=0, name=None, debug=True):
+        self.blob = vars_or_blob if isinstance(vars_or_blob, (bytes, bytearray)) else _blob.pack(vars_or_blob)
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.spcies_hip_create(self.blob, len(self.blob), int(device), C.byref(h)))
+        self._h = h
+        self._lib = lib
+        info = _lib.Info()
+        _lib.check(lib.spcies_hip_get_info(h, C.byref(info)))
+        self.n, self.m, self.N, self.dim = info.n, info.m, info.N, info.dim
+        self.device = info.device
+        self.formulation = {v: k for k, v in _blob.FORMULATION.items()}[info.formulation]
+        self.name = name or self.formulation
+        self.debug = bool(debug)  # reference option `debug`: copy z, v, lambda out (Spcies_options.m:121)
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.spcies_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- knobs
+    @property
+    def variant(self):
+        info = _lib.Info()
+        _lib.check(self._lib.spcies_hip_get_info(self._h, C.byref(info)))
+        return {v: k for k, v in _lib.VARIANTS.items()}[info.variant]
+
+    def set_variant(self, name):
+        _lib.check(self._lib.spcies_hip_set_variant(self._h, _lib.VARIANTS[name]))
+
+    def set_exit(self, k_max=0, tol=-1.0):
+        _lib.check(self._lib.spcies_hip_set_exit(self._h, int(k_max), float(tol)))
+
+    def reserve(self, B):
+        _lib.check(self._lib.spcies_hip_reserve(self._h, int(B)))
+
+    # -- the generated-solver call
+    def _check_args(self, x0, xr, ur):
+        f = self.formulation
+        x0 = np.asarray(x0, dtype=np.float64)
+        single = x0.ndim == 1
+        x0 = np.ascontiguousarray(np.atleast_2d(x0))
+        if x0.ndim != 2 or x0.shape[1] != self.n:
+            raise SpciesArgError(f"Spcies:{f}:nrhs:x0", f"x0 must be of dimension {self.n}")
+        B = x0.shape[0]
+        xr = np.ascontiguousarray(np.asarray(xr, dtype=np.float64))
+        ur = np.ascontiguousarray(np.asarray(ur, dtype=np.float64))
+        if xr.ndim == 2 and xr.shape[0] == 1 and ur.ndim <= 2:
+            xr = xr.reshape(-1)
+        if ur.ndim == 2 and ur.shape[0] == 1 and xr.ndim == 1:
+            ur = ur.reshape(-1)
+        per = xr.ndim == 2
+        if (xr.shape != ((B, self.n) if per else (self.n,))):
+            raise SpciesArgError(f"Spcies:{f}:nrhs:xr", f"xr must be of dimension {self.n}")
+        if (ur.shape != ((B, self.m) if per else (self.m,))):
+            raise SpciesArgError(f"Spcies:{f}:nrhs:ur", f"ur must be of dimension {self.m}")
+        return x0, xr, ur, B, per, single
+
+    def __call__(self, x0, xr, ur, want_sol=None):
+        """``u, k, e_flag, sol = solver(x0, xr, ur)``; host (numpy) buffers in and out."""
+        x0, xr, ur, B, per, single = self._check_args(x0, xr, ur)
+        want_sol = self.debug if want_sol is None else want_sol
+        u = np.zeros((B, self.m))
+        k = np.zeros(B, dtype=np.int32)
+        e = np.zeros(B, dtype=np.int32)
+        z = v = lam = None
+        if want_sol:
+            z, v, lam = (np.zeros((B, self.dim)) for _ in range(3))
+        t = _lib.Timing()
+        _lib.check(self._lib.spcies_hip_solve_batch(
+            self._h, _dp(x0), _dp(xr), _dp(ur), int(per), B, _dp(u), _ip(k), _ip(e),
+            _dp(z) if want_sol else None, _dp(v) if want_sol else None, _dp(lam) if want_sol else None, C.byref(t)))
+        sol = SimpleNamespace(z=z, v=v, **{"lambda": lam}, lam=lam, update_time=t.update_time,
+                              solve_time=t.solve_time, polish_time=t.polish_time, run_time=t.run_time)
+        if single:
+            sol.z, sol.v, sol.lam = (a[0] if a is not None else None for a in (z, v, lam))
+            setattr(sol, "lambda", sol.lam)
+            return u[0], int(k[0]), int(e[0]), sol
+        return u, k, e, sol
+
+    def solve_device(self, x0, xr, ur, u, k, e_flag, z=None, v=None, lam=None, stream=0):
+        """Device-resident call: arguments are objects with ``data_ptr()`` (torch tensors on this GPU)
+        or raw integer device addresses; asynchronous on ``stream`` (a raw ``hipStream_t`` value)."""
+        ptr = lambda a: None if a is None else C.c_void_p(a if isinstance(a, int) else a.data_ptr())
+        B = x0.shape[0]
+        per = 1 if xr.dim() == 2 else 0
+        _lib.check(self._lib.spcies_hip_solve_batch_device(self._h, ptr(x0), ptr(xr), ptr(ur), per, B, ptr(u), ptr(k),
+                                                          ptr(e_flag), ptr(z), ptr(v), ptr(lam), C.c_void_p(stream)))
+
+    def time_device(self, x0, xr, ur, u, k, e_flag, stream=0, reps=1):
+        """Mean ms per launch over ``reps`` back-to-back solves, hipEvents on ``stream``."""
+        ptr = lambda a: C.c_void_p(a.data_ptr())
+        ms = C.c_double(0)
+        per = 1 if xr.dim() == 2 else 0
+        _lib.check(self._lib.spcies_hip_time_device(self._h, ptr(x0), ptr(xr), ptr(ur), per, x0.shape[0], ptr(u),
+                                                   ptr(k), ptr(e_flag), C.c_void_p(stream), int(reps), C.byref(ms)))
+        return ms.value
