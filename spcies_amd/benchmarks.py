@@ -57,14 +57,19 @@ def config(name):
     raise KeyError(name)
 
 
-def sample_batch(cfg, B=None, seed=None):
-    """Seeded instances: ``x0 ~ U(-0.1, 0.1)^n``, ``ur = 0.5 + 0.1 U(-1, 1)^m``, ``xr`` the steady state of ``ur``."""
+def sample_batch(cfg, B=None, seed=None, around_xr=None):
+    """Seeded instances: ``x0 ~ U(-0.1, 0.1)^n``, ``ur = 0.5 + 0.1 U(-1, 1)^m``, ``xr`` the steady state of ``ur``.
+
+    ``around_xr=s`` instead draws ``x0 = xr + U(-s, s)^n`` - starts close enough to the reference for the
+    terminal equality of equMPC (``x_N = xr``) to be reachable inside the horizon."""
     B = cfg.B if B is None else B
     rng = np.random.default_rng(cfg.seed if seed is None else seed)
     sys = cfg.sys
     x0 = rng.uniform(-0.1, 0.1, size=(B, sys.n))
     ur = 0.5 + 0.1 * rng.uniform(-1.0, 1.0, size=(B, sys.m))
     xr = np.linalg.solve(sys.A - np.eye(sys.n), -(sys.B @ ur.T)).T.copy()
+    if around_xr is not None:
+        x0 = xr + x0 * (around_xr / 0.1)
     return x0, xr, ur
 
 
