@@ -29,6 +29,27 @@ PEAK_FP64_MFMA_TFLOPS = 78.6          # MI355X dense FP64 matrix peak = 256 CU x
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def traffic_from_profile(variant):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_<variant>_pmc_summary.txt: separate FETCH_SIZE / WRITE_SIZE runs of this same command),
+    corrected as MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE x 2 on gfx950, values in KB."""
+    path = os.path.join(ROOT, "profiles", f"r01_{variant}_pmc_summary.txt")
+    if not os.path.exists(path):
+        return None
+    fetch = write = None
+    for line in open(path):
+        if f"admm_{variant}_kernel" not in line:
+            continue
+        val = float(line.split("mean=")[1].split()[0])
+        if line.startswith("FETCH_SIZE"):
+            fetch = val
+        elif line.startswith("WRITE_SIZE"):
+            write = val
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
+
+
 def cpu_baseline(cfg, v, n_sample):
     """Oracle (the C port of the reference's loop nests) on ONE host core, bounded sample of the same workload."""
     from oracle import oracle
@@ -144,13 +165,13 @@ def main():
         if variant == "mfma":
             ach = FLOP_PER_SOLVE * B / secs / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                               "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic_from_profile("mfma"),
                                "kernel_ms": kernel_ms, "flop_per_solve": FLOP_PER_SOLVE}
         else:
             # STREAM variant: state is streamed through HBM by design; algorithmic bytes are only the I/O
             ach = IO_BYTES_PER_SOLVE * B / secs / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": ach / PEAK_HBM_GBS, "traffic": None, "kernel_ms": kernel_ms,
+                               "frac": ach / PEAK_HBM_GBS, "traffic": traffic_from_profile("stream"), "kernel_ms": kernel_ms,
                                "algorithmic_bytes_per_solve": IO_BYTES_PER_SOLVE}
         if world == 1 and not args.no_cpu_baseline:
             if v is None:
