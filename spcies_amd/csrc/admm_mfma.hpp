@@ -234,7 +234,7 @@ inline int mfma_plan_build(MfmaPlan &p, const AdmmHost &a) {
         if (!std::isfinite(x)) { p.why = "non-finite folded constant (singular Beta block?)"; return 0; }
     p.table_bytes = tab.size() * sizeof(double);
     if (p.table_bytes > 160 * 1024 - 512) { p.why = "tile table exceeds the 160 KB LDS"; return 0; }
-    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_table, p.table_bytes));
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_table, p.table_bytes + 64));  // + a dump word for masked-off stores
     SPCIES_HIP_CHECK(hipMemcpy(p.d_table, tab.data(), p.table_bytes, hipMemcpyHostToDevice));
     hipDeviceProp_t prop;
     int dev = 0;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
                                                            const double *__restrict__ urg, double *__restrict__ u_out,
                                                            int *__restrict__ k_out, int *__restrict__ e_out,
                                                            double *__restrict__ z_out, double *__restrict__ v_out,
-                                                           double *__restrict__ lam_out) {
+                                                           double *__restrict__ lam_out, double *__restrict__ dump) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = p.n, m = p.m, nm = n + m;
     // Every shape instantiated in this library keeps the u rows inside the last k-step (KU0 == KS-1;
@@ -342,106 +342,166 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
             for (int i = 0; i < 4; i++) r[i] = fmin(fmax(x[i], lb[i]), ub[i]);  // == the reference's two ?: for non-NaN
             return r;
         };
-        auto LBt = [&](int t) -> d4 { return RC(t == 0 ? MfmaLayout::RC_LB_0 : (t == N ? MfmaLayout::RC_LB_N : MfmaLayout::RC_LB_MID)); };
-        auto UBt = [&](int t) -> d4 { return RC(t == 0 ? MfmaLayout::RC_UB_0 : (t == N ? MfmaLayout::RC_UB_N : MfmaLayout::RC_UB_MID)); };
+        // resident: bounds of the middle stages and the shared Zmid tiles
+        
+        double zm[KX];
+#pragma unroll
+        for (int s = 0; s < KX; s++) zm[s] = A(LL.zmid() + s);
+        auto LBt = [&](int t) -> d4 { return t == 0 ? RC(MfmaLayout::RC_LB_0) : (t == N ? RC(MfmaLayout::RC_LB_N) : RC(MfmaLayout::RC_LB_MID)); };
+        auto UBt = [&](int t) -> d4 { return t == 0 ? RC(MfmaLayout::RC_UB_0) : (t == N ? RC(MfmaLayout::RC_UB_N) : RC(MfmaLayout::RC_UB_MID)); };
+
+        // Tile prefetch: the first PF A-operands of segment j+1 are read from LDS while segment j computes
+        // (a segment's other tiles are read at its start and land behind its first MFMAs).
+        // Segments: N forward blocks, N backward blocks (+ the terminal-stage tiles), one final (stage 0).
+        constexpr int PF = 2;
+        double pfc[PF], pfn[PF];
+#pragma unroll
+        for (int i = 0; i < PF; i++) pfc[i] = A(LL.fwd_off(0) + i);
 
         while (true) {
             kk += 1;
             // cold start: v = lambda = 0 in iteration 1 whatever clamp(0) is
             const double fz = (kk == 1) ? 0.0 : 1.0, rf = rho * fz;
             asm volatile("" : "+v"(lo), "+v"(go));
-            // q_hat_t = q_t + lambda_t - rho v_t  with (v, lambda) rebuilt from w_t
-            auto qhat = [&](int t, d4 &vo, d4 &la) -> d4 {
-                const d4 cw = clampv(w[t], LBt(t), UBt(t));
-                vo = fz * cw;
-                la = rf * (w[t] - cw);
-                return ((t == N) ? qT : qm) + la - rho * vo;
+            long il = inst;  // laundered too: otherwise every output address is hoisted out of the loop and spills
+            asm volatile("" : "+v"(il));
+            double *zp = WANT_SOL ? z_out + il * dim + g : nullptr;  // row 4r+g of stage t lives at zp[off_t + 4r]
+            // q_hat_t = q_t + lambda_t - rho v_t = q_t + rho fz (w_t - 2 clamp(w_t))
+            auto qhat = [&](int t, d4 &cw) -> d4 {
+                cw = clampv(w[t], LBt(t), UBt(t));
+                return ((t == N) ? qT : qm) + rf * (w[t] - 2.0 * cw);
             };
-            d4 vo, la;
+            d4 cw;
             // ============ forward sweep ============
-            d4 qh = qhat(0, vo, la);
+            d4 qh = qhat(0, cw);
 #pragma unroll
             for (int l = 0; l < N; l++) {
+                const int nxt = (l + 1 < N) ? LL.fwd_off(l + 1) : LL.b1(N - 1);
+#pragma unroll
+                for (int i = 0; i < PF; i++) pfn[i] = A(nxt + i);
+                auto T = [&](int i) -> double { return i < PF ? pfc[i] : A(LL.fwd_off(l) + i); };
                 d4 acc = (l == 0) ? c0 : d4{0, 0, 0, 0};
                 if constexpr (!TERMINAL) {
                     if (l == N - 1) acc = cN;
                 }
+                int ti = 0;
                 // F2_l qh_l
                 if (l == 0) {
-                    SPCIES_MFMA(acc, A(LL.f2(0)), qh[KS - 1]);
+                    SPCIES_MFMA(acc, T(ti), qh[KS - 1]);
+                    ti++;
                 } else {
 #pragma unroll
-                    for (int s = 0; s < KS; s++) SPCIES_MFMA(acc, A(LL.f2(l) + s), qh[s]);
+                    for (int s = 0; s < KS; s++) {
+                        SPCIES_MFMA(acc, T(ti), qh[s]);
+                        ti++;
+                    }
                 }
                 // F1_l qh_{l+1}
                 if (TERMINAL || l < N - 1) {
-                    const d4 qn = qhat(l + 1, vo, la);
+                    const d4 qn = qhat(l + 1, cw);
 #pragma unroll
-                    for (int s = 0; s < KX; s++) SPCIES_MFMA(acc, A(LL.f1(l) + s), qn[s]);
+                    for (int s = 0; s < KX; s++) {
+                        SPCIES_MFMA(acc, T(ti), qn[s]);
+                        ti++;
+                    }
                     qh = qn;
                 }
                 // F3_l y_{l-1}
                 if (l >= 1) {
 #pragma unroll
-                    for (int s = 0; s < KX; s++) SPCIES_MFMA(acc, A(LL.f3(l) + s), mu[l - 1][s]);
+                    for (int s = 0; s < KX; s++) {
+                        SPCIES_MFMA(acc, T(ti), mu[l - 1][s]);
+                        ti++;
+                    }
                 }
                 mu[l] = acc;
-                __builtin_amdgcn_sched_barrier(0);  // keep tile reads of later blocks from piling up in registers
+                __builtin_amdgcn_sched_barrier(0);  // a segment's tile reads must not drift into earlier segments
+#pragma unroll
+                for (int i = 0; i < PF; i++) pfc[i] = pfn[i];
             }
             // ============ backward sweep, primal update, projection, dual update ============
+            asm volatile("" : "+v"(go));  // re-read (not keep alive) the stage-0 / stage-N row constants
             bool res = false;
             // one stage: z_t, then w_t <- z_t + lambda_t / rho  (v_t, lambda_t follow from w_t)
-            auto stage = [&](int t) {
+            auto stage = [&](int t, double z0t, double z1t, double z2t, double z3t) {
+                const double zt[4] = {z0t, z1t, z2t, z3t};
                 d4 z;
+                const d4 qq = qhat(t, cw);
                 if (t == N) {  // terminal stage, dense Hi_N: z_N = -Hi_N (qh_N - mu_{N-1})
-                    const d4 wv = qhat(N, vo, la) - mu[N - 1];
+                    const d4 wv = qq - mu[N - 1];
                     z = d4{0, 0, 0, 0};
 #pragma unroll
-                    for (int s = 0; s < KX; s++) SPCIES_MFMA(z, A(LL.zN() + s), wv[s]);
+                    for (int s = 0; s < KX; s++) SPCIES_MFMA(z, zt[s], wv[s]);
                 } else if (t == 0) {
-                    z = RC(MfmaLayout::RC_NEGHD_0) * qhat(0, vo, la);
+                    z = RC(MfmaLayout::RC_NEGHD_0) * qq;
 #pragma unroll
-                    for (int s = 0; s < KX; s++) SPCIES_MFMA(z, A(LL.z0() + s), mu[0][s]);
+                    for (int s = 0; s < KX; s++) SPCIES_MFMA(z, zt[s], mu[0][s]);
                 } else {
-                    z = RC(MfmaLayout::RC_NEGHD_MID) * (qhat(t, vo, la) - mu[t - 1]);
+                    z = RC(MfmaLayout::RC_NEGHD_MID) * (qq - mu[t - 1]);
 #pragma unroll
-                    for (int s = 0; s < KX; s++) SPCIES_MFMA(z, A(LL.zmid() + s), mu[t][s]);
+                    for (int s = 0; s < KX; s++) SPCIES_MFMA(z, zt[s], mu[t][s]);
                 }
-                const d4 wn = z + rho_i * la;
+                const d4 wn = z + fz * (w[t] - cw);  // z + lambda/rho
                 const d4 vn = clampv(wn, LBt(t), UBt(t));
+                const d4 vo = fz * cw;
 #pragma unroll
-                for (int r = 0; r < 4; r++) res = res || (fabs(vo[r] - vn[r]) > tol) || (fabs(z[r] - vn[r]) > tol);
+                for (int r = 0; r < 4; r++) res |= (fabs(vo[r] - vn[r]) > tol) | (fabs(z[r] - vn[r]) > tol);  // no short-circuit: no branches
                 w[t] = wn;  // finished instances keep iterating harmlessly: their results are already stored
                 if constexpr (WANT_SOL) {
-                    if (active) {
-                        const int off = (t == 0) ? -n : (m + (t - 1) * nm);
+                    // Branch-free: lanes that must not write (finished instance, padding row) aim at a dump
+                    // word instead - an `if` per stage here splits the iteration into dozens of blocks and
+                    // the register allocator then spills hundreds of values.
+                    const int off = (t == 0) ? -n : (m + (t - 1) * nm);
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int row = 4 * r + g;
-                            const bool in = (t == 0) ? (row >= n && row < nm) : (t == N ? row < n : row < nm);
-                            if (in) z_out[inst * dim + off + row] = z[r];
-                        }
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 4 * r + g;
+                        const bool in = (t == 0) ? (row >= n && row < nm) : (t == N ? row < n : row < nm);
+                        double *ptr = (in && active) ? (zp + off + 4 * r) : dump;
+                        *ptr = z[r];
                     }
                 }
             };
+            auto zmid_stage = [&](int t) { stage(t, zm[0], KX > 1 ? zm[KX > 1 ? 1 : 0] : 0.0, KX > 2 ? zm[KX > 2 ? 2 : 0] : 0.0, KX > 3 ? zm[KX > 3 ? 3 : 0] : 0.0); };
             // stage t is issued one block late (after mu_{t-2}) so that its operands are never the
             // result of the immediately preceding MFMA
 #pragma unroll
             for (int l = N - 1; l >= 0; l--) {
+                // this segment's tiles: b1(l) [KX], b2(l) [KX, l < N-1], then zN [KX] when its stage is t = N
+                const int nb = (l < N - 1) ? 2 * KX : KX;
+                auto T = [&](int i) -> double {
+                    return i < PF ? pfc[i] : (i < nb ? A(LL.b1(l) + i) : A(LL.zN() + (i - nb)));
+                };
+                const int nxt = (l >= 1) ? LL.b1(l - 1) : LL.z0();
+#pragma unroll
+                for (int i = 0; i < PF; i++) pfn[i] = A(nxt + i);
                 d4 acc = {0, 0, 0, 0};
 #pragma unroll
-                for (int s = 0; s < KX; s++) SPCIES_MFMA(acc, A(LL.b1(l) + s), mu[l][s]);
+                for (int s = 0; s < KX; s++) SPCIES_MFMA(acc, T(s), mu[l][s]);
                 if (l < N - 1) {
 #pragma unroll
-                    for (int s = 0; s < KX; s++) SPCIES_MFMA(acc, A(LL.b2(l) + s), mu[l + 1][s]);
+                    for (int s = 0; s < KX; s++) SPCIES_MFMA(acc, T(KX + s), mu[l + 1][s]);
                 }
                 mu[l] = acc;
                 const int t = l + 2;
-                if (t < N || (t == N && TERMINAL)) stage(t);
+                if (t < N) zmid_stage(t);
+                else if (t == N && TERMINAL)
+                    stage(N, T(nb), KX > 1 ? T(nb + 1) : 0.0, KX > 2 ? T(nb + 2) : 0.0, KX > 3 ? T(nb + 3) : 0.0);
                 __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < PF; i++) pfc[i] = pfn[i];
             }
-            stage(1);
-            stage(0);
+            // final segment; meanwhile fetch the head of forward block 0 for the next iteration
+            {
+#pragma unroll
+                for (int i = 0; i < PF; i++) pfn[i] = A(LL.fwd_off(0) + i);
+                asm volatile("" : "+v"(go));
+                auto T = [&](int i) -> double { return i < PF ? pfc[i] : A(LL.z0() + i); };
+                zmid_stage(1);
+                stage(0, T(0), KX > 1 ? T(1) : 0.0, KX > 2 ? T(2) : 0.0, KX > 3 ? T(3) : 0.0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < PF; i++) pfc[i] = pfn[i];
+            }
             // ============ exit test per instance (code_laxMPC_ADMM_C.c:572-631) ============
             unsigned long long bal = __ballot(res);
             bal |= bal >> 32;
@@ -455,11 +515,11 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int row = 4 * r + g;
-                        if (row >= n && row < nm) u_out[inst * m + (row - n)] = v0[r];
+                        if (row >= n && row < nm) u_out[il * m + (row - n)] = v0[r];
                     }
                     if (g == 0) {
-                        k_out[inst] = kk;
-                        e_out[inst] = res_inst ? -1 : 1;
+                        k_out[il] = kk;
+                        e_out[il] = res_inst ? -1 : 1;
                     }
                     if constexpr (WANT_SOL) {
 #pragma unroll
@@ -473,8 +533,8 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
                                 const int row = 4 * r + g;
                                 const bool in = (t == 0) ? (row >= n && row < nm) : (t == N ? row < n : row < nm);
                                 if (in) {
-                                    v_out[inst * dim + off + row] = vt[r];
-                                    lam_out[inst * dim + off + row] = lt[r];
+                                    v_out[il * dim + off + row] = vt[r];
+                                    lam_out[il * dim + off + row] = lt[r];
                                 }
                             }
                         }
@@ -518,7 +578,8 @@ static int launch_mfma_shape(MfmaPlan &pl, const AdmmHost &a, const MfmaArgs &ar
                                                  160 * 1024));                                                      \
             attr_set = true;                                                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL(kern, grid, block, shmem, st, args, pl.d_table, x0, xr, ur, u, k, e, z, v, lam);          \
+        hipLaunchKernelGGL(kern, grid, block, shmem, st, args, pl.d_table, x0, xr, ur, u, k, e, z, v, lam,           \
+                           pl.d_table + pl.table_bytes / sizeof(double));          \
     } while (0)
     if (a.terminal) {
         if (want_sol) SPCIES_LAUNCH(true, true); else SPCIES_LAUNCH(true, false);
