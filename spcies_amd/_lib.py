@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspcies_hip.so")
+LIB_PATH = os.environ.get("SPCIES_HIP_LIB", os.path.join(_HERE, "libspcies_hip.so"))  # env override: diagnostic builds
 
 EXPORTS = (
     "spcies_hip_abi_version", "spcies_hip_last_error", "spcies_hip_device_count", "spcies_hip_create",

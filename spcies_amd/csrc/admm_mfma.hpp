@@ -256,6 +256,7 @@ struct MfmaArgs {
     int ref_stride;
 };
 
+#define LAUNDER4(x) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
 #define SPCIES_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (acc), 0, 0, 0)
 
 template <int N, int KX, int KS, bool TERMINAL, bool WANT_SOL>
@@ -342,13 +343,12 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
             for (int i = 0; i < 4; i++) r[i] = fmin(fmax(x[i], lb[i]), ub[i]);  // == the reference's two ?: for non-NaN
             return r;
         };
-        // resident: bounds of the middle stages and the shared Zmid tiles
+        // resident: row constants of the middle stages and the shared Zmid tiles
+        d4 lbm = RC(MfmaLayout::RC_LB_MID), ubm = RC(MfmaLayout::RC_UB_MID), nhm = RC(MfmaLayout::RC_NEGHD_MID);
         
         double zm[KX];
 #pragma unroll
         for (int s = 0; s < KX; s++) zm[s] = A(LL.zmid() + s);
-        auto LBt = [&](int t) -> d4 { return t == 0 ? RC(MfmaLayout::RC_LB_0) : (t == N ? RC(MfmaLayout::RC_LB_N) : RC(MfmaLayout::RC_LB_MID)); };
-        auto UBt = [&](int t) -> d4 { return t == 0 ? RC(MfmaLayout::RC_UB_0) : (t == N ? RC(MfmaLayout::RC_UB_N) : RC(MfmaLayout::RC_UB_MID)); };
 
         // Tile prefetch: the first PF A-operands of segment j+1 are read from LDS while segment j computes
         // (a segment's other tiles are read at its start and land behind its first MFMAs).
@@ -366,14 +366,28 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
             long il = inst;  // laundered too: otherwise every output address is hoisted out of the loop and spills
             asm volatile("" : "+v"(il));
             double *zp = WANT_SOL ? z_out + il * dim + g : nullptr;  // row 4r+g of stage t lives at zp[off_t + 4r]
+            // (the empty asm keeps the compiler from proving that the backward sweep recomputes what the forward
+            //  sweep already had - it would otherwise keep 14 stages of clamp(w) / q_hat alive and spill)
+            LAUNDER4(lbm); LAUNDER4(ubm);
+            auto LBt = [&](int t) -> d4 { return t == 0 ? RC(MfmaLayout::RC_LB_0) : (t == N ? RC(MfmaLayout::RC_LB_N) : lbm); };
+            auto UBt = [&](int t) -> d4 { return t == 0 ? RC(MfmaLayout::RC_UB_0) : (t == N ? RC(MfmaLayout::RC_UB_N) : ubm); };
             // q_hat_t = q_t + lambda_t - rho v_t = q_t + rho fz (w_t - 2 clamp(w_t))
             auto qhat = [&](int t, d4 &cw) -> d4 {
+#if defined(SPCIES_ABLATE) && (SPCIES_ABLATE & 1)  // timing-only diagnostic build: no elementwise work
+                cw = w[t];
+                return w[t];
+#else
                 cw = clampv(w[t], LBt(t), UBt(t));
                 return ((t == N) ? qT : qm) + rf * (w[t] - 2.0 * cw);
+#endif
             };
             d4 cw;
+            // Both sweeps are software-pipelined by one segment: the elementwise work a segment issues never
+            // depends on that segment's own MFMAs, so VALU and matrix pipe overlap instead of alternating.
             // ============ forward sweep ============
+            // carried: qh = q_hat_l, qn = q_hat_{l+1} (both ready before block l starts)
             d4 qh = qhat(0, cw);
+            d4 qn = qhat(1, cw);
 #pragma unroll
             for (int l = 0; l < N; l++) {
                 const int nxt = (l + 1 < N) ? LL.fwd_off(l + 1) : LL.b1(N - 1);
@@ -396,15 +410,16 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
                         ti++;
                     }
                 }
+                // q_hat_{l+2} for the next block: independent of everything in flight
+                d4 qnn = qn;
+                if (l + 2 < N || (l + 2 == N && TERMINAL)) qnn = qhat(l + 2, cw);
                 // F1_l qh_{l+1}
                 if (TERMINAL || l < N - 1) {
-                    const d4 qn = qhat(l + 1, cw);
 #pragma unroll
                     for (int s = 0; s < KX; s++) {
                         SPCIES_MFMA(acc, T(ti), qn[s]);
                         ti++;
                     }
-                    qh = qn;
                 }
                 // F3_l y_{l-1}
                 if (l >= 1) {
@@ -415,18 +430,21 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
                     }
                 }
                 mu[l] = acc;
+                qh = qn;
+                qn = qnn;
                 __builtin_amdgcn_sched_barrier(0);  // a segment's tile reads must not drift into earlier segments
 #pragma unroll
                 for (int i = 0; i < PF; i++) pfc[i] = pfn[i];
             }
             // ============ backward sweep, primal update, projection, dual update ============
             asm volatile("" : "+v"(go));  // re-read (not keep alive) the stage-0 / stage-N row constants
+            LAUNDER4(lbm); LAUNDER4(ubm);
             bool res = false;
-            // one stage: z_t, then w_t <- z_t + lambda_t / rho  (v_t, lambda_t follow from w_t)
-            auto stage = [&](int t, double z0t, double z1t, double z2t, double z3t) {
+            // stage t, first half: z_t = Z mu_t - Hd o (qh_t - [mu_{t-1}; 0])   (MFMA + the VALU that feeds it)
+            auto stage_z = [&](int t, double z0t, double z1t, double z2t, double z3t, d4 &cwt) -> d4 {
                 const double zt[4] = {z0t, z1t, z2t, z3t};
                 d4 z;
-                const d4 qq = qhat(t, cw);
+                const d4 qq = qhat(t, cwt);
                 if (t == N) {  // terminal stage, dense Hi_N: z_N = -Hi_N (qh_N - mu_{N-1})
                     const d4 wv = qq - mu[N - 1];
                     z = d4{0, 0, 0, 0};
@@ -437,15 +455,24 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
 #pragma unroll
                     for (int s = 0; s < KX; s++) SPCIES_MFMA(z, zt[s], mu[0][s]);
                 } else {
-                    z = RC(MfmaLayout::RC_NEGHD_MID) * (qq - mu[t - 1]);
+                    z = nhm * (qq - mu[t - 1]);
 #pragma unroll
                     for (int s = 0; s < KX; s++) SPCIES_MFMA(z, zt[s], mu[t][s]);
                 }
-                const d4 wn = z + fz * (w[t] - cw);  // z + lambda/rho
+                return z;
+            };
+            // stage t, second half (issued one segment later): w_t <- z_t + lambda_t / rho, residuals
+            auto stage_w = [&](int t, const d4 &z, const d4 &cwt) {
+#if defined(SPCIES_ABLATE) && (SPCIES_ABLATE & 1)
+                const d4 wn = z * 1e-3;
+                res |= (wn[0] < 1e300);
+#else
+                const d4 wn = z + fz * (w[t] - cwt);  // z + lambda/rho
                 const d4 vn = clampv(wn, LBt(t), UBt(t));
-                const d4 vo = fz * cw;
+                const d4 vo = fz * cwt;
 #pragma unroll
                 for (int r = 0; r < 4; r++) res |= (fabs(vo[r] - vn[r]) > tol) | (fabs(z[r] - vn[r]) > tol);  // no short-circuit: no branches
+#endif
                 w[t] = wn;  // finished instances keep iterating harmlessly: their results are already stored
                 if constexpr (WANT_SOL) {
                     // Branch-free: lanes that must not write (finished instance, padding row) aim at a dump
@@ -461,9 +488,13 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
                     }
                 }
             };
-            auto zmid_stage = [&](int t) { stage(t, zm[0], KX > 1 ? zm[KX > 1 ? 1 : 0] : 0.0, KX > 2 ? zm[KX > 2 ? 2 : 0] : 0.0, KX > 3 ? zm[KX > 3 ? 3 : 0] : 0.0); };
-            // stage t is issued one block late (after mu_{t-2}) so that its operands are never the
-            // result of the immediately preceding MFMA
+            auto zmid = [&](int t, d4 &cwt) -> d4 {
+                return stage_z(t, zm[0], KX > 1 ? zm[KX > 1 ? 1 : 0] : 0.0, KX > 2 ? zm[KX > 2 ? 2 : 0] : 0.0,
+                               KX > 3 ? zm[KX > 3 ? 3 : 0] : 0.0, cwt);
+            };
+            // segment for block l:  (1) finish stage l+3 (VALU only, z from the previous segment)
+            //                       (2) B1_l y_l   (3) z of stage l+2   (4) B2_l mu_{l+1}
+            d4 zc = {0, 0, 0, 0}, cwc = {0, 0, 0, 0};  // z and clamp(w) of the stage awaiting its second half
 #pragma unroll
             for (int l = N - 1; l >= 0; l--) {
                 // this segment's tiles: b1(l) [KX], b2(l) [KX, l < N-1], then zN [KX] when its stage is t = N
@@ -474,30 +505,36 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
                 const int nxt = (l >= 1) ? LL.b1(l - 1) : LL.z0();
 #pragma unroll
                 for (int i = 0; i < PF; i++) pfn[i] = A(nxt + i);
+                const int tp = l + 3;  // stage whose z was produced by the previous segment
+                if (tp < N || (tp == N && TERMINAL)) stage_w(tp, zc, cwc);
                 d4 acc = {0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < KX; s++) SPCIES_MFMA(acc, T(s), mu[l][s]);
+                const int t = l + 2;
+                if (t < N) zc = zmid(t, cwc);
+                else if (t == N && TERMINAL)
+                    zc = stage_z(N, T(nb), KX > 1 ? T(nb + 1) : 0.0, KX > 2 ? T(nb + 2) : 0.0, KX > 3 ? T(nb + 3) : 0.0, cwc);
                 if (l < N - 1) {
 #pragma unroll
                     for (int s = 0; s < KX; s++) SPCIES_MFMA(acc, T(KX + s), mu[l + 1][s]);
                 }
                 mu[l] = acc;
-                const int t = l + 2;
-                if (t < N) zmid_stage(t);
-                else if (t == N && TERMINAL)
-                    stage(N, T(nb), KX > 1 ? T(nb + 1) : 0.0, KX > 2 ? T(nb + 2) : 0.0, KX > 3 ? T(nb + 3) : 0.0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < PF; i++) pfc[i] = pfn[i];
             }
-            // final segment; meanwhile fetch the head of forward block 0 for the next iteration
+            // tail: stages 2 (second half), 1, 0; meanwhile fetch the head of forward block 0 for the next iteration
             {
 #pragma unroll
                 for (int i = 0; i < PF; i++) pfn[i] = A(LL.fwd_off(0) + i);
                 asm volatile("" : "+v"(go));
                 auto T = [&](int i) -> double { return i < PF ? pfc[i] : A(LL.z0() + i); };
-                zmid_stage(1);
-                stage(0, T(0), KX > 1 ? T(1) : 0.0, KX > 2 ? T(2) : 0.0, KX > 3 ? T(3) : 0.0);
+                d4 cw1, cw0;
+                const d4 z1 = zmid(1, cw1);
+                const d4 z0 = stage_z(0, T(0), KX > 1 ? T(1) : 0.0, KX > 2 ? T(2) : 0.0, KX > 3 ? T(3) : 0.0, cw0);
+                stage_w(2, zc, cwc);
+                stage_w(1, z1, cw1);
+                stage_w(0, z0, cw0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < PF; i++) pfc[i] = pfn[i];
