@@ -507,17 +507,19 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
                 for (int i = 0; i < PF; i++) pfn[i] = A(nxt + i);
                 const int tp = l + 3;  // stage whose z was produced by the previous segment
                 if (tp < N || (tp == N && TERMINAL)) stage_w(tp, zc, cwc);
+                // one accumulator chain (B1 then B2, starting from C = 0), then the Z chain: every switch of
+                // accumulator costs the matrix pipe ~50 cycles (profiles/r01_microbench_f64_v2.txt)
                 d4 acc = {0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < KX; s++) SPCIES_MFMA(acc, T(s), mu[l][s]);
-                const int t = l + 2;
-                if (t < N) zc = zmid(t, cwc);
-                else if (t == N && TERMINAL)
-                    zc = stage_z(N, T(nb), KX > 1 ? T(nb + 1) : 0.0, KX > 2 ? T(nb + 2) : 0.0, KX > 3 ? T(nb + 3) : 0.0, cwc);
                 if (l < N - 1) {
 #pragma unroll
                     for (int s = 0; s < KX; s++) SPCIES_MFMA(acc, T(KX + s), mu[l + 1][s]);
                 }
+                const int t = l + 2;
+                if (t < N) zc = zmid(t, cwc);
+                else if (t == N && TERMINAL)
+                    zc = stage_z(N, T(nb), KX > 1 ? T(nb + 1) : 0.0, KX > 2 ? T(nb + 2) : 0.0, KX > 3 ? T(nb + 3) : 0.0, cwc);
                 mu[l] = acc;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
