@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--variant", default="auto", choices=["auto", "stream", "mfma"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "stream", "mfma", "mfma4"])
     ap.add_argument("--cpu-sample", type=int, default=12288)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -162,7 +162,7 @@ def main():
                        "batch_per_gpu": B, "variant": variant, "all_k_200_eflag_-1": k_ok},
         }
         secs = kernel_ms * 1e-3
-        if variant == "mfma":
+        if variant in ("mfma", "mfma4"):
             ach = FLOP_PER_SOLVE * B / secs / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic_from_profile("mfma"),

@@ -105,6 +105,7 @@ typedef struct spcies_hip_solver_s *spcies_hip_handle;
 #define SPCIES_VARIANT_AUTO 0
 #define SPCIES_VARIANT_STREAM 1 /* one lane per instance, reference operation order, state streamed through HBM */
 #define SPCIES_VARIANT_MFMA 2   /* 16 instances per wavefront on v_mfma_f64_16x16x4, state in registers          */
+#define SPCIES_VARIANT_MFMA4 3  /* same on v_mfma_f64_4x4x4 (4 blocks): no row padding, zero blocks skipped      */
 
 typedef struct {
     int formulation, method, submethod;

@@ -16,8 +16,8 @@ EXPORTS = (
     "spcies_hip_reserve", "spcies_hip_solve_batch", "spcies_hip_solve_batch_device", "spcies_hip_time_device",
 )
 
-VARIANT_AUTO, VARIANT_STREAM, VARIANT_MFMA = 0, 1, 2
-VARIANTS = {"auto": VARIANT_AUTO, "stream": VARIANT_STREAM, "mfma": VARIANT_MFMA}
+VARIANT_AUTO, VARIANT_STREAM, VARIANT_MFMA, VARIANT_MFMA4 = 0, 1, 2, 3
+VARIANTS = {"auto": VARIANT_AUTO, "stream": VARIANT_STREAM, "mfma": VARIANT_MFMA, "mfma4": VARIANT_MFMA4}
 
 
 class SpciesHipError(RuntimeError):

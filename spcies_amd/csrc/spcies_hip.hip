@@ -4,6 +4,7 @@
 #include <mutex>
 
 #include "admm_mfma.hpp"
+#include "admm_mfma4.hpp"
 #include "admm_stream.hpp"
 #include "common.hpp"
 
@@ -21,6 +22,7 @@ struct Solver {
     AdmmDev dev{};
     // MFMA-variant packing
     MfmaPlan mfma;
+    Mfma4Plan mfma4;
     // scratch of the STREAM variant (grown on demand)
     double *d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -107,6 +109,7 @@ static bool stream_shape_built(int n, int m) {
 
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
+    if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
     if (s.mfma.ok) return SPCIES_VARIANT_MFMA;
     return SPCIES_VARIANT_STREAM;
 }
@@ -174,6 +177,10 @@ static int solve_device(Solver &s, const double *x0, const double *xr, const dou
                         double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
     if (B <= 0) return 0;
     const int variant = resolve_variant(s);
+    if (variant == SPCIES_VARIANT_MFMA4) {
+        if (!s.mfma4.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s.mfma4.why.c_str());
+        return launch_mfma4(s.mfma4, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
+    }
     if (variant == SPCIES_VARIANT_MFMA) {
         if (!s.mfma.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA variant not available for this shape: %s", s.mfma.why.c_str());
         return launch_mfma(s.mfma, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
@@ -224,6 +231,8 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     if (rc) return rc;
     rc = mfma_plan_build(s->mfma, s->host);
     if (rc) return rc;
+    rc = mfma4_plan_build(s->mfma4, s->host);
+    if (rc) return rc;
     *out = reinterpret_cast<spcies_hip_handle>(s.release());
     return 0;
 }
@@ -236,6 +245,7 @@ int spcies_hip_destroy(spcies_hip_handle h) {
     if (s->d_scratch) hipFree(s->d_scratch);
     if (s->d_io) hipFree(s->d_io);
     mfma_plan_free(s->mfma);
+    mfma4_plan_free(s->mfma4);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
     return 0;
@@ -257,7 +267,9 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
 int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_MFMA) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_MFMA4) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant == SPCIES_VARIANT_MFMA4 && !s->mfma4.ok)
+        return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s->mfma4.why.c_str());
     if (variant == SPCIES_VARIANT_MFMA && !s->mfma.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA variant not available for this shape: %s", s->mfma.why.c_str());
     if (variant == SPCIES_VARIANT_STREAM && !stream_shape_built(s->host.n, s->host.m))

@@ -55,7 +55,7 @@ def _compare(variant, got, ref, v):
         assert (np.abs(sol.lam - lo) / (tol * (1.0 + lscale)))[same].max() <= 1.0
 
 
-VARIANTS = ["stream", "mfma"]
+VARIANTS = ["stream", "mfma", "mfma4"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
