@@ -11,6 +11,9 @@
  *                     examples/cl_in_C/main_cl_in_C.c:103)
  *     void equMPC_ADMM(...same signature...)
  *         reference: formulations/+equMPC/header_equMPC_ADMM_C.h
+ *     void laxMPC_FISTA(...same signature...), void equMPC_FISTA(...)
+ *         reference: formulations/+laxMPC/header_laxMPC_FISTA_C.h:27, +equMPC/header_equMPC_FISTA_C.h
+ *         (sol record holds z and lambda only: pass v = NULL; lambda is [B][N*n])
  *
  * with a batched equivalent: B independent (x0, xr, ur) instances per call.  The reference bakes the
  * controller's constants into the generated C file (`$INSERT_CONSTANTS$`,
@@ -70,7 +73,11 @@ enum spcies_array_id {
     SPCIES_A_R = 8,     /* [m]   negated diag(R)                                           */
     SPCIES_A_T = 9,     /* [n][n] negated T                                                */
     SPCIES_A_LB = 10,   /* [n+m]                                                           */
-    SPCIES_A_UB = 11    /* [n+m]                                                           */
+    SPCIES_A_UB = 11,   /* [n+m]                                                           */
+    /* FISTA solvers (cons_laxMPC_FISTA_C.m:94-107) */
+    SPCIES_A_QRI = 12,  /* [n+m] -1/diag([Q, R])                                           */
+    SPCIES_A_TDIAG = 13,/* [n]   negated diag(T)                                           */
+    SPCIES_A_TI = 14    /* [n]   -1/diag(T)                                                */
 };
 
 typedef struct {
@@ -114,6 +121,7 @@ typedef struct {
     double tol, rho;
     int variant;      /* variant a solve would use now   */
     int device;
+    int dim_lambda;   /* length of the lambda output per instance: dim (ADMM), N*n (FISTA: the dual y) */
 } spcies_hip_info;
 
 /* Batch-level mirror of the reference's four timers (docs/timing.md:9-22, sol_<name> fields of

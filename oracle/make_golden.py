@@ -47,7 +47,10 @@ def main():
         json.dump(extract_z_opt(), f, indent=0)
     for name, B, overrides in (("C1_lax", 16, {}), ("C1_lax_denseT", 16, {}), ("C1_equ", 16, {}),
                                ("C2_lax", 32, {}), ("C2_lax", 32, dict(tol=1e-6, k_max=3000)),
-                               ("C2_equ", 32, dict(tol=1e-6, k_max=3000))):
+                               ("C2_equ", 32, dict(tol=1e-6, k_max=3000)),
+                               ("C1_lax_FISTA", 16, {}), ("C1_equ_FISTA", 16, dict(k_max=500)),
+                               ("C2_lax_FISTA", 32, {}), ("C2_lax_FISTA", 32, dict(tol=1e-6, k_max=2000)),
+                               ("C2_equ_FISTA", 32, {})):
         cfg = benchmarks.config(name)
         v = benchmarks.ingredients(cfg, **overrides)
         x0, xr, ur = benchmarks.sample_batch(cfg, B)
@@ -57,9 +60,13 @@ def main():
         tag = name + ("_conv" if overrides else "")
         so = ref_template.build_admm(v, "golden_" + tag)
         ut, kt, et, zt, vt, lt = ref_template.run_admm(so, v, x0, xr, ur)
-        uo, ko, eo, zo, vo, lo = oracle.admm_banded_batch(v, x0, xr, ur)
-        print(tag, "template-vs-oracle(full doubles): z %.2e v %.2e lam %.2e  dk %d" % (
-            np.abs(zt - zo).max(), np.abs(vt - vo).max(), np.abs(lt - lo).max(), np.abs(kt - ko).max()))
+        if v["method"] == "FISTA":
+            uo, ko, eo, zo, lo = oracle.fista_banded_batch(v, x0, xr, ur)
+            vt = np.zeros((0,))
+        else:
+            uo, ko, eo, zo, vo, lo = oracle.admm_banded_batch(v, x0, xr, ur)
+        print(tag, "template-vs-oracle(full doubles): z %.2e lam %.2e  dk %d" % (
+            np.abs(zt - zo).max(), np.abs(lt - lo).max(), np.abs(kt - ko).max()))
         np.savez_compressed(os.path.join(OUT, f"template_{tag}.npz"), x0=x0, xr=xr, ur=ur, u=ut, k=kt, e_flag=et,
                             z=zt, v=vt, lam=lt, solver_overrides=json.dumps(overrides))
 

@@ -13,8 +13,8 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "admm_banded_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return so
 
@@ -83,3 +83,40 @@ def admm_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     if rc != 0:
         raise RuntimeError(f"oracle_admm_banded_batch failed rc={rc}")
     return u, k, e, z, vv, lam
+
+
+class _FistaData(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("N", C.c_int), ("k_max", C.c_int), ("terminal", C.c_int),
+                ("tol", C.c_double)] + [
+        (name, C.POINTER(C.c_double)) for name in ("AB", "Alpha", "Beta", "Q", "R", "QRi", "T", "Ti", "LB", "UB")]
+
+
+def fista_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False):
+    """C oracle of the lax/equ FISTA solver.  Returns ``u, k, e_flag, z, lam`` (``lam`` = the reference's ``y``)."""
+    n, m, N = int(v["n"]), int(v["m"]), int(v["N"])
+    terminal = bool(v.get("terminal", True))
+    qz = quantize_like_reference if quantize else (lambda a: a)
+    src = dict(AB="AB", Alpha="Alpha", Beta="Beta", Q="Q", R="R", QRi="QRi", T="Tdiag", Ti="Ti", LB="LB", UB="UB")
+    keep = {k_: np.ascontiguousarray(qz(np.asarray(v[s_], dtype=float))) for k_, s_ in src.items()}
+    if quantize:
+        for nm_ in ("LB", "UB"):
+            keep[nm_] = np.clip(keep[nm_], -1e20, 1e20)
+    d = _FistaData(n=n, m=m, N=N, k_max=int(v["k_max"]), terminal=int(terminal),
+                   tol=float(qz(v["tol"])) if quantize else float(v["tol"]), **{k_: _dp(a) for k_, a in keep.items()})
+    x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
+    B = x0.shape[0]
+    xr = np.ascontiguousarray(np.asarray(xr, dtype=float))
+    ur = np.ascontiguousarray(np.asarray(ur, dtype=float))
+    stride = 1 if xr.ndim == 2 else 0
+    dim = N * (n + m) - (0 if terminal else n)
+    u = np.zeros((B, m)); k = np.zeros(B, dtype=np.int32); e = np.zeros(B, dtype=np.int32)
+    z = np.zeros((B, dim)) if want_sol else None
+    lam = np.zeros((B, N * n)) if want_sol else None
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    lib = _lib()
+    lib.oracle_fista_banded_batch.restype = C.c_int
+    rc = lib.oracle_fista_banded_batch(C.byref(d), C.c_long(B), _dp(x0), _dp(xr), _dp(ur), C.c_int(stride), _dp(u),
+                                       ip(k), ip(e), _dp(z) if want_sol else None, _dp(lam) if want_sol else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle_fista_banded_batch failed rc={rc}")
+    return u, k, e, z, lam

@@ -78,22 +78,26 @@ def _snippets(text, ext):
 
 
 def build_admm(v, name):
-    """Instantiate + compile the lax/equ ADMM template for ingredients ``v``; returns the .so path."""
-    form = v["formulation"]
+    """Instantiate + compile the lax/equ ADMM or FISTA template for ingredients ``v``; returns the .so path."""
+    form, method = v["formulation"], v.get("method", "ADMM")
     fdir = os.path.join(REF, "formulations", f"+{form}")
     n, m, N = v["n"], v["m"], v["N"]
     defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
             "#define IS_DIAG 1", f"#define nn_ {n}", f"#define mm_ {m}", f"#define nm_ {n + m}", f"#define NN_ {N}",
-            f"#define k_max {int(v['k_max'])}", f"#define tol {_fmt(v['tol'])}", "#define SCALAR_RHO",
-            f"#define rho {_fmt(v['rho'])}", f"#define rho_i {_fmt(v['rho_i'])}"]
-    order = ["LB", "UB", "Hi", "Hi_0"] + (["Hi_N"] if v["terminal"] else []) + ["Q", "R", "AB", "Alpha", "Beta"] \
-        + (["T"] if v["terminal"] else [])
-    consts = "".join(_decl(k, v[k]) for k in order)
+            f"#define k_max {int(v['k_max'])}", f"#define tol {_fmt(v['tol'])}"]
+    if method == "ADMM":  # cons_laxMPC_ADMM_C.m:72-130
+        defs += ["#define SCALAR_RHO", f"#define rho {_fmt(v['rho'])}", f"#define rho_i {_fmt(v['rho_i'])}"]
+        order = [(k, k) for k in ["LB", "UB", "Hi", "Hi_0"] + (["Hi_N"] if v["terminal"] else [])
+                 + ["Q", "R", "AB", "Alpha", "Beta"] + (["T"] if v["terminal"] else [])]
+    else:  # cons_laxMPC_FISTA_C.m:94-107 / cons_equMPC_FISTA_C.m
+        order = [(k, k) for k in ["LB", "UB", "AB", "Alpha", "Beta", "Q", "R", "QRi"]] \
+            + ([("T", "Tdiag"), ("Ti", "Ti")] if v["terminal"] else [])
+    consts = "".join(_decl(cn, v[k]) for cn, k in order)
     with open(os.path.join(REF, "platforms", "+C_code", "generic_solver_struct.c")) as f:
         code = f.read()
-    with open(os.path.join(fdir, f"code_{form}_ADMM_C.c")) as f:
+    with open(os.path.join(fdir, f"code_{form}_{method}_C.c")) as f:
         code = code.replace("$INSERT_SOLVER$", f.read())
-    with open(os.path.join(fdir, f"header_{form}_ADMM_C.h")) as f:
+    with open(os.path.join(fdir, f"header_{form}_{method}_C.h")) as f:
         header = f.read()
     code = code.replace("$INSERT_CONSTANTS$", consts)
     header = header.replace("$INSERT_DEFINES$", "\n".join(defs))
@@ -112,20 +116,25 @@ def build_admm(v, name):
 
 
 def run_admm(so, v, x0, xr, ur):
-    """Call ``laxMPC_ADMM`` / ``equMPC_ADMM`` of the compiled template once per instance."""
+    """Call ``<formulation>_<method>`` of the compiled template once per instance.  Returns
+    ``u, k, e, z, v, lam`` (``v`` is ``None`` for FISTA, whose record holds ``z`` and ``lambda`` only)."""
     n, m, N = v["n"], v["m"], v["N"]
+    method = v.get("method", "ADMM")
     dim = N * (n + m) - (0 if v["terminal"] else n)
     lib = C.CDLL(so)
-    fn = getattr(lib, f"{v['formulation']}_ADMM")
+    fn = getattr(lib, f"{v['formulation']}_{method}")
+    fista = method == "FISTA"
+    # header_equMPC_FISTA_C.h declares z[(NN_-1)*nm_+mm_]; the lax one z[NN_*nm_]; lambda[NN_*nn_] in both
+    ldim = N * n if fista else dim
 
     class Sol(C.Structure):
-        _fields_ = [("z", C.c_double * dim), ("v", C.c_double * dim), ("lam", C.c_double * dim),
-                    ("t", C.c_double * 4)]
+        _fields_ = [("z", C.c_double * dim)] + ([] if fista else [("v", C.c_double * dim)]) + \
+                   [("lam", C.c_double * ldim), ("t", C.c_double * 4)]
     x0 = np.atleast_2d(np.asarray(x0, float))
     B = x0.shape[0]
     per = np.ndim(xr) == 2
     u = np.zeros((B, m)); k = np.zeros(B, np.int32); e = np.zeros(B, np.int32)
-    z = np.zeros((B, dim)); vv = np.zeros((B, dim)); lam = np.zeros((B, dim))
+    z = np.zeros((B, dim)); vv = None if fista else np.zeros((B, dim)); lam = np.zeros((B, ldim))
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     for i in range(B):
         sol = Sol()
@@ -134,5 +143,7 @@ def run_admm(so, v, x0, xr, ur):
         ui = np.zeros(m); ki = C.c_int(0); ei = C.c_int(0)
         fn(dp(xi), dp(xri), dp(uri), dp(ui), C.byref(ki), C.byref(ei), C.byref(sol))
         u[i] = ui; k[i] = ki.value; e[i] = ei.value
-        z[i] = np.frombuffer(sol.z); vv[i] = np.frombuffer(sol.v); lam[i] = np.frombuffer(sol.lam)
+        z[i] = np.frombuffer(sol.z); lam[i] = np.frombuffer(sol.lam)
+        if not fista:
+            vv[i] = np.frombuffer(sol.v)
     return u, k, e, z, vv, lam

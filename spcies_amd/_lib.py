@@ -27,7 +27,7 @@ class SpciesHipError(RuntimeError):
 class Info(C.Structure):
     _fields_ = [("formulation", C.c_int), ("method", C.c_int), ("submethod", C.c_int), ("n", C.c_int),
                 ("m", C.c_int), ("N", C.c_int), ("dim", C.c_int), ("k_max", C.c_int), ("tol", C.c_double),
-                ("rho", C.c_double), ("variant", C.c_int), ("device", C.c_int)]
+                ("rho", C.c_double), ("variant", C.c_int), ("device", C.c_int), ("dim_lambda", C.c_int)]
 
 
 class Timing(C.Structure):

@@ -54,6 +54,20 @@ def config(name):
         c = config("C2")
         c.name, c.formulation = name, "equMPC"
         return c
+    if name in ("C1_lax_FISTA", "C1_equ_FISTA"):  # tests/test_laxMPC_FISTA.m:6-15, tests/test_equMPC_FISTA.m:6-13
+        c = config("C1")
+        c.name, c.method, c.solver_options = name, "FISTA", dict(k_max=5000, tol=1e-7)
+        c.formulation = "laxMPC" if "lax" in name else "equMPC"
+        return c
+    if name in ("C2_lax_FISTA", "C2_equ_FISTA", "C3"):  # C3: equMPC-FISTA, 12-state, N=30, 100 fixed iterations
+        c = config("C2")
+        c.name, c.method = name, "FISTA"
+        c.formulation = "laxMPC" if "lax" in name else "equMPC"
+        c.param.T = np.diag(np.diag(c.param.T))  # FISTA needs a diagonal T (compute_laxMPC_FISTA_ingredients.m:50-52)
+        c.solver_options = dict(k_max=100, tol=0.0)
+        if name == "C3":
+            c.param.N, c.B, c.seed = 30, 262144, 1203
+        return c
     raise KeyError(name)
 
 
@@ -80,5 +94,8 @@ def ingredients(cfg, **solver_overrides):
     so.update(solver_overrides)
     opt = SpciesOptions(formulation=cfg.formulation, method=cfg.method, options=so)
     ctrl = SimpleNamespace(sys=cfg.sys, param=cfg.param)
-    fn = {"laxMPC": laxMPC.compute_laxMPC_ADMM_ingredients, "equMPC": laxMPC.compute_equMPC_ADMM_ingredients}
-    return fn[cfg.formulation](ctrl, opt)
+    fn = {("laxMPC", "ADMM"): laxMPC.compute_laxMPC_ADMM_ingredients,
+          ("equMPC", "ADMM"): laxMPC.compute_equMPC_ADMM_ingredients,
+          ("laxMPC", "FISTA"): laxMPC.compute_laxMPC_FISTA_ingredients,
+          ("equMPC", "FISTA"): laxMPC.compute_equMPC_FISTA_ingredients}
+    return fn[(cfg.formulation, cfg.method)](ctrl, opt)

@@ -18,7 +18,8 @@ ENTRY_BYTES = 48
 
 FORMULATION = {"laxMPC": 1, "equMPC": 2, "MPCT": 3, "ellipMPC": 4, "HMPC": 5}
 METHOD = {"ADMM": 1, "FISTA": 2, "EADMM": 3, "SADMM": 4}
-ARRAY_ID = {"AB": 1, "Alpha": 2, "Beta": 3, "Hi": 4, "Hi_0": 5, "Hi_N": 6, "Q": 7, "R": 8, "T": 9, "LB": 10, "UB": 11}
+ARRAY_ID = {"AB": 1, "Alpha": 2, "Beta": 3, "Hi": 4, "Hi_0": 5, "Hi_N": 6, "Q": 7, "R": 8, "T": 9, "LB": 10, "UB": 11,
+            "QRi": 12, "Tdiag": 13, "Ti": 14}
 _ID_NAME = {v: k for k, v in ARRAY_ID.items()}
 _HDR = "<8sIIIIIIIIIIIIQddd5d"
 assert struct.calcsize(_HDR) == HEADER_BYTES

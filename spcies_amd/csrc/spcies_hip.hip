@@ -6,6 +6,7 @@
 #include "admm_mfma.hpp"
 #include "admm_mfma4.hpp"
 #include "admm_stream.hpp"
+#include "fista_stream.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -20,6 +21,9 @@ struct Solver {
     // device constants (one allocation) + pointers
     double *d_consts = nullptr;
     AdmmDev dev{};
+    FistaDev fdev{};
+    std::vector<double> QRi, Td, Ti;  // FISTA-only ingredients
+    int lam_dim() const { return method == SPCIES_FISTA ? host.N * host.n : host.dim(); }
     // MFMA-variant packing
     MfmaPlan mfma;
     Mfma4Plan mfma4;
@@ -55,9 +59,10 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         return fail(SPCIES_HIP_EINVAL, "blob version/size mismatch");
     if ((size_t)h.header_bytes + (size_t)h.n_arrays * sizeof(spcies_blob_entry) > bytes)
         return fail(SPCIES_HIP_EINVAL, "blob directory out of range");
-    if (h.method != SPCIES_ADMM || (h.formulation != SPCIES_LAXMPC && h.formulation != SPCIES_EQUMPC))
+    if ((h.method != SPCIES_ADMM && h.method != SPCIES_FISTA) ||
+        (h.formulation != SPCIES_LAXMPC && h.formulation != SPCIES_EQUMPC))
         return fail(SPCIES_HIP_ENOSUP, "formulation %u / method %u not built in this library", h.formulation, h.method);
-    if (!(h.flags & 1u)) return fail(SPCIES_HIP_ENOSUP, "vector rho not built");
+    if (h.method == SPCIES_ADMM && !(h.flags & 1u)) return fail(SPCIES_HIP_ENOSUP, "vector rho not built");
     if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.N > 100000) return fail(SPCIES_HIP_EINVAL, "bad n/m/N");
     s.formulation = (int)h.formulation;
     s.method = (int)h.method;
@@ -66,15 +71,23 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max;
     a.terminal = (h.formulation == SPCIES_LAXMPC);
     a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
-    if (!(a.rho > 0) || a.k_max <= 0) return fail(SPCIES_HIP_EINVAL, "bad rho / k_max");
+    if (a.k_max <= 0 || (h.method == SPCIES_ADMM && !(a.rho > 0))) return fail(SPCIES_HIP_EINVAL, "bad rho / k_max");
     const uint64_t n = h.n, m = h.m, N = h.N, nm = n + m;
     struct Want { uint32_t id; uint64_t count; std::vector<double> *dst; };
-    Want want[] = {{SPCIES_A_AB, n * nm, &a.AB},       {SPCIES_A_ALPHA, (N - 1) * n * n, &a.Alpha},
-                   {SPCIES_A_BETA, N * n * n, &a.Beta}, {SPCIES_A_HI, (N - 1) * nm, &a.Hi},
-                   {SPCIES_A_HI_0, m, &a.Hi_0},         {SPCIES_A_HI_N, n * n, &a.Hi_N},
-                   {SPCIES_A_Q, n, &a.Q},               {SPCIES_A_R, m, &a.R},
-                   {SPCIES_A_T, n * n, &a.T},           {SPCIES_A_LB, nm, &a.LB},
-                   {SPCIES_A_UB, nm, &a.UB}};
+    std::vector<Want> want = {{SPCIES_A_AB, n * nm, &a.AB},       {SPCIES_A_ALPHA, (N - 1) * n * n, &a.Alpha},
+                              {SPCIES_A_BETA, N * n * n, &a.Beta}, {SPCIES_A_Q, n, &a.Q},
+                              {SPCIES_A_R, m, &a.R},               {SPCIES_A_LB, nm, &a.LB},
+                              {SPCIES_A_UB, nm, &a.UB}};
+    if (h.method == SPCIES_ADMM) {
+        want.push_back({SPCIES_A_HI, (N - 1) * nm, &a.Hi});
+        want.push_back({SPCIES_A_HI_0, m, &a.Hi_0});
+        want.push_back({SPCIES_A_HI_N, n * n, &a.Hi_N});
+        want.push_back({SPCIES_A_T, n * n, &a.T});
+    } else {
+        want.push_back({SPCIES_A_QRI, nm, &s.QRi});
+        want.push_back({SPCIES_A_TDIAG, n, &s.Td});
+        want.push_back({SPCIES_A_TI, n, &s.Ti});
+    }
     for (auto &w : want) {
         const double *p = find_array(blob, bytes, h, w.id, w.count);
         if (!p) return fail(SPCIES_HIP_EINVAL, "blob array id %u missing or mis-sized", w.id);
@@ -87,6 +100,7 @@ static int upload_consts(Solver &s) {
     AdmmHost &a = s.host;
     std::vector<const std::vector<double> *> arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Hi, &a.Hi_0, &a.Hi_N,
                                                      &a.Q,  &a.R,     &a.T,    &a.LB, &a.UB};
+    if (s.method == SPCIES_FISTA) arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Q, &a.R, &s.QRi, &s.Td, &s.Ti, &a.LB, &a.UB};
     std::vector<double> flat;
     std::vector<size_t> offs;
     for (auto *v : arrs) {
@@ -96,6 +110,11 @@ static int upload_consts(Solver &s) {
     }
     SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_consts, flat.size() * sizeof(double)));
     SPCIES_HIP_CHECK(hipMemcpy(s.d_consts, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (s.method == SPCIES_FISTA) {
+        s.fdev = FistaDev{(int)offs[0], (int)offs[1], (int)offs[2], (int)offs[3], (int)offs[4], (int)offs[5],
+                          (int)offs[6], (int)offs[7], (int)offs[8], (int)offs[9], a.N, a.k_max, a.tol};
+        return 0;
+    }
     s.dev = AdmmDev{(int)offs[0], (int)offs[1], (int)offs[2], (int)offs[3], (int)offs[4], (int)offs[5],
                     (int)offs[6], (int)offs[7], (int)offs[8], (int)offs[9], (int)offs[10],
                     a.N,          a.k_max,      a.tol,        a.rho,        a.rho_i};
@@ -117,6 +136,7 @@ static int resolve_variant(const Solver &s) {
 static size_t stream_scratch_bytes(const Solver &s, long B, bool want_sol) {
     long Bp = (B + 63) / 64 * 64;
     size_t rows = 2 * (size_t)s.host.dim() + (size_t)s.host.N * s.host.n + (want_sol ? (size_t)s.host.dim() : 0);
+    if (s.method == SPCIES_FISTA) rows = 3 * (size_t)s.host.N * s.host.n + (want_sol ? (size_t)s.host.dim() : 0);
     return rows * (size_t)Bp * sizeof(double);
 }
 
@@ -158,6 +178,49 @@ static int launch_stream_nm(Solver &s, const double *x0, const double *xr, const
     return 0;
 }
 
+template <int n, int m>
+static int launch_fista_nm(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
+                           double *u, int *k, int *e, double *z, double *lam, hipStream_t st) {
+    const bool want_sol = (z || lam);
+    const long Bp = (B + 63) / 64 * 64;
+    const size_t Nn = (size_t)s.host.N * n, dim = (size_t)s.host.dim();
+    double *Y = s.d_scratch, *LAM = Y + Nn * Bp, *DL = LAM + Nn * Bp;
+    double *ZS = want_sol ? DL + Nn * Bp : nullptr;
+    dim3 grid((unsigned)(Bp / 64)), block(64);
+    if (s.host.terminal)
+        hipLaunchKernelGGL((fista_stream_kernel<n, m, true, true>), grid, block, 0, st, s.fdev, s.d_consts, x0, xr, ur,
+                           ref_stride, B, Bp, Y, LAM, DL, ZS, u, k, e);
+    else
+        hipLaunchKernelGGL((fista_stream_kernel<n, m, false, true>), grid, block, 0, st, s.fdev, s.d_consts, x0, xr, ur,
+                           ref_stride, B, Bp, Y, LAM, DL, ZS, u, k, e);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    if (z) {
+        dim3 tg((unsigned)(Bp / 64), (unsigned)((dim + 63) / 64));
+        hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, ZS, Bp, B, (int)dim, z);
+    }
+    if (lam) {  // the reference returns y as sol.lambda (code_laxMPC_FISTA_C.c:439-445)
+        dim3 tg((unsigned)(Bp / 64), (unsigned)((Nn + 63) / 64));
+        hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, Y, Bp, B, (int)Nn, lam);
+    }
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int launch_fista(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
+                        double *u, int *k, int *e, double *z, double *lam, hipStream_t st) {
+    const int n = s.host.n, m = s.host.m;
+#define SPCIES_CASE(NN, MM) \
+    if (n == NN && m == MM) return launch_fista_nm<NN, MM>(s, x0, xr, ur, ref_stride, B, u, k, e, z, lam, st);
+    SPCIES_CASE(6, 2)
+    SPCIES_CASE(12, 2)
+    SPCIES_CASE(20, 2)
+    SPCIES_CASE(8, 2)
+    SPCIES_CASE(4, 1)
+    SPCIES_CASE(2, 1)
+#undef SPCIES_CASE
+    return fail(SPCIES_HIP_ENOSUP, "FISTA STREAM variant not instantiated for n=%d m=%d", n, m);
+}
+
 static int launch_stream(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                          double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
     const int n = s.host.n, m = s.host.m;
@@ -176,6 +239,16 @@ static int launch_stream(Solver &s, const double *x0, const double *xr, const do
 static int solve_device(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                         double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
     if (B <= 0) return 0;
+    if (s.method == SPCIES_FISTA) {
+        if (v) return fail(SPCIES_HIP_EINVAL, "FISTA solvers have no v output (sol fields: z, lambda)");
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
+            return fail(SPCIES_HIP_ENOSUP, "FISTA: only the STREAM variant is built");
+        if (!stream_shape_built(s.host.n, s.host.m))
+            return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
+        int rc = ensure_scratch(s, stream_scratch_bytes(s, B, z || lam));
+        if (rc) return rc;
+        return launch_fista(s, x0, xr, ur, ref_stride, B, u, k, e, z, lam, st);
+    }
     const int variant = resolve_variant(s);
     if (variant == SPCIES_VARIANT_MFMA4) {
         if (!s.mfma4.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s.mfma4.why.c_str());
@@ -229,10 +302,12 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     SPCIES_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     rc = upload_consts(*s);
     if (rc) return rc;
-    rc = mfma_plan_build(s->mfma, s->host);
-    if (rc) return rc;
-    rc = mfma4_plan_build(s->mfma4, s->host);
-    if (rc) return rc;
+    if (s->method == SPCIES_ADMM) {
+        rc = mfma_plan_build(s->mfma, s->host);
+        if (rc) return rc;
+        rc = mfma4_plan_build(s->mfma4, s->host);
+        if (rc) return rc;
+    }
     *out = reinterpret_cast<spcies_hip_handle>(s.release());
     return 0;
 }
@@ -259,7 +334,8 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
     info->submethod = s->submethod;
     info->n = s->host.n; info->m = s->host.m; info->N = s->host.N; info->dim = s->host.dim();
     info->k_max = s->host.k_max; info->tol = s->host.tol; info->rho = s->host.rho;
-    info->variant = resolve_variant(*s);
+    info->variant = s->method == SPCIES_FISTA ? SPCIES_VARIANT_STREAM : resolve_variant(*s);
+    info->dim_lambda = s->lam_dim();
     info->device = s->device;
     return 0;
 }
@@ -281,8 +357,8 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
 int spcies_hip_set_exit(spcies_hip_handle h, int k_max, double tol) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (k_max > 0) s->host.k_max = s->dev.k_max = k_max;
-    if (tol >= 0) s->host.tol = s->dev.tol = tol;
+    if (k_max > 0) s->host.k_max = s->dev.k_max = s->fdev.k_max = k_max;
+    if (tol >= 0) s->host.tol = s->dev.tol = s->fdev.tol = tol;
     return 0;
 }
 
@@ -328,7 +404,8 @@ int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *
     size_t o_z = nd, o_v = 0, o_l = 0;
     if (z) { o_z = nd; nd += (size_t)B * dim; }
     if (v) { o_v = nd; nd += (size_t)B * dim; }
-    if (lambda) { o_l = nd; nd += (size_t)B * dim; }
+    const size_t ldim = (size_t)s->lam_dim();
+    if (lambda) { o_l = nd; nd += (size_t)B * ldim; }
     size_t need = nd * sizeof(double) + 2 * (size_t)B * sizeof(int);
     if (need > s->io_bytes) {
         if (s->d_io) SPCIES_HIP_CHECK(hipFree(s->d_io));
@@ -354,7 +431,7 @@ int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *
     SPCIES_HIP_CHECK(hipMemcpyAsync(e_flag, de, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
     if (z) SPCIES_HIP_CHECK(hipMemcpyAsync(z, d + o_z, (size_t)B * dim * 8, hipMemcpyDeviceToHost, st));
     if (v) SPCIES_HIP_CHECK(hipMemcpyAsync(v, d + o_v, (size_t)B * dim * 8, hipMemcpyDeviceToHost, st));
-    if (lambda) SPCIES_HIP_CHECK(hipMemcpyAsync(lambda, d + o_l, (size_t)B * dim * 8, hipMemcpyDeviceToHost, st));
+    if (lambda) SPCIES_HIP_CHECK(hipMemcpyAsync(lambda, d + o_l, (size_t)B * ldim * 8, hipMemcpyDeviceToHost, st));
     SPCIES_HIP_CHECK(hipStreamSynchronize(st));
     auto t3 = clk::now();
     if (timing) {

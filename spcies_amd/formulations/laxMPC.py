@@ -124,3 +124,60 @@ def compute_equMPC_ADMM_ingredients(controller, opt):
     ``Aeq = Aeq(:, 1:end-n)``); the solver then imposes ``x_N = xr`` through ``mu[N-1] -= xr``
     (``code_equMPC_ADMM_C.c:351``)."""
     return compute_laxMPC_ADMM_ingredients(controller, opt, terminal=False)
+
+
+def compute_laxMPC_FISTA_ingredients(controller, opt, terminal=True):
+    """laxMPC / equMPC FISTA ingredients (dual fast-gradient method; no ``rho``).
+
+    Reference: ``formulations/+laxMPC/compute_laxMPC_FISTA_ingredients.m:50-165`` and
+    ``formulations/+equMPC/compute_equMPC_FISTA_ingredients.m``.  ``W = G H^-1 G'`` with the *plain*
+    Hessian; ``Q``, ``R`` and (lax) ``T`` must be diagonal (``:50-52``); ``QRi = -1/diag([Q, R])``,
+    ``T = -diag(T)``, ``Ti = -1/diag(T)`` (``:111-119``); Alpha/Beta as in the ADMM solvers.
+    """
+    sys, param = _get(controller, "sys"), _get(controller, "param")
+    A = np.asarray(_get(sys, "A"), dtype=float)
+    B = np.asarray(_get(sys, "B"), dtype=float)
+    n, m = B.shape
+    N = int(_get(param, "N"))
+    Q = np.asarray(_get(param, "Q"), dtype=float)
+    R = np.asarray(_get(param, "R"), dtype=float)
+    T = np.asarray(_get(param, "T"), dtype=float) if terminal else np.eye(n)
+    if not (_is_diag(Q) and _is_diag(R) and _is_diag(T)):
+        raise ValueError("Spcies:laxMPC:FISTA:non_diagonal - matrices Q, R and T must be diagonal")
+    if opt.time_varying:
+        raise NotImplementedError("HIP platform: time_varying solvers are not built yet")
+    nm = n + m
+    dim = N * nm if terminal else N * nm - n
+    hdiag = np.concatenate([np.diag(R)] + [np.concatenate([np.diag(Q), np.diag(R)])] * (N - 1)
+                           + ([np.diag(T)] if terminal else []))
+    G = build_G(A, B, N, terminal=terminal)
+    W = (G / hdiag[None, :]) @ G.T
+    Wc = np.linalg.cholesky(W).T
+    v = dict(n=n, m=m, N=N, formulation="laxMPC" if terminal else "equMPC", method="FISTA", terminal=bool(terminal))
+    v["AB"] = np.hstack([A, B])
+    v["Q"] = -np.diag(Q).copy()
+    v["R"] = -np.diag(R).copy()
+    v["QRi"] = -np.concatenate([1.0 / np.diag(Q), 1.0 / np.diag(R)])
+    v["Tdiag"] = -np.diag(T).copy() if terminal else np.zeros(n)
+    v["Ti"] = -1.0 / np.diag(T) if terminal else np.zeros(n)
+    v["LB"] = np.concatenate([np.ravel(_get(sys, "LBx")), np.ravel(_get(sys, "LBu"))]).astype(float)
+    v["UB"] = np.concatenate([np.ravel(_get(sys, "UBx")), np.ravel(_get(sys, "UBu"))]).astype(float)
+    Beta = np.zeros((N, n, n))
+    Alpha = np.zeros((N - 1, n, n))
+    for i in range(N):
+        Beta[i] = Wc[i * n:(i + 1) * n, i * n:(i + 1) * n]
+        Beta[i][np.diag_indices(n)] = 1.0 / np.diag(Beta[i])
+    for i in range(N - 1):
+        Alpha[i] = Wc[i * n:(i + 1) * n, (i + 1) * n:(i + 2) * n]
+    v["Alpha"], v["Beta"] = Alpha, Beta
+    v["k_max"] = int(opt.solver["k_max"])
+    v["tol"] = float(opt.solver["tol"])
+    v["rho"] = 0.0  # unused by FISTA; kept so the blob header is uniform
+    v["rho_i"] = 0.0
+    v["rho_is_scalar"] = True
+    v["dim"] = dim
+    return v
+
+
+def compute_equMPC_FISTA_ingredients(controller, opt):
+    return compute_laxMPC_FISTA_ingredients(controller, opt, terminal=False)

@@ -26,7 +26,18 @@ def cons_equMPC_ADMM_HIP(recipe, device=0):
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 
-_CONSTRUCTORS = {f.__name__: f for f in (cons_laxMPC_ADMM_HIP, cons_equMPC_ADMM_HIP)}
+def cons_laxMPC_FISTA_HIP(recipe, device=0):
+    v = _lax.compute_laxMPC_FISTA_ingredients(recipe.controller, recipe.options)
+    return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
+
+
+def cons_equMPC_FISTA_HIP(recipe, device=0):
+    v = _lax.compute_equMPC_FISTA_ingredients(recipe.controller, recipe.options)
+    return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
+
+
+_CONSTRUCTORS = {f.__name__: f for f in (cons_laxMPC_ADMM_HIP, cons_equMPC_ADMM_HIP, cons_laxMPC_FISTA_HIP,
+                                         cons_equMPC_FISTA_HIP)}
 
 
 def spcies_gen_controller(*, sys=None, param=None, device=0, **kw):

@@ -45,6 +45,8 @@ class HipSolver:
         info = _lib.Info()
         _lib.check(lib.spcies_hip_get_info(h, C.byref(info)))
         self.n, self.m, self.N, self.dim = info.n, info.m, info.N, info.dim
+        self.dim_lambda = info.dim_lambda
+        self.method = {v: k for k, v in _blob.METHOD.items()}[info.method]
         self.device = info.device
         self.formulation = {v: k for k, v in _blob.FORMULATION.items()}[info.formulation]
         self.name = name or self.formulation
@@ -115,11 +117,14 @@ class HipSolver:
         e = np.zeros(B, dtype=np.int32)
         z = v = lam = None
         if want_sol:
-            z, v, lam = (np.zeros((B, self.dim)) for _ in range(3))
+            z = np.zeros((B, self.dim))
+            v = np.zeros((B, self.dim)) if self.method != "FISTA" else None  # FISTA record: z, lambda only
+            lam = np.zeros((B, self.dim_lambda))
         t = _lib.Timing()
         _lib.check(self._lib.spcies_hip_solve_batch(
             self._h, _dp(x0), _dp(xr), _dp(ur), int(per), B, _dp(u), _ip(k), _ip(e),
-            _dp(z) if want_sol else None, _dp(v) if want_sol else None, _dp(lam) if want_sol else None, C.byref(t)))
+            _dp(z) if want_sol else None, _dp(v) if v is not None else None, _dp(lam) if want_sol else None,
+            C.byref(t)))
         sol = SimpleNamespace(z=z, v=v, **{"lambda": lam}, lam=lam, update_time=t.update_time,
                               solve_time=t.solve_time, polish_time=t.polish_time, run_time=t.run_time)
         if single:

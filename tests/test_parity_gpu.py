@@ -181,3 +181,80 @@ def test_full_size_properties(variant):
         assert np.array_equal(u[idx], uo)
     else:
         assert np.abs(u[idx] - uo).max() <= TOL_SPCIES
+
+
+# ----------------------------------------------------------------------------------------------
+# FISTA (laxMPC / equMPC): STREAM variant, reference operation order -> bit-exact
+# ----------------------------------------------------------------------------------------------
+def _fista_solver(cfg_name, **overrides):
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = benchmarks.config(cfg_name)
+    v = benchmarks.ingredients(cfg, **overrides)
+    return cfg, v, HipSolver(v)
+
+
+@pytest.mark.parametrize("cfg_name,test_name", [("C1_lax_FISTA", "test_laxMPC_FISTA"), ("C1_equ_FISTA", "test_equMPC_FISTA")])
+def test_fista_reference_test_instance(cfg_name, test_name, golden_dir):
+    """tests/test_laxMPC_FISTA.m / test_equMPC_FISTA.m on the tester's instance: z_opt to 1e-4, flag 1."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver(cfg_name)
+    st = benchmarks.tester_status(cfg.sys)
+    u, k, e, sol = s(st.x, st.xr, st.ur)
+    with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
+        z_opt = np.array(json.load(f)[test_name])
+    assert e == 1 and np.abs(sol.z - z_opt).max() <= TOL_OPT and sol.v is None
+    uo, ko, eo, zo, lo = oracle.fista_banded_batch(v, st.x[None], st.xr, st.ur)
+    assert k == ko[0] and np.array_equal(u, uo[0]) and np.array_equal(sol.z, zo[0]) and np.array_equal(sol.lam, lo[0])
+
+
+@pytest.mark.parametrize("cfg_name,B,overrides", [
+    ("C1_lax_FISTA", 70, {}), ("C1_equ_FISTA", 40, dict(k_max=400)),
+    ("C2_lax_FISTA", 200, {}),                              # 100 fixed iterations
+    ("C2_lax_FISTA", 130, dict(tol=1e-6, k_max=2000)),      # converging, per-instance exit
+    ("C2_equ_FISTA", 96, {}),
+    ("C3", 70, {}),                                         # BASELINE config 3 shape: equMPC-FISTA, N = 30
+])
+def test_fista_seeded_batch_vs_oracle(cfg_name, B, overrides):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver(cfg_name, **overrides)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    u, k, e, sol = s(x0, xr, ur)
+    uo, ko, eo, zo, lo = oracle.fista_banded_batch(v, x0, xr, ur)
+    assert np.array_equal(k, ko) and np.array_equal(e, eo) and np.array_equal(u, uo)
+    assert np.array_equal(sol.z, zo) and np.array_equal(sol.lam, lo)
+    nosol = s(x0[:33], xr[:33], ur[:33], want_sol=False)
+    assert np.array_equal(nosol[0], uo[:33]) and np.array_equal(nosol[1], ko[:33])
+
+
+@pytest.mark.parametrize("tag", ["C1_lax_FISTA", "C2_lax_FISTA_conv", "C2_equ_FISTA"])
+def test_fista_vs_reference_template_fixture(tag, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"template_{tag}.npz"))
+    overrides = json.loads(str(g["solver_overrides"]))
+    cfg, v, s = _fista_solver(tag.replace("_conv", ""), **overrides)
+    u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
+    assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
+    same = k == g["k"]
+    assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-9
+    assert np.abs(sol.lam - g["lam"])[same].max() <= 1e-7
+
+
+def test_fista_full_size_properties():
+    """BASELINE config 3 (equMPC-FISTA, N = 30, 100 iterations) at B = 262144: determinism, shard
+    invariance, and a random subset against the oracle."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver("C3")
+    B = cfg.B
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    u, k, e, _ = s(x0, xr, ur, want_sol=False)
+    assert (k == 100).all() and (e == -1).all() and (np.abs(u) <= 0.8 + 1e-15).all()
+    h = B // 2
+    ua, *_ = s(x0[:h], xr[:h], ur[:h], want_sol=False)
+    ub, *_ = s(x0[h:], xr[h:], ur[h:], want_sol=False)
+    assert np.array_equal(np.vstack([ua, ub]), u)
+    idx = np.random.default_rng(9).choice(B, 48, replace=False)
+    uo, *_ = oracle.fista_banded_batch(v, x0[idx], xr[idx], ur[idx], want_sol=False)
+    assert np.array_equal(u[idx], uo)
