@@ -14,6 +14,8 @@
  *     void laxMPC_FISTA(...same signature...), void equMPC_FISTA(...)
  *         reference: formulations/+laxMPC/header_laxMPC_FISTA_C.h:27, +equMPC/header_equMPC_FISTA_C.h
  *         (sol record holds z and lambda only: pass v = NULL; lambda is [B][N*n])
+ *     void MPCT_EADMM(...same signature...)
+ *         reference: formulations/+MPCT/header_MPCT_EADMM_C.h:26 (record z1, z2, z3, lambda: _ex entry points)
  *
  * with a batched equivalent: B independent (x0, xr, ur) instances per call.  The reference bakes the
  * controller's constants into the generated C file (`$INSERT_CONSTANTS$`,
@@ -77,7 +79,16 @@ enum spcies_array_id {
     /* FISTA solvers (cons_laxMPC_FISTA_C.m:94-107) */
     SPCIES_A_QRI = 12,  /* [n+m] -1/diag([Q, R])                                           */
     SPCIES_A_TDIAG = 13,/* [n]   negated diag(T)                                           */
-    SPCIES_A_TI = 14    /* [n]   -1/diag(T)                                                */
+    SPCIES_A_TI = 14,   /* [n]   -1/diag(T)                                                */
+    /* MPCT EADMM (cons_MPCT_EADMM_C.m:82-100); T (id 9) is [n][n] negated, LB/UB ids 10/11 */
+    SPCIES_A_S = 15,       /* [m][m] negated S                                             */
+    SPCIES_A_RHO_MAT = 16, /* [N+1][n+m]                                                   */
+    SPCIES_A_RHO_0 = 17,   /* [n+m]                                                        */
+    SPCIES_A_RHO_S = 18,   /* [n+m]                                                        */
+    SPCIES_A_LB_0 = 19, SPCIES_A_UB_0 = 20, SPCIES_A_LB_S = 21, SPCIES_A_UB_S = 22, /* [n+m] each */
+    SPCIES_A_H1I = 23,     /* [N+1][n+m]                                                   */
+    SPCIES_A_W2 = 24,      /* [n+m][n+m]                                                   */
+    SPCIES_A_H3I = 25      /* [N+1][n+m]                                                   */
 };
 
 typedef struct {
@@ -157,6 +168,19 @@ int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *
 int spcies_hip_solve_batch_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
                                   int ref_stride, long B, double *u, int *k, int *e_flag, double *z,
                                   double *v, double *lambda, void *stream);
+
+/* Solvers whose record is not (z, v, lambda) - and any solver, uniformly: `fields` holds one pointer per
+ * field of the generated solver's sol_<name> struct, in the reference's order
+ *     ADMM (lax/equ): z, v, lambda     FISTA: z, lambda     MPCT-EADMM: z1, z2, z3, lambda
+ * (header_laxMPC_ADMM_C.h:14-22, header_laxMPC_FISTA_C.h:14-21, header_MPCT_EADMM_C.h:14-23); a NULL entry
+ * (or fields == NULL) skips that output.  spcies_hip_get_sol_layout reports count, per-instance lengths, names. */
+int spcies_hip_get_sol_layout(spcies_hip_handle h, int *n_fields, int *dims, const char **names);
+int spcies_hip_solve_batch_ex(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
+                              int ref_stride, long B, double *u, int *k, int *e_flag, double *const *fields,
+                              int n_fields, spcies_hip_timing *timing);
+int spcies_hip_solve_batch_device_ex(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
+                                     int ref_stride, long B, double *u, int *k, int *e_flag, double *const *fields,
+                                     int n_fields, void *stream);
 
 /* Time `reps` back-to-back device solves with hipEvents recorded on `stream` (the stream the
  * kernel is launched on); returns the mean milliseconds per launch in *ms_per_launch. */

@@ -50,7 +50,7 @@ def main():
                                ("C2_equ", 32, dict(tol=1e-6, k_max=3000)),
                                ("C1_lax_FISTA", 16, {}), ("C1_equ_FISTA", 16, dict(k_max=500)),
                                ("C2_lax_FISTA", 32, {}), ("C2_lax_FISTA", 32, dict(tol=1e-6, k_max=2000)),
-                               ("C2_equ_FISTA", 32, {})):
+                               ("C2_equ_FISTA", 32, {}), ("C1_MPCT", 16, {}), ("C4", 8, {})):
         cfg = benchmarks.config(name)
         v = benchmarks.ingredients(cfg, **overrides)
         x0, xr, ur = benchmarks.sample_batch(cfg, B)
@@ -59,6 +59,14 @@ def main():
             x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
         tag = name + ("_conv" if overrides else "")
         so = ref_template.build_admm(v, "golden_" + tag)
+        if v["method"] == "EADMM":
+            ut, kt, et, z1t, z2t, z3t, lt = ref_template.run_admm(so, v, x0, xr, ur)
+            O = oracle.eadmm_mpct_batch(v, x0, xr, ur)
+            print(tag, "template-vs-oracle(full doubles): z1 %.2e z3 %.2e dk %d" % (
+                np.abs(z1t - O[3]).max(), np.abs(z3t - O[5]).max(), np.abs(kt - O[1]).max()))
+            np.savez_compressed(os.path.join(OUT, f"template_{tag}.npz"), x0=x0, xr=xr, ur=ur, u=ut, k=kt, e_flag=et,
+                                z1=z1t, z2=z2t, z3=z3t, lam=lt, solver_overrides=json.dumps(overrides))
+            continue
         ut, kt, et, zt, vt, lt = ref_template.run_admm(so, v, x0, xr, ur)
         if v["method"] == "FISTA":
             uo, ko, eo, zo, lo = oracle.fista_banded_batch(v, x0, xr, ur)

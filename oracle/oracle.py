@@ -13,7 +13,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c", "eadmm_mpct_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return so
@@ -120,3 +120,42 @@ def fista_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     if rc != 0:
         raise RuntimeError(f"oracle_fista_banded_batch failed rc={rc}")
     return u, k, e, z, lam
+
+
+_EADMM_ARRAYS = (("rho", "rho_mat"), ("rho_0", "rho_0"), ("rho_s", "rho_s"), ("LB", "LB"), ("UB", "UB"), ("LB_0", "LB0"),
+                 ("UB_0", "UB0"), ("LB_s", "LBs"), ("UB_s", "UBs"), ("AB", "AB"), ("T", "T"), ("S", "S"),
+                 ("Alpha", "Alpha"), ("Beta", "Beta"), ("H1i", "H1i"), ("W2", "W2"), ("H3i", "H3i"))
+
+
+class _EadmmData(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("N", C.c_int), ("k_max", C.c_int), ("tol", C.c_double)] + [
+        (name, C.POINTER(C.c_double)) for name, _ in _EADMM_ARRAYS]
+
+
+def eadmm_mpct_batch(v, x0, xr, ur, want_sol=True, quantize=False):
+    """C oracle of the MPCT EADMM solver.  Returns ``u, k, e_flag, z1, z2, z3, lam``."""
+    n, m, N = int(v["n"]), int(v["m"]), int(v["N"])
+    nm = n + m
+    qz = quantize_like_reference if quantize else (lambda a: a)
+    keep = {k_: np.ascontiguousarray(qz(np.asarray(v[s_], dtype=float))) for k_, s_ in _EADMM_ARRAYS}
+    d = _EadmmData(n=n, m=m, N=N, k_max=int(v["k_max"]), tol=float(qz(v["tol"])) if quantize else float(v["tol"]),
+                   **{k_: _dp(a) for k_, a in keep.items()})
+    x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
+    B = x0.shape[0]
+    xr = np.ascontiguousarray(np.asarray(xr, dtype=float))
+    ur = np.ascontiguousarray(np.asarray(ur, dtype=float))
+    stride = 1 if xr.ndim == 2 else 0
+    u = np.zeros((B, m)); k = np.zeros(B, dtype=np.int32); e = np.zeros(B, dtype=np.int32)
+    z1 = np.zeros((B, (N + 1) * nm)) if want_sol else None
+    z3 = np.zeros((B, (N + 1) * nm)) if want_sol else None
+    z2 = np.zeros((B, nm)) if want_sol else None
+    lam = np.zeros((B, (N + 3) * nm)) if want_sol else None
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    o = lambda a: _dp(a) if a is not None else None
+    lib = _lib()
+    lib.oracle_eadmm_mpct_batch.restype = C.c_int
+    rc = lib.oracle_eadmm_mpct_batch(C.byref(d), C.c_long(B), _dp(x0), _dp(xr), _dp(ur), C.c_int(stride), _dp(u), ip(k),
+                                     ip(e), o(z1), o(z2), o(z3), o(lam))
+    if rc != 0:
+        raise RuntimeError(f"oracle_eadmm_mpct_batch failed rc={rc}")
+    return u, k, e, z1, z2, z3, lam

@@ -89,9 +89,13 @@ def build_admm(v, name):
         defs += ["#define SCALAR_RHO", f"#define rho {_fmt(v['rho'])}", f"#define rho_i {_fmt(v['rho_i'])}"]
         order = [(k, k) for k in ["LB", "UB", "Hi", "Hi_0"] + (["Hi_N"] if v["terminal"] else [])
                  + ["Q", "R", "AB", "Alpha", "Beta"] + (["T"] if v["terminal"] else [])]
-    else:  # cons_laxMPC_FISTA_C.m:94-107 / cons_equMPC_FISTA_C.m
+    elif method == "FISTA":  # cons_laxMPC_FISTA_C.m:94-107 / cons_equMPC_FISTA_C.m
         order = [(k, k) for k in ["LB", "UB", "AB", "Alpha", "Beta", "Q", "R", "QRi"]] \
             + ([("T", "Tdiag"), ("Ti", "Ti")] if v["terminal"] else [])
+    else:  # EADMM, cons_MPCT_EADMM_C.m:82-100 (force_diagonal path: H3i)
+        order = [("rho", "rho_mat"), ("rho_0", "rho_0"), ("rho_s", "rho_s"), ("LB", "LB"), ("UB", "UB"), ("LB_0", "LB0"),
+                 ("UB_0", "UB0"), ("LB_s", "LBs"), ("UB_s", "UBs"), ("AB", "AB"), ("T", "T"), ("S", "S"),
+                 ("Alpha", "Alpha"), ("Beta", "Beta"), ("H1i", "H1i"), ("W2", "W2"), ("H3i", "H3i")]
     consts = "".join(_decl(cn, v[k]) for cn, k in order)
     with open(os.path.join(REF, "platforms", "+C_code", "generic_solver_struct.c")) as f:
         code = f.read()
@@ -123,6 +127,8 @@ def run_admm(so, v, x0, xr, ur):
     dim = N * (n + m) - (0 if v["terminal"] else n)
     lib = C.CDLL(so)
     fn = getattr(lib, f"{v['formulation']}_{method}")
+    if method == "EADMM":
+        return _run_eadmm(lib, fn, v, x0, xr, ur)
     fista = method == "FISTA"
     # header_equMPC_FISTA_C.h declares z[(NN_-1)*nm_+mm_]; the lax one z[NN_*nm_]; lambda[NN_*nn_] in both
     ldim = N * n if fista else dim
@@ -147,3 +153,29 @@ def run_admm(so, v, x0, xr, ur):
         if not fista:
             vv[i] = np.frombuffer(sol.v)
     return u, k, e, z, vv, lam
+
+
+def _run_eadmm(lib, fn, v, x0, xr, ur):
+    """MPCT_EADMM: record z1, z2, z3, lambda (header_MPCT_EADMM_C.h:14-24).  Returns u, k, e, z1, z2, z3, lam."""
+    n, m, N = v["n"], v["m"], v["N"]
+    nm = n + m
+
+    class Sol(C.Structure):
+        _fields_ = [("z1", C.c_double * ((N + 1) * nm)), ("z2", C.c_double * nm), ("z3", C.c_double * ((N + 1) * nm)),
+                    ("lam", C.c_double * ((N + 3) * nm)), ("t", C.c_double * 4)]
+    x0 = np.atleast_2d(np.asarray(x0, float))
+    B = x0.shape[0]
+    per = np.ndim(xr) == 2
+    u = np.zeros((B, m)); k = np.zeros(B, np.int32); e = np.zeros(B, np.int32)
+    z1 = np.zeros((B, (N + 1) * nm)); z3 = np.zeros((B, (N + 1) * nm)); z2 = np.zeros((B, nm)); lam = np.zeros((B, (N + 3) * nm))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for i in range(B):
+        sol = Sol()
+        xi = np.ascontiguousarray(x0[i]); xri = np.ascontiguousarray(xr[i] if per else xr)
+        uri = np.ascontiguousarray(ur[i] if per else ur)
+        ui = np.zeros(m); ki = C.c_int(0); ei = C.c_int(0)
+        fn(dp(xi), dp(xri), dp(uri), dp(ui), C.byref(ki), C.byref(ei), C.byref(sol))
+        u[i] = ui; k[i] = ki.value; e[i] = ei.value
+        z1[i] = np.frombuffer(sol.z1); z2[i] = np.frombuffer(sol.z2); z3[i] = np.frombuffer(sol.z3)
+        lam[i] = np.frombuffer(sol.lam)
+    return u, k, e, z1, z2, z3, lam

@@ -14,6 +14,7 @@ EXPORTS = (
     "spcies_hip_abi_version", "spcies_hip_last_error", "spcies_hip_device_count", "spcies_hip_create",
     "spcies_hip_destroy", "spcies_hip_get_info", "spcies_hip_set_variant", "spcies_hip_set_exit",
     "spcies_hip_reserve", "spcies_hip_solve_batch", "spcies_hip_solve_batch_device", "spcies_hip_time_device",
+    "spcies_hip_get_sol_layout", "spcies_hip_solve_batch_ex", "spcies_hip_solve_batch_device_ex",
 )
 
 VARIANT_AUTO, VARIANT_STREAM, VARIANT_MFMA, VARIANT_MFMA4 = 0, 1, 2, 3
@@ -61,6 +62,11 @@ def load():
     lib.spcies_hip_solve_batch.argtypes = [vp, dp, dp, dp, C.c_int, C.c_long, dp, ip, ip, dp, dp, dp,
                                            C.POINTER(Timing)]
     lib.spcies_hip_solve_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, C.c_long, vp, vp, vp, vp, vp, vp, vp]
+    lib.spcies_hip_get_sol_layout.argtypes = [vp, ip, ip, C.POINTER(C.c_char_p)]
+    lib.spcies_hip_solve_batch_ex.argtypes = [vp, dp, dp, dp, C.c_int, C.c_long, dp, ip, ip, C.POINTER(dp), C.c_int,
+                                              C.POINTER(Timing)]
+    lib.spcies_hip_solve_batch_device_ex.argtypes = [vp, vp, vp, vp, C.c_int, C.c_long, vp, vp, vp, C.POINTER(vp),
+                                                     C.c_int, vp]
     lib.spcies_hip_time_device.argtypes = [vp, vp, vp, vp, C.c_int, C.c_long, vp, vp, vp, vp, C.c_int, dp]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here = header and library out of sync

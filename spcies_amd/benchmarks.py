@@ -68,6 +68,16 @@ def config(name):
         if name == "C3":
             c.param.N, c.B, c.seed = 30, 262144, 1203
         return c
+    if name in ("C1_MPCT", "C4"):  # tests/test_MPCT_EADMM.m:6-17; C4: 20-state, N = 20, 200 fixed iterations
+        sys = sp_utils.oscillating_masses_sys(3 if name == "C1_MPCT" else 10)
+        Q, R, _ = _weights(sys, "diag")
+        c = SimpleNamespace(name=name, sys=sys, param=SimpleNamespace(Q=Q, R=R, T=10 * Q, S=R, N=10),
+                            formulation="MPCT", method="EADMM",
+                            solver_options=dict(rho_base=2, rho_mult=20, k_max=5000, tol=1e-7), B=1, seed=1201)
+        if name == "C4":
+            c.param.N, c.B, c.seed = 20, 1048576, 1204
+            c.solver_options.update(k_max=200, tol=0.0)
+        return c
     raise KeyError(name)
 
 
@@ -88,7 +98,7 @@ def sample_batch(cfg, B=None, seed=None, around_xr=None):
 
 
 def ingredients(cfg, **solver_overrides):
-    from .formulations import laxMPC
+    from .formulations import MPCT, laxMPC
     from .options import SpciesOptions
     so = dict(cfg.solver_options)
     so.update(solver_overrides)
@@ -97,5 +107,6 @@ def ingredients(cfg, **solver_overrides):
     fn = {("laxMPC", "ADMM"): laxMPC.compute_laxMPC_ADMM_ingredients,
           ("equMPC", "ADMM"): laxMPC.compute_equMPC_ADMM_ingredients,
           ("laxMPC", "FISTA"): laxMPC.compute_laxMPC_FISTA_ingredients,
-          ("equMPC", "FISTA"): laxMPC.compute_equMPC_FISTA_ingredients}
+          ("equMPC", "FISTA"): laxMPC.compute_equMPC_FISTA_ingredients,
+          ("MPCT", "EADMM"): MPCT.compute_MPCT_EADMM_ingredients}
     return fn[(cfg.formulation, cfg.method)](ctrl, opt)

@@ -19,7 +19,9 @@ ENTRY_BYTES = 48
 FORMULATION = {"laxMPC": 1, "equMPC": 2, "MPCT": 3, "ellipMPC": 4, "HMPC": 5}
 METHOD = {"ADMM": 1, "FISTA": 2, "EADMM": 3, "SADMM": 4}
 ARRAY_ID = {"AB": 1, "Alpha": 2, "Beta": 3, "Hi": 4, "Hi_0": 5, "Hi_N": 6, "Q": 7, "R": 8, "T": 9, "LB": 10, "UB": 11,
-            "QRi": 12, "Tdiag": 13, "Ti": 14}
+            "QRi": 12, "Tdiag": 13, "Ti": 14,
+            "S": 15, "rho_mat": 16, "rho_0": 17, "rho_s": 18, "LB0": 19, "UB0": 20, "LBs": 21, "UBs": 22,
+            "H1i": 23, "W2": 24, "H3i": 25}
 _ID_NAME = {v: k for k, v in ARRAY_ID.items()}
 _HDR = "<8sIIIIIIIIIIIIQddd5d"
 assert struct.calcsize(_HDR) == HEADER_BYTES
@@ -39,7 +41,7 @@ def pack(v):
     arrays = []
     for k in names:
         a = np.ascontiguousarray(np.asarray(v[k], dtype="<f8"))
-        if k in ("LB", "UB"):
+        if k in ("LB", "UB", "LB0", "UB0", "LBs", "UBs"):
             a = np.clip(a, -INF_VALUE, INF_VALUE)
         arrays.append((k, a))
     off = _align(HEADER_BYTES + ENTRY_BYTES * len(arrays))

@@ -7,6 +7,7 @@
 #include "admm_mfma4.hpp"
 #include "admm_stream.hpp"
 #include "fista_stream.hpp"
+#include "eadmm_stream.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -23,7 +24,28 @@ struct Solver {
     AdmmDev dev{};
     FistaDev fdev{};
     std::vector<double> QRi, Td, Ti;  // FISTA-only ingredients
-    int lam_dim() const { return method == SPCIES_FISTA ? host.N * host.n : host.dim(); }
+    EadmmDev edev{};
+    std::vector<double> e_rho, e_rho0, e_rhos, e_LB0, e_UB0, e_LBs, e_UBs, e_S, e_H1i, e_W2, e_H3i;  // EADMM-only
+    int lam_dim() const {
+        if (method == SPCIES_FISTA) return host.N * host.n;
+        if (method == SPCIES_EADMM) return (host.N + 3) * (host.n + host.m);
+        return host.dim();
+    }
+    // solution record of the generated solver, in the reference's field order
+    //   ADMM  : z, v, lambda            (header_laxMPC_ADMM_C.h:14-22)
+    //   FISTA : z, lambda               (header_laxMPC_FISTA_C.h:14-21)
+    //   EADMM : z1, z2, z3, lambda      (header_MPCT_EADMM_C.h:14-23)
+    int n_fields() const { return method == SPCIES_FISTA ? 2 : (method == SPCIES_EADMM ? 4 : 3); }
+    int field_dim(int i) const {
+        const int nm = host.n + host.m;
+        if (method == SPCIES_FISTA) return i == 0 ? host.dim() : lam_dim();
+        if (method == SPCIES_EADMM) return i == 1 ? nm : (i == 3 ? lam_dim() : (host.N + 1) * nm);
+        return host.dim();
+    }
+    const char *field_name(int i) const {
+        static const char *admm[] = {"z", "v", "lambda"}, *fista[] = {"z", "lambda"}, *eadmm[] = {"z1", "z2", "z3", "lambda"};
+        return method == SPCIES_FISTA ? fista[i] : (method == SPCIES_EADMM ? eadmm[i] : admm[i]);
+    }
     // MFMA-variant packing
     MfmaPlan mfma;
     Mfma4Plan mfma4;
@@ -59,8 +81,10 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         return fail(SPCIES_HIP_EINVAL, "blob version/size mismatch");
     if ((size_t)h.header_bytes + (size_t)h.n_arrays * sizeof(spcies_blob_entry) > bytes)
         return fail(SPCIES_HIP_EINVAL, "blob directory out of range");
-    if ((h.method != SPCIES_ADMM && h.method != SPCIES_FISTA) ||
-        (h.formulation != SPCIES_LAXMPC && h.formulation != SPCIES_EQUMPC))
+    const bool banded = (h.method == SPCIES_ADMM || h.method == SPCIES_FISTA) &&
+                        (h.formulation == SPCIES_LAXMPC || h.formulation == SPCIES_EQUMPC);
+    const bool mpct = (h.method == SPCIES_EADMM && h.formulation == SPCIES_MPCT);
+    if (!banded && !mpct)
         return fail(SPCIES_HIP_ENOSUP, "formulation %u / method %u not built in this library", h.formulation, h.method);
     if (h.method == SPCIES_ADMM && !(h.flags & 1u)) return fail(SPCIES_HIP_ENOSUP, "vector rho not built");
     if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.N > 100000) return fail(SPCIES_HIP_EINVAL, "bad n/m/N");
@@ -69,16 +93,32 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     s.submethod = (int)h.submethod;
     AdmmHost &a = s.host;
     a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max;
-    a.terminal = (h.formulation == SPCIES_LAXMPC);
+    a.terminal = (h.formulation != SPCIES_EQUMPC);
     a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
     if (a.k_max <= 0 || (h.method == SPCIES_ADMM && !(a.rho > 0))) return fail(SPCIES_HIP_EINVAL, "bad rho / k_max");
     const uint64_t n = h.n, m = h.m, N = h.N, nm = n + m;
     struct Want { uint32_t id; uint64_t count; std::vector<double> *dst; };
     std::vector<Want> want = {{SPCIES_A_AB, n * nm, &a.AB},       {SPCIES_A_ALPHA, (N - 1) * n * n, &a.Alpha},
-                              {SPCIES_A_BETA, N * n * n, &a.Beta}, {SPCIES_A_Q, n, &a.Q},
-                              {SPCIES_A_R, m, &a.R},               {SPCIES_A_LB, nm, &a.LB},
+                              {SPCIES_A_BETA, N * n * n, &a.Beta}, {SPCIES_A_LB, nm, &a.LB},
                               {SPCIES_A_UB, nm, &a.UB}};
-    if (h.method == SPCIES_ADMM) {
+    if (h.method != SPCIES_EADMM) {
+        want.push_back({SPCIES_A_Q, n, &a.Q});
+        want.push_back({SPCIES_A_R, m, &a.R});
+    }
+    if (h.method == SPCIES_EADMM) {
+        want.push_back({SPCIES_A_T, n * n, &a.T});
+        want.push_back({SPCIES_A_S, m * m, &s.e_S});
+        want.push_back({SPCIES_A_RHO_MAT, (N + 1) * nm, &s.e_rho});
+        want.push_back({SPCIES_A_RHO_0, nm, &s.e_rho0});
+        want.push_back({SPCIES_A_RHO_S, nm, &s.e_rhos});
+        want.push_back({SPCIES_A_LB_0, nm, &s.e_LB0});
+        want.push_back({SPCIES_A_UB_0, nm, &s.e_UB0});
+        want.push_back({SPCIES_A_LB_S, nm, &s.e_LBs});
+        want.push_back({SPCIES_A_UB_S, nm, &s.e_UBs});
+        want.push_back({SPCIES_A_H1I, (N + 1) * nm, &s.e_H1i});
+        want.push_back({SPCIES_A_W2, nm * nm, &s.e_W2});
+        want.push_back({SPCIES_A_H3I, (N + 1) * nm, &s.e_H3i});
+    } else if (h.method == SPCIES_ADMM) {
         want.push_back({SPCIES_A_HI, (N - 1) * nm, &a.Hi});
         want.push_back({SPCIES_A_HI_0, m, &a.Hi_0});
         want.push_back({SPCIES_A_HI_N, n * n, &a.Hi_N});
@@ -101,6 +141,9 @@ static int upload_consts(Solver &s) {
     std::vector<const std::vector<double> *> arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Hi, &a.Hi_0, &a.Hi_N,
                                                      &a.Q,  &a.R,     &a.T,    &a.LB, &a.UB};
     if (s.method == SPCIES_FISTA) arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Q, &a.R, &s.QRi, &s.Td, &s.Ti, &a.LB, &a.UB};
+    if (s.method == SPCIES_EADMM)
+        arrs = {&s.e_rho, &s.e_rho0, &s.e_rhos, &a.LB,    &a.UB,   &s.e_LB0, &s.e_UB0, &s.e_LBs, &s.e_UBs,
+                &a.AB,    &a.T,      &s.e_S,    &a.Alpha, &a.Beta, &s.e_H1i, &s.e_W2,  &s.e_H3i};
     std::vector<double> flat;
     std::vector<size_t> offs;
     for (auto *v : arrs) {
@@ -110,6 +153,12 @@ static int upload_consts(Solver &s) {
     }
     SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_consts, flat.size() * sizeof(double)));
     SPCIES_HIP_CHECK(hipMemcpy(s.d_consts, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (s.method == SPCIES_EADMM) {
+        s.edev = EadmmDev{(int)offs[0],  (int)offs[1],  (int)offs[2],  (int)offs[3],  (int)offs[4],  (int)offs[5],
+                          (int)offs[6],  (int)offs[7],  (int)offs[8],  (int)offs[9],  (int)offs[10], (int)offs[11],
+                          (int)offs[12], (int)offs[13], (int)offs[14], (int)offs[15], (int)offs[16], a.N, a.k_max, a.tol};
+        return 0;
+    }
     if (s.method == SPCIES_FISTA) {
         s.fdev = FistaDev{(int)offs[0], (int)offs[1], (int)offs[2], (int)offs[3], (int)offs[4], (int)offs[5],
                           (int)offs[6], (int)offs[7], (int)offs[8], (int)offs[9], a.N, a.k_max, a.tol};
@@ -137,6 +186,8 @@ static size_t stream_scratch_bytes(const Solver &s, long B, bool want_sol) {
     long Bp = (B + 63) / 64 * 64;
     size_t rows = 2 * (size_t)s.host.dim() + (size_t)s.host.N * s.host.n + (want_sol ? (size_t)s.host.dim() : 0);
     if (s.method == SPCIES_FISTA) rows = 3 * (size_t)s.host.N * s.host.n + (want_sol ? (size_t)s.host.dim() : 0);
+    if (s.method == SPCIES_EADMM)
+        rows = (size_t)(3 * s.host.N + 5) * (s.host.n + s.host.m) + (size_t)s.host.N * s.host.n;
     return rows * (size_t)Bp * sizeof(double);
 }
 
@@ -221,6 +272,41 @@ static int launch_fista(Solver &s, const double *x0, const double *xr, const dou
     return fail(SPCIES_HIP_ENOSUP, "FISTA STREAM variant not instantiated for n=%d m=%d", n, m);
 }
 
+template <int n, int m>
+static int launch_eadmm_nm(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
+                           double *u, int *k, int *e, double *z1, double *z2, double *z3, double *lam, hipStream_t st) {
+    const long Bp = (B + 63) / 64 * 64;
+    const int nm = n + m, N = s.host.N;
+    const size_t dz = (size_t)(N + 1) * nm;
+    double *Z1 = s.d_scratch, *Z3 = Z1 + dz * Bp, *LAM = Z3 + dz * Bp, *MU = LAM + (size_t)(N + 3) * nm * Bp;
+    dim3 grid((unsigned)(Bp / 64)), block(64);
+    hipLaunchKernelGGL((eadmm_stream_kernel<n, m>), grid, block, 0, st, s.edev, s.d_consts, x0, xr, ur, ref_stride, B, Bp,
+                       Z1, Z3, LAM, MU, z2, u, k, e);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    dim3 tg((unsigned)(Bp / 64), (unsigned)((dz + 63) / 64));
+    if (z1) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, Z1, Bp, B, (int)dz, z1);
+    if (z3) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, Z3, Bp, B, (int)dz, z3);
+    if (lam) {
+        const long tot = B * (long)(N + 3) * nm;
+        hipLaunchKernelGGL(eadmm_pack_lambda_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, LAM, Bp, B, N,
+                           n, nm, lam);
+    }
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int launch_eadmm(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
+                        double *u, int *k, int *e, double *z1, double *z2, double *z3, double *lam, hipStream_t st) {
+    const int n = s.host.n, m = s.host.m;
+#define SPCIES_CASE(NN, MM) \
+    if (n == NN && m == MM) return launch_eadmm_nm<NN, MM>(s, x0, xr, ur, ref_stride, B, u, k, e, z1, z2, z3, lam, st);
+    SPCIES_CASE(6, 2)
+    SPCIES_CASE(12, 2)
+    SPCIES_CASE(20, 2)
+#undef SPCIES_CASE
+    return fail(SPCIES_HIP_ENOSUP, "EADMM STREAM variant not instantiated for n=%d m=%d", n, m);
+}
+
 static int launch_stream(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                          double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
     const int n = s.host.n, m = s.host.m;
@@ -236,11 +322,19 @@ static int launch_stream(Solver &s, const double *x0, const double *xr, const do
     return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", n, m);
 }
 
+// f[] = the solver's record fields in reference order (Solver::field_name), NULL entries are not produced
 static int solve_device(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
-                        double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
+                        double *u, int *k, int *e, double *const *f, hipStream_t st) {
     if (B <= 0) return 0;
+    if (s.method == SPCIES_EADMM) {
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
+            return fail(SPCIES_HIP_ENOSUP, "EADMM: only the STREAM variant is built");
+        int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
+        if (rc) return rc;
+        return launch_eadmm(s, x0, xr, ur, ref_stride, B, u, k, e, f[0], f[1], f[2], f[3], st);
+    }
+    double *z = f[0], *v = (s.method == SPCIES_FISTA) ? nullptr : f[1], *lam = (s.method == SPCIES_FISTA) ? f[1] : f[2];
     if (s.method == SPCIES_FISTA) {
-        if (v) return fail(SPCIES_HIP_EINVAL, "FISTA solvers have no v output (sol fields: z, lambda)");
         if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
             return fail(SPCIES_HIP_ENOSUP, "FISTA: only the STREAM variant is built");
         if (!stream_shape_built(s.host.n, s.host.m))
@@ -302,7 +396,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     SPCIES_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     rc = upload_consts(*s);
     if (rc) return rc;
-    if (s->method == SPCIES_ADMM) {
+    if (s->method == SPCIES_ADMM && s->formulation != SPCIES_MPCT) {
         rc = mfma_plan_build(s->mfma, s->host);
         if (rc) return rc;
         rc = mfma4_plan_build(s->mfma4, s->host);
@@ -334,7 +428,7 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
     info->submethod = s->submethod;
     info->n = s->host.n; info->m = s->host.m; info->N = s->host.N; info->dim = s->host.dim();
     info->k_max = s->host.k_max; info->tol = s->host.tol; info->rho = s->host.rho;
-    info->variant = s->method == SPCIES_FISTA ? SPCIES_VARIANT_STREAM : resolve_variant(*s);
+    info->variant = s->method != SPCIES_ADMM ? SPCIES_VARIANT_STREAM : resolve_variant(*s);
     info->dim_lambda = s->lam_dim();
     info->device = s->device;
     return 0;
@@ -357,8 +451,8 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
 int spcies_hip_set_exit(spcies_hip_handle h, int k_max, double tol) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (k_max > 0) s->host.k_max = s->dev.k_max = s->fdev.k_max = k_max;
-    if (tol >= 0) s->host.tol = s->dev.tol = s->fdev.tol = tol;
+    if (k_max > 0) s->host.k_max = s->dev.k_max = s->fdev.k_max = s->edev.k_max = k_max;
+    if (tol >= 0) s->host.tol = s->dev.tol = s->fdev.tol = s->edev.tol = tol;
     return 0;
 }
 
@@ -370,42 +464,81 @@ int spcies_hip_reserve(spcies_hip_handle h, long B) {
     return ensure_scratch(*s, stream_scratch_bytes(*s, B, true));
 }
 
-int spcies_hip_solve_batch_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
-                                  int ref_stride, long B, double *u, int *k, int *e_flag, double *z, double *v,
-                                  double *lambda, void *stream) {
+// map the (z, v, lambda) triple of the classic entry points onto the record fields
+static int classic_fields(Solver *s, double *z, double *v, double *lambda, double **f) {
+    f[0] = f[1] = f[2] = f[3] = nullptr;
+    if (s->method == SPCIES_EADMM) {
+        if (z || v || lambda) return fail(SPCIES_HIP_EINVAL, "EADMM record is (z1, z2, z3, lambda): use the _ex entry points");
+    } else if (s->method == SPCIES_FISTA) {
+        if (v) return fail(SPCIES_HIP_EINVAL, "FISTA solvers have no v output (sol fields: z, lambda)");
+        f[0] = z; f[1] = lambda;
+    } else {
+        f[0] = z; f[1] = v; f[2] = lambda;
+    }
+    return 0;
+}
+
+int spcies_hip_get_sol_layout(spcies_hip_handle h, int *n_fields, int *dims, const char **names) {
+    if (!h || !n_fields) return fail(SPCIES_HIP_EINVAL, "NULL argument");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    *n_fields = s->n_fields();
+    for (int i = 0; i < s->n_fields(); i++) {
+        if (dims) dims[i] = s->field_dim(i);
+        if (names) names[i] = s->field_name(i);
+    }
+    return 0;
+}
+
+int spcies_hip_solve_batch_device_ex(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
+                                     int ref_stride, long B, double *u, int *k, int *e_flag, double *const *fields,
+                                     int n_fields, void *stream) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     if (B < 0) return fail(SPCIES_HIP_EINVAL, "negative batch");
     if (B == 0) return 0;
     if (!x0 || !xr || !ur || !u || !k || !e_flag) return fail(SPCIES_HIP_EINVAL, "NULL buffer");
     Solver *s = reinterpret_cast<Solver *>(h);
+    if (fields && n_fields != s->n_fields()) return fail(SPCIES_HIP_EINVAL, "this solver's record has %d fields", s->n_fields());
+    double *f[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (fields) for (int i = 0; i < n_fields; i++) f[i] = fields[i];
     std::lock_guard<std::mutex> lk(s->mu);
     SPCIES_HIP_CHECK(hipSetDevice(s->device));
-    return solve_device(*s, x0, xr, ur, ref_stride, B, u, k, e_flag, z, v, lambda, (hipStream_t)stream);
+    return solve_device(*s, x0, xr, ur, ref_stride, B, u, k, e_flag, f, (hipStream_t)stream);
 }
 
-int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride,
-                           long B, double *u, int *k, int *e_flag, double *z, double *v, double *lambda,
-                           spcies_hip_timing *timing) {
+int spcies_hip_solve_batch_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
+                                  int ref_stride, long B, double *u, int *k, int *e_flag, double *z, double *v,
+                                  double *lambda, void *stream) {
+    if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    double *f[4];
+    int rc = classic_fields(s, z, v, lambda, f);
+    if (rc) return rc;
+    return spcies_hip_solve_batch_device_ex(h, x0, xr, ur, ref_stride, B, u, k, e_flag, (z || v || lambda) ? f : nullptr,
+                                            s->n_fields(), stream);
+}
+
+int spcies_hip_solve_batch_ex(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride,
+                              long B, double *u, int *k, int *e_flag, double *const *fields, int n_fields,
+                              spcies_hip_timing *timing) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     if (B < 0) return fail(SPCIES_HIP_EINVAL, "negative batch");
     if (timing) *timing = spcies_hip_timing{0, 0, 0, 0};
     if (B == 0) return 0;
     if (!x0 || !xr || !ur || !u || !k || !e_flag) return fail(SPCIES_HIP_EINVAL, "NULL buffer");
     Solver *s = reinterpret_cast<Solver *>(h);
+    if (fields && n_fields != s->n_fields()) return fail(SPCIES_HIP_EINVAL, "this solver's record has %d fields", s->n_fields());
     std::lock_guard<std::mutex> lk(s->mu);
     SPCIES_HIP_CHECK(hipSetDevice(s->device));
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
-    const size_t n = s->host.n, m = s->host.m, dim = s->host.dim();
+    const size_t n = s->host.n, m = s->host.m;
     const size_t nref = ref_stride ? (size_t)B : 1;
-    // device staging: x0 | xr | ur | u | z | v | lam | k | e   (doubles first, ints last)
+    // device staging: x0 | xr | ur | u | fields... | k | e   (doubles first, ints last)
     size_t nd = (size_t)B * n + nref * n + nref * m + (size_t)B * m;
-    size_t o_x0 = 0, o_xr = (size_t)B * n, o_ur = o_xr + nref * n, o_u = o_ur + nref * m;
-    size_t o_z = nd, o_v = 0, o_l = 0;
-    if (z) { o_z = nd; nd += (size_t)B * dim; }
-    if (v) { o_v = nd; nd += (size_t)B * dim; }
-    const size_t ldim = (size_t)s->lam_dim();
-    if (lambda) { o_l = nd; nd += (size_t)B * ldim; }
+    const size_t o_x0 = 0, o_xr = (size_t)B * n, o_ur = o_xr + nref * n, o_u = o_ur + nref * m;
+    size_t o_f[4] = {0, 0, 0, 0};
+    for (int i = 0; fields && i < n_fields; i++)
+        if (fields[i]) { o_f[i] = nd; nd += (size_t)B * s->field_dim(i); }
     size_t need = nd * sizeof(double) + 2 * (size_t)B * sizeof(int);
     if (need > s->io_bytes) {
         if (s->d_io) SPCIES_HIP_CHECK(hipFree(s->d_io));
@@ -421,17 +554,19 @@ int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *
     SPCIES_HIP_CHECK(hipMemcpyAsync(d + o_ur, ur, nref * m * 8, hipMemcpyHostToDevice, st));
     SPCIES_HIP_CHECK(hipStreamSynchronize(st));
     auto t1 = clk::now();
-    int rc = solve_device(*s, d + o_x0, d + o_xr, d + o_ur, ref_stride, B, d + o_u, dk, de, z ? d + o_z : nullptr,
-                          v ? d + o_v : nullptr, lambda ? d + o_l : nullptr, st);
+    double *f[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; fields && i < n_fields; i++)
+        if (fields[i]) f[i] = d + o_f[i];
+    int rc = solve_device(*s, d + o_x0, d + o_xr, d + o_ur, ref_stride, B, d + o_u, dk, de, f, st);
     if (rc) return rc;
     SPCIES_HIP_CHECK(hipStreamSynchronize(st));
     auto t2 = clk::now();
     SPCIES_HIP_CHECK(hipMemcpyAsync(u, d + o_u, (size_t)B * m * 8, hipMemcpyDeviceToHost, st));
     SPCIES_HIP_CHECK(hipMemcpyAsync(k, dk, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
     SPCIES_HIP_CHECK(hipMemcpyAsync(e_flag, de, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
-    if (z) SPCIES_HIP_CHECK(hipMemcpyAsync(z, d + o_z, (size_t)B * dim * 8, hipMemcpyDeviceToHost, st));
-    if (v) SPCIES_HIP_CHECK(hipMemcpyAsync(v, d + o_v, (size_t)B * dim * 8, hipMemcpyDeviceToHost, st));
-    if (lambda) SPCIES_HIP_CHECK(hipMemcpyAsync(lambda, d + o_l, (size_t)B * ldim * 8, hipMemcpyDeviceToHost, st));
+    for (int i = 0; fields && i < n_fields; i++)
+        if (fields[i])
+            SPCIES_HIP_CHECK(hipMemcpyAsync(fields[i], f[i], (size_t)B * s->field_dim(i) * 8, hipMemcpyDeviceToHost, st));
     SPCIES_HIP_CHECK(hipStreamSynchronize(st));
     auto t3 = clk::now();
     if (timing) {
@@ -442,6 +577,18 @@ int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *
         timing->run_time = ms(t0, t3);
     }
     return 0;
+}
+
+int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride,
+                           long B, double *u, int *k, int *e_flag, double *z, double *v, double *lambda,
+                           spcies_hip_timing *timing) {
+    if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    double *f[4];
+    int rc = classic_fields(s, z, v, lambda, f);
+    if (rc) return rc;
+    return spcies_hip_solve_batch_ex(h, x0, xr, ur, ref_stride, B, u, k, e_flag, (z || v || lambda) ? f : nullptr,
+                                     s->n_fields(), timing);
 }
 
 int spcies_hip_time_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride,

@@ -1,0 +1,91 @@
+"""MPCT (MPC for tracking) - EADMM ingredients, host-side (offline) restatement.
+
+Reference: ``formulations/+MPCT/compute_MPCT_EADMM_ingredients.m:75-282``.  Three-block extended
+ADMM on ``A1 z1 + A2 z2 + A3 z3 = b`` (``b[0:n] = x0``): ``z1 = (x_i, u_i)`` box-constrained,
+``z2 = (x_s, u_s)`` the artificial reference (explicit solution through ``W2``), ``z3 = (x^_i, u^_i)``
+the dynamics-constrained copy (banded Cholesky ``Alpha`` / ``Beta`` of ``W3 = Az3 H3^-1 Az3'``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .laxMPC import _get, _is_diag
+
+
+def compute_MPCT_EADMM_ingredients(controller, opt):
+    sys, param = _get(controller, "sys"), _get(controller, "param")
+    A = np.asarray(_get(sys, "A"), dtype=float)
+    B = np.asarray(_get(sys, "B"), dtype=float)
+    n, m = B.shape
+    nm = n + m
+    N = int(_get(param, "N"))
+    Q = np.asarray(_get(param, "Q"), dtype=float)
+    R = np.asarray(_get(param, "R"), dtype=float)
+    T = np.asarray(_get(param, "T"), dtype=float)
+    S = np.asarray(_get(param, "S"), dtype=float)
+    inf_value = float(opt.inf_value)
+    bnd = lambda name, sign: np.asarray(_get(sys, name, sign * inf_value * np.ones(n if "x" in name else m)), dtype=float)
+    LBx, UBx, LBu, UBu = bnd("LBx", -1), bnd("UBx", 1), bnd("LBu", -1), bnd("UBu", 1)
+    so = dict(opt.solver)
+    if "rho" in so:  # (:76-79)
+        so["rho_base"], so["rho_mult"] = so["rho"], 1
+    rho_base, rho_mult = float(so["rho_base"]), float(so["rho_mult"])
+    if not (opt.force_diagonal and _is_diag(Q) and _is_diag(R)):
+        raise NotImplementedError("HIP platform: MPCT-EADMM is built for diagonal Q, R (IS_DIAG path)")
+    L = (N + 1) * nm + n + nm
+    rho = rho_base * np.ones(L)
+    rho[:2 * n] = rho_mult * rho_base          # x_0 = x (6b) and stage-0 state rows of z1 + z2 + z3 = 0
+    rho[L - 2 * nm:] = rho_mult * rho_base     # stage-N rows and x_N = x_s, u_N = u_s
+    # A1, A2, A3 (:94-101)
+    A1 = -np.vstack([np.hstack([-np.eye(n), np.zeros((n, N * nm + m))]), np.eye((N + 1) * nm),
+                     np.hstack([np.zeros((nm, N * nm)), np.eye(nm)])])
+    A2 = np.vstack([np.zeros((n, nm)), np.kron(np.ones((N, 1)), np.eye(nm)), np.kron(np.ones((2, 1)), np.eye(nm))])
+    A3 = np.vstack([np.zeros((n, (N + 1) * nm)), np.eye((N + 1) * nm), np.zeros((nm, (N + 1) * nm))])
+    H1 = (rho[:, None] * A1).T @ A1
+    H1i = 1.0 / np.diag(H1)
+    H2 = np.block([[T, np.zeros((n, m))], [np.zeros((m, n)), S]]) + (rho[:, None] * A2).T @ A2
+    Az2 = np.hstack([A - np.eye(n), B])
+    H2i = np.linalg.inv(H2)
+    W2 = H2i @ Az2.T @ np.linalg.inv(Az2 @ H2i @ Az2.T) @ Az2 @ H2i - H2i
+    QR = np.block([[Q, np.zeros((n, m))], [np.zeros((m, n)), R]])
+    H3 = np.kron(np.eye(N + 1), QR) + (rho[:, None] * A3).T @ A3
+    Az3 = np.kron(np.eye(N), np.hstack([A, B]))
+    for j in range(N - 1):  # -I at block (j, j+1) (:127-131)
+        Az3[j * n:(j + 1) * n, (j + 1) * nm:(j + 1) * nm + n] = -np.eye(n)
+    Az3 = np.hstack([Az3, np.vstack([np.zeros(((N - 1) * n, n)), -np.eye(n)]), np.zeros((N * n, m))])
+    H3i = 1.0 / np.diag(H3)
+    W3 = (Az3 * H3i[None, :]) @ Az3.T
+    W3c = np.linalg.cholesky(W3).T
+    eps_x, eps_u = float(so["epsilon_x"]), float(so["epsilon_u"])
+    fin = lambda a: np.where(np.isinf(a), np.sign(a) * inf_value, a)
+    v = dict(n=n, m=m, N=N, formulation="MPCT", method="EADMM", terminal=True)
+    v["H1i"] = H1i.reshape(N + 1, nm).copy()
+    v["H3i"] = H3i.reshape(N + 1, nm).copy()
+    v["AB"] = np.hstack([A, B])
+    v["W2"] = W2
+    v["T"] = -T
+    v["S"] = -S
+    v["LB"] = fin(np.concatenate([LBx, LBu]))
+    v["UB"] = fin(np.concatenate([UBx, UBu]))
+    v["LBs"] = fin(np.concatenate([LBx + eps_x, LBu + eps_u]))
+    v["UBs"] = fin(np.concatenate([UBx - eps_x, UBu - eps_u]))
+    v["LB0"] = np.concatenate([-inf_value * np.ones(n), LBu])
+    v["UB0"] = np.concatenate([inf_value * np.ones(n), UBu])
+    v["rho_mat"] = rho[n:L - nm].reshape(N + 1, nm).copy()
+    v["rho_0"] = np.concatenate([rho[:n], np.zeros(m)])
+    v["rho_s"] = rho[L - nm:].copy()
+    Beta = np.zeros((N, n, n))
+    Alpha = np.zeros((N - 1, n, n))
+    for i in range(N):
+        Beta[i] = W3c[i * n:(i + 1) * n, i * n:(i + 1) * n]
+        Beta[i][np.diag_indices(n)] = 1.0 / np.diag(Beta[i])
+    for i in range(N - 1):
+        Alpha[i] = W3c[i * n:(i + 1) * n, (i + 1) * n:(i + 2) * n]
+    v["Alpha"], v["Beta"] = Alpha, Beta
+    v["k_max"] = int(so["k_max"])
+    v["tol"] = float(so["tol"])
+    v["rho"] = rho_base
+    v["rho_i"] = 1.0 / rho_base
+    v["rho_is_scalar"] = True
+    v["dim"] = (N + 1) * nm
+    return v

@@ -49,6 +49,8 @@ _DEF_SOLVER = {
     ("equMPC", "ADMM", ""): dict(rho=1e-2, tol=1e-4, k_max=1000, force_vector_rho=False),
     ("laxMPC", "FISTA", ""): dict(tol=1e-4, k_max=1000),
     ("equMPC", "FISTA", ""): dict(tol=1e-4, k_max=1000),
+    # formulations/+MPCT/def_options_MPCT_EADMM.m
+    ("MPCT", "EADMM", ""): dict(rho_base=3, rho_mult=20, epsilon_x=1e-6, epsilon_u=1e-6, tol=1e-4, k_max=1000),
 }
 
 

@@ -47,6 +47,12 @@ class HipSolver:
         self.n, self.m, self.N, self.dim = info.n, info.m, info.N, info.dim
         self.dim_lambda = info.dim_lambda
         self.method = {v: k for k, v in _blob.METHOD.items()}[info.method]
+        nf = C.c_int(0)
+        dims = (C.c_int * 8)()
+        names = (C.c_char_p * 8)()
+        _lib.check(lib.spcies_hip_get_sol_layout(h, C.byref(nf), dims, names))
+        # record fields of the generated solver, in the reference's order (e.g. z, v, lambda)
+        self.sol_fields = [(names[i].decode(), int(dims[i])) for i in range(nf.value)]
         self.device = info.device
         self.formulation = {v: k for k, v in _blob.FORMULATION.items()}[info.formulation]
         self.name = name or self.formulation
@@ -115,21 +121,22 @@ class HipSolver:
         u = np.zeros((B, self.m))
         k = np.zeros(B, dtype=np.int32)
         e = np.zeros(B, dtype=np.int32)
-        z = v = lam = None
-        if want_sol:
-            z = np.zeros((B, self.dim))
-            v = np.zeros((B, self.dim)) if self.method != "FISTA" else None  # FISTA record: z, lambda only
-            lam = np.zeros((B, self.dim_lambda))
+        dp = C.POINTER(C.c_double)
+        arrays = [np.zeros((B, d)) for _, d in self.sol_fields] if want_sol else None
+        ptrs = (dp * len(self.sol_fields))(*[_dp(a) for a in arrays]) if want_sol else None
         t = _lib.Timing()
-        _lib.check(self._lib.spcies_hip_solve_batch(
-            self._h, _dp(x0), _dp(xr), _dp(ur), int(per), B, _dp(u), _ip(k), _ip(e),
-            _dp(z) if want_sol else None, _dp(v) if v is not None else None, _dp(lam) if want_sol else None,
+        _lib.check(self._lib.spcies_hip_solve_batch_ex(
+            self._h, _dp(x0), _dp(xr), _dp(ur), int(per), B, _dp(u), _ip(k), _ip(e), ptrs, len(self.sol_fields),
             C.byref(t)))
-        sol = SimpleNamespace(z=z, v=v, **{"lambda": lam}, lam=lam, update_time=t.update_time,
-                              solve_time=t.solve_time, polish_time=t.polish_time, run_time=t.run_time)
+        fields = {name: (arrays[i] if want_sol else None) for i, (name, _) in enumerate(self.sol_fields)}
         if single:
-            sol.z, sol.v, sol.lam = (a[0] if a is not None else None for a in (z, v, lam))
-            setattr(sol, "lambda", sol.lam)
+            fields = {kf: (a[0] if a is not None else None) for kf, a in fields.items()}
+        sol = SimpleNamespace(update_time=t.update_time, solve_time=t.solve_time, polish_time=t.polish_time,
+                              run_time=t.run_time, **fields)
+        sol.lam = fields.get("lambda")  # `lambda` is a Python keyword: sol.lam is the same array
+        if "v" not in fields:
+            sol.v = None
+        if single:
             return u[0], int(k[0]), int(e[0]), sol
         return u, k, e, sol
 

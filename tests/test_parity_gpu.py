@@ -258,3 +258,45 @@ def test_fista_full_size_properties():
     idx = np.random.default_rng(9).choice(B, 48, replace=False)
     uo, *_ = oracle.fista_banded_batch(v, x0[idx], xr[idx], ur[idx], want_sol=False)
     assert np.array_equal(u[idx], uo)
+
+
+# ----------------------------------------------------------------------------------------------
+# MPCT EADMM: STREAM variant, reference operation order -> bit-exact
+# ----------------------------------------------------------------------------------------------
+def test_mpct_reference_test_instance(golden_dir):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver("C1_MPCT")
+    assert [f for f, _ in s.sol_fields] == ["z1", "z2", "z3", "lambda"]  # header_MPCT_EADMM_C.h:14-23
+    st = benchmarks.tester_status(cfg.sys)
+    u, k, e, sol = s(st.x, st.xr, st.ur)
+    with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
+        z_opt = np.array(json.load(f)["test_MPCT_EADMM"])
+    assert e == 1 and np.abs(sol.z1 - z_opt).max() <= TOL_OPT
+    O = oracle.eadmm_mpct_batch(v, st.x[None], st.xr, st.ur)
+    assert k == O[1][0] and np.array_equal(u, O[0][0])
+    assert np.array_equal(sol.z1, O[3][0]) and np.array_equal(sol.z2, O[4][0]) and np.array_equal(sol.z3, O[5][0])
+    assert np.array_equal(sol.lam, O[6][0])
+
+
+@pytest.mark.parametrize("cfg_name,B,overrides", [("C1_MPCT", 100, {}), ("C4", 130, {}), ("C4", 70, dict(tol=1e-5, k_max=4000))])
+def test_mpct_seeded_batch_vs_oracle(cfg_name, B, overrides):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver(cfg_name, **overrides)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    u, k, e, sol = s(x0, xr, ur)
+    uo, ko, eo, z1o, z2o, z3o, lo = oracle.eadmm_mpct_batch(v, x0, xr, ur)
+    assert np.array_equal(k, ko) and np.array_equal(e, eo) and np.array_equal(u, uo)
+    assert np.array_equal(sol.z1, z1o) and np.array_equal(sol.z2, z2o) and np.array_equal(sol.z3, z3o)
+    assert np.array_equal(sol.lam, lo)
+    nosol = s(x0[:33], xr[:33], ur[:33], want_sol=False)
+    assert np.array_equal(nosol[0], uo[:33]) and np.array_equal(nosol[1], ko[:33]) and nosol[3].z1 is None
+
+
+def test_mpct_vs_reference_template_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "template_C4.npz"))
+    cfg, v, s = _fista_solver("C4")
+    u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
+    assert np.array_equal(e, g["e_flag"]) and np.array_equal(k, g["k"])
+    assert np.abs(u - g["u"]).max() <= 1e-9 and np.abs(sol.z1 - g["z1"]).max() <= 1e-9
