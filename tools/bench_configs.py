@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Kernel timings of the BASELINE.json configurations other than the headline one (run on the GPU box).
+
+    python tools/bench_configs.py            # C2 (all ADMM variants), C3 (equMPC-FISTA), C4 (MPCT-EADMM shard)
+
+Inputs resident in HBM, hipEvents on the launch stream (spcies_hip_time_device), 3 launches after 1 warm-up.
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from spcies_amd import benchmarks
+from spcies_amd.solver import HipSolver
+
+
+def run(name, B, variant=None, reps=3):
+    cfg = benchmarks.config(name)
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    if variant:
+        s.set_variant(variant)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tx0, txr, tur = t(x0), t(xr), t(ur)
+    tu = torch.empty((B, cfg.sys.m), dtype=torch.float64, device=dev)
+    tk = torch.empty(B, dtype=torch.int32, device=dev)
+    te = torch.empty(B, dtype=torch.int32, device=dev)
+    s.reserve(B)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    s.time_device(tx0, txr, tur, tu, tk, te, stream=st, reps=1)
+    ms = s.time_device(tx0, txr, tur, tu, tk, te, stream=st, reps=reps)
+    out = dict(config=name, formulation=cfg.formulation, method=cfg.method, n=cfg.sys.n, m=cfg.sys.m, N=cfg.param.N,
+               B=B, variant=s.variant, kernel_ms=round(ms, 3), solves_per_s=round(B / ms * 1e3),
+               k_unique=np.unique(tk.cpu().numpy()).tolist()[:4])
+    print(json.dumps(out), flush=True)
+    s.close()
+
+
+if __name__ == "__main__":
+    for var in ("mfma4", "mfma", "stream"):
+        run("C2", 65536, var)
+    run("C2_equ", 65536, "mfma4")
+    run("C3", 262144)
+    run("C4", 131072)
