@@ -14,6 +14,8 @@
  *     void laxMPC_FISTA(...same signature...), void equMPC_FISTA(...)
  *         reference: formulations/+laxMPC/header_laxMPC_FISTA_C.h:27, +equMPC/header_equMPC_FISTA_C.h
  *         (sol record holds z and lambda only: pass v = NULL; lambda is [B][N*n])
+ *     void ellipMPC_ADMM_soc(double *x0_in, double *xr_in, double *ur_in, double *r_ellip, double *u_opt, ...)
+ *         reference: formulations/+ellipMPC/header_ellipMPC_ADMM_soc_C.h:26 (extra input r, 6-field record: _ex)
  *     void MPCT_EADMM(...same signature...)
  *         reference: formulations/+MPCT/header_MPCT_EADMM_C.h:26 (record z1, z2, z3, lambda: _ex entry points)
  *
@@ -88,7 +90,15 @@ enum spcies_array_id {
     SPCIES_A_LB_0 = 19, SPCIES_A_UB_0 = 20, SPCIES_A_LB_S = 21, SPCIES_A_UB_S = 22, /* [n+m] each */
     SPCIES_A_H1I = 23,     /* [N+1][n+m]                                                   */
     SPCIES_A_W2 = 24,      /* [n+m][n+m]                                                   */
-    SPCIES_A_H3I = 25      /* [N+1][n+m]                                                   */
+    SPCIES_A_H3I = 25,     /* [N+1][n+m]                                                   */
+    /* ellipMPC ADMM soc (cons_ellipMPC_ADMM_soc_C.m:82-110).  Here Q (7), R (8), T (9) are dense negated
+     * [n][n] / [m][m] / [n][n]; LB / UB (10 / 11) have dim-n-1 entries; index arrays are dtype 1 (i32), 0-based. */
+    SPCIES_A_A = 26, SPCIES_A_PHIP = 27,                                  /* [n][n] each               */
+    SPCIES_A_L_VAL = 28, SPCIES_A_L_COL = 29, SPCIES_A_L_ROW = 30,        /* CSC of L - I              */
+    SPCIES_A_DINV = 31,                                                   /* [n_eq + n_s]              */
+    SPCIES_A_GHHHI_VAL = 32, SPCIES_A_GHHHI_COL = 33, SPCIES_A_GHHHI_ROW = 34, /* CSR of -Gh Hh^-1     */
+    SPCIES_A_HHIGH_VAL = 35, SPCIES_A_HHIGH_COL = 36, SPCIES_A_HHIGH_ROW = 37, /* CSR of -Hh^-1 Gh'    */
+    SPCIES_A_HHI_VAL = 38, SPCIES_A_HHI_COL = 39, SPCIES_A_HHI_ROW = 40   /* CSR of -Hh^-1             */
 };
 
 typedef struct {
@@ -104,7 +114,7 @@ typedef struct {
     uint32_t reserved0;
     uint64_t total_bytes;
     double tol, rho, rho_i;
-    double reserved[5];
+    double reserved[5];    /* ellipMPC soc: [0] sigma, [1] 1/sigma, [2] tol_d (tol is tol_p)   */
 } spcies_blob_header;
 
 typedef struct {
@@ -172,15 +182,19 @@ int spcies_hip_solve_batch_device(spcies_hip_handle h, const double *x0, const d
 /* Solvers whose record is not (z, v, lambda) - and any solver, uniformly: `fields` holds one pointer per
  * field of the generated solver's sol_<name> struct, in the reference's order
  *     ADMM (lax/equ): z, v, lambda     FISTA: z, lambda     MPCT-EADMM: z1, z2, z3, lambda
- * (header_laxMPC_ADMM_C.h:14-22, header_laxMPC_FISTA_C.h:14-21, header_MPCT_EADMM_C.h:14-23); a NULL entry
- * (or fields == NULL) skips that output.  spcies_hip_get_sol_layout reports count, per-instance lengths, names. */
+ *     ellipMPC-ADMM-soc: z, s, z_hat, s_hat, lambda, mu
+ * (header_laxMPC_ADMM_C.h:14-22, header_laxMPC_FISTA_C.h:14-21, header_MPCT_EADMM_C.h:14-23,
+ * header_ellipMPC_ADMM_soc_C.h:14-24); a NULL entry (or fields == NULL) skips that output.
+ * `extra` carries formulation-specific extra inputs: the ellipsoid radius r of ellipMPC soc
+ * (4th argument of ellipMPC_ADMM_soc, header_ellipMPC_ADMM_soc_C.h:26) as [B] (extra_stride = 1) or one
+ * shared value (extra_stride = 0); NULL for the other solvers.  spcies_hip_get_sol_layout reports count, per-instance lengths, names. */
 int spcies_hip_get_sol_layout(spcies_hip_handle h, int *n_fields, int *dims, const char **names);
 int spcies_hip_solve_batch_ex(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
-                              int ref_stride, long B, double *u, int *k, int *e_flag, double *const *fields,
-                              int n_fields, spcies_hip_timing *timing);
+                              int ref_stride, const double *extra, int extra_stride, long B, double *u, int *k,
+                              int *e_flag, double *const *fields, int n_fields, spcies_hip_timing *timing);
 int spcies_hip_solve_batch_device_ex(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
-                                     int ref_stride, long B, double *u, int *k, int *e_flag, double *const *fields,
-                                     int n_fields, void *stream);
+                                     int ref_stride, const double *extra, int extra_stride, long B, double *u, int *k,
+                                     int *e_flag, double *const *fields, int n_fields, void *stream);
 
 /* Time `reps` back-to-back device solves with hipEvents recorded on `stream` (the stream the
  * kernel is launched on); returns the mean milliseconds per launch in *ms_per_launch. */

@@ -13,7 +13,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c", "eadmm_mpct_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c", "eadmm_mpct_oracle.c", "admm_soc_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return so
@@ -159,3 +159,56 @@ def eadmm_mpct_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     if rc != 0:
         raise RuntimeError(f"oracle_eadmm_mpct_batch failed rc={rc}")
     return u, k, e, z1, z2, z3, lam
+
+
+_SOC_F64 = ("A", "Q", "R", "T", "LB", "UB", "PhiP")
+
+
+class _SocData(C.Structure):
+    _fields_ = ([(k_, C.c_int) for k_ in ("n", "m", "N", "dim", "n_s", "n_eq", "k_max")]
+                + [(k_, C.c_double) for k_ in ("tol_p", "tol_d", "rho", "rho_i", "sigma", "sigma_i")]
+                + [(k_, C.POINTER(C.c_double)) for k_ in _SOC_F64]
+                + [("L_val", C.POINTER(C.c_double)), ("L_col", C.POINTER(C.c_int)), ("L_row", C.POINTER(C.c_int)),
+                   ("Dinv", C.POINTER(C.c_double))]
+                + sum([[(p_ + "_val", C.POINTER(C.c_double)), (p_ + "_col", C.POINTER(C.c_int)),
+                        (p_ + "_row", C.POINTER(C.c_int))] for p_ in ("GhHhi", "HhiGh", "Hhi")], []))
+
+
+def admm_soc_batch(v, x0, xr, ur, r, want_sol=True, quantize=False):
+    """C oracle of ellipMPC ADMM-soc.  Returns ``u, k, e_flag, z, s, z_hat, s_hat, lam, mu``."""
+    n, m = int(v["n"]), int(v["m"])
+    qz = quantize_like_reference if quantize else (lambda a: a)
+    keep = {}
+    fields = {}
+    ipt = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    for k_ in _SOC_F64 + ("L_val", "Dinv", "GhHhi_val", "HhiGh_val", "Hhi_val"):
+        a = np.ascontiguousarray(qz(np.asarray(v[k_], dtype=float)))
+        if quantize and k_ in ("LB", "UB"):
+            a = np.clip(a, -1e20, 1e20)
+        keep[k_] = a
+        fields[k_] = _dp(a)
+    for k_ in ("L_col", "L_row", "GhHhi_col", "GhHhi_row", "HhiGh_col", "HhiGh_row", "Hhi_col", "Hhi_row"):
+        keep[k_] = np.ascontiguousarray(np.asarray(v[k_], dtype=np.int32))
+        fields[k_] = ipt(keep[k_])
+    sc = {k_: (float(qz(v[k_])) if quantize else float(v[k_])) for k_ in ("tol_p", "tol_d", "rho", "rho_i", "sigma", "sigma_i")}
+    d = _SocData(n=n, m=m, N=int(v["N"]), dim=int(v["dim"]), n_s=int(v["n_s"]), n_eq=int(v["n_eq"]), k_max=int(v["k_max"]),
+                 **sc, **fields)
+    x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
+    B = x0.shape[0]
+    xr = np.ascontiguousarray(np.asarray(xr, dtype=float))
+    ur = np.ascontiguousarray(np.asarray(ur, dtype=float))
+    r = np.ascontiguousarray(np.atleast_1d(np.asarray(r, dtype=float)))
+    stride = 1 if xr.ndim == 2 else 0
+    rstride = 1 if r.size == B and B > 1 else 0
+    dim, n_s = int(v["dim"]), int(v["n_s"])
+    u = np.zeros((B, m)); k = np.zeros(B, dtype=np.int32); e = np.zeros(B, dtype=np.int32)
+    mk = lambda w: np.zeros((B, w)) if want_sol else None
+    z, s, zh, sh, lam, mu = mk(dim), mk(n_s), mk(dim), mk(n_s), mk(dim), mk(n_s)
+    o = lambda a: _dp(a) if a is not None else None
+    lib = _lib()
+    lib.oracle_admm_soc_batch.restype = C.c_int
+    rc = lib.oracle_admm_soc_batch(C.byref(d), C.c_long(B), _dp(x0), _dp(xr), _dp(ur), C.c_int(stride), _dp(r),
+                                   C.c_int(rstride), _dp(u), ipt(k), ipt(e), o(z), o(s), o(zh), o(sh), o(lam), o(mu))
+    if rc != 0:
+        raise RuntimeError(f"oracle_admm_soc_batch failed rc={rc}")
+    return u, k, e, z, s, zh, sh, lam, mu

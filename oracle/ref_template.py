@@ -65,6 +65,15 @@ def _decl(name, a):
     return f"const static double {name}{dims} = {body};\n"
 
 
+def _decl_scalar(name, x):
+    return f"const static double {name} = {_fmt(x)};\n"
+
+
+def _decl_int(name, a):
+    a = np.asarray(a).ravel()
+    return f"const static int {name}[{a.size}] = " + "{ " + ", ".join("%d" % int(x) for x in a) + " };\n"
+
+
 def _unescape(text):
     """``fprintf(fid, text)`` semantics of Spcies_constructor.m:222."""
     return text.replace("%%", "%").replace("\\\\", "\\")
@@ -80,6 +89,8 @@ def _snippets(text, ext):
 def build_admm(v, name):
     """Instantiate + compile the lax/equ ADMM or FISTA template for ingredients ``v``; returns the .so path."""
     form, method = v["formulation"], v.get("method", "ADMM")
+    if v.get("submethod") == "soc":
+        return _build_soc(v, name)
     fdir = os.path.join(REF, "formulations", f"+{form}")
     n, m, N = v["n"], v["m"], v["N"]
     defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
@@ -124,6 +135,8 @@ def run_admm(so, v, x0, xr, ur):
     ``u, k, e, z, v, lam`` (``v`` is ``None`` for FISTA, whose record holds ``z`` and ``lambda`` only)."""
     n, m, N = v["n"], v["m"], v["N"]
     method = v.get("method", "ADMM")
+    if v.get("submethod") == "soc":
+        raise ValueError("use run_soc for the ellipMPC soc solver (extra input r)")
     dim = N * (n + m) - (0 if v["terminal"] else n)
     lib = C.CDLL(so)
     fn = getattr(lib, f"{v['formulation']}_{method}")
@@ -179,3 +192,70 @@ def _run_eadmm(lib, fn, v, x0, xr, ur):
         z1[i] = np.frombuffer(sol.z1); z2[i] = np.frombuffer(sol.z2); z3[i] = np.frombuffer(sol.z3)
         lam[i] = np.frombuffer(sol.lam)
     return u, k, e, z1, z2, z3, lam
+
+
+def _build_soc(v, name):
+    """ellipMPC ADMM soc: cons_ellipMPC_ADMM_soc_C.m:66-117 (scalars are plain `const static double`: the
+    var_options there carry no 'array' flag)."""
+    fdir = os.path.join(REF, "formulations", "+ellipMPC")
+    n, m, N = v["n"], v["m"], v["N"]
+    defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
+            "#define IS_DIAG 1", f"#define dim {v['dim']}", f"#define n_s {v['n_s']}", f"#define n_eq {v['n_eq']}",
+            f"#define nn_ {n}", f"#define mm_ {m}", f"#define nm_ {n + m}", f"#define NN_ {N}",
+            f"#define nrow_GhHhi {len(v['GhHhi_row']) - 1}", f"#define nrow_HhiGh {len(v['HhiGh_row']) - 1}",
+            f"#define nrow_Hhi {len(v['Hhi_row']) - 1}", f"#define k_max {int(v['k_max'])}",
+            f"#define tol_p {_fmt(v['tol_p'])}", f"#define tol_d {_fmt(v['tol_d'])}"]
+    consts = "".join(_decl_scalar(k, v[k]) for k in ("rho", "rho_i", "sigma", "sigma_i"))
+    consts += "".join(_decl(k, v[k]) for k in ("Q", "R", "T", "A", "LB", "UB", "PhiP"))
+    consts += _decl("L_val", v["L_val"]) + _decl_int("L_col", v["L_col"]) + _decl_int("L_row", v["L_row"]) + _decl("Dinv", v["Dinv"])
+    for pfx in ("GhHhi", "HhiGh", "Hhi"):
+        consts += _decl(pfx + "_val", v[pfx + "_val"]) + _decl_int(pfx + "_col", v[pfx + "_col"]) + _decl_int(pfx + "_row", v[pfx + "_row"])
+    with open(os.path.join(REF, "platforms", "+C_code", "generic_solver_struct.c")) as f:
+        code = f.read()
+    with open(os.path.join(fdir, "code_ellipMPC_ADMM_soc_C.c")) as f:
+        code = code.replace("$INSERT_SOLVER$", f.read())
+    with open(os.path.join(fdir, "header_ellipMPC_ADMM_soc_C.h")) as f:
+        header = f.read()
+    code = code.replace("$INSERT_CONSTANTS$", consts)
+    header = header.replace("$INSERT_DEFINES$", "\n".join(defs))
+    code, header = _snippets(code, "c"), _snippets(header, "h")
+    code = _unescape(code.replace("$INSERT_NAME$", name))
+    header = _unescape(header.replace("$INSERT_NAME$", name))
+    os.makedirs(OUT, exist_ok=True)
+    so = os.path.join(OUT, f"lib{name}.so")
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, f"{name}.c"), "w") as f:
+            f.write(code)
+        with open(os.path.join(td, f"{name}.h"), "w") as f:
+            f.write(header)
+        subprocess.check_call(["gcc", "-O3", "-fPIC", "-shared", "-w", "-o", so, os.path.join(td, f"{name}.c"), "-lm"])
+    return so
+
+
+def run_soc(so, v, x0, xr, ur, r):
+    """``ellipMPC_ADMM_soc(x0, xr, ur, &r, u, &k, &e, &sol)``; returns u, k, e, z, s, z_hat, s_hat, lam, mu."""
+    n, m, dim, n_s = v["n"], v["m"], v["dim"], v["n_s"]
+    lib = C.CDLL(so)
+    fn = lib.ellipMPC_ADMM_soc
+
+    class Sol(C.Structure):
+        _fields_ = [("z", C.c_double * dim), ("s", C.c_double * n_s), ("z_hat", C.c_double * dim),
+                    ("s_hat", C.c_double * n_s), ("lam", C.c_double * dim), ("mu", C.c_double * n_s), ("t", C.c_double * 4)]
+    x0 = np.atleast_2d(np.asarray(x0, float))
+    B = x0.shape[0]
+    per = np.ndim(xr) == 2
+    r = np.atleast_1d(np.asarray(r, float))
+    u = np.zeros((B, m)); k = np.zeros(B, np.int32); e = np.zeros(B, np.int32)
+    out = {f: np.zeros((B, w)) for f, w in (("z", dim), ("s", n_s), ("z_hat", dim), ("s_hat", n_s), ("lam", dim), ("mu", n_s))}
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for i in range(B):
+        sol = Sol()
+        xi = np.ascontiguousarray(x0[i]); xri = np.ascontiguousarray(xr[i] if per else xr)
+        uri = np.ascontiguousarray(ur[i] if per else ur)
+        ri = C.c_double(r[i] if r.size == B and B > 1 else r[0])
+        ui = np.zeros(m); ki = C.c_int(0); ei = C.c_int(0)
+        fn(dp(xi), dp(xri), dp(uri), C.byref(ri), dp(ui), C.byref(ki), C.byref(ei), C.byref(sol))
+        u[i] = ui; k[i] = ki.value; e[i] = ei.value
+        for f in out:
+            out[f][i] = np.frombuffer(getattr(sol, f))
+    return (u, k, e, out["z"], out["s"], out["z_hat"], out["s_hat"], out["lam"], out["mu"])

@@ -63,10 +63,10 @@ def load():
                                            C.POINTER(Timing)]
     lib.spcies_hip_solve_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, C.c_long, vp, vp, vp, vp, vp, vp, vp]
     lib.spcies_hip_get_sol_layout.argtypes = [vp, ip, ip, C.POINTER(C.c_char_p)]
-    lib.spcies_hip_solve_batch_ex.argtypes = [vp, dp, dp, dp, C.c_int, C.c_long, dp, ip, ip, C.POINTER(dp), C.c_int,
-                                              C.POINTER(Timing)]
-    lib.spcies_hip_solve_batch_device_ex.argtypes = [vp, vp, vp, vp, C.c_int, C.c_long, vp, vp, vp, C.POINTER(vp),
-                                                     C.c_int, vp]
+    lib.spcies_hip_solve_batch_ex.argtypes = [vp, dp, dp, dp, C.c_int, dp, C.c_int, C.c_long, dp, ip, ip,
+                                              C.POINTER(dp), C.c_int, C.POINTER(Timing)]
+    lib.spcies_hip_solve_batch_device_ex.argtypes = [vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_long, vp, vp, vp,
+                                                     C.POINTER(vp), C.c_int, vp]
     lib.spcies_hip_time_device.argtypes = [vp, vp, vp, vp, C.c_int, C.c_long, vp, vp, vp, vp, C.c_int, dp]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here = header and library out of sync

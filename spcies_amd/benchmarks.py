@@ -78,6 +78,17 @@ def config(name):
             c.param.N, c.B, c.seed = 20, 1048576, 1204
             c.solver_options.update(k_max=200, tol=0.0)
         return c
+    if name in ("C1_soc", "C5_soc"):  # tests/test_ellipMPC_ADMM_soc.m:8-25; C5: 12-state, N = 15, 200 fixed iterations
+        sys = sp_utils.oscillating_masses_sys(3 if name == "C1_soc" else 6)
+        Q, R, T = _weights(sys, "diag")
+        st = tester_status(sys)
+        c = SimpleNamespace(name=name, sys=sys, param=SimpleNamespace(Q=Q, R=R, T=T, N=10, P=np.eye(sys.n), c=st.xr, r=0.0),
+                            formulation="ellipMPC", method="ADMM", submethod="soc",
+                            solver_options=dict(rho=15, sigma=10, k_max=5000, tol_p=1e-7, tol_d=1e-7), B=1, seed=1205)
+        if name == "C5_soc":
+            c.param.N, c.param.r, c.B = 15, 0.5, 524288
+            c.solver_options.update(k_max=200, tol_p=0.0, tol_d=0.0)
+        return c
     raise KeyError(name)
 
 
@@ -98,15 +109,16 @@ def sample_batch(cfg, B=None, seed=None, around_xr=None):
 
 
 def ingredients(cfg, **solver_overrides):
-    from .formulations import MPCT, laxMPC
+    from .formulations import MPCT, ellipMPC, laxMPC
     from .options import SpciesOptions
     so = dict(cfg.solver_options)
     so.update(solver_overrides)
-    opt = SpciesOptions(formulation=cfg.formulation, method=cfg.method, options=so)
+    opt = SpciesOptions(formulation=cfg.formulation, method=cfg.method, submethod=getattr(cfg, "submethod", ""), options=so)
     ctrl = SimpleNamespace(sys=cfg.sys, param=cfg.param)
     fn = {("laxMPC", "ADMM"): laxMPC.compute_laxMPC_ADMM_ingredients,
           ("equMPC", "ADMM"): laxMPC.compute_equMPC_ADMM_ingredients,
           ("laxMPC", "FISTA"): laxMPC.compute_laxMPC_FISTA_ingredients,
           ("equMPC", "FISTA"): laxMPC.compute_equMPC_FISTA_ingredients,
-          ("MPCT", "EADMM"): MPCT.compute_MPCT_EADMM_ingredients}
+          ("MPCT", "EADMM"): MPCT.compute_MPCT_EADMM_ingredients,
+          ("ellipMPC", "ADMM"): ellipMPC.compute_ellipMPC_ADMM_soc_ingredients}
     return fn[(cfg.formulation, cfg.method)](ctrl, opt)

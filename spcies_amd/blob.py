@@ -21,7 +21,12 @@ METHOD = {"ADMM": 1, "FISTA": 2, "EADMM": 3, "SADMM": 4}
 ARRAY_ID = {"AB": 1, "Alpha": 2, "Beta": 3, "Hi": 4, "Hi_0": 5, "Hi_N": 6, "Q": 7, "R": 8, "T": 9, "LB": 10, "UB": 11,
             "QRi": 12, "Tdiag": 13, "Ti": 14,
             "S": 15, "rho_mat": 16, "rho_0": 17, "rho_s": 18, "LB0": 19, "UB0": 20, "LBs": 21, "UBs": 22,
-            "H1i": 23, "W2": 24, "H3i": 25}
+            "H1i": 23, "W2": 24, "H3i": 25,
+            "A": 26, "PhiP": 27, "L_val": 28, "L_col": 29, "L_row": 30, "Dinv": 31, "GhHhi_val": 32, "GhHhi_col": 33,
+            "GhHhi_row": 34, "HhiGh_val": 35, "HhiGh_col": 36, "HhiGh_row": 37, "Hhi_val": 38, "Hhi_col": 39,
+            "Hhi_row": 40}
+INT_ARRAYS = {"L_col", "L_row", "GhHhi_col", "GhHhi_row", "HhiGh_col", "HhiGh_row", "Hhi_col", "Hhi_row"}
+SUBMETHOD = {"": 0, "soc": 1, "split": 2, "cs": 3, "semiband": 4}
 _ID_NAME = {v: k for k, v in ARRAY_ID.items()}
 _HDR = "<8sIIIIIIIIIIIIQddd5d"
 assert struct.calcsize(_HDR) == HEADER_BYTES
@@ -40,6 +45,9 @@ def pack(v):
     names = [k for k in ARRAY_ID if k in v]
     arrays = []
     for k in names:
+        if k in INT_ARRAYS:
+            arrays.append((k, np.ascontiguousarray(np.asarray(v[k], dtype="<i4"))))
+            continue
         a = np.ascontiguousarray(np.asarray(v[k], dtype="<f8"))
         if k in ("LB", "UB", "LB0", "UB0", "LBs", "UBs"):
             a = np.clip(a, -INF_VALUE, INF_VALUE)
@@ -48,14 +56,15 @@ def pack(v):
     entries, payload = [], []
     for k, a in arrays:
         dims = list(a.shape)[:4] + [0] * (4 - min(a.ndim, 4))
-        entries.append(struct.pack(_ENT, ARRAY_ID[k], 0, off, a.size, *dims, 0, 0))
+        entries.append(struct.pack(_ENT, ARRAY_ID[k], 1 if k in INT_ARRAYS else 0, off, a.size, *dims, 0, 0))
         payload.append((off, a.tobytes()))
         off = _align(off + a.nbytes)
     total = off
     flags = 1 if v.get("rho_is_scalar", True) else 0
+    res = [float(v.get("sigma", 0.0)), float(v.get("sigma_i", 0.0)), float(v.get("tol_d", 0.0)), 0.0, 0.0]
     hdr = struct.pack(_HDR, MAGIC, VERSION, HEADER_BYTES, FORMULATION[v["formulation"]], METHOD[v["method"]],
-                      0, flags, int(v["n"]), int(v["m"]), int(v["N"]), int(v["k_max"]), len(arrays), 0, total,
-                      float(v["tol"]), float(v["rho"]), float(v["rho_i"]), 0.0, 0.0, 0.0, 0.0, 0.0)
+                      SUBMETHOD[v.get("submethod", "")], flags, int(v["n"]), int(v["m"]), int(v["N"]), int(v["k_max"]),
+                      len(arrays), 0, total, float(v["tol"]), float(v["rho"]), float(v["rho_i"]), *res)
     buf = bytearray(total)
     buf[:HEADER_BYTES] = hdr
     p = HEADER_BYTES
@@ -80,5 +89,6 @@ def unpack(blob):
     for i in range(n_arr):
         aid, dtype, off, count, d0, d1, d2, d3, _p0, _p1 = struct.unpack_from(_ENT, blob, HEADER_BYTES + i * ENTRY_BYTES)
         shape = tuple(d for d in (d0, d1, d2, d3) if d) or (count,)
-        v[_ID_NAME[aid]] = np.frombuffer(blob, dtype="<f8", count=count, offset=off).reshape(shape).copy()
+        v[_ID_NAME[aid]] = np.frombuffer(blob, dtype="<i4" if dtype == 1 else "<f8", count=count,
+                                         offset=off).reshape(shape).copy()
     return v

@@ -8,6 +8,7 @@
 #include "admm_stream.hpp"
 #include "fista_stream.hpp"
 #include "eadmm_stream.hpp"
+#include "soc_stream.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -24,8 +25,13 @@ struct Solver {
     AdmmDev dev{};
     FistaDev fdev{};
     std::vector<double> QRi, Td, Ti;  // FISTA-only ingredients
+    SocDev sdev{};
+    std::vector<double> soc_f64;   // ellipMPC-soc: all FP64 constants, concatenated
+    std::vector<int> soc_i32;      //               all index arrays, concatenated
+    int *d_idx = nullptr;
     EadmmDev edev{};
     std::vector<double> e_rho, e_rho0, e_rhos, e_LB0, e_UB0, e_LBs, e_UBs, e_S, e_H1i, e_W2, e_H3i;  // EADMM-only
+    bool is_soc() const { return formulation == SPCIES_ELLIPMPC; }
     int lam_dim() const {
         if (method == SPCIES_FISTA) return host.N * host.n;
         if (method == SPCIES_EADMM) return (host.N + 3) * (host.n + host.m);
@@ -35,15 +41,19 @@ struct Solver {
     //   ADMM  : z, v, lambda            (header_laxMPC_ADMM_C.h:14-22)
     //   FISTA : z, lambda               (header_laxMPC_FISTA_C.h:14-21)
     //   EADMM : z1, z2, z3, lambda      (header_MPCT_EADMM_C.h:14-23)
-    int n_fields() const { return method == SPCIES_FISTA ? 2 : (method == SPCIES_EADMM ? 4 : 3); }
+    //   soc   : z, s, z_hat, s_hat, lambda, mu   (header_ellipMPC_ADMM_soc_C.h:14-24)
+    int n_fields() const { return is_soc() ? 6 : (method == SPCIES_FISTA ? 2 : (method == SPCIES_EADMM ? 4 : 3)); }
     int field_dim(int i) const {
         const int nm = host.n + host.m;
+        if (is_soc()) return (i % 2 == 0) ? sdev.dim : sdev.n_s;
         if (method == SPCIES_FISTA) return i == 0 ? host.dim() : lam_dim();
         if (method == SPCIES_EADMM) return i == 1 ? nm : (i == 3 ? lam_dim() : (host.N + 1) * nm);
         return host.dim();
     }
     const char *field_name(int i) const {
         static const char *admm[] = {"z", "v", "lambda"}, *fista[] = {"z", "lambda"}, *eadmm[] = {"z1", "z2", "z3", "lambda"};
+        static const char *soc[] = {"z", "s", "z_hat", "s_hat", "lambda", "mu"};
+        if (is_soc()) return soc[i];
         return method == SPCIES_FISTA ? fista[i] : (method == SPCIES_EADMM ? eadmm[i] : admm[i]);
     }
     // MFMA-variant packing
@@ -71,6 +81,94 @@ static const double *find_array(const uint8_t *blob, size_t bytes, const spcies_
     return nullptr;
 }
 
+static const int *find_iarray(const uint8_t *blob, size_t bytes, const spcies_blob_header &h, uint32_t id, uint64_t *count) {
+    for (uint32_t i = 0; i < h.n_arrays; i++) {
+        spcies_blob_entry e;
+        memcpy(&e, blob + h.header_bytes + (size_t)i * sizeof(e), sizeof(e));
+        if (e.id != id) continue;
+        if (e.dtype != 1 || e.offset % 4 != 0 || e.offset + e.count * 4 > bytes) return nullptr;
+        *count = e.count;
+        return reinterpret_cast<const int *>(blob + e.offset);
+    }
+    return nullptr;
+}
+
+static const double *find_farray_any(const uint8_t *blob, size_t bytes, const spcies_blob_header &h, uint32_t id, uint64_t *count) {
+    for (uint32_t i = 0; i < h.n_arrays; i++) {
+        spcies_blob_entry e;
+        memcpy(&e, blob + h.header_bytes + (size_t)i * sizeof(e), sizeof(e));
+        if (e.id != id) continue;
+        if (e.dtype != 0 || e.offset % 8 != 0 || e.offset + e.count * 8 > bytes) return nullptr;
+        *count = e.count;
+        return reinterpret_cast<const double *>(blob + e.offset);
+    }
+    return nullptr;
+}
+
+// ellipMPC ADMM soc (cons_ellipMPC_ADMM_soc_C.m:66-117): dense Q, R, T, A, PhiP, bounds, and the sparse
+// factors (CSC of L - I, Dinv, three CSR matrices).  Everything is validated here because the kernel
+// follows these indices without further checks.
+static int parse_soc(const uint8_t *blob, size_t bytes, const spcies_blob_header &h, Solver &s) {
+    s.formulation = (int)h.formulation; s.method = (int)h.method; s.submethod = (int)h.submethod;
+    AdmmHost &a = s.host;
+    a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max; a.terminal = true;
+    a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
+    if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0) || !(h.reserved[0] > 0))
+        return fail(SPCIES_HIP_EINVAL, "bad n/m/N/k_max/rho/sigma");
+    const int n = a.n, m = a.m, N = a.N, nm = n + m;
+    SocDev &d = s.sdev;
+    d.n = n; d.m = m; d.N = N; d.dim = N * nm + 1; d.n_s = n + 1; d.n_eq = N * n + 1; d.k_max = a.k_max;
+    d.tol_p = h.tol; d.tol_d = h.reserved[2]; d.rho = h.rho; d.rho_i = h.rho_i; d.sigma = h.reserved[0]; d.sigma_i = h.reserved[1];
+    const int np = d.dim + d.n_s, nr = d.n_eq + d.n_s;
+    struct F { uint32_t id; uint64_t want; int *off; };  // want == 0: any length
+    F fs[] = {{SPCIES_A_A, (uint64_t)n * n, &d.A}, {SPCIES_A_Q, (uint64_t)n * n, &d.Q}, {SPCIES_A_R, (uint64_t)m * m, &d.R},
+              {SPCIES_A_T, (uint64_t)n * n, &d.T}, {SPCIES_A_LB, (uint64_t)(d.dim - n - 1), &d.LB},
+              {SPCIES_A_UB, (uint64_t)(d.dim - n - 1), &d.UB}, {SPCIES_A_PHIP, (uint64_t)n * n, &d.PhiP},
+              {SPCIES_A_L_VAL, 0, &d.L_val}, {SPCIES_A_DINV, (uint64_t)nr, &d.Dinv}, {SPCIES_A_GHHHI_VAL, 0, &d.GhHhi_val},
+              {SPCIES_A_HHIGH_VAL, 0, &d.HhiGh_val}, {SPCIES_A_HHI_VAL, 0, &d.Hhi_val}};
+    uint64_t nnz[4] = {0, 0, 0, 0};  // L, GhHhi, HhiGh, Hhi
+    int vi = 0;
+    for (auto &f : fs) {
+        uint64_t cnt = 0;
+        const double *p = find_farray_any(blob, bytes, h, f.id, &cnt);
+        if (!p || (f.want && cnt != f.want)) return fail(SPCIES_HIP_EINVAL, "blob array id %u missing or mis-sized", f.id);
+        *f.off = (int)s.soc_f64.size();
+        s.soc_f64.insert(s.soc_f64.end(), p, p + cnt);
+        while (s.soc_f64.size() % 8) s.soc_f64.push_back(0.0);
+        if (f.want == 0) nnz[vi++] = cnt;
+    }
+    struct G { uint32_t id; uint64_t want; int *off; int maxval; bool is_ptr; };  // is_ptr: row/column pointer array
+    G gs[] = {{SPCIES_A_L_COL, (uint64_t)nr + 1, &d.L_col, (int)nnz[0], true},
+              {SPCIES_A_L_ROW, nnz[0], &d.L_row, nr - 1, false},
+              {SPCIES_A_GHHHI_COL, nnz[1], &d.GhHhi_col, np - 1, false},
+              {SPCIES_A_GHHHI_ROW, (uint64_t)nr + 1, &d.GhHhi_row, (int)nnz[1], true},
+              {SPCIES_A_HHIGH_COL, nnz[2], &d.HhiGh_col, nr - 1, false},
+              {SPCIES_A_HHIGH_ROW, (uint64_t)np + 1, &d.HhiGh_row, (int)nnz[2], true},
+              {SPCIES_A_HHI_COL, nnz[3], &d.Hhi_col, np - 1, false},
+              {SPCIES_A_HHI_ROW, (uint64_t)np + 1, &d.Hhi_row, (int)nnz[3], true}};
+    for (auto &g : gs) {
+        uint64_t cnt = 0;
+        const int *p = find_iarray(blob, bytes, h, g.id, &cnt);
+        if (!p || cnt != g.want) return fail(SPCIES_HIP_EINVAL, "blob index array id %u missing or mis-sized", g.id);
+        const bool is_ptr = g.is_ptr;
+        for (uint64_t i = 0; i < cnt; i++) {
+            if (p[i] < 0 || p[i] > g.maxval) return fail(SPCIES_HIP_EINVAL, "blob index array id %u: value out of range", g.id);
+            if (is_ptr && i > 0 && p[i] < p[i - 1]) return fail(SPCIES_HIP_EINVAL, "blob pointer array id %u not monotone", g.id);
+        }
+        if (is_ptr && (p[0] != 0 || p[cnt - 1] != g.maxval)) return fail(SPCIES_HIP_EINVAL, "blob pointer array id %u: bad ends", g.id);
+        *g.off = (int)s.soc_i32.size();
+        s.soc_i32.insert(s.soc_i32.end(), p, p + cnt);
+    }
+    // CSC of L - I must be strictly lower triangular (the forward sweep relies on it)
+    {
+        const int *Lc = s.soc_i32.data() + d.L_col, *Lr = s.soc_i32.data() + d.L_row;
+        for (int i = 0; i < nr; i++)
+            for (int j = Lc[i]; j < Lc[i + 1]; j++)
+                if (Lr[j] <= i) return fail(SPCIES_HIP_EINVAL, "L - I is not strictly lower triangular");
+    }
+    return 0;
+}
+
 static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     const uint8_t *blob = static_cast<const uint8_t *>(blobv);
     if (!blob || bytes < sizeof(spcies_blob_header)) return fail(SPCIES_HIP_EINVAL, "blob too small");
@@ -84,6 +182,8 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     const bool banded = (h.method == SPCIES_ADMM || h.method == SPCIES_FISTA) &&
                         (h.formulation == SPCIES_LAXMPC || h.formulation == SPCIES_EQUMPC);
     const bool mpct = (h.method == SPCIES_EADMM && h.formulation == SPCIES_MPCT);
+    const bool soc = (h.method == SPCIES_ADMM && h.formulation == SPCIES_ELLIPMPC && h.submethod == 1);
+    if (soc) return parse_soc(blob, bytes, h, s);
     if (!banded && !mpct)
         return fail(SPCIES_HIP_ENOSUP, "formulation %u / method %u not built in this library", h.formulation, h.method);
     if (h.method == SPCIES_ADMM && !(h.flags & 1u)) return fail(SPCIES_HIP_ENOSUP, "vector rho not built");
@@ -138,6 +238,13 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
 
 static int upload_consts(Solver &s) {
     AdmmHost &a = s.host;
+    if (s.is_soc()) {
+        SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_consts, s.soc_f64.size() * sizeof(double)));
+        SPCIES_HIP_CHECK(hipMemcpy(s.d_consts, s.soc_f64.data(), s.soc_f64.size() * sizeof(double), hipMemcpyHostToDevice));
+        SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_idx, s.soc_i32.size() * sizeof(int)));
+        SPCIES_HIP_CHECK(hipMemcpy(s.d_idx, s.soc_i32.data(), s.soc_i32.size() * sizeof(int), hipMemcpyHostToDevice));
+        return 0;
+    }
     std::vector<const std::vector<double> *> arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Hi, &a.Hi_0, &a.Hi_N,
                                                      &a.Q,  &a.R,     &a.T,    &a.LB, &a.UB};
     if (s.method == SPCIES_FISTA) arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Q, &a.R, &s.QRi, &s.Td, &s.Ti, &a.LB, &a.UB};
@@ -188,6 +295,7 @@ static size_t stream_scratch_bytes(const Solver &s, long B, bool want_sol) {
     if (s.method == SPCIES_FISTA) rows = 3 * (size_t)s.host.N * s.host.n + (want_sol ? (size_t)s.host.dim() : 0);
     if (s.method == SPCIES_EADMM)
         rows = (size_t)(3 * s.host.N + 5) * (s.host.n + s.host.m) + (size_t)s.host.N * s.host.n;
+    if (s.is_soc()) rows = 4 * (size_t)(s.sdev.dim + s.sdev.n_s) + 2 * (size_t)(s.sdev.n_eq + s.sdev.n_s) + (size_t)s.sdev.dim;
     return rows * (size_t)Bp * sizeof(double);
 }
 
@@ -323,9 +431,40 @@ static int launch_stream(Solver &s, const double *x0, const double *xr, const do
 }
 
 // f[] = the solver's record fields in reference order (Solver::field_name), NULL entries are not produced
+static int launch_soc(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, const double *r,
+                      int r_stride, long B, double *u, int *k, int *e, double *const *f, hipStream_t st) {
+    const long Bp = (B + 63) / 64 * 64;
+    const SocDev &d = s.sdev;
+    const long np = d.dim + d.n_s;
+    double *S = s.d_scratch;
+    hipLaunchKernelGGL(soc_stream_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, st, d, s.d_consts, s.d_idx, x0, xr, ur,
+                       ref_stride, r, r_stride, B, Bp, S, u, k, e);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    // record fields z, s, z_hat, s_hat, lambda, mu = row slices of PR, PH, DU
+    const double *base[3] = {S, S + np * Bp, S + 2 * np * Bp};
+    for (int i = 0; i < 6; i++) {
+        if (!f[i]) continue;
+        const int rows = (i % 2 == 0) ? d.dim : d.n_s;
+        const double *src = base[i / 2] + ((i % 2 == 0) ? 0 : (long)d.dim * Bp);
+        dim3 tg((unsigned)(Bp / 64), (unsigned)((rows + 63) / 64));
+        hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, src, Bp, B, rows, f[i]);
+    }
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int solve_device(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
-                        double *u, int *k, int *e, double *const *f, hipStream_t st) {
+                        double *u, int *k, int *e, double *const *f, const double *extra, int extra_stride,
+                        hipStream_t st) {
     if (B <= 0) return 0;
+    if (s.is_soc()) {
+        if (!extra) return fail(SPCIES_HIP_EINVAL, "ellipMPC soc solvers take a 4th input r (extra): Spcies:ellipMPC:nrhs:r");
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
+            return fail(SPCIES_HIP_ENOSUP, "ellipMPC soc: only the STREAM variant is built");
+        int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
+        if (rc) return rc;
+        return launch_soc(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, f, st);
+    }
     if (s.method == SPCIES_EADMM) {
         if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
             return fail(SPCIES_HIP_ENOSUP, "EADMM: only the STREAM variant is built");
@@ -396,7 +535,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     SPCIES_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     rc = upload_consts(*s);
     if (rc) return rc;
-    if (s->method == SPCIES_ADMM && s->formulation != SPCIES_MPCT) {
+    if (s->method == SPCIES_ADMM && (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC)) {
         rc = mfma_plan_build(s->mfma, s->host);
         if (rc) return rc;
         rc = mfma4_plan_build(s->mfma4, s->host);
@@ -413,6 +552,7 @@ int spcies_hip_destroy(spcies_hip_handle h) {
     if (s->d_consts) hipFree(s->d_consts);
     if (s->d_scratch) hipFree(s->d_scratch);
     if (s->d_io) hipFree(s->d_io);
+    if (s->d_idx) hipFree(s->d_idx);
     mfma_plan_free(s->mfma);
     mfma4_plan_free(s->mfma4);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -426,9 +566,9 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
     info->formulation = s->formulation;
     info->method = s->method;
     info->submethod = s->submethod;
-    info->n = s->host.n; info->m = s->host.m; info->N = s->host.N; info->dim = s->host.dim();
+    info->n = s->host.n; info->m = s->host.m; info->N = s->host.N; info->dim = s->is_soc() ? s->sdev.dim : s->host.dim();
     info->k_max = s->host.k_max; info->tol = s->host.tol; info->rho = s->host.rho;
-    info->variant = s->method != SPCIES_ADMM ? SPCIES_VARIANT_STREAM : resolve_variant(*s);
+    info->variant = (s->method != SPCIES_ADMM || s->is_soc()) ? SPCIES_VARIANT_STREAM : resolve_variant(*s);
     info->dim_lambda = s->lam_dim();
     info->device = s->device;
     return 0;
@@ -451,8 +591,8 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
 int spcies_hip_set_exit(spcies_hip_handle h, int k_max, double tol) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (k_max > 0) s->host.k_max = s->dev.k_max = s->fdev.k_max = s->edev.k_max = k_max;
-    if (tol >= 0) s->host.tol = s->dev.tol = s->fdev.tol = s->edev.tol = tol;
+    if (k_max > 0) s->host.k_max = s->dev.k_max = s->fdev.k_max = s->edev.k_max = s->sdev.k_max = k_max;
+    if (tol >= 0) s->host.tol = s->dev.tol = s->fdev.tol = s->edev.tol = s->sdev.tol_p = s->sdev.tol_d = tol;
     return 0;
 }
 
@@ -466,7 +606,8 @@ int spcies_hip_reserve(spcies_hip_handle h, long B) {
 
 // map the (z, v, lambda) triple of the classic entry points onto the record fields
 static int classic_fields(Solver *s, double *z, double *v, double *lambda, double **f) {
-    f[0] = f[1] = f[2] = f[3] = nullptr;
+    for (int i = 0; i < 6; i++) f[i] = nullptr;
+    if (s->is_soc()) return fail(SPCIES_HIP_EINVAL, "ellipMPC soc takes a 4th input r and a 6-field record: use the _ex entry points");
     if (s->method == SPCIES_EADMM) {
         if (z || v || lambda) return fail(SPCIES_HIP_EINVAL, "EADMM record is (z1, z2, z3, lambda): use the _ex entry points");
     } else if (s->method == SPCIES_FISTA) {
@@ -490,19 +631,19 @@ int spcies_hip_get_sol_layout(spcies_hip_handle h, int *n_fields, int *dims, con
 }
 
 int spcies_hip_solve_batch_device_ex(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
-                                     int ref_stride, long B, double *u, int *k, int *e_flag, double *const *fields,
-                                     int n_fields, void *stream) {
+                                     int ref_stride, const double *extra, int extra_stride, long B, double *u, int *k,
+                                     int *e_flag, double *const *fields, int n_fields, void *stream) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     if (B < 0) return fail(SPCIES_HIP_EINVAL, "negative batch");
     if (B == 0) return 0;
     if (!x0 || !xr || !ur || !u || !k || !e_flag) return fail(SPCIES_HIP_EINVAL, "NULL buffer");
     Solver *s = reinterpret_cast<Solver *>(h);
     if (fields && n_fields != s->n_fields()) return fail(SPCIES_HIP_EINVAL, "this solver's record has %d fields", s->n_fields());
-    double *f[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *f[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (fields) for (int i = 0; i < n_fields; i++) f[i] = fields[i];
     std::lock_guard<std::mutex> lk(s->mu);
     SPCIES_HIP_CHECK(hipSetDevice(s->device));
-    return solve_device(*s, x0, xr, ur, ref_stride, B, u, k, e_flag, f, (hipStream_t)stream);
+    return solve_device(*s, x0, xr, ur, ref_stride, B, u, k, e_flag, f, extra, extra_stride, (hipStream_t)stream);
 }
 
 int spcies_hip_solve_batch_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
@@ -510,16 +651,16 @@ int spcies_hip_solve_batch_device(spcies_hip_handle h, const double *x0, const d
                                   double *lambda, void *stream) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    double *f[4];
+    double *f[6];
     int rc = classic_fields(s, z, v, lambda, f);
     if (rc) return rc;
-    return spcies_hip_solve_batch_device_ex(h, x0, xr, ur, ref_stride, B, u, k, e_flag, (z || v || lambda) ? f : nullptr,
-                                            s->n_fields(), stream);
+    return spcies_hip_solve_batch_device_ex(h, x0, xr, ur, ref_stride, nullptr, 0, B, u, k, e_flag,
+                                            (z || v || lambda) ? f : nullptr, s->n_fields(), stream);
 }
 
 int spcies_hip_solve_batch_ex(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride,
-                              long B, double *u, int *k, int *e_flag, double *const *fields, int n_fields,
-                              spcies_hip_timing *timing) {
+                              const double *extra, int extra_stride, long B, double *u, int *k, int *e_flag,
+                              double *const *fields, int n_fields, spcies_hip_timing *timing) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     if (B < 0) return fail(SPCIES_HIP_EINVAL, "negative batch");
     if (timing) *timing = spcies_hip_timing{0, 0, 0, 0};
@@ -533,10 +674,11 @@ int spcies_hip_solve_batch_ex(spcies_hip_handle h, const double *x0, const doubl
     auto t0 = clk::now();
     const size_t n = s->host.n, m = s->host.m;
     const size_t nref = ref_stride ? (size_t)B : 1;
-    // device staging: x0 | xr | ur | u | fields... | k | e   (doubles first, ints last)
-    size_t nd = (size_t)B * n + nref * n + nref * m + (size_t)B * m;
-    const size_t o_x0 = 0, o_xr = (size_t)B * n, o_ur = o_xr + nref * n, o_u = o_ur + nref * m;
-    size_t o_f[4] = {0, 0, 0, 0};
+    // device staging: x0 | xr | ur | u | extra | fields... | k | e   (doubles first, ints last)
+    const size_t nex = extra ? (extra_stride ? (size_t)B : 1) : 0;
+    size_t nd = (size_t)B * n + nref * n + nref * m + (size_t)B * m + nex;
+    const size_t o_x0 = 0, o_xr = (size_t)B * n, o_ur = o_xr + nref * n, o_u = o_ur + nref * m, o_ex = o_u + (size_t)B * m;
+    size_t o_f[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; fields && i < n_fields; i++)
         if (fields[i]) { o_f[i] = nd; nd += (size_t)B * s->field_dim(i); }
     size_t need = nd * sizeof(double) + 2 * (size_t)B * sizeof(int);
@@ -552,12 +694,14 @@ int spcies_hip_solve_batch_ex(spcies_hip_handle h, const double *x0, const doubl
     SPCIES_HIP_CHECK(hipMemcpyAsync(d + o_x0, x0, (size_t)B * n * 8, hipMemcpyHostToDevice, st));
     SPCIES_HIP_CHECK(hipMemcpyAsync(d + o_xr, xr, nref * n * 8, hipMemcpyHostToDevice, st));
     SPCIES_HIP_CHECK(hipMemcpyAsync(d + o_ur, ur, nref * m * 8, hipMemcpyHostToDevice, st));
+    if (nex) SPCIES_HIP_CHECK(hipMemcpyAsync(d + o_ex, extra, nex * 8, hipMemcpyHostToDevice, st));
     SPCIES_HIP_CHECK(hipStreamSynchronize(st));
     auto t1 = clk::now();
-    double *f[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *f[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; fields && i < n_fields; i++)
         if (fields[i]) f[i] = d + o_f[i];
-    int rc = solve_device(*s, d + o_x0, d + o_xr, d + o_ur, ref_stride, B, d + o_u, dk, de, f, st);
+    int rc = solve_device(*s, d + o_x0, d + o_xr, d + o_ur, ref_stride, B, d + o_u, dk, de, f, nex ? d + o_ex : nullptr,
+                          extra_stride, st);
     if (rc) return rc;
     SPCIES_HIP_CHECK(hipStreamSynchronize(st));
     auto t2 = clk::now();
@@ -584,11 +728,11 @@ int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *
                            spcies_hip_timing *timing) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    double *f[4];
+    double *f[6];
     int rc = classic_fields(s, z, v, lambda, f);
     if (rc) return rc;
-    return spcies_hip_solve_batch_ex(h, x0, xr, ur, ref_stride, B, u, k, e_flag, (z || v || lambda) ? f : nullptr,
-                                     s->n_fields(), timing);
+    return spcies_hip_solve_batch_ex(h, x0, xr, ur, ref_stride, nullptr, 0, B, u, k, e_flag,
+                                     (z || v || lambda) ? f : nullptr, s->n_fields(), timing);
 }
 
 int spcies_hip_time_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride,

@@ -1,0 +1,83 @@
+"""ellipMPC, ADMM with the terminal ellipsoid imposed as a second-order cone ('soc' submethod) -
+host-side (offline) ingredients.
+
+Reference: ``formulations/+ellipMPC/compute_ellipMPC_ADMM_soc_ingredients.m:22-215``.  Decision
+vector ``z = (u0, x1, u1, ..., x_N, t)`` (``dim = N(n+m)+1``; the last entry is the cone's radius
+slack, fixed to ``r`` by the last equality row), slack ``s in R^{n+1}`` with
+``C z + s = d`` and ``s`` in the SOC.  ``W = Gh Hh^-1 Gh'`` is factorised ``L D L'`` (from its
+Cholesky factor) and stored as CSC of ``L - I`` plus ``Dinv``; ``-Gh Hh^-1``, ``-Hh^-1 Gh'`` and
+``-Hh^-1`` are stored CSR (0-based indices here; the reference subtracts 1 when printing,
+``cons_ellipMPC_ADMM_soc_C.m:98-110``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg as sla
+
+from .. import sp_utils
+from .laxMPC import _get, _is_diag, build_G
+
+
+def compute_ellipMPC_ADMM_soc_ingredients(controller, opt):
+    sys, param = _get(controller, "sys"), _get(controller, "param")
+    A = np.asarray(_get(sys, "A"), dtype=float)
+    B = np.asarray(_get(sys, "B"), dtype=float)
+    n, m = B.shape
+    nm = n + m
+    N = int(_get(param, "N"))
+    Q = np.asarray(_get(param, "Q"), dtype=float)
+    R = np.asarray(_get(param, "R"), dtype=float)
+    T = np.asarray(_get(param, "T"), dtype=float)
+    P = np.asarray(_get(param, "P"), dtype=float)
+    r = float(_get(param, "r", 1.0))
+    if not (_is_diag(Q) and _is_diag(R)):
+        raise ValueError("Spcies:ellipMPC:ADMM:non_diagonal - matrices Q and R must be diagonal")
+    if _get(param, "incBx") is not None or _get(param, "incBu") is not None:
+        raise NotImplementedError("HIP platform: incBx / incBu tightening is not built")
+    rho, sigma = float(opt.solver["rho"]), float(opt.solver["sigma"])
+    dim = N * nm + 1
+    H = np.zeros((dim, dim))
+    H[:m, :m] = R
+    for l in range(N - 1):
+        o = m + l * nm
+        H[o:o + n, o:o + n] = Q
+        H[o + n:o + nm, o + n:o + nm] = R
+    H[dim - 1 - n:dim - 1, dim - 1 - n:dim - 1] = T
+    G = build_G(A, B, N, terminal=True)
+    G = np.block([[G, np.zeros((G.shape[0], 1))], [np.zeros((1, G.shape[1])), np.ones((1, 1))]])
+    n_eq = G.shape[0]
+    P_half = np.real(sla.sqrtm(P))
+    Cm = np.hstack([np.zeros((n + 1, dim - n - 1)),
+                    np.block([[np.zeros((1, n)), -np.ones((1, 1))], [-P_half, np.zeros((n, 1))]])])
+    n_s = n + 1
+    LBx, UBx = np.ravel(_get(sys, "LBx")), np.ravel(_get(sys, "UBx"))
+    LBu, UBu = np.ravel(_get(sys, "LBu")), np.ravel(_get(sys, "UBu"))
+    LB = np.concatenate([LBu] + [np.concatenate([LBx, LBu])] * (N - 1)).astype(float)
+    UB = np.concatenate([UBu] + [np.concatenate([UBx, UBu])] * (N - 1)).astype(float)
+    Hh = np.block([[H + sigma * np.eye(dim), np.zeros((dim, n_s))], [np.zeros((n_s, dim)), rho * np.eye(n_s)]])
+    Gh = np.block([[G, np.zeros((n_eq, n_s))], [Cm, np.eye(n_s)]])
+    Hhi = np.linalg.inv(Hh)
+    W = Gh @ Hhi @ Gh.T
+    Wc = np.linalg.cholesky(W).T
+    wd = np.diag(Wc)
+    L = Wc.T / wd[None, :]
+    Dinv = 1.0 / (wd * wd)
+    Lv, Lr, Lc, *_ = sp_utils.full2CSC(L - np.eye(L.shape[0]))
+    csr = lambda M: sp_utils.full2CSR(M)[:3]
+    v = dict(n=n, m=m, N=N, formulation="ellipMPC", method="ADMM", submethod="soc", terminal=True,
+             dim=dim, n_s=n_s, n_eq=n_eq)
+    v["A"] = A.copy()
+    v["Q"], v["R"], v["T"] = -Q, -R, -T
+    v["LB"], v["UB"] = LB, UB
+    v["PhiP"] = np.linalg.inv(P_half) @ P
+    v["rho"], v["rho_i"], v["sigma"], v["sigma_i"] = rho, 1.0 / rho, sigma, 1.0 / sigma
+    v["L_val"], v["L_row"], v["L_col"], v["Dinv"] = Lv, Lr, Lc, Dinv
+    v["GhHhi_val"], v["GhHhi_col"], v["GhHhi_row"] = csr(-Gh @ Hhi)
+    v["HhiGh_val"], v["HhiGh_col"], v["HhiGh_row"] = csr(-Hhi @ Gh.T)
+    v["Hhi_val"], v["Hhi_col"], v["Hhi_row"] = csr(-Hhi)
+    v["k_max"] = int(opt.solver["k_max"])
+    v["tol_p"], v["tol_d"] = float(opt.solver["tol_p"]), float(opt.solver["tol_d"])
+    v["tol"] = v["tol_p"]
+    v["rho_is_scalar"] = True
+    v["r_default"] = r
+    return v

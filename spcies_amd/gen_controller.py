@@ -12,6 +12,7 @@ from __future__ import annotations
 from types import SimpleNamespace
 
 from .formulations import MPCT as _mpct
+from .formulations import ellipMPC as _ellip
 from .formulations import laxMPC as _lax
 from .options import SpciesOptions
 from .solver import HipSolver
@@ -42,8 +43,13 @@ def cons_MPCT_EADMM_HIP(recipe, device=0):
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 
+def cons_ellipMPC_ADMM_soc_HIP(recipe, device=0):
+    v = _ellip.compute_ellipMPC_ADMM_soc_ingredients(recipe.controller, recipe.options)
+    return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
+
+
 _CONSTRUCTORS = {f.__name__: f for f in (cons_laxMPC_ADMM_HIP, cons_equMPC_ADMM_HIP, cons_laxMPC_FISTA_HIP,
-                                         cons_equMPC_FISTA_HIP, cons_MPCT_EADMM_HIP)}
+                                         cons_equMPC_FISTA_HIP, cons_MPCT_EADMM_HIP, cons_ellipMPC_ADMM_soc_HIP)}
 
 
 def spcies_gen_controller(*, sys=None, param=None, device=0, **kw):

@@ -50,6 +50,8 @@ _DEF_SOLVER = {
     ("laxMPC", "FISTA", ""): dict(tol=1e-4, k_max=1000),
     ("equMPC", "FISTA", ""): dict(tol=1e-4, k_max=1000),
     # formulations/+MPCT/def_options_MPCT_EADMM.m
+    # formulations/+ellipMPC/def_options_ellipMPC_ADMM_soc.m
+    ("ellipMPC", "ADMM", "soc"): dict(rho=5, sigma=5, tol_p=1e-4, tol_d=1e-4, k_max=1000),
     ("MPCT", "EADMM", ""): dict(rho_base=3, rho_mult=20, epsilon_x=1e-6, epsilon_u=1e-6, tol=1e-4, k_max=1000),
 }
 

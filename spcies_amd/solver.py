@@ -114,9 +114,21 @@ class HipSolver:
             raise SpciesArgError(f"Spcies:{f}:nrhs:ur", f"ur must be of dimension {self.m}")
         return x0, xr, ur, B, per, single
 
-    def __call__(self, x0, xr, ur, want_sol=None):
-        """``u, k, e_flag, sol = solver(x0, xr, ur)``; host (numpy) buffers in and out."""
+    def __call__(self, x0, xr, ur, *extra_in, want_sol=None):
+        """``u, k, e_flag, sol = solver(x0, xr, ur)``; host (numpy) buffers in and out.  The ellipMPC soc
+        solver takes the ellipsoid radius as a 4th input, ``solver(x0, xr, ur, r)``
+        (``struct_ellipMPC_ADMM_soc_C_Matlab.c:24``), scalar or one value per instance."""
         x0, xr, ur, B, per, single = self._check_args(x0, xr, ur)
+        extra, extra_stride = None, 0
+        if self.formulation == "ellipMPC":
+            if len(extra_in) != 1:
+                raise SpciesArgError("Spcies:ellipMPC:nrhs:number", "Four inputs are required")
+            extra = np.ascontiguousarray(np.atleast_1d(np.asarray(extra_in[0], dtype=np.float64)).ravel())
+            if extra.size not in (1, B):
+                raise SpciesArgError("Spcies:ellipMPC:nrhs:r", "r must be a scalar (or one value per instance)")
+            extra_stride = 1 if (extra.size == B and B > 1) else 0
+        elif extra_in:
+            raise SpciesArgError(f"Spcies:{self.formulation}:nrhs:number", "Three inputs are required")
         want_sol = self.debug if want_sol is None else want_sol
         u = np.zeros((B, self.m))
         k = np.zeros(B, dtype=np.int32)
@@ -126,8 +138,8 @@ class HipSolver:
         ptrs = (dp * len(self.sol_fields))(*[_dp(a) for a in arrays]) if want_sol else None
         t = _lib.Timing()
         _lib.check(self._lib.spcies_hip_solve_batch_ex(
-            self._h, _dp(x0), _dp(xr), _dp(ur), int(per), B, _dp(u), _ip(k), _ip(e), ptrs, len(self.sol_fields),
-            C.byref(t)))
+            self._h, _dp(x0), _dp(xr), _dp(ur), int(per), _dp(extra) if extra is not None else None, extra_stride, B,
+            _dp(u), _ip(k), _ip(e), ptrs, len(self.sol_fields), C.byref(t)))
         fields = {name: (arrays[i] if want_sol else None) for i, (name, _) in enumerate(self.sol_fields)}
         if single:
             fields = {kf: (a[0] if a is not None else None) for kf, a in fields.items()}

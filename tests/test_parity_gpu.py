@@ -300,3 +300,54 @@ def test_mpct_vs_reference_template_fixture(golden_dir):
     u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
     assert np.array_equal(e, g["e_flag"]) and np.array_equal(k, g["k"])
     assert np.abs(u - g["u"]).max() <= 1e-9 and np.abs(sol.z1 - g["z1"]).max() <= 1e-9
+
+
+# ----------------------------------------------------------------------------------------------
+# ellipMPC ADMM soc: STREAM variant (CSR SpMV + CSC-LDL solve + SOC projection) -> bit-exact
+# ----------------------------------------------------------------------------------------------
+_SOC_FIELDS = ("z", "s", "z_hat", "s_hat", "lam", "mu")
+
+
+def test_soc_reference_test_instance(golden_dir):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import SpciesArgError
+    cfg, v, s = _fista_solver("C1_soc")
+    assert [f for f, _ in s.sol_fields] == ["z", "s", "z_hat", "s_hat", "lambda", "mu"]  # header_ellipMPC_ADMM_soc_C.h:14-24
+    st = benchmarks.tester_status(cfg.sys)
+    with pytest.raises(SpciesArgError):
+        s(st.x, st.xr, st.ur)  # the 4th input r is mandatory (struct_ellipMPC_ADMM_soc_C_Matlab.c:24)
+    u, k, e, sol = s(st.x, st.xr, st.ur, cfg.param.r)
+    with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
+        z_opt = np.array(json.load(f)["test_ellipMPC_ADMM_soc"])
+    assert e == 1 and np.abs(sol.z[:-1] - z_opt).max() <= TOL_OPT
+    O = oracle.admm_soc_batch(v, st.x[None], st.xr, st.ur, cfg.param.r)
+    assert k == O[1][0] and np.array_equal(u, O[0][0])
+    for name, ref in zip(_SOC_FIELDS, O[3:]):
+        assert np.array_equal(getattr(sol, name), ref[0]), name
+
+
+@pytest.mark.parametrize("cfg_name,B,overrides", [("C1_soc", 70, {}), ("C5_soc", 130, {}),
+                                                  ("C5_soc", 40, dict(tol_p=1e-6, tol_d=1e-6, k_max=3000))])
+def test_soc_seeded_batch_vs_oracle(cfg_name, B, overrides):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver(cfg_name, **overrides)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    r = cfg.param.r + 0.3 * np.random.default_rng(3).random(B)  # one radius per instance
+    u, k, e, sol = s(x0, xr, ur, r)
+    O = oracle.admm_soc_batch(v, x0, xr, ur, r)
+    assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+    for name, ref in zip(_SOC_FIELDS, O[3:]):
+        assert np.array_equal(getattr(sol, name), ref), name
+    shared = s(x0[:20], xr[:20], ur[:20], 0.4, want_sol=False)  # shared scalar radius
+    Os = oracle.admm_soc_batch(v, x0[:20], xr[:20], ur[:20], 0.4, want_sol=False)
+    assert np.array_equal(shared[0], Os[0]) and np.array_equal(shared[1], Os[1])
+
+
+def test_soc_vs_reference_template_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "template_C5_soc.npz"))
+    cfg, v, s = _fista_solver("C5_soc")
+    u, k, e, sol = s(g["x0"], g["xr"], g["ur"], g["r"])
+    assert np.array_equal(e, g["e_flag"]) and np.array_equal(k, g["k"])
+    assert np.abs(u - g["u"]).max() <= 1e-9 and np.abs(sol.z - g["z"]).max() <= 1e-9 and np.abs(sol.s - g["s"]).max() <= 1e-9
