@@ -19,6 +19,8 @@ from spcies_amd.solver import HipSolver
 
 def run(name, B, variant=None, reps=3):
     cfg = benchmarks.config(name)
+    if cfg.formulation == "ellipMPC":
+        return run_ex(cfg, name, B)
     v = benchmarks.ingredients(cfg)
     s = HipSolver(v)
     if variant:
@@ -41,9 +43,23 @@ def run(name, B, variant=None, reps=3):
     s.close()
 
 
+def run_ex(cfg, name, B):
+    """Solvers that need the _ex entry point (extra input): host-buffer call, kernel time from the timing record."""
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    s(x0[:256], xr[:256], ur[:256], cfg.param.r, want_sol=False)
+    u, k, e, sol = s(x0, xr, ur, cfg.param.r, want_sol=False)
+    print(json.dumps(dict(config=name, formulation=cfg.formulation, method=cfg.method, n=cfg.sys.n, m=cfg.sys.m,
+                          N=cfg.param.N, B=B, variant=s.variant, kernel_ms=round(sol.solve_time, 3),
+                          solves_per_s=round(B / sol.solve_time * 1e3), k_unique=np.unique(k).tolist()[:4])), flush=True)
+    s.close()
+
+
 if __name__ == "__main__":
     for var in ("mfma4", "mfma", "stream"):
         run("C2", 65536, var)
     run("C2_equ", 65536, "mfma4")
     run("C3", 262144)
     run("C4", 131072)
+    run("C5_soc", 65536)
