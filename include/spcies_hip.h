@@ -16,6 +16,8 @@
  *         (sol record holds z and lambda only: pass v = NULL; lambda is [B][N*n])
  *     void ellipMPC_ADMM_soc(double *x0_in, double *xr_in, double *ur_in, double *r_ellip, double *u_opt, ...)
  *         reference: formulations/+ellipMPC/header_ellipMPC_ADMM_soc_C.h:26 (extra input r, 6-field record: _ex)
+ *     void HMPC_ADMM(...same signature as laxMPC_ADMM...)   (ADMM or SADMM, split, sparse KKT, box constraints)
+ *         reference: formulations/+HMPC/header_HMPC_ADMM_split_C.h:27 (6-field record: _ex)
  *     void MPCT_EADMM(...same signature...)
  *         reference: formulations/+MPCT/header_MPCT_EADMM_C.h:26 (record z1, z2, z3, lambda: _ex entry points)
  *
@@ -98,7 +100,14 @@ enum spcies_array_id {
     SPCIES_A_DINV = 31,                                                   /* [n_eq + n_s]              */
     SPCIES_A_GHHHI_VAL = 32, SPCIES_A_GHHHI_COL = 33, SPCIES_A_GHHHI_ROW = 34, /* CSR of -Gh Hh^-1     */
     SPCIES_A_HHIGH_VAL = 35, SPCIES_A_HHIGH_COL = 36, SPCIES_A_HHIGH_ROW = 37, /* CSR of -Hh^-1 Gh'    */
-    SPCIES_A_HHI_VAL = 38, SPCIES_A_HHI_COL = 39, SPCIES_A_HHI_ROW = 40   /* CSR of -Hh^-1             */
+    SPCIES_A_HHI_VAL = 38, SPCIES_A_HHI_COL = 39, SPCIES_A_HHI_ROW = 40,  /* CSR of -Hh^-1             */
+    /* HMPC ADMM / SADMM split (cons_HMPC_ADMM_split_C.m:121-142): A (26), QQ as Q (7, dense [n][n]), LB / UB with
+     * dim-3(n+m) entries, L_* / Dinv (28-31) for the KKT factor; header flags bit1 = use_soc,
+     * reserved = {sigma, 1/sigma, tol_d, alpha_SADMM} */
+    SPCIES_A_TE = 41, SPCIES_A_SE = 42,      /* [n][n], [m][m]                                      */
+    SPCIES_A_LBY = 43, SPCIES_A_UBY = 44,    /* [n+m]                                               */
+    SPCIES_A_IDX_X0 = 45,                    /* i32 [n]: rows of bh that hold -A x0                 */
+    SPCIES_A_BH = 46                         /* [n_eq + n_s]                                        */
 };
 
 typedef struct {
@@ -182,7 +191,7 @@ int spcies_hip_solve_batch_device(spcies_hip_handle h, const double *x0, const d
 /* Solvers whose record is not (z, v, lambda) - and any solver, uniformly: `fields` holds one pointer per
  * field of the generated solver's sol_<name> struct, in the reference's order
  *     ADMM (lax/equ): z, v, lambda     FISTA: z, lambda     MPCT-EADMM: z1, z2, z3, lambda
- *     ellipMPC-ADMM-soc: z, s, z_hat, s_hat, lambda, mu
+ *     ellipMPC-ADMM-soc and HMPC-(S)ADMM-split: z, s, z_hat, s_hat, lambda, mu
  * (header_laxMPC_ADMM_C.h:14-22, header_laxMPC_FISTA_C.h:14-21, header_MPCT_EADMM_C.h:14-23,
  * header_ellipMPC_ADMM_soc_C.h:14-24); a NULL entry (or fields == NULL) skips that output.
  * `extra` carries formulation-specific extra inputs: the ellipsoid radius r of ellipMPC soc

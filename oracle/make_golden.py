@@ -51,7 +51,9 @@ def main():
                                ("C1_lax_FISTA", 16, {}), ("C1_equ_FISTA", 16, dict(k_max=500)),
                                ("C2_lax_FISTA", 32, {}), ("C2_lax_FISTA", 32, dict(tol=1e-6, k_max=2000)),
                                ("C2_equ_FISTA", 32, {}), ("C1_MPCT", 16, {}), ("C4", 8, {}),
-                               ("C1_soc", 12, {}), ("C5_soc", 8, {})):
+                               ("C1_soc", 12, {}), ("C5_soc", 8, {}),
+                               ("C1_HMPC", 6, {}), ("C1_HMPC_SADMM", 6, {}), ("C1_HMPC_soc", 4, {}),
+                               ("C1_HMPC_SADMM_soc", 4, {}), ("C5_HMPC_SADMM", 4, {})):
         cfg = benchmarks.config(name)
         v = benchmarks.ingredients(cfg, **overrides)
         x0, xr, ur = benchmarks.sample_batch(cfg, B)
@@ -60,6 +62,15 @@ def main():
             x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
         tag = name + ("_conv" if overrides else "")
         so = ref_template.build_admm(v, "golden_" + tag)
+        if v.get("submethod") == "split":
+            T = ref_template.run_hmpc(so, v, x0, xr, ur)
+            O = oracle.admm_hmpc_batch(v, x0, xr, ur)
+            print(tag, "template-vs-oracle(full doubles): z %.2e s %.2e dk %d" % (
+                np.abs(T[3] - O[3]).max(), np.abs(T[4] - O[4]).max(), np.abs(T[1] - O[1]).max()))
+            np.savez_compressed(os.path.join(OUT, f"template_{tag}.npz"), x0=x0, xr=xr, ur=ur, u=T[0], k=T[1],
+                                e_flag=T[2], z=T[3], s=T[4], z_hat=T[5], s_hat=T[6], lam=T[7], mu=T[8],
+                                solver_overrides=json.dumps(overrides))
+            continue
         if v.get("submethod") == "soc":
             r = cfg.param.r + 0.01 * np.arange(B)
             if name == "C1_soc":

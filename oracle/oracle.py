@@ -13,7 +13,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c", "eadmm_mpct_oracle.c", "admm_soc_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c", "eadmm_mpct_oracle.c", "admm_soc_oracle.c", "admm_hmpc_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return so
@@ -211,4 +211,53 @@ def admm_soc_batch(v, x0, xr, ur, r, want_sol=True, quantize=False):
                                    C.c_int(rstride), _dp(u), ipt(k), ipt(e), o(z), o(s), o(zh), o(sh), o(lam), o(mu))
     if rc != 0:
         raise RuntimeError(f"oracle_admm_soc_batch failed rc={rc}")
+    return u, k, e, z, s, zh, sh, lam, mu
+
+
+_HMPC_F64 = (("A", "A"), ("QQ", "Q"), ("Te", "Te"), ("Se", "Se"), ("LB", "LB"), ("UB", "UB"), ("LBy", "LBy"), ("UBy", "UBy"))
+
+
+class _HmpcData(C.Structure):
+    _fields_ = ([(k_, C.c_int) for k_ in ("n", "m", "N", "dim", "n_s", "n_eq", "n_soc", "nrow_M", "k_max", "use_soc", "symmetric")]
+                + [(k_, C.c_double) for k_ in ("tol_p", "tol_d", "rho", "rho_i", "sigma", "sigma_i", "alpha")]
+                + [(k_, C.POINTER(C.c_double)) for k_, _ in _HMPC_F64]
+                + [("L_val", C.POINTER(C.c_double)), ("L_col", C.POINTER(C.c_int)), ("L_row", C.POINTER(C.c_int)),
+                   ("Dinv", C.POINTER(C.c_double)), ("idx_x0", C.POINTER(C.c_int)), ("bh", C.POINTER(C.c_double))])
+
+
+def admm_hmpc_batch(v, x0, xr, ur, want_sol=True, quantize=False):
+    """C oracle of HMPC ADMM / SADMM split.  Returns ``u, k, e_flag, z, s, z_hat, s_hat, lam, mu``."""
+    n, m = int(v["n"]), int(v["m"])
+    qz = quantize_like_reference if quantize else (lambda a: a)
+    keep, fields = {}, {}
+    ipt = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    for k_, s_ in _HMPC_F64 + (("L_val", "L_val"), ("Dinv", "Dinv"), ("bh", "bh")):
+        a = np.ascontiguousarray(qz(np.asarray(v[s_], dtype=float)))
+        if quantize and k_ in ("LB", "UB", "LBy", "UBy"):
+            a = np.clip(a, -1e20, 1e20)
+        keep[k_] = a
+        fields[k_] = _dp(a)
+    for k_ in ("L_col", "L_row", "idx_x0"):
+        keep[k_] = np.ascontiguousarray(np.asarray(v[k_], dtype=np.int32))
+        fields[k_] = ipt(keep[k_])
+    sc = {k_: (float(qz(v[k_])) if quantize else float(v[k_])) for k_ in ("tol_p", "tol_d", "rho", "rho_i", "sigma", "sigma_i")}
+    d = _HmpcData(n=n, m=m, N=int(v["N"]), dim=int(v["dim"]), n_s=int(v["n_s"]), n_eq=int(v["n_eq"]), n_soc=int(v["n_soc"]),
+                  nrow_M=int(v["nrow_M"]), k_max=int(v["k_max"]), use_soc=int(v["use_soc"]),
+                  symmetric=int(v["method"] == "SADMM"), alpha=float(v["alpha"]), **sc, **fields)
+    x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
+    B = x0.shape[0]
+    xr = np.ascontiguousarray(np.asarray(xr, dtype=float))
+    ur = np.ascontiguousarray(np.asarray(ur, dtype=float))
+    stride = 1 if xr.ndim == 2 else 0
+    dim, n_s = int(v["dim"]), int(v["n_s"])
+    u = np.zeros((B, m)); k = np.zeros(B, dtype=np.int32); e = np.zeros(B, dtype=np.int32)
+    mk = lambda w: np.zeros((B, w)) if want_sol else None
+    z, s, zh, sh, lam, mu = mk(dim), mk(n_s), mk(dim), mk(n_s), mk(dim), mk(n_s)
+    o = lambda a: _dp(a) if a is not None else None
+    lib = _lib()
+    lib.oracle_admm_hmpc_batch.restype = C.c_int
+    rc = lib.oracle_admm_hmpc_batch(C.byref(d), C.c_long(B), _dp(x0), _dp(xr), _dp(ur), C.c_int(stride), _dp(u), ipt(k),
+                                    ipt(e), o(z), o(s), o(zh), o(sh), o(lam), o(mu))
+    if rc != 0:
+        raise RuntimeError(f"oracle_admm_hmpc_batch failed rc={rc}")
     return u, k, e, z, s, zh, sh, lam, mu

@@ -91,6 +91,8 @@ def build_admm(v, name):
     form, method = v["formulation"], v.get("method", "ADMM")
     if v.get("submethod") == "soc":
         return _build_soc(v, name)
+    if v.get("submethod") == "split":
+        return _build_hmpc(v, name)
     fdir = os.path.join(REF, "formulations", f"+{form}")
     n, m, N = v["n"], v["m"], v["N"]
     defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
@@ -255,6 +257,74 @@ def run_soc(so, v, x0, xr, ur, r):
         ri = C.c_double(r[i] if r.size == B and B > 1 else r[0])
         ui = np.zeros(m); ki = C.c_int(0); ei = C.c_int(0)
         fn(dp(xi), dp(xri), dp(uri), C.byref(ri), dp(ui), C.byref(ki), C.byref(ei), C.byref(sol))
+        u[i] = ui; k[i] = ki.value; e[i] = ei.value
+        for f in out:
+            out[f][i] = np.frombuffer(getattr(sol, f))
+    return (u, k, e, out["z"], out["s"], out["z_hat"], out["s_hat"], out["lam"], out["mu"])
+
+
+def _build_hmpc(v, name):
+    """HMPC ADMM / SADMM split, sparse + box constraints: cons_HMPC_ADMM_split_C.m:88-181.  (`bh` goes to
+    $INSERT_VARIABLES$ as a non-const array; scalars rho.. carry no 'array' flag.)"""
+    fdir = os.path.join(REF, "formulations", "+HMPC")
+    n, m, N = v["n"], v["m"], v["N"]
+    defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
+            "#define IS_DIAG 1", f"#define nn_ {n}", f"#define mm_ {m}", f"#define nm_ {n + m}", f"#define NN_ {N}",
+            f"#define dim {v['dim']}", f"#define n_s {v['n_s']}", f"#define n_eq {v['n_eq']}", f"#define n_soc {v['n_soc']}",
+            f"#define nrow_M {v['nrow_M']}", f"#define k_max {int(v['k_max'])}", f"#define tol_p {_fmt(v['tol_p'])}",
+            f"#define tol_d {_fmt(v['tol_d'])}"]
+    if v["method"] == "SADMM":
+        defs += [f"#define alpha_SADMM {_fmt(v['alpha'])}", "#define IS_SYMMETRIC 1"]
+    if v["use_soc"]:
+        defs += ["#define USE_SOC 1"]
+    consts = "".join(_decl_scalar(k, v[k]) for k in ("rho", "rho_i", "sigma", "sigma_i"))
+    consts += "".join(_decl(cn, v[k]) for cn, k in (("A", "A"), ("QQ", "Q"), ("Te", "Te"), ("Se", "Se"), ("LB", "LB"),
+                                                    ("UB", "UB"), ("LBy", "LBy"), ("UBy", "UBy"), ("L_val", "L_val")))
+    consts += _decl_int("L_col", v["L_col"]) + _decl_int("L_row", v["L_row"]) + _decl("Dinv", v["Dinv"]) + _decl_int("idx_x0", v["idx_x0"])
+    variables = _decl("bh", v["bh"]).replace("const static ", "")
+    with open(os.path.join(REF, "platforms", "+C_code", "generic_solver_struct.c")) as f:
+        code = f.read()
+    with open(os.path.join(fdir, "code_HMPC_ADMM_split_C.c")) as f:
+        code = code.replace("$INSERT_SOLVER$", f.read())
+    with open(os.path.join(fdir, "header_HMPC_ADMM_split_C.h")) as f:
+        header = f.read()
+    code = code.replace("$INSERT_CONSTANTS$", consts).replace("$INSERT_VARIABLES$", variables)
+    header = header.replace("$INSERT_DEFINES$", "\n".join(defs))
+    code, header = _snippets(code, "c"), _snippets(header, "h")
+    code = _unescape(code.replace("$INSERT_NAME$", name))
+    header = _unescape(header.replace("$INSERT_NAME$", name))
+    os.makedirs(OUT, exist_ok=True)
+    so = os.path.join(OUT, f"lib{name}.so")
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, f"{name}.c"), "w") as f:
+            f.write(code)
+        with open(os.path.join(td, f"{name}.h"), "w") as f:
+            f.write(header)
+        subprocess.check_call(["gcc", "-O3", "-fPIC", "-shared", "-w", "-o", so, os.path.join(td, f"{name}.c"), "-lm"])
+    return so
+
+
+def run_hmpc(so, v, x0, xr, ur):
+    """``HMPC_ADMM(x0, xr, ur, u, &k, &e, &sol)``; returns u, k, e, z, s, z_hat, s_hat, lam, mu."""
+    n, m, dim, n_s = v["n"], v["m"], v["dim"], v["n_s"]
+    lib = C.CDLL(so)
+    fn = lib.HMPC_ADMM
+
+    class Sol(C.Structure):
+        _fields_ = [("z", C.c_double * dim), ("s", C.c_double * n_s), ("z_hat", C.c_double * dim),
+                    ("s_hat", C.c_double * n_s), ("lam", C.c_double * dim), ("mu", C.c_double * n_s), ("t", C.c_double * 4)]
+    x0 = np.atleast_2d(np.asarray(x0, float))
+    B = x0.shape[0]
+    per = np.ndim(xr) == 2
+    u = np.zeros((B, m)); k = np.zeros(B, np.int32); e = np.zeros(B, np.int32)
+    out = {f: np.zeros((B, w)) for f, w in (("z", dim), ("s", n_s), ("z_hat", dim), ("s_hat", n_s), ("lam", dim), ("mu", n_s))}
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for i in range(B):
+        sol = Sol()
+        xi = np.ascontiguousarray(x0[i]); xri = np.ascontiguousarray(xr[i] if per else xr)
+        uri = np.ascontiguousarray(ur[i] if per else ur)
+        ui = np.zeros(m); ki = C.c_int(0); ei = C.c_int(0)
+        fn(dp(xi), dp(xri), dp(uri), dp(ui), C.byref(ki), C.byref(ei), C.byref(sol))
         u[i] = ui; k[i] = ki.value; e[i] = ei.value
         for f in out:
             out[f][i] = np.frombuffer(getattr(sol, f))

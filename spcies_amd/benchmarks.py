@@ -89,6 +89,22 @@ def config(name):
             c.param.N, c.param.r, c.B = 15, 0.5, 524288
             c.solver_options.update(k_max=200, tol_p=0.0, tol_d=0.0)
         return c
+    if name.startswith("C1_HMPC") or name.startswith("C5_HMPC"):
+        # tests/test_HMPC_ADMM_s.m / test_HMPC_SADMM_s.m:6-22; C5: 12-state, N = 15, 200 fixed iterations
+        sys = sp_utils.oscillating_masses_sys(3 if name.startswith("C1") else 6)
+        Q, R, _ = _weights(sys, "diag")
+        N = 10 if name.startswith("C1") else 15
+        c = SimpleNamespace(name=name, sys=sys, formulation="HMPC", method="SADMM" if "SADMM" in name else "ADMM",
+                            submethod="split",
+                            param=SimpleNamespace(N=N, w=3 * 1.627 * 0.2, Q=Q, R=R, Te=10 * N * Q, Th=10 * N * Q, Se=R,
+                                                  Sh=0.5 * R),
+                            solver_options=dict(rho=2, sigma=20, k_max=5000, tol_p=1e-7, tol_d=1e-7, sparse=True,
+                                                use_soc="soc" in name, box_constraints=True),
+                            B=1, seed=1205)
+        if name.startswith("C5"):
+            c.B = 524288
+            c.solver_options.update(k_max=200, tol_p=0.0, tol_d=0.0)
+        return c
     raise KeyError(name)
 
 
@@ -109,7 +125,7 @@ def sample_batch(cfg, B=None, seed=None, around_xr=None):
 
 
 def ingredients(cfg, **solver_overrides):
-    from .formulations import MPCT, ellipMPC, laxMPC
+    from .formulations import HMPC, MPCT, ellipMPC, laxMPC
     from .options import SpciesOptions
     so = dict(cfg.solver_options)
     so.update(solver_overrides)
@@ -120,5 +136,7 @@ def ingredients(cfg, **solver_overrides):
           ("laxMPC", "FISTA"): laxMPC.compute_laxMPC_FISTA_ingredients,
           ("equMPC", "FISTA"): laxMPC.compute_equMPC_FISTA_ingredients,
           ("MPCT", "EADMM"): MPCT.compute_MPCT_EADMM_ingredients,
-          ("ellipMPC", "ADMM"): ellipMPC.compute_ellipMPC_ADMM_soc_ingredients}
+          ("ellipMPC", "ADMM"): ellipMPC.compute_ellipMPC_ADMM_soc_ingredients,
+          ("HMPC", "ADMM"): HMPC.compute_HMPC_ADMM_split_ingredients,
+          ("HMPC", "SADMM"): HMPC.compute_HMPC_ADMM_split_ingredients}
     return fn[(cfg.formulation, cfg.method)](ctrl, opt)

@@ -9,6 +9,7 @@
 #include "fista_stream.hpp"
 #include "eadmm_stream.hpp"
 #include "soc_stream.hpp"
+#include "hmpc_stream.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -26,12 +27,16 @@ struct Solver {
     FistaDev fdev{};
     std::vector<double> QRi, Td, Ti;  // FISTA-only ingredients
     SocDev sdev{};
+    HmpcDev hdev{};
     std::vector<double> soc_f64;   // ellipMPC-soc: all FP64 constants, concatenated
     std::vector<int> soc_i32;      //               all index arrays, concatenated
     int *d_idx = nullptr;
     EadmmDev edev{};
     std::vector<double> e_rho, e_rho0, e_rhos, e_LB0, e_UB0, e_LBs, e_UBs, e_S, e_H1i, e_W2, e_H3i;  // EADMM-only
-    bool is_soc() const { return formulation == SPCIES_ELLIPMPC; }
+    bool is_soc() const { return formulation == SPCIES_ELLIPMPC || formulation == SPCIES_HMPC; }  // 6-field (z, s, ...) record
+    bool is_hmpc() const { return formulation == SPCIES_HMPC; }
+    int soc_dim() const { return is_hmpc() ? hdev.dim : sdev.dim; }
+    int soc_ns() const { return is_hmpc() ? hdev.n_s : sdev.n_s; }
     int lam_dim() const {
         if (method == SPCIES_FISTA) return host.N * host.n;
         if (method == SPCIES_EADMM) return (host.N + 3) * (host.n + host.m);
@@ -45,7 +50,7 @@ struct Solver {
     int n_fields() const { return is_soc() ? 6 : (method == SPCIES_FISTA ? 2 : (method == SPCIES_EADMM ? 4 : 3)); }
     int field_dim(int i) const {
         const int nm = host.n + host.m;
-        if (is_soc()) return (i % 2 == 0) ? sdev.dim : sdev.n_s;
+        if (is_soc()) return (i % 2 == 0) ? soc_dim() : soc_ns();
         if (method == SPCIES_FISTA) return i == 0 ? host.dim() : lam_dim();
         if (method == SPCIES_EADMM) return i == 1 ? nm : (i == 3 ? lam_dim() : (host.N + 1) * nm);
         return host.dim();
@@ -169,6 +174,61 @@ static int parse_soc(const uint8_t *blob, size_t bytes, const spcies_blob_header
     return 0;
 }
 
+// HMPC ADMM / SADMM split, sparse KKT path, box constraints (cons_HMPC_ADMM_split_C.m:88-181)
+static int parse_hmpc(const uint8_t *blob, size_t bytes, const spcies_blob_header &h, Solver &s) {
+    s.formulation = (int)h.formulation; s.method = (int)h.method; s.submethod = (int)h.submethod;
+    AdmmHost &a = s.host;
+    a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max; a.terminal = true;
+    a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
+    if (h.n == 0 || h.m == 0 || h.N < 3 || h.n > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0) || !(h.reserved[0] > 0))
+        return fail(SPCIES_HIP_EINVAL, "bad n/m/N/k_max/rho/sigma");
+    const int n = a.n, m = a.m, N = a.N, nm = n + m;
+    HmpcDev &d = s.hdev;
+    d.n = n; d.m = m; d.N = N; d.use_soc = (h.flags & 2u) ? 1 : 0; d.symmetric = (h.method == SPCIES_SADMM);
+    d.dim = (N - 1) * nm + m + 3 * nm; d.n_eq = (N + 3) * n; d.n_soc = d.use_soc ? 2 * nm : nm; d.n_s = 3 * d.n_soc;
+    d.nrow_M = d.dim + d.n_s + d.n_eq + d.n_s; d.k_max = a.k_max;
+    d.tol_p = h.tol; d.tol_d = h.reserved[2]; d.rho = h.rho; d.rho_i = h.rho_i; d.sigma = h.reserved[0];
+    d.sigma_i = h.reserved[1]; d.alpha = h.reserved[3];
+    const int nc = d.n_eq + d.n_s;
+    struct F { uint32_t id; uint64_t want; int *off; };
+    F fs[] = {{SPCIES_A_A, (uint64_t)n * n, &d.A}, {SPCIES_A_Q, (uint64_t)n * n, &d.QQ}, {SPCIES_A_TE, (uint64_t)n * n, &d.Te},
+              {SPCIES_A_SE, (uint64_t)m * m, &d.Se}, {SPCIES_A_LB, (uint64_t)(d.dim - 3 * nm), &d.LB},
+              {SPCIES_A_UB, (uint64_t)(d.dim - 3 * nm), &d.UB}, {SPCIES_A_LBY, (uint64_t)nm, &d.LBy},
+              {SPCIES_A_UBY, (uint64_t)nm, &d.UBy}, {SPCIES_A_L_VAL, 0, &d.L_val}, {SPCIES_A_DINV, (uint64_t)d.nrow_M, &d.Dinv},
+              {SPCIES_A_BH, (uint64_t)nc, &d.bh}};
+    uint64_t nnz = 0;
+    for (auto &f : fs) {
+        uint64_t cnt = 0;
+        const double *p = find_farray_any(blob, bytes, h, f.id, &cnt);
+        if (!p || (f.want && cnt != f.want)) return fail(SPCIES_HIP_EINVAL, "blob array id %u missing or mis-sized", f.id);
+        *f.off = (int)s.soc_f64.size();
+        s.soc_f64.insert(s.soc_f64.end(), p, p + cnt);
+        while (s.soc_f64.size() % 8) s.soc_f64.push_back(0.0);
+        if (f.want == 0) nnz = cnt;
+    }
+    struct G { uint32_t id; uint64_t want; int *off; int maxval; bool is_ptr; };
+    G gs[] = {{SPCIES_A_L_COL, (uint64_t)d.nrow_M + 1, &d.L_col, (int)nnz, true},
+              {SPCIES_A_L_ROW, nnz, &d.L_row, d.nrow_M - 1, false},
+              {SPCIES_A_IDX_X0, (uint64_t)n, &d.idx_x0, nc - 1, false}};
+    for (auto &g : gs) {
+        uint64_t cnt = 0;
+        const int *p = find_iarray(blob, bytes, h, g.id, &cnt);
+        if (!p || cnt != g.want) return fail(SPCIES_HIP_EINVAL, "blob index array id %u missing or mis-sized", g.id);
+        for (uint64_t i = 0; i < cnt; i++) {
+            if (p[i] < 0 || p[i] > g.maxval) return fail(SPCIES_HIP_EINVAL, "blob index array id %u: value out of range", g.id);
+            if (g.is_ptr && i > 0 && p[i] < p[i - 1]) return fail(SPCIES_HIP_EINVAL, "blob pointer array id %u not monotone", g.id);
+        }
+        if (g.is_ptr && (p[0] != 0 || p[cnt - 1] != g.maxval)) return fail(SPCIES_HIP_EINVAL, "blob pointer array id %u: bad ends", g.id);
+        *g.off = (int)s.soc_i32.size();
+        s.soc_i32.insert(s.soc_i32.end(), p, p + cnt);
+    }
+    const int *Lc = s.soc_i32.data() + d.L_col, *Lr = s.soc_i32.data() + d.L_row;
+    for (int i = 0; i < d.nrow_M; i++)
+        for (int j = Lc[i]; j < Lc[i + 1]; j++)
+            if (Lr[j] <= i) return fail(SPCIES_HIP_EINVAL, "L - I is not strictly lower triangular");
+    return 0;
+}
+
 static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     const uint8_t *blob = static_cast<const uint8_t *>(blobv);
     if (!blob || bytes < sizeof(spcies_blob_header)) return fail(SPCIES_HIP_EINVAL, "blob too small");
@@ -184,6 +244,8 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     const bool mpct = (h.method == SPCIES_EADMM && h.formulation == SPCIES_MPCT);
     const bool soc = (h.method == SPCIES_ADMM && h.formulation == SPCIES_ELLIPMPC && h.submethod == 1);
     if (soc) return parse_soc(blob, bytes, h, s);
+    if (h.formulation == SPCIES_HMPC && (h.method == SPCIES_ADMM || h.method == SPCIES_SADMM) && h.submethod == 2)
+        return parse_hmpc(blob, bytes, h, s);
     if (!banded && !mpct)
         return fail(SPCIES_HIP_ENOSUP, "formulation %u / method %u not built in this library", h.formulation, h.method);
     if (h.method == SPCIES_ADMM && !(h.flags & 1u)) return fail(SPCIES_HIP_ENOSUP, "vector rho not built");
@@ -296,6 +358,8 @@ static size_t stream_scratch_bytes(const Solver &s, long B, bool want_sol) {
     if (s.method == SPCIES_EADMM)
         rows = (size_t)(3 * s.host.N + 5) * (s.host.n + s.host.m) + (size_t)s.host.N * s.host.n;
     if (s.is_soc()) rows = 4 * (size_t)(s.sdev.dim + s.sdev.n_s) + 2 * (size_t)(s.sdev.n_eq + s.sdev.n_s) + (size_t)s.sdev.dim;
+    if (s.is_hmpc())
+        rows = 2 * (size_t)(s.hdev.dim + s.hdev.n_s) + (size_t)s.hdev.nrow_M + (size_t)(s.hdev.n_eq + s.hdev.n_s) + (size_t)s.hdev.dim;
     return rows * (size_t)Bp * sizeof(double);
 }
 
@@ -453,10 +517,39 @@ static int launch_soc(Solver &s, const double *x0, const double *xr, const doubl
     return 0;
 }
 
+static int launch_hmpc(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u,
+                       int *k, int *e, double *const *f, hipStream_t st) {
+    const long Bp = (B + 63) / 64 * 64;
+    const HmpcDev &d = s.hdev;
+    const long np = d.dim + d.n_s;
+    double *S = s.d_scratch;
+    hipLaunchKernelGGL(hmpc_stream_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, st, d, s.d_consts, s.d_idx, x0, xr, ur,
+                       ref_stride, B, Bp, S, u, k, e);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    // record fields z, s, z_hat, s_hat, lambda, mu: row slices of PR, RH (the solved rhs holds z_hat, s_hat), DU
+    const double *base[3] = {S, S + 2 * np * Bp, S + np * Bp};
+    for (int i = 0; i < 6; i++) {
+        if (!f[i]) continue;
+        const int rows = (i % 2 == 0) ? d.dim : d.n_s;
+        const double *src = base[i / 2] + ((i % 2 == 0) ? 0 : (long)d.dim * Bp);
+        dim3 tg((unsigned)(Bp / 64), (unsigned)((rows + 63) / 64));
+        hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, src, Bp, B, rows, f[i]);
+    }
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int solve_device(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                         double *u, int *k, int *e, double *const *f, const double *extra, int extra_stride,
                         hipStream_t st) {
     if (B <= 0) return 0;
+    if (s.is_hmpc()) {
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
+            return fail(SPCIES_HIP_ENOSUP, "HMPC: only the STREAM variant is built");
+        int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
+        if (rc) return rc;
+        return launch_hmpc(s, x0, xr, ur, ref_stride, B, u, k, e, f, st);
+    }
     if (s.is_soc()) {
         if (!extra) return fail(SPCIES_HIP_EINVAL, "ellipMPC soc solvers take a 4th input r (extra): Spcies:ellipMPC:nrhs:r");
         if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
@@ -591,8 +684,9 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
 int spcies_hip_set_exit(spcies_hip_handle h, int k_max, double tol) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (k_max > 0) s->host.k_max = s->dev.k_max = s->fdev.k_max = s->edev.k_max = s->sdev.k_max = k_max;
-    if (tol >= 0) s->host.tol = s->dev.tol = s->fdev.tol = s->edev.tol = s->sdev.tol_p = s->sdev.tol_d = tol;
+    if (k_max > 0) s->host.k_max = s->dev.k_max = s->fdev.k_max = s->edev.k_max = s->sdev.k_max = s->hdev.k_max = k_max;
+    if (tol >= 0)
+        s->host.tol = s->dev.tol = s->fdev.tol = s->edev.tol = s->sdev.tol_p = s->sdev.tol_d = s->hdev.tol_p = s->hdev.tol_d = tol;
     return 0;
 }
 
@@ -607,7 +701,7 @@ int spcies_hip_reserve(spcies_hip_handle h, long B) {
 // map the (z, v, lambda) triple of the classic entry points onto the record fields
 static int classic_fields(Solver *s, double *z, double *v, double *lambda, double **f) {
     for (int i = 0; i < 6; i++) f[i] = nullptr;
-    if (s->is_soc()) return fail(SPCIES_HIP_EINVAL, "ellipMPC soc takes a 4th input r and a 6-field record: use the _ex entry points");
+    if (s->is_soc()) return fail(SPCIES_HIP_EINVAL, "this solver has a 6-field record (z, s, z_hat, s_hat, lambda, mu): use the _ex entry points");
     if (s->method == SPCIES_EADMM) {
         if (z || v || lambda) return fail(SPCIES_HIP_EINVAL, "EADMM record is (z1, z2, z3, lambda): use the _ex entry points");
     } else if (s->method == SPCIES_FISTA) {

@@ -1,0 +1,151 @@
+"""HMPC (harmonic MPC), ADMM / SADMM with the (z_hat, s_hat) = (z, s) splitting ('split' submethod),
+sparse KKT path, box constraints - host-side (offline) ingredients.
+
+Reference: ``formulations/+HMPC/compute_HMPC_ADMM_split_ingredients.m:23-323`` (the SADMM file is the
+same computation).  Decision vector ``z = (u0, x1, u1, ..., x_{N-1}, u_{N-1}, xe, xs, xc, ue, us, uc)``
+(``dim = (N-1)(n+m) + m + 3(n+m)``), slack ``s`` with ``C z + s = d`` in a product of 3-D cones
+("diamond" = two shifted SOCs per constrained signal, or plain SOCs with ``use_soc``).  The KKT
+matrix ``M = [Hh Gh'; Gh 0]`` (quasi-definite) is factorised ``L D L'`` with diagonal ``D``.
+
+The reference takes whatever permutation MATLAB's ``ldl`` returns (``:228-234``) - the iterates do
+not depend on it - so the factorisation order is ours to choose: primal block first in natural order
+(the solver writes its right-hand side there, ``code_HMPC_ADMM_split_C.c:156-165``), constraint rows
+after it in a reverse-Cuthill-McKee order of their Schur complement to limit fill.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+from .. import sp_utils
+from .laxMPC import _get
+
+
+def _ldl_nopivot(M):
+    """Dense L D L' without pivoting (exists for every symmetric permutation of a quasi-definite matrix)."""
+    n = M.shape[0]
+    L = np.eye(n)
+    D = np.zeros(n)
+    A = M.copy()
+    for j in range(n):
+        D[j] = A[j, j]
+        if D[j] == 0.0:
+            raise np.linalg.LinAlgError("zero pivot in the KKT LDL factorisation")
+        L[j + 1:, j] = A[j + 1:, j] / D[j]
+        A[j + 1:, j + 1:] -= np.outer(L[j + 1:, j], A[j, j + 1:])
+    return L, D
+
+
+def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
+    sys, param = _get(controller, "sys"), _get(controller, "param")
+    A = np.asarray(_get(sys, "A"), dtype=float)
+    B = np.asarray(_get(sys, "B"), dtype=float)
+    n, m = B.shape
+    nm = n + m
+    so = opt.solver
+    if so.get("box_constraints") is False or _get(sys, "E") is not None:
+        raise NotImplementedError("HIP platform: HMPC with coupled output constraints (E, F) is not built")
+    if not so.get("sparse", False):
+        raise NotImplementedError("HIP platform: HMPC split is built for the sparse KKT path (options.sparse = true)")
+    use_soc = bool(so.get("use_soc", False))
+    LBx, UBx = np.ravel(_get(sys, "LBx")).astype(float), np.ravel(_get(sys, "UBx")).astype(float)
+    LBu, UBu = np.ravel(_get(sys, "LBu")).astype(float), np.ravel(_get(sys, "UBu")).astype(float)
+    LBy, UBy = np.concatenate([LBx, LBu]), np.concatenate([UBx, UBu])
+    n_y = nm
+    N = int(_get(param, "N"))
+    w = float(_get(param, "w"))
+    Q, R = np.asarray(_get(param, "Q"), float), np.asarray(_get(param, "R"), float)
+    Te, Th = np.asarray(_get(param, "Te"), float), np.asarray(_get(param, "Th"), float)
+    Se, Sh = np.asarray(_get(param, "Se"), float), np.asarray(_get(param, "Sh"), float)
+    rho, sigma = float(so["rho"]), float(so["sigma"])
+    sj, cj = np.sin(w * np.arange(N)), np.cos(w * np.arange(N))
+    s_sum, c_sum, s2, c2, sc = sj.sum(), cj.sum(), (sj ** 2).sum(), (cj ** 2).sum(), (sj * cj).sum()
+    # ---- Hessian (:98-127)
+    d1 = (N - 1) * nm + m
+    H11 = np.zeros((d1, d1))
+    H11[:m, :m] = R
+    for l in range(N - 1):
+        o = m + l * nm
+        H11[o:o + n, o:o + n] = Q
+        H11[o + n:o + nm, o + n:o + nm] = R
+    H12 = np.zeros((d1, 3 * n))
+    for j in range(N - 1):
+        H12[j * nm + m:(j + 1) * nm, :] = np.kron(np.array([[1.0, sj[j + 1], cj[j + 1]]]), -Q)
+    H13 = np.zeros((d1, 3 * m))
+    for j in range(N):
+        H13[j * nm:j * nm + m, :] = np.kron(np.array([[1.0, sj[j], cj[j]]]), -R)
+    H22 = np.block([[Te + N * Q, s_sum * Q, c_sum * Q], [s_sum * Q, Th + s2 * Q, sc * Q], [c_sum * Q, sc * Q, Th + c2 * Q]])
+    H33 = np.block([[Se + N * R, s_sum * R, c_sum * R], [s_sum * R, Sh + s2 * R, sc * R], [c_sum * R, sc * R, Sh + c2 * R]])
+    H = np.block([[H11, H12, H13], [H12.T, H22, np.zeros((3 * n, 3 * m))], [H13.T, np.zeros((3 * m, 3 * n)), H33]])
+    dim = H.shape[0]
+    # ---- equality constraints (:131-142): N-2 interior -I blocks, harmonic closure of the last dynamics row,
+    #      three steady-state / harmonic-oscillator rows
+    G = np.kron(np.eye(N - 1), np.hstack([A, B]))
+    for j in range(N - 2):
+        G[j * n:(j + 1) * n, j * nm + nm:j * nm + nm + n] = -np.eye(n)
+    G = np.block([[B, -np.eye(n), np.zeros((n, G.shape[1] - n))], [np.zeros((G.shape[0], m)), G]])
+    G = np.hstack([G, np.vstack([np.zeros((G.shape[0] - n, 3 * nm)),
+                                 np.hstack([-np.eye(n), -np.eye(n) * np.sin(w * N), -np.eye(n) * np.cos(w * N),
+                                            np.zeros((n, 3 * m))])])])
+    I_n, Z_n = np.eye(n), np.zeros((n, n))
+    tail = np.block([[A - I_n, Z_n, Z_n, B, np.zeros((n, 2 * m))],
+                     [Z_n, A - np.cos(w) * I_n, np.sin(w) * I_n, np.zeros((n, m)), B, np.zeros((n, m))],
+                     [Z_n, -np.sin(w) * I_n, A - np.cos(w) * I_n, np.zeros((n, 2 * m)), B]])
+    G = np.vstack([G, np.hstack([np.zeros((3 * n, G.shape[1] - 3 * nm)), tail])])
+    n_eq = G.shape[0]
+    b = np.zeros(n_eq)
+    # ---- cone constraints, box case (:183-218)
+    E = np.vstack([np.eye(n), np.zeros((m, n))])
+    F = np.vstack([np.zeros((n, m)), np.eye(m)])
+    if use_soc:
+        bd3 = lambda a, b_, c_: np.block([[a, np.zeros_like(a), np.zeros_like(a)], [np.zeros_like(a), b_, np.zeros_like(a)],
+                                          [np.zeros_like(a), np.zeros_like(a), c_]])
+        rows, dsoc = [], []
+        for j in range(n_y):
+            e, f = E[j:j + 1, :], F[j:j + 1, :]
+            rows.append(np.hstack([bd3(e, -e, -e), bd3(f, -f, -f)]))
+            rows.append(np.hstack([bd3(-e, -e, -e), bd3(-f, -f, -f)]))
+            dsoc += [UBy[j], 0.0, 0.0, -LBy[j], 0.0, 0.0]
+        C_aux, dsoc, n_soc = np.vstack(rows), np.array(dsoc), 2 * n_y
+    else:
+        C_n = np.vstack([np.kron(np.eye(3), -np.eye(n)[j:j + 1, :]) for j in range(n)])
+        C_m = np.vstack([np.kron(np.eye(3), -np.eye(m)[j:j + 1, :]) for j in range(m)])
+        C_aux = np.block([[C_n, np.zeros((3 * n, 3 * m))], [np.zeros((3 * m, 3 * n)), C_m]])
+        dsoc, n_soc = np.zeros(3 * n_y), n_y
+    C = np.hstack([np.zeros((3 * n_soc, dim - 3 * nm)), C_aux])
+    n_s = C.shape[0]
+    # ---- KKT matrix and its L D L' (:221-234)
+    Hh = np.block([[H + sigma * np.eye(dim), np.zeros((dim, n_s))], [np.zeros((n_s, dim)), rho * np.eye(n_s)]])
+    Gh = np.block([[G, np.zeros((n_eq, n_s))], [C, np.eye(n_s)]])
+    bh = np.concatenate([b, dsoc])
+    nc = n_eq + n_s
+    perm2 = np.arange(nc)
+    if reorder:
+        S = Gh @ np.linalg.solve(Hh, Gh.T)
+        perm2 = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(np.abs(S) > 1e-14), symmetric_mode=True))
+    Ghp = Gh[perm2]
+    M = np.block([[Hh, Ghp.T], [Ghp, np.zeros((nc, nc))]])
+    L, D = _ldl_nopivot(M)
+    if not np.all(np.isfinite(L)) or np.abs(L @ np.diag(D) @ L.T - M).max() > 1e-8 * max(1.0, np.abs(M).max()):
+        raise np.linalg.LinAlgError("KKT LDL factorisation failed")
+    Lv, Lr, Lc, *_ = sp_utils.full2CSC(L - np.eye(L.shape[0]), threshold=0.0)
+    inv = np.empty(nc, dtype=int)
+    inv[perm2] = np.arange(nc)
+    v = dict(n=n, m=m, N=N, formulation="HMPC", method=opt.method or "ADMM", submethod="split", terminal=True,
+             dim=dim, n_s=n_s, n_eq=n_eq, n_soc=n_soc, use_soc=use_soc, nrow_M=dim + n_s + nc)
+    v["A"], v["Q"], v["Te"], v["Se"] = A.copy(), Q.copy(), Te.copy(), Se.copy()
+    v["LB"] = np.concatenate([LBu] + [np.concatenate([LBx, LBu])] * (N - 1))
+    v["UB"] = np.concatenate([UBu] + [np.concatenate([UBx, UBu])] * (N - 1))
+    v["LBy"], v["UBy"] = LBy, UBy
+    v["L_val"], v["L_row"], v["L_col"], v["Dinv"] = Lv, Lr, Lc, 1.0 / D
+    v["idx_x0"] = inv[:n].astype(np.int32)       # where the first n equality rows (x0 rows) sit in the permuted tail
+    v["bh"] = bh[perm2]
+    v["rho"], v["rho_i"], v["sigma"], v["sigma_i"] = rho, 1.0 / rho, sigma, 1.0 / sigma
+    v["alpha"] = float(so.get("alpha", 0.95))
+    v["k_max"] = int(so["k_max"])
+    v["tol_p"], v["tol_d"] = float(so["tol_p"]), float(so["tol_d"])
+    v["tol"] = v["tol_p"]
+    v["rho_is_scalar"] = True
+    v["H"], v["G"], v["C"], v["d"] = H, G, C, dsoc  # dense forms, for tests (KKT residual of the solution)
+    return v

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 from types import SimpleNamespace
 
+from .formulations import HMPC as _hmpc
 from .formulations import MPCT as _mpct
 from .formulations import ellipMPC as _ellip
 from .formulations import laxMPC as _lax
@@ -48,8 +49,17 @@ def cons_ellipMPC_ADMM_soc_HIP(recipe, device=0):
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 
+def cons_HMPC_ADMM_split_HIP(recipe, device=0):
+    v = _hmpc.compute_HMPC_ADMM_split_ingredients(recipe.controller, recipe.options)
+    return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
+
+
+cons_HMPC_SADMM_split_HIP = cons_HMPC_ADMM_split_HIP  # same ingredients; the method selects the symmetric dual steps
+
 _CONSTRUCTORS = {f.__name__: f for f in (cons_laxMPC_ADMM_HIP, cons_equMPC_ADMM_HIP, cons_laxMPC_FISTA_HIP,
-                                         cons_equMPC_FISTA_HIP, cons_MPCT_EADMM_HIP, cons_ellipMPC_ADMM_soc_HIP)}
+                                         cons_equMPC_FISTA_HIP, cons_MPCT_EADMM_HIP, cons_ellipMPC_ADMM_soc_HIP,
+                                         cons_HMPC_ADMM_split_HIP)}
+_CONSTRUCTORS["cons_HMPC_SADMM_split_HIP"] = cons_HMPC_SADMM_split_HIP
 
 
 def spcies_gen_controller(*, sys=None, param=None, device=0, **kw):

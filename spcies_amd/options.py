@@ -52,6 +52,11 @@ _DEF_SOLVER = {
     # formulations/+MPCT/def_options_MPCT_EADMM.m
     # formulations/+ellipMPC/def_options_ellipMPC_ADMM_soc.m
     ("ellipMPC", "ADMM", "soc"): dict(rho=5, sigma=5, tol_p=1e-4, tol_d=1e-4, k_max=1000),
+    # formulations/+HMPC/def_options_HMPC_ADMM.m / def_options_HMPC_SADMM.m
+    ("HMPC", "ADMM", "split"): dict(rho=1e-2, sigma=1e-2, tol_p=1e-4, tol_d=1e-4, k_max=1000, box_constraints=None,
+                                    sparse=False, use_soc=False, alpha=0.95),
+    ("HMPC", "SADMM", "split"): dict(rho=1e-2, sigma=1e-2, tol_p=1e-4, tol_d=1e-4, k_max=1000, box_constraints=None,
+                                     sparse=False, use_soc=False, alpha=0.95),
     ("MPCT", "EADMM", ""): dict(rho_base=3, rho_mult=20, epsilon_x=1e-6, epsilon_u=1e-6, tol=1e-4, k_max=1000),
 }
 

@@ -351,3 +351,38 @@ def test_soc_vs_reference_template_fixture(golden_dir):
     u, k, e, sol = s(g["x0"], g["xr"], g["ur"], g["r"])
     assert np.array_equal(e, g["e_flag"]) and np.array_equal(k, g["k"])
     assert np.abs(u - g["u"]).max() <= 1e-9 and np.abs(sol.z - g["z"]).max() <= 1e-9 and np.abs(sol.s - g["s"]).max() <= 1e-9
+
+
+# ----------------------------------------------------------------------------------------------
+# HMPC ADMM / SADMM split (KKT CSC-LDL + proj_SOC3): STREAM variant -> bit-exact
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg_name,B,overrides", [
+    ("C1_HMPC", 40, {}), ("C1_HMPC_SADMM", 70, {}), ("C1_HMPC_soc", 33, {}), ("C1_HMPC_SADMM_soc", 20, {}),
+    ("C5_HMPC_SADMM", 65, {}),                                  # BASELINE config 5 shape, 200 fixed iterations
+    ("C5_HMPC_SADMM", 12, dict(tol_p=1e-5, tol_d=1e-5, k_max=2500)),
+])
+def test_hmpc_seeded_batch_vs_oracle(cfg_name, B, overrides):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver(cfg_name, **overrides)
+    assert [f for f, _ in s.sol_fields] == ["z", "s", "z_hat", "s_hat", "lambda", "mu"]  # header_HMPC_ADMM_split_C.h:14-24
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    if cfg_name.startswith("C1"):
+        st = benchmarks.tester_status(cfg.sys)
+        x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
+    u, k, e, sol = s(x0, xr, ur)
+    O = oracle.admm_hmpc_batch(v, x0, xr, ur)
+    assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+    for name, ref in zip(_SOC_FIELDS, O[3:]):
+        assert np.array_equal(getattr(sol, name), ref), name
+    nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
+    assert np.array_equal(nosol[0], O[0][:9]) and np.array_equal(nosol[1], O[1][:9])
+
+
+def test_hmpc_vs_reference_template_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "template_C1_HMPC_SADMM.npz"))
+    cfg, v, s = _fista_solver("C1_HMPC_SADMM")
+    u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
+    assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
+    same = k == g["k"]
+    assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-8
