@@ -121,6 +121,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # Untimed queue priming: the HIP runtime grows its per-queue signal / kernarg pools the first time more
+    # launches are in flight than ever before, and that one-off growth (tens of ms, tools/wall_jitter.py) would
+    # otherwise land inside the timed region, which queues all K launches back to back.
+    torch.cuda.synchronize(dev)
+    for _ in range(args.steps):
+        step()
 
     def fence():
         torch.cuda.synchronize(dev)

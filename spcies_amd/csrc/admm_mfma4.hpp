@@ -63,8 +63,10 @@ struct Mfma4Layout {
         c += Zmid().count() + Z0().count();
         return c;
     }
-    __host__ __device__ constexpr int setup_base() const { return stream_tiles(); }  // S0, then ST (lax) or SN (equ)
-    __host__ __device__ constexpr int n_tiles() const { return stream_tiles() + 2 * S().count(); }
+    // the stream is padded to an even number of blocks (blocks are stored in pairs)
+    __host__ __device__ constexpr int stream_pairs() const { return (stream_tiles() + 1) / 2; }
+    __host__ __device__ constexpr int setup_base() const { return 2 * stream_pairs(); }  // S0, then ST (lax) or SN (equ)
+    __host__ __device__ constexpr int n_tiles() const { return setup_base() + 2 * S().count(); }
     enum { RC_NEGHD_MID = 0, RC_NEGHD_0, RC_LB_MID, RC_UB_MID, RC_LB_0, RC_UB_0, RC_LB_N, RC_UB_N, RC_QR, RC_COUNT };
     __host__ __device__ constexpr int rc_off(int i) const { return n_tiles() * 16 + i * 16; }
     __host__ __device__ constexpr int total_doubles() const { return n_tiles() * 16 + RC_COUNT * 16; }
@@ -115,9 +117,11 @@ inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
                                 if (M[(4 * I + i) * 16 + 4 * J + k] != 0.0) structure_ok = false;
                     continue;
                 }
-                double *t = tab.data() + (size_t)cursor * 16;
+                // tiles are stored in PAIRS, element-interleaved, so one ds_read_b128 per lane fetches its
+                // element of two consecutive blocks: pair p, element e = 4k+i, tile 2p+h at double 32p + 2e + h
+                double *t = tab.data() + (size_t)(cursor / 2) * 32 + (cursor % 2);
                 for (int k = 0; k < 4; k++)
-                    for (int i = 0; i < 4; i++) t[k * 4 + i] = M[(4 * I + i) * 16 + 4 * J + k];
+                    for (int i = 0; i < 4; i++) t[2 * (k * 4 + i)] = M[(4 * I + i) * 16 + 4 * J + k];
                 cursor++;
             }
     };
@@ -176,6 +180,7 @@ inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
     emit(Zmid, L.Zmid());                                // stage 1
     emit(neg(scale_rows(ABt, hd_0)), L.Z0());            // stage 0
     if (cursor != L.stream_tiles()) return fail(SPCIES_HIP_EINVAL, "MFMA4 packer/stream mismatch (%d vs %d)", cursor, L.stream_tiles());
+    cursor = L.setup_base();
     emit(mul(transpose(Bi[0]), A), L.S());               // x0 -> c0
     if (a.terminal) emit(Tm, L.S());                     // xr -> qT
     else emit(neg(transpose(Bi[N - 1])), L.S());         // xr -> cN
@@ -245,11 +250,17 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
 
     // (laundered once per iteration: keeps LICM from hoisting every LDS read out of the iteration loop)
     int ao = g * 4 + (lane & 3), go = g;  // A operand: element [i = lane%4][k = lane/16] of a 16-double block
-    auto BLK = [&](int t) -> double { return lds[t * 16 + ao]; };
+    auto BLK = [&](int t) -> double { return lds[(t / 2) * 32 + 2 * ao + (t % 2)]; };                 // single block
+    auto PAIR = [&](int p) -> double2 { return *reinterpret_cast<const double2 *>(lds + p * 32 + 2 * ao); };  // ds_read_b128
     auto RC = [&](int i) -> d4 {
         const double *r = lds + LL.rc_off(i);
         return d4{r[go], r[4 + go], r[8 + go], r[12 + go]};
     };
+#ifdef SPCIES_NO_SEG_BARRIER
+#define SPCIES_SEG_BARRIER
+#else
+#define SPCIES_SEG_BARRIER __builtin_amdgcn_sched_barrier(0)
+#endif
 #define MFMA4(acc, a, b) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (acc), 0, 0, 0)
 
     for (long tile = (long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long)gridDim.x * 4) {
@@ -305,6 +316,31 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
             return r;
         };
 
+        // A-operand stream: a ring of block pairs kept PF pairs ahead of the MFMA that consumes them (the LDS
+        // round trip is ~130 cycles = 8 small MFMAs); it carries over from one iteration to the next.
+#ifndef SPCIES_MFMA4_PF
+#define SPCIES_MFMA4_PF 6
+#endif
+        constexpr int NP = LL.stream_pairs(), PF = SPCIES_MFMA4_PF;
+        static_assert(NP > PF, "ring");
+        // a shift register of named values (an indexed array is not promoted to registers here): after
+        // unrolling the shifts are register renames
+#define SPCIES_R(i) r##i = PAIR(i)
+        double2 SPCIES_R(0), SPCIES_R(1), SPCIES_R(2), SPCIES_R(3), cur = r0;
+#if SPCIES_MFMA4_PF >= 6
+        double2 SPCIES_R(4), SPCIES_R(5);
+#endif
+#if SPCIES_MFMA4_PF >= 8
+        double2 SPCIES_R(6), SPCIES_R(7);
+#endif
+#if SPCIES_MFMA4_PF >= 10
+        double2 SPCIES_R(8), SPCIES_R(9);
+#endif
+#if SPCIES_MFMA4_PF >= 12
+        double2 SPCIES_R(10), SPCIES_R(11);
+#endif
+#undef SPCIES_R
+
         while (true) {
             kk += 1;
             const double fz = (kk == 1) ? 0.0 : 1.0, rf = rho * fz;  // cold start: v = lambda = 0 in iteration 1
@@ -321,7 +357,24 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
 #pragma unroll
                     for (int I = 0; I < 4; I++)
                         if (P.nz(I, J)) {
-                            MFMA4(acc[I], BLK(tix), x[J]);
+                            if (tix % 2 == 0) {
+                                const double2 nw = PAIR((tix / 2 + PF) % NP);
+                                cur = r0, r0 = r1, r1 = r2, r2 = r3;
+#if SPCIES_MFMA4_PF == 4
+                                r3 = nw;
+#elif SPCIES_MFMA4_PF == 6
+                                r3 = r4, r4 = r5, r5 = nw;
+#elif SPCIES_MFMA4_PF == 8
+                                r3 = r4, r4 = r5, r5 = r6, r6 = r7, r7 = nw;
+#elif SPCIES_MFMA4_PF == 10
+                                r3 = r4, r4 = r5, r5 = r6, r6 = r7, r7 = r8, r8 = r9, r9 = nw;
+#elif SPCIES_MFMA4_PF == 12
+                                r3 = r4, r4 = r5, r5 = r6, r6 = r7, r7 = r8, r8 = r9, r9 = r10, r10 = r11, r11 = nw;
+#else
+#error "SPCIES_MFMA4_PF must be 4, 6, 8, 10 or 12"
+#endif
+                            }
+                            MFMA4(acc[I], (tix % 2 == 0) ? cur.x : cur.y, x[J]);
                             tix++;
                         }
             };
@@ -347,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
                 mu[l] = acc;
                 qh = qn;
                 qn = qnn;
-                __builtin_amdgcn_sched_barrier(0);
+                SPCIES_SEG_BARRIER;
             }
             // ============ backward sweep ============
             asm volatile("" : "+v"(go));
@@ -372,9 +425,10 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
             auto stage_w = [&](int t, const d4 &z, const d4 &cwt) {
                 const d4 wn = z + fz * (w[t] - cwt);  // z + lambda/rho
                 const d4 vn = clampv(wn, LBt(t), UBt(t));
-                const d4 vo = fz * cwt;
+                // v_old = fz * clamp(w_old); the product folds into the subtraction (exact: fz is 0 or 1)
 #pragma unroll
-                for (int r = 0; r < 4; r++) res |= (fabs(vo[r] - vn[r]) > tol) | (fabs(z[r] - vn[r]) > tol);
+                for (int r = 0; r < 4; r++)
+                    res |= (fabs(__builtin_fma(fz, cwt[r], -vn[r])) > tol) | (fabs(z[r] - vn[r]) > tol);
                 w[t] = wn;
                 if constexpr (WANT_SOL) {
                     const int off = (t == 0) ? -n : (m + (t - 1) * nm);
@@ -398,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
                 const int t = l + 2;
                 if (LL.stage_exists(t)) zc = stage_z(t, cwc);
                 mu[l] = acc;
-                __builtin_amdgcn_sched_barrier(0);
+                SPCIES_SEG_BARRIER;
             }
             {
                 asm volatile("" : "+v"(go));
@@ -408,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
                 stage_w(2, zc, cwc);
                 stage_w(1, z1, cw1);
                 stage_w(0, z0, cw0);
-                __builtin_amdgcn_sched_barrier(0);
+                SPCIES_SEG_BARRIER;
             }
             // ============ exit test per instance (code_laxMPC_ADMM_C.c:572-631) ============
             unsigned long long bal = __ballot(res);
