@@ -171,7 +171,7 @@ def main():
         if variant in ("mfma", "mfma4"):
             ach = FLOP_PER_SOLVE * B / secs / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic_from_profile("mfma"),
+                               "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic_from_profile(variant),
                                "kernel_ms": kernel_ms, "flop_per_solve": FLOP_PER_SOLVE}
         else:
             # STREAM variant: state is streamed through HBM by design; algorithmic bytes are only the I/O
