@@ -7,6 +7,7 @@
 #include "admm_mfma4.hpp"
 #include "admm_stream.hpp"
 #include "fista_stream.hpp"
+#include "fista_mfma4g.hpp"
 #include "eadmm_stream.hpp"
 #include "soc_stream.hpp"
 #include "hmpc_stream.hpp"
@@ -64,6 +65,7 @@ struct Solver {
     // MFMA-variant packing
     MfmaPlan mfma;
     Mfma4Plan mfma4;
+    g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     // scratch of the STREAM variant (grown on demand)
     double *d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -346,6 +348,8 @@ static bool stream_shape_built(int n, int m) {
 
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
+    if (s.is_soc()) return SPCIES_VARIANT_STREAM;
+    if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
     if (s.mfma.ok) return SPCIES_VARIANT_MFMA;
     return SPCIES_VARIANT_STREAM;
@@ -567,8 +571,14 @@ static int solve_device(Solver &s, const double *x0, const double *xr, const dou
     }
     double *z = f[0], *v = (s.method == SPCIES_FISTA) ? nullptr : f[1], *lam = (s.method == SPCIES_FISTA) ? f[1] : f[2];
     if (s.method == SPCIES_FISTA) {
-        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
-            return fail(SPCIES_HIP_ENOSUP, "FISTA: only the STREAM variant is built");
+        const int fv = resolve_variant(s);
+        if (fv == SPCIES_VARIANT_MFMA4G) {
+            if (!s.g4plan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available: %s", s.g4plan.why.c_str());
+            int rc = ensure_scratch(s, g4::fista_state_bytes(s.g4plan, s.host, B));
+            if (rc) return rc;
+            return g4::launch_fista_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, z, lam, st);
+        }
+        if (fv != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "FISTA: variants STREAM and MFMA4G are built");
         if (!stream_shape_built(s.host.n, s.host.m))
             return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, z || lam));
@@ -634,6 +644,11 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         rc = mfma4_plan_build(s->mfma4, s->host);
         if (rc) return rc;
     }
+    if (s->method == SPCIES_FISTA) {
+        g4::FistaGHost fh{&s->QRi, &s->Td, &s->Ti};
+        rc = g4::fista_plan_build(s->g4plan, s->host, fh);
+        if (rc) return rc;
+    }
     *out = reinterpret_cast<spcies_hip_handle>(s.release());
     return 0;
 }
@@ -648,6 +663,7 @@ int spcies_hip_destroy(spcies_hip_handle h) {
     if (s->d_idx) hipFree(s->d_idx);
     mfma_plan_free(s->mfma);
     mfma4_plan_free(s->mfma4);
+    g4::plan_free(s->g4plan);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
     return 0;
@@ -661,7 +677,7 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
     info->submethod = s->submethod;
     info->n = s->host.n; info->m = s->host.m; info->N = s->host.N; info->dim = s->is_soc() ? s->sdev.dim : s->host.dim();
     info->k_max = s->host.k_max; info->tol = s->host.tol; info->rho = s->host.rho;
-    info->variant = (s->method != SPCIES_ADMM || s->is_soc()) ? SPCIES_VARIANT_STREAM : resolve_variant(*s);
+    info->variant = resolve_variant(*s);
     info->dim_lambda = s->lam_dim();
     info->device = s->device;
     return 0;
@@ -670,7 +686,9 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
 int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_MFMA4) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_MFMA4G) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant == SPCIES_VARIANT_MFMA4G && !s->g4plan.ok)
+        return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available for this solver: %s", s->g4plan.why.c_str());
     if (variant == SPCIES_VARIANT_MFMA4 && !s->mfma4.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s->mfma4.why.c_str());
     if (variant == SPCIES_VARIANT_MFMA && !s->mfma.ok)
@@ -695,7 +713,9 @@ int spcies_hip_reserve(spcies_hip_handle h, long B) {
     Solver *s = reinterpret_cast<Solver *>(h);
     std::lock_guard<std::mutex> lk(s->mu);
     SPCIES_HIP_CHECK(hipSetDevice(s->device));
-    return ensure_scratch(*s, stream_scratch_bytes(*s, B, true));
+    size_t need = stream_scratch_bytes(*s, B, true);
+    if (s->g4plan.ok && s->method == SPCIES_FISTA) need = std::max(need, g4::fista_state_bytes(s->g4plan, s->host, B));
+    return ensure_scratch(*s, need);
 }
 
 // map the (z, v, lambda) triple of the classic entry points onto the record fields

@@ -184,29 +184,56 @@ def test_full_size_properties(variant):
 
 
 # ----------------------------------------------------------------------------------------------
-# FISTA (laxMPC / equMPC): STREAM variant, reference operation order -> bit-exact
+# FISTA (laxMPC / equMPC): STREAM variant, reference operation order -> bit-exact;
+# MFMA4G variant (re-associated block products, state streamed through HBM) -> 1e-10
 # ----------------------------------------------------------------------------------------------
-def _fista_solver(cfg_name, **overrides):
+def _fista_solver(cfg_name, variant=None, **overrides):
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
     cfg = benchmarks.config(cfg_name)
     v = benchmarks.ingredients(cfg, **overrides)
-    return cfg, v, HipSolver(v)
+    s = HipSolver(v)
+    if variant is not None:
+        s.set_variant(variant)  # a variant that is not built for this shape raises: a failure, not a skip
+        assert s.variant == variant
+    return cfg, v, s
 
 
+def _compare_fista(variant, got, ref):
+    u, k, e, sol = got
+    uo, ko, eo, zo, lo = ref
+    if variant == "stream":
+        assert np.array_equal(k, ko) and np.array_equal(e, eo) and np.array_equal(u, uo)
+        assert np.array_equal(sol.z, zo) and np.array_equal(sol.lam, lo)
+        return
+    # an exit test |r| <= tol decided within rounding may fire one iteration apart on a few instances
+    dk = np.abs(k.astype(int) - ko.astype(int))
+    assert dk.max() <= 1 and (dk > 0).mean() <= 1e-3 + 1.0 / max(len(k), 1) * (len(k) < 1000)
+    same = dk == 0
+    assert np.array_equal(e[same], eo[same])
+    lscale = np.maximum(1.0, np.abs(lo).max(axis=1, keepdims=True))
+    assert np.abs(u - uo)[same].max() <= TOL_SPCIES and np.abs(sol.z - zo)[same].max() <= TOL_SPCIES
+    assert (np.abs(sol.lam - lo) / lscale)[same].max() <= TOL_SPCIES
+
+
+FISTA_VARIANTS = ["stream", "mfma4g"]
+
+
+@pytest.mark.parametrize("variant", FISTA_VARIANTS)
 @pytest.mark.parametrize("cfg_name,test_name", [("C1_lax_FISTA", "test_laxMPC_FISTA"), ("C1_equ_FISTA", "test_equMPC_FISTA")])
-def test_fista_reference_test_instance(cfg_name, test_name, golden_dir):
+def test_fista_reference_test_instance(variant, cfg_name, test_name, golden_dir):
     """tests/test_laxMPC_FISTA.m / test_equMPC_FISTA.m on the tester's instance: z_opt to 1e-4, flag 1."""
     from oracle import oracle
     from spcies_amd import benchmarks
-    cfg, v, s = _fista_solver(cfg_name)
+    cfg, v, s = _fista_solver(cfg_name, variant)
     st = benchmarks.tester_status(cfg.sys)
     u, k, e, sol = s(st.x, st.xr, st.ur)
     with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
         z_opt = np.array(json.load(f)[test_name])
     assert e == 1 and np.abs(sol.z - z_opt).max() <= TOL_OPT and sol.v is None
-    uo, ko, eo, zo, lo = oracle.fista_banded_batch(v, st.x[None], st.xr, st.ur)
-    assert k == ko[0] and np.array_equal(u, uo[0]) and np.array_equal(sol.z, zo[0]) and np.array_equal(sol.lam, lo[0])
+    ref = oracle.fista_banded_batch(v, st.x[None], st.xr, st.ur)
+    got = (u[None], np.array([k]), np.array([e]), type(sol)(z=sol.z[None], v=None, lam=sol.lam[None]))
+    _compare_fista(variant, got, ref)
 
 
 @pytest.mark.parametrize("cfg_name,B,overrides", [
@@ -216,24 +243,25 @@ def test_fista_reference_test_instance(cfg_name, test_name, golden_dir):
     ("C2_equ_FISTA", 96, {}),
     ("C3", 70, {}),                                         # BASELINE config 3 shape: equMPC-FISTA, N = 30
 ])
-def test_fista_seeded_batch_vs_oracle(cfg_name, B, overrides):
+@pytest.mark.parametrize("variant", FISTA_VARIANTS)
+def test_fista_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
-    cfg, v, s = _fista_solver(cfg_name, **overrides)
+    cfg, v, s = _fista_solver(cfg_name, variant, **overrides)
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
-    u, k, e, sol = s(x0, xr, ur)
-    uo, ko, eo, zo, lo = oracle.fista_banded_batch(v, x0, xr, ur)
-    assert np.array_equal(k, ko) and np.array_equal(e, eo) and np.array_equal(u, uo)
-    assert np.array_equal(sol.z, zo) and np.array_equal(sol.lam, lo)
-    nosol = s(x0[:33], xr[:33], ur[:33], want_sol=False)
-    assert np.array_equal(nosol[0], uo[:33]) and np.array_equal(nosol[1], ko[:33])
+    got = s(x0, xr, ur)
+    ref = oracle.fista_banded_batch(v, x0, xr, ur)
+    _compare_fista(variant, got, ref)
+    nosol = s(x0[:33], xr[:33], ur[:33], want_sol=False)  # the no-record kernel gives the same u, k
+    assert np.array_equal(nosol[0], got[0][:33]) and np.array_equal(nosol[1], got[1][:33])
 
 
+@pytest.mark.parametrize("variant", FISTA_VARIANTS)
 @pytest.mark.parametrize("tag", ["C1_lax_FISTA", "C2_lax_FISTA_conv", "C2_equ_FISTA"])
-def test_fista_vs_reference_template_fixture(tag, golden_dir):
+def test_fista_vs_reference_template_fixture(variant, tag, golden_dir):
     g = np.load(os.path.join(golden_dir, f"template_{tag}.npz"))
     overrides = json.loads(str(g["solver_overrides"]))
-    cfg, v, s = _fista_solver(tag.replace("_conv", ""), **overrides)
+    cfg, v, s = _fista_solver(tag.replace("_conv", ""), variant, **overrides)
     u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
     assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
     same = k == g["k"]
@@ -241,12 +269,13 @@ def test_fista_vs_reference_template_fixture(tag, golden_dir):
     assert np.abs(sol.lam - g["lam"])[same].max() <= 1e-7
 
 
-def test_fista_full_size_properties():
+@pytest.mark.parametrize("variant", FISTA_VARIANTS)
+def test_fista_full_size_properties(variant):
     """BASELINE config 3 (equMPC-FISTA, N = 30, 100 iterations) at B = 262144: determinism, shard
     invariance, and a random subset against the oracle."""
     from oracle import oracle
     from spcies_amd import benchmarks
-    cfg, v, s = _fista_solver("C3")
+    cfg, v, s = _fista_solver("C3", variant)
     B = cfg.B
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
     u, k, e, _ = s(x0, xr, ur, want_sol=False)
@@ -257,7 +286,10 @@ def test_fista_full_size_properties():
     assert np.array_equal(np.vstack([ua, ub]), u)
     idx = np.random.default_rng(9).choice(B, 48, replace=False)
     uo, *_ = oracle.fista_banded_batch(v, x0[idx], xr[idx], ur[idx], want_sol=False)
-    assert np.array_equal(u[idx], uo)
+    if variant == "stream":
+        assert np.array_equal(u[idx], uo)
+    else:
+        assert np.abs(u[idx] - uo).max() <= TOL_SPCIES
 
 
 # ----------------------------------------------------------------------------------------------

@@ -57,9 +57,11 @@ def run_ex(cfg, name, B):
 
 
 if __name__ == "__main__":
-    for var in ("mfma4", "mfma", "stream"):
-        run("C2", 65536, var)
-    run("C2_equ", 65536, "mfma4")
-    run("C3", 262144)
-    run("C4", 131072)
-    run("C5_soc", 65536)
+    only = sys.argv[1:]
+    jobs = [("C2", 65536, "mfma4"), ("C2", 65536, "mfma"), ("C2", 65536, "stream"), ("C2_equ", 65536, "mfma4"),
+            ("C3", 262144, "mfma4g"), ("C3", 262144, "stream"), ("C2_lax_FISTA", 65536, "mfma4g"),
+            ("C4", 131072, None), ("C5_soc", 65536, None)]
+    for name, B, var in jobs:
+        if only and name not in only:
+            continue
+        run(name, B, var)
