@@ -1,0 +1,521 @@
+// Variant MFMA4G of the MPCT EADMM solver (diagonal Q, R), see mfma4g.hpp for the design.
+// Algorithm: formulations/+MPCT/code_MPCT_EADMM_C.c:85-457.  In block form, z1_l, z3_l (n+m rows, l = 0..N),
+// z2 (n+m rows), lambda_b (b = 0..N+2), Bi_l = Beta_l^-1, K_l = per-stage diagonals (rho_l, H1i_l, H3i_l):
+//   P1 (:97-117)   z1_l = clamp( H1i_l o ( rho_l (z3_l + z2) + lambda_{l+1} [+ rho_0 o x0 - lambda_0 | l = 0] ) ),
+//                  z1_N = clamp( H1i_N o ( rho_N z3_N + (rho_N + rho_s) z2 + lambda_{N+1} + lambda_{N+2} ) )
+//   P2 (:123-151)  z2 = W2 ( [T xr; S ur] + sum_l rho_l (z3_l - z1_l) + lambda_{l+1}  (- rho_s z1_N + lambda_{N+2}) )
+//   P3 (:157-320)  q3_l = rho_l (z2 - z1_l) + lambda_{l+1};  y_l = (H3i q3)_{l+1}[x] - AB (H3i_l o q3_l)
+//                  mu_l = Bi_l' y_l - Bi_l' Alpha_{l-1}' mu_{l-1};   mu_l = Bi_l mu_l - Bi_l Alpha_l mu_{l+1}
+//                  z3_l = -H3i_l o ( q3_l - [mu_{l-1}; 0] + AB' mu_l )
+//   duals (:371-405) lambda_{l+1} += rho_l (z2 + z3_l - z1_l), lambda_0 += rho_0 (z1_0[x] - x0), lambda_{N+2} += rho_s (z2 - z1_N)
+// Three sweeps per iteration (A: P1 + q2, B: forward substitution, C: backward substitution, z3, duals).
+// State in HBM per 16 instances: z1, z3 ((N+1) KS slab vectors each), lambda ((N+3) KS), mu (N KX), KS =
+// ceil((n+m)/4), KX = ceil(n/4); traffic per iteration and stage: (10 KS + 2 KX) x 512 B.
+#pragma once
+#include "mfma4g.hpp"
+
+namespace spcies {
+namespace g4 {
+
+template <int KX, int KS>
+struct EadmmGLayout {
+    static constexpr int RC = 4 * KS;
+    // stage-invariant blocks: -AB (KX x KS), AB' (KS x KX), W2 (KS x KS), blkdiag(T, S) (KS x KS)
+    static constexpr int T_NAB = 0, T_ABT = KX * KS, T_W2 = 2 * KX * KS, T_TS = 2 * KX * KS + KS * KS;
+    static constexpr int INV_TILES = 2 * KX * KS + 2 * KS * KS;
+    enum { C_RHO0, C_RHOS, C_COUNT };
+    static constexpr int INV_D = INV_TILES * 16 + C_COUNT * RC;
+    // per-stage diagonals and bounds
+    enum { K_RHO, K_H1I, K_H3I, K_LB, K_UB, K_COUNT };
+    static constexpr int KD = K_COUNT * RC;
+    static constexpr int NT = blk_count(KX, KX, LOWER) + KX * KX, NT_PAD = (NT + 1) / 2 * 2;
+    static constexpr int CHD = NT_PAD * 16 + 2 * KD;  // blocks, K_a, K_b
+    static constexpr int LDS_D = INV_D + 2 * CHD;
+    static int n_seq(int N) { return 3 * N + 1; }
+    static size_t table_doubles(int N) { return (size_t)INV_D + (size_t)n_seq(N) * CHD; }
+};
+
+struct EadmmGHost {
+    const std::vector<double> *rho, *rho0, *rhos, *LB0, *UB0, *LBs, *UBs, *S, *H1i, *W2, *H3i;
+};
+
+template <int KX, int KS>
+inline int eadmm_plan_build_shape(Plan &p, const AdmmHost &a, const EadmmGHost &h) {
+    using LY = EadmmGLayout<KX, KS>;
+    const int n = a.n, m = a.m, N = a.N, nm = n + m;
+    std::vector<double> tab(LY::table_doubles(N), 0.0);
+    DM AB(n, nm), W2(nm, nm), TS(nm, nm);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < nm; j++) AB(i, j) = a.AB[(size_t)i * nm + j];
+    for (int i = 0; i < nm; i++)
+        for (int j = 0; j < nm; j++) W2(i, j) = (*h.W2)[(size_t)i * nm + j];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) TS(i, j) = a.T[(size_t)i * n + j];
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < m; j++) TS(n + i, n + j) = (*h.S)[(size_t)i * m + j];
+    bool ok = true;
+    {
+        BlockWriter w(tab, 0);
+        w.emit(neg(AB), KX, KS, DENSE);
+        w.emit(tr(AB), KS, KX, DENSE);
+        w.emit(W2, KS, KS, DENSE);
+        w.emit(TS, KS, KS, DENSE);
+        ok = ok && w.structure_ok && w.cursor == LY::INV_TILES;
+        double *rc = tab.data() + LY::INV_TILES * 16;
+        for (int j = 0; j < nm; j++) {
+            rc[LY::C_RHO0 * LY::RC + j] = (*h.rho0)[j];
+            rc[LY::C_RHOS * LY::RC + j] = (*h.rhos)[j];
+        }
+    }
+    auto put_K = [&](double *dst, int l) {
+        const double *lb = (l == 0) ? h.LB0->data() : (l == N ? h.LBs->data() : a.LB.data());
+        const double *ub = (l == 0) ? h.UB0->data() : (l == N ? h.UBs->data() : a.UB.data());
+        for (int j = 0; j < nm; j++) {
+            dst[LY::K_RHO * LY::RC + j] = (*h.rho)[(size_t)l * nm + j];
+            dst[LY::K_H1I * LY::RC + j] = (*h.H1i)[(size_t)l * nm + j];
+            dst[LY::K_H3I * LY::RC + j] = (*h.H3i)[(size_t)l * nm + j];
+            dst[LY::K_LB * LY::RC + j] = lb[j];
+            dst[LY::K_UB * LY::RC + j] = ub[j];
+        }
+    };
+    std::vector<DM> Bi(N), Al(N - 1);
+    for (int l = 0; l < N; l++) Bi[l] = beta_inverse(a.Beta.data() + (size_t)l * n * n, n);
+    for (int l = 0; l < N - 1; l++) {
+        Al[l] = DM(n, n);
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) Al[l](i, j) = a.Alpha[((size_t)l * n + i) * n + j];
+    }
+    const DM Zero(n, n);
+    for (int s = 0; s < LY::n_seq(N); s++) {
+        const size_t base = (size_t)LY::INV_D + (size_t)s * LY::CHD;
+        double *Ka = tab.data() + base + LY::NT_PAD * 16, *Kb = Ka + LY::KD;
+        BlockWriter w(tab, base);
+        if (s <= N) {  // sweep A: stage N first, then 0..N-1
+            put_K(Ka, s == 0 ? N : s - 1);
+            continue;
+        }
+        if (s <= 2 * N) {  // sweep B: block l
+            const int l = s - N - 1;
+            const DM BiT = tr(Bi[l]);
+            w.emit(BiT, KX, KX, LOWER);
+            w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
+            put_K(Ka, l);
+            put_K(Kb, l + 1);
+        } else {  // sweep C: block l
+            const int l = 3 * N - s;
+            w.emit(Bi[l], KX, KX, UPPER);
+            w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : Zero, KX, KX, DENSE);
+            put_K(Ka, l);
+            put_K(Kb, l + 1);
+        }
+        ok = ok && w.structure_ok && w.cursor == LY::NT;
+    }
+    if (!ok) { p.why = "MFMA4G packer: block structure mismatch"; return 0; }
+    p.KX = KX;
+    p.KS = KS;
+    return plan_upload(p, tab);
+}
+
+// -------------------------------------------------------------------------------------------------
+template <int KX, int KS, int WG_PER_CU>
+__global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const double *__restrict__ tab,
+                                                                 const double *__restrict__ x0g,
+                                                                 const double *__restrict__ xrg,
+                                                                 const double *__restrict__ urg, double *__restrict__ Z1g,
+                                                                 double *__restrict__ Z3g, double *__restrict__ LAMg,
+                                                                 double *__restrict__ MUg, double *__restrict__ u_out,
+                                                                 int *__restrict__ k_out, int *__restrict__ e_out,
+                                                                 double *__restrict__ z2_out) {
+    using LY = EadmmGLayout<KX, KS>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = p.n, m = p.m, nm = n + m, N = p.N;
+    for (int i = threadIdx.x; i < LY::INV_D / 2; i += 256)
+        reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(tab)[i];
+    double *ring = lds + LY::INV_D;
+    const double *seq = tab + LY::INV_D;
+    const double *inv_rc = lds + LY::INV_TILES * 16;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int ao = g * 4 + (lane & 3);
+    const long n_tiles = (p.B + 15) / 16, n_groups = (n_tiles + 3) / 4;
+    const double tol = p.tol;
+    const int n_seq = 3 * N + 1;
+    Stager<LY::CHD> stg;
+#define SPCIES_K(K, which, s) (K)[(which) * LY::RC + 4 * (s) + g]
+
+    for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        const long tile = group * 4 + wave;
+        const long inst = tile * 16 + c;
+        const bool valid = inst < p.B;
+        double *Z1 = Z1g + tile * (long)(N + 1) * KS * 64 + lane, *Z3 = Z3g + tile * (long)(N + 1) * KS * 64 + lane;
+        double *LAM = LAMg + tile * (long)(N + 3) * KS * 64 + lane, *MU = MUg + tile * (long)N * KX * 64 + lane;
+#define SPCIES_V(P, blk, s) (P)[((long)(blk) * KS + (s)) * 64]
+        // ---- per-instance setup: x0 and c2 = [T xr; S ur] (:128-137)
+        double x0v[KS], c2[KS], z2[KS];
+        {
+            double xu[KS];
+            const double *xrp = p.ref_stride ? xrg + inst * n : xrg;
+            const double *urp = p.ref_stride ? urg + inst * m : urg;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const int row = 4 * s + g;
+                x0v[s] = 0.0;
+                xu[s] = 0.0;
+                if (valid && row < n) {
+                    x0v[s] = x0g[inst * n + row];
+                    xu[s] = xrp[row];
+                } else if (valid && row < nm) {
+                    xu[s] = urp[row - n];
+                }
+                c2[s] = 0.0;
+                z2[s] = 0.0;
+            }
+            __syncthreads();  // invariant region visible / previous group done with the ring
+            int tix = LY::T_TS;
+            double2 cur;
+            prod<KS, KS, DENSE>(c2, xu, lds, ao, tix, cur);
+        }
+        stg.issue(seq);
+        stg.commit(ring);
+        __syncthreads();
+        int slot = 0, sq = 0;  // sq: index of the chunk in the current slot
+        auto next_chunk = [&]() {  // prefetch chunk sq + 1 (cyclic); to be followed by commit_chunk() at the end of the stage
+            const int nx = (sq + 1 == n_seq) ? 0 : sq + 1;
+            stg.issue(seq + (long)nx * LY::CHD);
+        };
+        auto commit_chunk = [&]() {
+            stg.commit(ring + (slot ^ 1) * LY::CHD);
+            __syncthreads();
+            slot ^= 1;
+            sq = (sq + 1 == n_seq) ? 0 : sq + 1;
+        };
+
+        bool active = valid;
+        int kk = 0;
+        while (true) {
+            kk += 1;
+            const bool first = (kk == 1);  // z1 = z3 = lambda = 0: skip the state reads
+            double z2p[KS], q2[KS];
+#pragma unroll
+            for (int s = 0; s < KS; s++) z2p[s] = z2[s];
+            // ======================= sweep A: P1 and the q2 accumulation =======================
+            {  // stage N
+                next_chunk();
+                const double *K = ring + slot * LY::CHD + LY::NT_PAD * 16;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const double z3v = first ? 0.0 : SPCIES_V(Z3, N, s);
+                    const double l1 = first ? 0.0 : SPCIES_V(LAM, N + 1, s), l2 = first ? 0.0 : SPCIES_V(LAM, N + 2, s);
+                    const double r = SPCIES_K(K, LY::K_RHO, s), rs = SPCIES_K(inv_rc, LY::C_RHOS, s);
+                    double v = (r * z3v + (r + rs) * z2[s] + l1 + l2) * SPCIES_K(K, LY::K_H1I, s);
+                    v = fmin(fmax(v, SPCIES_K(K, LY::K_LB, s)), SPCIES_K(K, LY::K_UB, s));
+                    if (active) SPCIES_V(Z1, N, s) = v;
+                    q2[s] = r * z3v - (r + rs) * v + l1 + l2 + c2[s];
+                }
+                commit_chunk();
+            }
+            {
+                double z3n[KS], l1n[KS];  // stage l + 1, in flight
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    z3n[s] = first ? 0.0 : SPCIES_V(Z3, 0, s);
+                    l1n[s] = first ? 0.0 : SPCIES_V(LAM, 1, s);
+                }
+                for (int l = 0; l < N; l++) {
+                    next_chunk();
+                    const double *K = ring + slot * LY::CHD + LY::NT_PAD * 16;
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        const double z3v = z3n[s], l1 = l1n[s];
+                        if (l + 1 < N) {
+                            z3n[s] = first ? 0.0 : SPCIES_V(Z3, l + 1, s);
+                            l1n[s] = first ? 0.0 : SPCIES_V(LAM, l + 2, s);
+                        }
+                        const double r = SPCIES_K(K, LY::K_RHO, s);
+                        double v = r * (z3v + z2[s]) + l1;
+                        if (l == 0) {
+                            const double l0 = first ? 0.0 : SPCIES_V(LAM, 0, s);
+                            v = v + SPCIES_K(inv_rc, LY::C_RHO0, s) * x0v[s] - l0;
+                        }
+                        v = v * SPCIES_K(K, LY::K_H1I, s);
+                        v = fmin(fmax(v, SPCIES_K(K, LY::K_LB, s)), SPCIES_K(K, LY::K_UB, s));
+                        if (active) SPCIES_V(Z1, l, s) = v;
+                        q2[s] += r * (z3v - v) + l1;
+                    }
+                    if (l == N - 1) {  // z2 = W2 q2 (:145-151)
+#pragma unroll
+                        for (int s = 0; s < KS; s++) z2[s] = 0.0;
+                        int tix = LY::T_W2;
+                        double2 cur;
+                        prod<KS, KS, DENSE>(z2, q2, lds, ao, tix, cur);
+                    }
+                    commit_chunk();
+                }
+            }
+            // ======================= sweep B: q3, right-hand side, forward substitution =======================
+            {
+                double q3c[KS], mup[KX], z1n[KS], ln[KS];
+#pragma unroll
+                for (int s = 0; s < KX; s++) mup[s] = 0.0;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    z1n[s] = SPCIES_V(Z1, 1, s);
+                    ln[s] = first ? 0.0 : SPCIES_V(LAM, 2, s);
+                }
+                for (int l = 0; l < N; l++) {
+                    next_chunk();
+                    const double *ch = ring + slot * LY::CHD;
+                    const double *Ka = ch + LY::NT_PAD * 16, *Kb = Ka + LY::KD;
+                    if (l == 0) {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            const double l1 = first ? 0.0 : SPCIES_V(LAM, 1, s);
+                            q3c[s] = SPCIES_K(Ka, LY::K_RHO, s) * (z2[s] - SPCIES_V(Z1, 0, s)) + l1;
+                        }
+                    }
+                    double q3n[KS], t[KS], y[KX];
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        q3n[s] = SPCIES_K(Kb, LY::K_RHO, s) * (z2[s] - z1n[s]) + ln[s];
+                        if (l + 1 < N) {
+                            z1n[s] = SPCIES_V(Z1, l + 2, s);
+                            ln[s] = first ? 0.0 : SPCIES_V(LAM, l + 3, s);
+                        }
+                        t[s] = SPCIES_K(Ka, LY::K_H3I, s) * q3c[s];
+                    }
+#pragma unroll
+                    for (int s = 0; s < KX; s++) y[s] = (4 * s + g < n) ? SPCIES_K(Kb, LY::K_H3I, s) * q3n[s] : 0.0;
+                    {
+                        int tix = LY::T_NAB;
+                        double2 cur;
+                        prod<KX, KS, DENSE>(y, t, lds, ao, tix, cur);
+                    }
+                    double mu[KX];
+#pragma unroll
+                    for (int s = 0; s < KX; s++) mu[s] = 0.0;
+                    {
+                        int tix = 0;
+                        double2 cur;
+                        prod<KX, KX, LOWER>(mu, y, ch, ao, tix, cur);
+                        prod<KX, KX, DENSE>(mu, mup, ch, ao, tix, cur);
+                    }
+#pragma unroll
+                    for (int s = 0; s < KX; s++) {
+                        MU[((long)l * KX + s) * 64] = mu[s];
+                        mup[s] = mu[s];
+                    }
+#pragma unroll
+                    for (int s = 0; s < KS; s++) q3c[s] = q3n[s];
+                    commit_chunk();
+                }
+            }
+            // ======================= sweep C: backward substitution, z3, residuals, duals =======================
+            bool res = false;
+#pragma unroll
+            for (int s = 0; s < KS; s++) res |= fabs(z2p[s] - z2[s]) > tol;
+            {
+                double mun[KX], z1_0[KS], z1_N[KS];
+#pragma unroll
+                for (int s = 0; s < KX; s++) mun[s] = 0.0;
+                // z3_t, residual and lambda_{t+1} of one stage (:289-320, :371-402)
+                auto finish_stage = [&](int t, const double *K, const double (&mu_sub)[KX], const double (&mu_abt)[KX],
+                                        const double (&lam)[KS], const double (&z1v)[KS], const double (&z3o)[KS]) {
+                    double v[KS];
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        v[s] = SPCIES_K(K, LY::K_RHO, s) * (z2[s] - z1v[s]) + lam[s];
+                        if (s < KX) v[s] -= mu_sub[s < KX ? s : 0];
+                    }
+                    {
+                        int tix = LY::T_ABT;
+                        double2 cur;
+                        prod<KS, KX, DENSE>(v, mu_abt, lds, ao, tix, cur);
+                    }
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        const double z3 = -SPCIES_K(K, LY::K_H3I, s) * v[s];
+                        const double r = z2[s] + z3 - z1v[s];
+                        if (active) {
+                            SPCIES_V(Z3, t, s) = z3;
+                            SPCIES_V(LAM, t + 1, s) = lam[s] + SPCIES_K(K, LY::K_RHO, s) * r;
+                        }
+                        res |= (fabs(r) > tol) | (fabs(z3o[s] - z3) > tol);
+                    }
+                };
+                double lamn[KS], z1vn[KS], z3on[KS], mufn[KX];  // stage l + 1 vectors / mu_l, in flight
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    lamn[s] = first ? 0.0 : SPCIES_V(LAM, N + 1, s);
+                    z1vn[s] = SPCIES_V(Z1, N, s);
+                    z3on[s] = first ? 0.0 : SPCIES_V(Z3, N, s);
+                }
+#pragma unroll
+                for (int s = 0; s < KX; s++) mufn[s] = MU[((long)(N - 1) * KX + s) * 64];
+                for (int l = N - 1; l >= 0; l--) {
+                    next_chunk();
+                    const double *ch = ring + slot * LY::CHD;
+                    const double *Ka = ch + LY::NT_PAD * 16, *Kb = Ka + LY::KD;
+                    double lam[KS], z1v[KS], z3o[KS], muf[KX];
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        lam[s] = lamn[s];
+                        z1v[s] = z1vn[s];
+                        z3o[s] = z3on[s];
+                        lamn[s] = first ? 0.0 : SPCIES_V(LAM, l + 1, s);  // stage l: next iteration, or finish_stage(0)
+                        z1vn[s] = SPCIES_V(Z1, l, s);
+                        z3on[s] = first ? 0.0 : SPCIES_V(Z3, l, s);
+                    }
+#pragma unroll
+                    for (int s = 0; s < KX; s++) {
+                        muf[s] = mufn[s];
+                        if (l > 0) mufn[s] = MU[((long)(l - 1) * KX + s) * 64];
+                    }
+                    if (l == N - 1) {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) z1_N[s] = z1v[s];
+                    }
+                    double mu[KX];
+#pragma unroll
+                    for (int s = 0; s < KX; s++) mu[s] = 0.0;
+                    {
+                        int tix = 0;
+                        double2 cur;
+                        prod<KX, KX, UPPER>(mu, muf, ch, ao, tix, cur);
+                        prod<KX, KX, DENSE>(mu, mun, ch, ao, tix, cur);
+                    }
+                    finish_stage(l + 1, Kb, mu, mun, lam, z1v, z3o);
+#pragma unroll
+                    for (int s = 0; s < KX; s++) mun[s] = mu[s];
+                    if (l == 0) {
+                        double zero[KX];
+#pragma unroll
+                        for (int s = 0; s < KX; s++) zero[s] = 0.0;
+#pragma unroll
+                        for (int s = 0; s < KS; s++) z1_0[s] = z1vn[s];
+                        finish_stage(0, Ka, zero, mun, lamn, z1vn, z3on);
+                    }
+                    commit_chunk();
+                }
+                // first and last residual rows and their multipliers (:374-376, 386-388, 391-393, 403-405)
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const int row = 4 * s + g;
+                    const double l0 = first ? 0.0 : SPCIES_V(LAM, 0, s);
+                    const double r0 = (row < n) ? z1_0[s] - x0v[s] : 0.0;
+                    const double l2 = first ? 0.0 : SPCIES_V(LAM, N + 2, s);
+                    const double rN = z2[s] - z1_N[s];
+                    if (active) {
+                        SPCIES_V(LAM, 0, s) = l0 + SPCIES_K(inv_rc, LY::C_RHO0, s) * r0;  // rows >= n stay 0
+                        SPCIES_V(LAM, N + 2, s) = l2 + SPCIES_K(inv_rc, LY::C_RHOS, s) * rN;
+                    }
+                    res |= (fabs(r0) > tol) | (fabs(rN) > tol);
+                }
+            }
+            // ======================= exit (:408-449) =======================
+            const bool res_inst = or_over_rows(res, c);
+            const bool done_now = active && (!res_inst || kk >= p.k_max);
+            if (done_now) {
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const int row = 4 * s + g;
+                    if (row >= n && row < nm) u_out[inst * m + (row - n)] = SPCIES_V(Z1, 0, s);
+                    if (z2_out && row < nm) z2_out[inst * nm + row] = z2[s];
+                }
+                if (g == 0) {
+                    k_out[inst] = kk;
+                    e_out[inst] = res_inst ? -1 : 1;
+                }
+                active = false;
+            }
+            if (!__syncthreads_or(active ? 1 : 0)) break;
+        }
+        // leave the ring at chunk 0 for the next group: sq is 0 again after a whole iteration
+    }
+#undef SPCIES_K
+#undef SPCIES_V
+}
+
+// lambda copy-out with the reference's packing (code_MPCT_EADMM_C.c:495-513): the first n entries of every
+// (n+m)-wide block, written contiguously; the rest of the (N+3)(n+m) record stays zero.
+__global__ __launch_bounds__(256) void eadmm_g_pack_lambda_kernel(const double *__restrict__ LAM, long B, int N, int n, int nm,
+                                                                   int KS, double *__restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long rows = (long)(N + 3) * nm;
+    if (i >= B * rows) return;
+    const long inst = i / rows;
+    const int e = (int)(i % rows);
+    double v = 0.0;
+    if (e < (N + 3) * n) {
+        const int b = e / n, row = e % n;
+        const long tile = inst / 16;
+        v = LAM[((tile * (N + 3) + b) * KS + row / 4) * 64 + 16 * (row % 4) + (inst % 16)];
+    }
+    out[i] = v;
+}
+
+#define SPCIES_G4_EADMM_SHAPES(X) X(2, 2) X(3, 4) X(5, 6)
+
+inline int eadmm_plan_build(Plan &p, const AdmmHost &a, const EadmmGHost &h) {
+    p.ok = false;
+    const int KX = (a.n + 3) / 4, KS = (a.n + a.m + 3) / 4;
+    if (a.N < 2) { p.why = "N < 2"; return 0; }
+#define X(KKX, KKS) \
+    if (KX == KKX && KS == KKS) return eadmm_plan_build_shape<KKX, KKS>(p, a, h);
+    SPCIES_G4_EADMM_SHAPES(X)
+#undef X
+    p.why = "MFMA4G EADMM kernel not instantiated for this (ceil(n/4), ceil((n+m)/4))";
+    return 0;
+}
+
+inline size_t eadmm_state_bytes(const Plan &p, const AdmmHost &a, long B) {
+    return (size_t)padded_tiles(B) * ((size_t)(3 * a.N + 5) * p.KS + (size_t)a.N * p.KX) * 64 * sizeof(double);
+}
+
+template <int KX, int KS>
+static int launch_eadmm_g_shape(Plan &pl, const AdmmHost &a, const Args &args, const double *x0, const double *xr,
+                                const double *ur, double *state, double *u, int *k, int *e, double *z1, double *z2,
+                                double *z3, double *lam, hipStream_t st) {
+    using LY = EadmmGLayout<KX, KS>;
+    constexpr int WGS = 2;
+    const long tiles = padded_tiles(args.B);
+    const int N = a.N, nm = a.n + a.m;
+    double *Z1 = state, *Z3 = Z1 + tiles * (long)(N + 1) * KS * 64, *LAM = Z3 + tiles * (long)(N + 1) * KS * 64;
+    double *MU = LAM + tiles * (long)(N + 3) * KS * 64;
+    long wgs = tiles / 4;
+    if (wgs > (long)pl.num_cu * WGS) wgs = (long)pl.num_cu * WGS;
+    const size_t shmem = LY::LDS_D * sizeof(double);
+    hipLaunchKernelGGL((eadmm_g_kernel<KX, KS, WGS>), dim3((unsigned)wgs), dim3(256), shmem, st, args, pl.d_table, x0, xr, ur,
+                       Z1, Z3, LAM, MU, u, k, e, z2);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    const long tz = args.B * (long)(N + 1) * nm;
+    if (z1)
+        hipLaunchKernelGGL(tile_state_to_aos_kernel, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, st, Z1, args.B, N + 1, KS,
+                           nm, z1);
+    if (z3)
+        hipLaunchKernelGGL(tile_state_to_aos_kernel, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, st, Z3, args.B, N + 1, KS,
+                           nm, z3);
+    if (lam) {
+        const long tl = args.B * (long)(N + 3) * nm;
+        hipLaunchKernelGGL(eadmm_g_pack_lambda_kernel, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, st, LAM, args.B, N, a.n,
+                           nm, KS, lam);
+    }
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+inline int launch_eadmm_g(Plan &pl, const AdmmHost &a, const double *x0, const double *xr, const double *ur, int ref_stride,
+                          long B, double *state, double *u, int *k, int *e, double *z1, double *z2, double *z3, double *lam,
+                          hipStream_t st) {
+    if (!pl.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant unavailable: %s", pl.why.c_str());
+    Args args{a.n, a.m, a.N, a.k_max, a.tol, B, ref_stride};
+#define X(KKX, KKS)                     \
+    if (pl.KX == KKX && pl.KS == KKS)   \
+        return launch_eadmm_g_shape<KKX, KKS>(pl, a, args, x0, xr, ur, state, u, k, e, z1, z2, z3, lam, st);
+    SPCIES_G4_EADMM_SHAPES(X)
+#undef X
+    return fail(SPCIES_HIP_ENOSUP, "MFMA4G EADMM kernel not instantiated for KX=%d KS=%d", pl.KX, pl.KS);
+}
+
+}  // namespace g4
+}  // namespace spcies

@@ -9,6 +9,7 @@
 #include "fista_stream.hpp"
 #include "fista_mfma4g.hpp"
 #include "eadmm_stream.hpp"
+#include "eadmm_mfma4g.hpp"
 #include "soc_stream.hpp"
 #include "hmpc_stream.hpp"
 #include "common.hpp"
@@ -471,6 +472,8 @@ static int launch_eadmm_nm(Solver &s, const double *x0, const double *xr, const 
     return 0;
 }
 
+static bool eadmm_stream_shape_built(int n, int m) { return m == 2 && (n == 6 || n == 12 || n == 20); }
+
 static int launch_eadmm(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                         double *u, int *k, int *e, double *z1, double *z2, double *z3, double *lam, hipStream_t st) {
     const int n = s.host.n, m = s.host.m;
@@ -563,8 +566,16 @@ static int solve_device(Solver &s, const double *x0, const double *xr, const dou
         return launch_soc(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, f, st);
     }
     if (s.method == SPCIES_EADMM) {
-        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
-            return fail(SPCIES_HIP_ENOSUP, "EADMM: only the STREAM variant is built");
+        const int ev = resolve_variant(s);
+        if (ev == SPCIES_VARIANT_MFMA4G) {
+            if (!s.g4plan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available: %s", s.g4plan.why.c_str());
+            int rc = ensure_scratch(s, g4::eadmm_state_bytes(s.g4plan, s.host, B));
+            if (rc) return rc;
+            return g4::launch_eadmm_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f[0], f[1], f[2], f[3], st);
+        }
+        if (ev != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "EADMM: variants STREAM and MFMA4G are built");
+        if (!eadmm_stream_shape_built(s.host.n, s.host.m))
+            return fail(SPCIES_HIP_ENOSUP, "EADMM STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
         if (rc) return rc;
         return launch_eadmm(s, x0, xr, ur, ref_stride, B, u, k, e, f[0], f[1], f[2], f[3], st);
@@ -644,6 +655,11 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         rc = mfma4_plan_build(s->mfma4, s->host);
         if (rc) return rc;
     }
+    if (s->method == SPCIES_EADMM) {
+        g4::EadmmGHost eh{&s->e_rho, &s->e_rho0, &s->e_rhos, &s->e_LB0, &s->e_UB0, &s->e_LBs, &s->e_UBs, &s->e_S, &s->e_H1i, &s->e_W2, &s->e_H3i};
+        rc = g4::eadmm_plan_build(s->g4plan, s->host, eh);
+        if (rc) return rc;
+    }
     if (s->method == SPCIES_FISTA) {
         g4::FistaGHost fh{&s->QRi, &s->Td, &s->Ti};
         rc = g4::fista_plan_build(s->g4plan, s->host, fh);
@@ -715,6 +731,7 @@ int spcies_hip_reserve(spcies_hip_handle h, long B) {
     SPCIES_HIP_CHECK(hipSetDevice(s->device));
     size_t need = stream_scratch_bytes(*s, B, true);
     if (s->g4plan.ok && s->method == SPCIES_FISTA) need = std::max(need, g4::fista_state_bytes(s->g4plan, s->host, B));
+    if (s->g4plan.ok && s->method == SPCIES_EADMM) need = std::max(need, g4::eadmm_state_bytes(s->g4plan, s->host, B));
     return ensure_scratch(*s, need);
 }
 

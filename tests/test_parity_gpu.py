@@ -293,12 +293,31 @@ def test_fista_full_size_properties(variant):
 
 
 # ----------------------------------------------------------------------------------------------
-# MPCT EADMM: STREAM variant, reference operation order -> bit-exact
+# MPCT EADMM: STREAM variant, reference operation order -> bit-exact; MFMA4G variant -> 1e-10
 # ----------------------------------------------------------------------------------------------
-def test_mpct_reference_test_instance(golden_dir):
+def _compare_mpct(variant, got, O):
+    u, k, e, sol = got
+    uo, ko, eo, z1o, z2o, z3o, lo = O
+    if variant == "stream":
+        assert np.array_equal(k, ko) and np.array_equal(e, eo) and np.array_equal(u, uo)
+        assert np.array_equal(sol.z1, z1o) and np.array_equal(sol.z2, z2o) and np.array_equal(sol.z3, z3o)
+        assert np.array_equal(sol.lam, lo)
+        return
+    dk = np.abs(k.astype(int) - ko.astype(int))
+    assert dk.max() <= 1 and (dk > 0).mean() <= 1e-3 + 1.0 / max(len(k), 1) * (len(k) < 1000)
+    same = dk == 0
+    assert np.array_equal(e[same], eo[same])
+    lscale = np.maximum(1.0, np.abs(lo).max(axis=1, keepdims=True))
+    for a, b in ((u, uo), (sol.z1, z1o), (sol.z2, z2o), (sol.z3, z3o)):
+        assert np.abs(a - b)[same].max() <= TOL_SPCIES
+    assert (np.abs(sol.lam - lo) / lscale)[same].max() <= TOL_SPCIES
+
+
+@pytest.mark.parametrize("variant", FISTA_VARIANTS)
+def test_mpct_reference_test_instance(variant, golden_dir):
     from oracle import oracle
     from spcies_amd import benchmarks
-    cfg, v, s = _fista_solver("C1_MPCT")
+    cfg, v, s = _fista_solver("C1_MPCT", variant)
     assert [f for f, _ in s.sol_fields] == ["z1", "z2", "z3", "lambda"]  # header_MPCT_EADMM_C.h:14-23
     st = benchmarks.tester_status(cfg.sys)
     u, k, e, sol = s(st.x, st.xr, st.ur)
@@ -306,29 +325,28 @@ def test_mpct_reference_test_instance(golden_dir):
         z_opt = np.array(json.load(f)["test_MPCT_EADMM"])
     assert e == 1 and np.abs(sol.z1 - z_opt).max() <= TOL_OPT
     O = oracle.eadmm_mpct_batch(v, st.x[None], st.xr, st.ur)
-    assert k == O[1][0] and np.array_equal(u, O[0][0])
-    assert np.array_equal(sol.z1, O[3][0]) and np.array_equal(sol.z2, O[4][0]) and np.array_equal(sol.z3, O[5][0])
-    assert np.array_equal(sol.lam, O[6][0])
+    got = (u[None], np.array([k]), np.array([e]),
+           type(sol)(z1=sol.z1[None], z2=sol.z2[None], z3=sol.z3[None], lam=sol.lam[None]))
+    _compare_mpct(variant, got, O)
 
 
 @pytest.mark.parametrize("cfg_name,B,overrides", [("C1_MPCT", 100, {}), ("C4", 130, {}), ("C4", 70, dict(tol=1e-5, k_max=4000))])
-def test_mpct_seeded_batch_vs_oracle(cfg_name, B, overrides):
+@pytest.mark.parametrize("variant", FISTA_VARIANTS)
+def test_mpct_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
-    cfg, v, s = _fista_solver(cfg_name, **overrides)
+    cfg, v, s = _fista_solver(cfg_name, variant, **overrides)
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
-    u, k, e, sol = s(x0, xr, ur)
-    uo, ko, eo, z1o, z2o, z3o, lo = oracle.eadmm_mpct_batch(v, x0, xr, ur)
-    assert np.array_equal(k, ko) and np.array_equal(e, eo) and np.array_equal(u, uo)
-    assert np.array_equal(sol.z1, z1o) and np.array_equal(sol.z2, z2o) and np.array_equal(sol.z3, z3o)
-    assert np.array_equal(sol.lam, lo)
+    got = s(x0, xr, ur)
+    _compare_mpct(variant, got, oracle.eadmm_mpct_batch(v, x0, xr, ur))
     nosol = s(x0[:33], xr[:33], ur[:33], want_sol=False)
-    assert np.array_equal(nosol[0], uo[:33]) and np.array_equal(nosol[1], ko[:33]) and nosol[3].z1 is None
+    assert np.array_equal(nosol[0], got[0][:33]) and np.array_equal(nosol[1], got[1][:33]) and nosol[3].z1 is None
 
 
-def test_mpct_vs_reference_template_fixture(golden_dir):
+@pytest.mark.parametrize("variant", FISTA_VARIANTS)
+def test_mpct_vs_reference_template_fixture(variant, golden_dir):
     g = np.load(os.path.join(golden_dir, "template_C4.npz"))
-    cfg, v, s = _fista_solver("C4")
+    cfg, v, s = _fista_solver("C4", variant)
     u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
     assert np.array_equal(e, g["e_flag"]) and np.array_equal(k, g["k"])
     assert np.abs(u - g["u"]).max() <= 1e-9 and np.abs(sol.z1 - g["z1"]).max() <= 1e-9

@@ -60,7 +60,7 @@ if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = [("C2", 65536, "mfma4"), ("C2", 65536, "mfma"), ("C2", 65536, "stream"), ("C2_equ", 65536, "mfma4"),
             ("C3", 262144, "mfma4g"), ("C3", 262144, "stream"), ("C2_lax_FISTA", 65536, "mfma4g"),
-            ("C4", 131072, None), ("C5_soc", 65536, None)]
+            ("C4", 131072, "mfma4g"), ("C4", 131072, "stream"), ("C5_soc", 65536, None)]
     for name, B, var in jobs:
         if only and name not in only:
             continue
