@@ -17,6 +17,8 @@
 namespace spcies {
 namespace g4 {
 
+#pragma clang fp contract(fast)  // (the STREAM headers included before this one switch contraction off)
+
 template <int KX, int KS>
 struct EadmmGLayout {
     static constexpr int RC = 4 * KS;
@@ -123,7 +125,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                                                                  const double *__restrict__ xrg,
                                                                  const double *__restrict__ urg, double *__restrict__ Z1g,
                                                                  double *__restrict__ Z3g, double *__restrict__ LAMg,
-                                                                 double *__restrict__ MUg, double *__restrict__ u_out,
+                                                                 double *__restrict__ MUg, double *__restrict__ C2g,
+                                                                 double *__restrict__ u_out,
                                                                  int *__restrict__ k_out, int *__restrict__ e_out,
                                                                  double *__restrict__ z2_out) {
     using LY = EadmmGLayout<KX, KS>;
@@ -135,7 +138,9 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
     const double *seq = tab + LY::INV_D;
     const double *inv_rc = lds + LY::INV_TILES * 16;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const unsigned ulane = lane;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: state addresses are SGPR base + lane offset
     const int g = lane >> 4, c = lane & 15;
     const int ao = g * 4 + (lane & 3);
     const long n_tiles = (p.B + 15) / 16, n_groups = (n_tiles + 3) / 4;
@@ -148,22 +153,27 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
         const long tile = group * 4 + wave;
         const long inst = tile * 16 + c;
         const bool valid = inst < p.B;
-        double *Z1 = Z1g + tile * (long)(N + 1) * KS * 64 + lane, *Z3 = Z3g + tile * (long)(N + 1) * KS * 64 + lane;
-        double *LAM = LAMg + tile * (long)(N + 3) * KS * 64 + lane, *MU = MUg + tile * (long)N * KX * 64 + lane;
-#define SPCIES_V(P, blk, s) (P)[((long)(blk) * KS + (s)) * 64]
+        const SlabBuf Z1(Z1g + tile * (long)(N + 1) * KS * 64, (long)(N + 1) * KS), Z3(Z3g + tile * (long)(N + 1) * KS * 64, (long)(N + 1) * KS);
+        const SlabBuf LAM(LAMg + tile * (long)(N + 3) * KS * 64, (long)(N + 3) * KS), MU(MUg + tile * (long)N * KX * 64, (long)N * KX);
+        const int voff = lane * 8;
+#define SPCIES_V(P, blk, s) (P).ld((blk) * KS + (s), voff)
+#define SPCIES_VST(P, blk, s, x) (P).st((blk) * KS + (s), voff, (x))
         // ---- per-instance setup: x0 and c2 = [T xr; S ur] (:128-137)
-        double x0v[KS], c2[KS], z2[KS];
+        double z2[KS];
+        const SlabBuf C2(C2g + tile * (long)KS * 64, KS);  // c2 = [T xr; S ur], parked in HBM (read once per iteration)
+        auto load_x0 = [&](int s) -> double {
+            const int row = 4 * s + g;
+            return (valid && row < n) ? x0g[inst * n + row] : 0.0;
+        };
         {
-            double xu[KS];
+            double xu[KS], c2[KS];
             const double *xrp = p.ref_stride ? xrg + inst * n : xrg;
             const double *urp = p.ref_stride ? urg + inst * m : urg;
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 const int row = 4 * s + g;
-                x0v[s] = 0.0;
                 xu[s] = 0.0;
                 if (valid && row < n) {
-                    x0v[s] = x0g[inst * n + row];
                     xu[s] = xrp[row];
                 } else if (valid && row < nm) {
                     xu[s] = urp[row - n];
@@ -175,12 +185,16 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
             int tix = LY::T_TS;
             double2 cur;
             prod<KS, KS, DENSE>(c2, xu, lds, ao, tix, cur);
+#pragma unroll
+            for (int s = 0; s < KS; s++) C2.st(s, lane * 8, c2[s]);
         }
         stg.issue(seq);
         stg.commit(ring);
         __syncthreads();
         int slot = 0, sq = 0;  // sq: index of the chunk in the current slot
+        int ao_l = ao;  // laundered once per stage: keeps LICM from hoisting the stage-invariant LDS block reads
         auto next_chunk = [&]() {  // prefetch chunk sq + 1 (cyclic); to be followed by commit_chunk() at the end of the stage
+            asm volatile("" : "+v"(ao_l));
             const int nx = (sq + 1 == n_seq) ? 0 : sq + 1;
             stg.issue(seq + (long)nx * LY::CHD);
         };
@@ -195,23 +209,27 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
         int kk = 0;
         while (true) {
             kk += 1;
-            const bool first = (kk == 1);  // z1 = z3 = lambda = 0: skip the state reads
-            double z2p[KS], q2[KS];
-#pragma unroll
-            for (int s = 0; s < KS; s++) z2p[s] = z2[s];
+            // (iteration 1 reads z3 = lambda = 0: the launcher zero-fills those arrays)
+            double q2[KS];
+            bool res = false;
             // ======================= sweep A: P1 and the q2 accumulation =======================
             {  // stage N
                 next_chunk();
                 const double *K = ring + slot * LY::CHD + LY::NT_PAD * 16;
+                double z1w[KS];
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
-                    const double z3v = first ? 0.0 : SPCIES_V(Z3, N, s);
-                    const double l1 = first ? 0.0 : SPCIES_V(LAM, N + 1, s), l2 = first ? 0.0 : SPCIES_V(LAM, N + 2, s);
+                    const double z3v = SPCIES_V(Z3, N, s);
+                    const double l1 = SPCIES_V(LAM, N + 1, s), l2 = SPCIES_V(LAM, N + 2, s);
                     const double r = SPCIES_K(K, LY::K_RHO, s), rs = SPCIES_K(inv_rc, LY::C_RHOS, s);
                     double v = (r * z3v + (r + rs) * z2[s] + l1 + l2) * SPCIES_K(K, LY::K_H1I, s);
                     v = fmin(fmax(v, SPCIES_K(K, LY::K_LB, s)), SPCIES_K(K, LY::K_UB, s));
-                    if (active) SPCIES_V(Z1, N, s) = v;
-                    q2[s] = r * z3v - (r + rs) * v + l1 + l2 + c2[s];
+                    z1w[s] = v;
+                    q2[s] = r * z3v - (r + rs) * v + l1 + l2 + C2.ld(s, voff);
+                }
+                if (active) {
+#pragma unroll
+                    for (int s = 0; s < KS; s++) SPCIES_VST(Z1, N, s, z1w[s]);
                 }
                 commit_chunk();
             }
@@ -219,36 +237,47 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                 double z3n[KS], l1n[KS];  // stage l + 1, in flight
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
-                    z3n[s] = first ? 0.0 : SPCIES_V(Z3, 0, s);
-                    l1n[s] = first ? 0.0 : SPCIES_V(LAM, 1, s);
+                    z3n[s] = SPCIES_V(Z3, 0, s);
+                    l1n[s] = SPCIES_V(LAM, 1, s);
                 }
                 for (int l = 0; l < N; l++) {
                     next_chunk();
                     const double *K = ring + slot * LY::CHD + LY::NT_PAD * 16;
+                    double z1w[KS];
 #pragma unroll
                     for (int s = 0; s < KS; s++) {
                         const double z3v = z3n[s], l1 = l1n[s];
                         if (l + 1 < N) {
-                            z3n[s] = first ? 0.0 : SPCIES_V(Z3, l + 1, s);
-                            l1n[s] = first ? 0.0 : SPCIES_V(LAM, l + 2, s);
+                            z3n[s] = SPCIES_V(Z3, l + 1, s);
+                            l1n[s] = SPCIES_V(LAM, l + 2, s);
                         }
                         const double r = SPCIES_K(K, LY::K_RHO, s);
                         double v = r * (z3v + z2[s]) + l1;
                         if (l == 0) {
-                            const double l0 = first ? 0.0 : SPCIES_V(LAM, 0, s);
-                            v = v + SPCIES_K(inv_rc, LY::C_RHO0, s) * x0v[s] - l0;
+                            const double l0 = SPCIES_V(LAM, 0, s);
+                            v = v + SPCIES_K(inv_rc, LY::C_RHO0, s) * load_x0(s) - l0;
                         }
                         v = v * SPCIES_K(K, LY::K_H1I, s);
                         v = fmin(fmax(v, SPCIES_K(K, LY::K_LB, s)), SPCIES_K(K, LY::K_UB, s));
-                        if (active) SPCIES_V(Z1, l, s) = v;
+                        z1w[s] = v;
                         q2[s] += r * (z3v - v) + l1;
                     }
-                    if (l == N - 1) {  // z2 = W2 q2 (:145-151)
+                    if (active) {
 #pragma unroll
-                        for (int s = 0; s < KS; s++) z2[s] = 0.0;
+                        for (int s = 0; s < KS; s++) SPCIES_VST(Z1, l, s, z1w[s]);
+                    }
+                    if (l == N - 1) {  // z2 = W2 q2 (:145-151) and its part of the exit test (:408-415)
+                        double z2n[KS];
+#pragma unroll
+                        for (int s = 0; s < KS; s++) z2n[s] = 0.0;
                         int tix = LY::T_W2;
                         double2 cur;
-                        prod<KS, KS, DENSE>(z2, q2, lds, ao, tix, cur);
+                        prod<KS, KS, DENSE>(z2n, q2, lds, ao_l, tix, cur);
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            res |= fabs(z2[s] - z2n[s]) > tol;
+                            z2[s] = z2n[s];
+                        }
                     }
                     commit_chunk();
                 }
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
                     z1n[s] = SPCIES_V(Z1, 1, s);
-                    ln[s] = first ? 0.0 : SPCIES_V(LAM, 2, s);
+                    ln[s] = SPCIES_V(LAM, 2, s);
                 }
                 for (int l = 0; l < N; l++) {
                     next_chunk();
@@ -270,7 +299,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                     if (l == 0) {
 #pragma unroll
                         for (int s = 0; s < KS; s++) {
-                            const double l1 = first ? 0.0 : SPCIES_V(LAM, 1, s);
+                            const double l1 = SPCIES_V(LAM, 1, s);
                             q3c[s] = SPCIES_K(Ka, LY::K_RHO, s) * (z2[s] - SPCIES_V(Z1, 0, s)) + l1;
                         }
                     }
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                         q3n[s] = SPCIES_K(Kb, LY::K_RHO, s) * (z2[s] - z1n[s]) + ln[s];
                         if (l + 1 < N) {
                             z1n[s] = SPCIES_V(Z1, l + 2, s);
-                            ln[s] = first ? 0.0 : SPCIES_V(LAM, l + 3, s);
+                            ln[s] = SPCIES_V(LAM, l + 3, s);
                         }
                         t[s] = SPCIES_K(Ka, LY::K_H3I, s) * q3c[s];
                     }
@@ -289,7 +318,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                     {
                         int tix = LY::T_NAB;
                         double2 cur;
-                        prod<KX, KS, DENSE>(y, t, lds, ao, tix, cur);
+                        prod<KX, KS, DENSE>(y, t, lds, ao_l, tix, cur);
                     }
                     double mu[KX];
 #pragma unroll
@@ -297,12 +326,12 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                     {
                         int tix = 0;
                         double2 cur;
-                        prod<KX, KX, LOWER>(mu, y, ch, ao, tix, cur);
-                        prod<KX, KX, DENSE>(mu, mup, ch, ao, tix, cur);
+                        prod<KX, KX, LOWER>(mu, y, ch, ao_l, tix, cur);
+                        prod<KX, KX, DENSE>(mu, mup, ch, ao_l, tix, cur);
                     }
 #pragma unroll
                     for (int s = 0; s < KX; s++) {
-                        MU[((long)l * KX + s) * 64] = mu[s];
+                        MU.st(l * KX + s, voff, mu[s]);
                         mup[s] = mu[s];
                     }
 #pragma unroll
@@ -311,11 +340,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                 }
             }
             // ======================= sweep C: backward substitution, z3, residuals, duals =======================
-            bool res = false;
-#pragma unroll
-            for (int s = 0; s < KS; s++) res |= fabs(z2p[s] - z2[s]) > tol;
             {
-                double mun[KX], z1_0[KS], z1_N[KS];
+                double mun[KX];
 #pragma unroll
                 for (int s = 0; s < KX; s++) mun[s] = 0.0;
                 // z3_t, residual and lambda_{t+1} of one stage (:289-320, :371-402)
@@ -330,28 +356,34 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                     {
                         int tix = LY::T_ABT;
                         double2 cur;
-                        prod<KS, KX, DENSE>(v, mu_abt, lds, ao, tix, cur);
+                        prod<KS, KX, DENSE>(v, mu_abt, lds, ao_l, tix, cur);
                     }
+                    double ln_[KS];
 #pragma unroll
                     for (int s = 0; s < KS; s++) {
                         const double z3 = -SPCIES_K(K, LY::K_H3I, s) * v[s];
                         const double r = z2[s] + z3 - z1v[s];
-                        if (active) {
-                            SPCIES_V(Z3, t, s) = z3;
-                            SPCIES_V(LAM, t + 1, s) = lam[s] + SPCIES_K(K, LY::K_RHO, s) * r;
-                        }
+                        ln_[s] = lam[s] + SPCIES_K(K, LY::K_RHO, s) * r;
                         res |= (fabs(r) > tol) | (fabs(z3o[s] - z3) > tol);
+                        v[s] = z3;
+                    }
+                    if (active) {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            SPCIES_VST(Z3, t, s, v[s]);
+                            SPCIES_VST(LAM, t + 1, s, ln_[s]);
+                        }
                     }
                 };
                 double lamn[KS], z1vn[KS], z3on[KS], mufn[KX];  // stage l + 1 vectors / mu_l, in flight
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
-                    lamn[s] = first ? 0.0 : SPCIES_V(LAM, N + 1, s);
+                    lamn[s] = SPCIES_V(LAM, N + 1, s);
                     z1vn[s] = SPCIES_V(Z1, N, s);
-                    z3on[s] = first ? 0.0 : SPCIES_V(Z3, N, s);
+                    z3on[s] = SPCIES_V(Z3, N, s);
                 }
 #pragma unroll
-                for (int s = 0; s < KX; s++) mufn[s] = MU[((long)(N - 1) * KX + s) * 64];
+                for (int s = 0; s < KX; s++) mufn[s] = MU.ld((N - 1) * KX + s, voff);
                 for (int l = N - 1; l >= 0; l--) {
                     next_chunk();
                     const double *ch = ring + slot * LY::CHD;
@@ -359,21 +391,28 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                     double lam[KS], z1v[KS], z3o[KS], muf[KX];
 #pragma unroll
                     for (int s = 0; s < KS; s++) {
+#ifdef SPCIES_G4_NOPF
+                        lam[s] = SPCIES_V(LAM, l + 2, s);
+                        z1v[s] = SPCIES_V(Z1, l + 1, s);
+                        z3o[s] = SPCIES_V(Z3, l + 1, s);
+                        if (l == 0) {
+                            lamn[s] = SPCIES_V(LAM, l + 1, s);
+                            z1vn[s] = SPCIES_V(Z1, l, s);
+                            z3on[s] = SPCIES_V(Z3, l, s);
+                        }
+#else
                         lam[s] = lamn[s];
                         z1v[s] = z1vn[s];
                         z3o[s] = z3on[s];
-                        lamn[s] = first ? 0.0 : SPCIES_V(LAM, l + 1, s);  // stage l: next iteration, or finish_stage(0)
+                        lamn[s] = SPCIES_V(LAM, l + 1, s);  // stage l: next iteration, or finish_stage(0)
                         z1vn[s] = SPCIES_V(Z1, l, s);
-                        z3on[s] = first ? 0.0 : SPCIES_V(Z3, l, s);
+                        z3on[s] = SPCIES_V(Z3, l, s);
+#endif
                     }
 #pragma unroll
                     for (int s = 0; s < KX; s++) {
                         muf[s] = mufn[s];
-                        if (l > 0) mufn[s] = MU[((long)(l - 1) * KX + s) * 64];
-                    }
-                    if (l == N - 1) {
-#pragma unroll
-                        for (int s = 0; s < KS; s++) z1_N[s] = z1v[s];
+                        if (l > 0) mufn[s] = MU.ld((l - 1) * KX + s, voff);
                     }
                     double mu[KX];
 #pragma unroll
@@ -381,8 +420,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                     {
                         int tix = 0;
                         double2 cur;
-                        prod<KX, KX, UPPER>(mu, muf, ch, ao, tix, cur);
-                        prod<KX, KX, DENSE>(mu, mun, ch, ao, tix, cur);
+                        prod<KX, KX, UPPER>(mu, muf, ch, ao_l, tix, cur);
+                        prod<KX, KX, DENSE>(mu, mun, ch, ao_l, tix, cur);
                     }
                     finish_stage(l + 1, Kb, mu, mun, lam, z1v, z3o);
 #pragma unroll
@@ -391,25 +430,27 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                         double zero[KX];
 #pragma unroll
                         for (int s = 0; s < KX; s++) zero[s] = 0.0;
-#pragma unroll
-                        for (int s = 0; s < KS; s++) z1_0[s] = z1vn[s];
                         finish_stage(0, Ka, zero, mun, lamn, z1vn, z3on);
                     }
                     commit_chunk();
                 }
                 // first and last residual rows and their multipliers (:374-376, 386-388, 391-393, 403-405)
+                double l0n[KS], l2n[KS];
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
                     const int row = 4 * s + g;
-                    const double l0 = first ? 0.0 : SPCIES_V(LAM, 0, s);
-                    const double r0 = (row < n) ? z1_0[s] - x0v[s] : 0.0;
-                    const double l2 = first ? 0.0 : SPCIES_V(LAM, N + 2, s);
-                    const double rN = z2[s] - z1_N[s];
-                    if (active) {
-                        SPCIES_V(LAM, 0, s) = l0 + SPCIES_K(inv_rc, LY::C_RHO0, s) * r0;  // rows >= n stay 0
-                        SPCIES_V(LAM, N + 2, s) = l2 + SPCIES_K(inv_rc, LY::C_RHOS, s) * rN;
-                    }
+                    const double r0 = (row < n) ? SPCIES_V(Z1, 0, s) - load_x0(s) : 0.0;
+                    const double rN = z2[s] - SPCIES_V(Z1, N, s);
+                    l0n[s] = SPCIES_V(LAM, 0, s) + SPCIES_K(inv_rc, LY::C_RHO0, s) * r0;  // rows >= n stay 0
+                    l2n[s] = SPCIES_V(LAM, N + 2, s) + SPCIES_K(inv_rc, LY::C_RHOS, s) * rN;
                     res |= (fabs(r0) > tol) | (fabs(rN) > tol);
+                }
+                if (active) {
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        SPCIES_VST(LAM, 0, s, l0n[s]);
+                        SPCIES_VST(LAM, N + 2, s, l2n[s]);
+                    }
                 }
             }
             // ======================= exit (:408-449) =======================
@@ -434,6 +475,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
     }
 #undef SPCIES_K
 #undef SPCIES_V
+#undef SPCIES_VST
 }
 
 // lambda copy-out with the reference's packing (code_MPCT_EADMM_C.c:495-513): the first n entries of every
@@ -469,7 +511,7 @@ inline int eadmm_plan_build(Plan &p, const AdmmHost &a, const EadmmGHost &h) {
 }
 
 inline size_t eadmm_state_bytes(const Plan &p, const AdmmHost &a, long B) {
-    return (size_t)padded_tiles(B) * ((size_t)(3 * a.N + 5) * p.KS + (size_t)a.N * p.KX) * 64 * sizeof(double);
+    return (size_t)padded_tiles(B) * ((size_t)(3 * a.N + 6) * p.KS + (size_t)a.N * p.KX) * 64 * sizeof(double);
 }
 
 template <int KX, int KS>
@@ -477,16 +519,21 @@ static int launch_eadmm_g_shape(Plan &pl, const AdmmHost &a, const Args &args, c
                                 const double *ur, double *state, double *u, int *k, int *e, double *z1, double *z2,
                                 double *z3, double *lam, hipStream_t st) {
     using LY = EadmmGLayout<KX, KS>;
-    constexpr int WGS = 2;
+#ifndef SPCIES_G4_EADMM_WGS_BIG
+#define SPCIES_G4_EADMM_WGS_BIG 2
+#endif
+    constexpr int WGS = (KS >= 5) ? SPCIES_G4_EADMM_WGS_BIG : 2;
     const long tiles = padded_tiles(args.B);
     const int N = a.N, nm = a.n + a.m;
     double *Z1 = state, *Z3 = Z1 + tiles * (long)(N + 1) * KS * 64, *LAM = Z3 + tiles * (long)(N + 1) * KS * 64;
-    double *MU = LAM + tiles * (long)(N + 3) * KS * 64;
+    double *MU = LAM + tiles * (long)(N + 3) * KS * 64, *C2 = MU + tiles * (long)N * KX * 64;
     long wgs = tiles / 4;
     if (wgs > (long)pl.num_cu * WGS) wgs = (long)pl.num_cu * WGS;
     const size_t shmem = LY::LDS_D * sizeof(double);
+    // iteration 1 starts from z3 = lambda = 0 (:85-95); Z3 and LAM are adjacent
+    SPCIES_HIP_CHECK(hipMemsetAsync(Z3, 0, (size_t)tiles * (size_t)(2 * N + 4) * KS * 64 * sizeof(double), st));
     hipLaunchKernelGGL((eadmm_g_kernel<KX, KS, WGS>), dim3((unsigned)wgs), dim3(256), shmem, st, args, pl.d_table, x0, xr, ur,
-                       Z1, Z3, LAM, MU, u, k, e, z2);
+                       Z1, Z3, LAM, MU, C2, u, k, e, z2);
     SPCIES_HIP_CHECK(hipGetLastError());
     const long tz = args.B * (long)(N + 1) * nm;
     if (z1)

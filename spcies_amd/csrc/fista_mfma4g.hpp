@@ -16,6 +16,8 @@
 namespace spcies {
 namespace g4 {
 
+#pragma clang fp contract(fast)  // (the STREAM headers included before this one switch contraction off)
+
 template <int KX, int KS>
 struct FistaGLayout {
     static constexpr int RC = 4 * KS;  // doubles per row-constant vector
@@ -124,7 +126,9 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
     const double *seq = tab + LY::INV_D;
     const double *inv_rc = lds + LY::INV_TILES * 16;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const unsigned ulane = lane;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: state addresses are SGPR base + lane offset
     const int g = lane >> 4, c = lane & 15;
     const int ao = g * 4 + (lane & 3);
     const long n_tiles = (p.B + 15) / 16, n_groups = (n_tiles + 3) / 4;
@@ -137,7 +141,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
         const long tile = group * 4 + wave;
         const long inst = tile * 16 + c;
         const bool valid = inst < p.B;
-        double *Yt = Yg + tile * NV * 64 + lane, *Lt = Lg + tile * NV * 64 + lane, *Dt = Dg + tile * NV * 64 + lane;
+        const SlabBuf Yt(Yg + tile * NV * 64, NV), Lt(Lg + tile * NV * 64, NV), Dt(Dg + tile * NV * 64, NV);
+        const int voff = lane * 8;
         // ---- per-instance setup (code_laxMPC_FISTA_C.c:274-289)
         double qm[KS], qN[KS], xrv[KS], bvec[KX];
         {
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
         __syncthreads();
         int slot = 0;
 
+        int ao_l = ao;
         bool active = valid, init = true;
         int kk = 0;
         double tk = 1.0, tk1 = 1.0;
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
             double yc[KX], zc[KS], dprev[KX], z0[KS];
 #pragma unroll
             for (int s = 0; s < KX; s++) {
-                yc[s] = init ? 0.0 : Yt[(long)s * 64];
+                yc[s] = Yt.ld(s, voff);  // (y = lambda = 0 before the initial step: zero-filled by the launcher)
                 dprev[s] = 0.0;
             }
             {  // z_0 (:474-491): only the u rows are free
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
                 for (int s = 0; s < KS; s++) acc[s] = qm[s];
                 int tix = LY::T_NABT;
                 double2 cur;
-                prod<KS, KX, DENSE>(acc, yc, lds, ao, tix, cur);
+                prod<KS, KX, DENSE>(acc, yc, lds, ao_l, tix, cur);
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
                     const int row = 4 * s + g;
@@ -208,8 +214,9 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
             }
             double ypre[KX];  // y_{l+2}, in flight during stage l
 #pragma unroll
-            for (int s = 0; s < KX; s++) ypre[s] = (init || N < 2) ? 0.0 : Yt[((long)KX + s) * 64];
+            for (int s = 0; s < KX; s++) ypre[s] = Yt.ld(KX + s, voff);
             for (int l = 0; l < N; l++) {
+                asm volatile("" : "+v"(ao_l));  // keeps LICM from hoisting the stage-invariant LDS block reads
                 stg.issue(seq + (long)(l + 1) * LY::CHD);
                 const double *ch = ring + slot * LY::CHD;
                 const double *rc = ch + LY::NT_PAD * 16;
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
 #pragma unroll
                 for (int s = 0; s < KX; s++) {
                     yn[s] = (l + 1 < N) ? ypre[s] : 0.0;
-                    ypre[s] = (!init && l + 2 < N) ? Yt[((long)(l + 2) * KX + s) * 64] : 0.0;
+                    ypre[s] = (l + 2 < N) ? Yt.ld((l + 2) * KX + s, voff) : 0.0;
                 }
                 // z_{l+1} (:494-537)
                 double zn[KS];
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
                     for (int s = 0; s < KS; s++) acc[s] = (lastt ? qN[s] : qm[s]) + (s < KX ? yc[s < KX ? s : 0] : 0.0);
                     int tix = LY::T_NABT;
                     double2 cur;
-                    prod<KS, KX, DENSE>(acc, yn, lds, ao, tix, cur);
+                    prod<KS, KX, DENSE>(acc, yn, lds, ao_l, tix, cur);
 #pragma unroll
                     for (int s = 0; s < KS; s++) {
                         const int row = 4 * s + g;
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
                 {
                     int tix = LY::T_NAB;
                     double2 cur;
-                    prod<KX, KS, DENSE>(r, zc, lds, ao, tix, cur);
+                    prod<KX, KS, DENSE>(r, zc, lds, ao_l, tix, cur);
                 }
 #pragma unroll
                 for (int s = 0; s < KX; s++) res |= fabs(r[s]) > tol;
@@ -269,12 +276,12 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
                 {
                     int tix = 0;
                     double2 cur;
-                    prod<KX, KX, LOWER>(d, r, ch, ao, tix, cur);
-                    prod<KX, KX, DENSE>(d, dprev, ch, ao, tix, cur);
+                    prod<KX, KX, LOWER>(d, r, ch, ao_l, tix, cur);
+                    prod<KX, KX, DENSE>(d, dprev, ch, ao_l, tix, cur);
                 }
 #pragma unroll
                 for (int s = 0; s < KX; s++) {
-                    Dt[((long)l * KX + s) * 64] = d[s];
+                    Dt.st(l * KX + s, voff, d[s]);
                     dprev[s] = d[s];
                     yc[s] = yn[s];
                 }
@@ -309,12 +316,13 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
 #pragma unroll
             for (int s = 0; s < KX; s++) {
                 dn[s] = 0.0;
-                dfp[s] = Dt[((long)(N - 1) * KX + s) * 64];
-                yp[s] = init ? 0.0 : Yt[((long)(N - 1) * KX + s) * 64];
-                lp[s] = init ? 0.0 : Lt[((long)(N - 1) * KX + s) * 64];
+                dfp[s] = Dt.ld((N - 1) * KX + s, voff);
+                yp[s] = Yt.ld((N - 1) * KX + s, voff);
+                lp[s] = Lt.ld((N - 1) * KX + s, voff);
             }
             for (int l = N - 1; l >= 0; l--) {
                 const int sq = 2 * N - 1 - l;
+                asm volatile("" : "+v"(ao_l));
                 stg.issue(seq + (long)((sq + 1 == 2 * N) ? 0 : sq + 1) * LY::CHD);
                 const double *ch = ring + slot * LY::CHD;
                 double df[KX], yv[KX], lv[KX];
@@ -324,9 +332,9 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
                     yv[s] = yp[s];
                     lv[s] = lp[s];
                     if (l > 0) {
-                        dfp[s] = Dt[((long)(l - 1) * KX + s) * 64];
-                        yp[s] = init ? 0.0 : Yt[((long)(l - 1) * KX + s) * 64];
-                        lp[s] = init ? 0.0 : Lt[((long)(l - 1) * KX + s) * 64];
+                        dfp[s] = Dt.ld((l - 1) * KX + s, voff);
+                        yp[s] = Yt.ld((l - 1) * KX + s, voff);
+                        lp[s] = Lt.ld((l - 1) * KX + s, voff);
                     }
                 }
                 double d[KX];
@@ -335,18 +343,22 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
                 {
                     int tix = 0;
                     double2 cur;
-                    prod<KX, KX, UPPER>(d, df, ch, ao, tix, cur);
-                    prod<KX, KX, DENSE>(d, dn, ch, ao, tix, cur);
+                    prod<KX, KX, UPPER>(d, df, ch, ao_l, tix, cur);
+                    prod<KX, KX, DENSE>(d, dn, ch, ao_l, tix, cur);
                 }
+                double lnw[KX], ynw[KX];
 #pragma unroll
                 for (int s = 0; s < KX; s++) {
-                    const double ln = yv[s] + d[s];
-                    const double ynew = ln + beta * (ln - lv[s]);
-                    if (active) {
-                        Lt[((long)l * KX + s) * 64] = ln;
-                        Yt[((long)l * KX + s) * 64] = ynew;
-                    }
+                    lnw[s] = yv[s] + d[s];
+                    ynw[s] = lnw[s] + beta * (lnw[s] - lv[s]);
                     dn[s] = d[s];
+                }
+                if (active) {
+#pragma unroll
+                    for (int s = 0; s < KX; s++) {
+                        Lt.st(l * KX + s, voff, lnw[s]);
+                        Yt.st(l * KX + s, voff, ynw[s]);
+                    }
                 }
                 stg.commit(ring + (slot ^ 1) * LY::CHD);
                 __syncthreads();
@@ -387,6 +399,8 @@ static int launch_fista_g_shape(Plan &pl, const AdmmHost &a, const Args &args, c
     if (wgs > (long)pl.num_cu * WGS) wgs = (long)pl.num_cu * WGS;
     const size_t shmem = LY::LDS_D * sizeof(double);
     dim3 grid((unsigned)wgs), block(256);
+    // y = lambda = 0 before the initial step (code_laxMPC_FISTA_C.c:296-318); Y and L are adjacent
+    SPCIES_HIP_CHECK(hipMemsetAsync(Y, 0, (size_t)2 * tiles * NV * 64 * sizeof(double), st));
 #define SPCIES_LAUNCH(TERM, SOL)                                                                                  \
     hipLaunchKernelGGL((fista_g_kernel<KX, KS, TERM, SOL, WGS>), grid, block, shmem, st, args, pl.d_table, x0, xr, ur, Y, \
                        L, D, u, k, e, z)

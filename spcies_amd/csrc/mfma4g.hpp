@@ -169,6 +169,9 @@ __device__ __forceinline__ void prod(double (&acc)[KI], const double (&x)[KJ], c
                 SPCIES_G4_MFMA(acc[I], (tix % 2 == 0) ? cur.x : cur.y, x[J]);
                 tix++;
             }
+#ifdef SPCIES_G4_PROD_BARRIER
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 // cooperative global -> LDS staging of one chunk of CHD doubles by 256 threads
@@ -191,6 +194,23 @@ struct Stager {
             const int idx = threadIdx.x + 256 * i;
             if (idx < CH16) d[idx] = r[i];
         }
+    }
+};
+
+// One tile's slice of a state array, addressed through a buffer resource: SGPR descriptor + SGPR vector
+// offset + one VGPR lane offset.  (With flat/global addressing hipcc materialises a 64-bit VGPR pointer per
+// access of the rolled stage loops, hoists them all out of the iteration loop and spills them.)
+struct SlabBuf {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ SlabBuf(double *tile_base, long vectors)
+        : r(__builtin_amdgcn_make_buffer_rsrc(tile_base, 0, (int)(vectors * 512), 0x00020000)) {}
+    // vector index `vec` is wave-uniform; voff = 8 * lane
+    __device__ __forceinline__ double ld(int vec, int voff) const {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, vec * 512, 0));
+    }
+    __device__ __forceinline__ void st(int vec, int voff, double x) const {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), r, voff, vec * 512, 0);
     }
 };
 
