@@ -527,8 +527,7 @@ static int launch_eadmm_g_shape(Plan &pl, const AdmmHost &a, const Args &args, c
     const int N = a.N, nm = a.n + a.m;
     double *Z1 = state, *Z3 = Z1 + tiles * (long)(N + 1) * KS * 64, *LAM = Z3 + tiles * (long)(N + 1) * KS * 64;
     double *MU = LAM + tiles * (long)(N + 3) * KS * 64, *C2 = MU + tiles * (long)N * KX * 64;
-    long wgs = tiles / 4;
-    if (wgs > (long)pl.num_cu * WGS) wgs = (long)pl.num_cu * WGS;
+    const long wgs = std::min(tiles / 4, (long)pl.num_cu * pick_wgs(tiles / 4, pl.num_cu, WGS));
     const size_t shmem = LY::LDS_D * sizeof(double);
     // iteration 1 starts from z3 = lambda = 0 (:85-95); Z3 and LAM are adjacent
     SPCIES_HIP_CHECK(hipMemsetAsync(Z3, 0, (size_t)tiles * (size_t)(2 * N + 4) * KS * 64 * sizeof(double), st));

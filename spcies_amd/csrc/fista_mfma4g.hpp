@@ -392,11 +392,11 @@ static int launch_fista_g_shape(Plan &pl, const AdmmHost &a, const Args &args, c
                                 const double *ur, double *state, double *u, int *k, int *e, double *z, double *lam,
                                 hipStream_t st) {
     using LY = FistaGLayout<KX, KS>;
-    constexpr int WGS = 2;
+    // compiled for up to 3 workgroups per CU (<= 170 registers) where the shape allows it; see pick_wgs()
+    constexpr int WGS = (KS >= 5) ? 2 : 3;
     const long tiles = padded_tiles(args.B), NV = (long)a.N * KX;
     double *Y = state, *L = Y + tiles * NV * 64, *D = L + tiles * NV * 64;
-    long wgs = tiles / 4;
-    if (wgs > (long)pl.num_cu * WGS) wgs = (long)pl.num_cu * WGS;
+    const long wgs = std::min(tiles / 4, (long)pl.num_cu * pick_wgs(tiles / 4, pl.num_cu, WGS));
     const size_t shmem = LY::LDS_D * sizeof(double);
     dim3 grid((unsigned)wgs), block(256);
     // y = lambda = 0 before the initial step (code_laxMPC_FISTA_C.c:296-318); Y and L are adjacent

@@ -12,6 +12,7 @@
 //     that do not depend on the stage (AB, AB') stay in LDS for the whole kernel.
 // The kernel is bound by HBM (state bytes per iteration), not by the matrix pipe: see DESIGN.md.
 #pragma once
+#include <algorithm>
 #include <cmath>
 
 #include "admm_mfma4.hpp"
@@ -149,6 +150,22 @@ struct Args {
 
 // number of 16-instance tiles the state arrays are sized for (whole workgroups of 4 tiles)
 inline long padded_tiles(long B) { return ((B + 15) / 16 + 3) / 4 * 4; }
+
+// Persistent grid: how many workgroups per CU to launch (<= max_wgs, what the kernel was compiled for).
+// More co-resident workgroups hide more HBM latency but each runs slower; what counts is the number of
+// rounds over the groups times the per-round time.  Relative round times measured on C3 (FISTA, N = 30):
+// 1 : 1.15 : 1.40 for 1 : 2 : 3 workgroups per CU.
+inline int pick_wgs(long groups, int num_cu, int max_wgs) {
+    static const double t[] = {1.0, 1.15, 1.40, 1.70};
+    int best = 1;
+    double best_cost = 1e300;
+    for (int w = 1; w <= max_wgs && w <= 4; w++) {
+        const long rounds = (groups + (long)num_cu * w - 1) / ((long)num_cu * w);
+        const double cost = rounds * t[w - 1];
+        if (cost < best_cost - 1e-12) { best_cost = cost; best = w; }
+    }
+    return best;
+}
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
