@@ -144,6 +144,7 @@ typedef struct spcies_hip_solver_s *spcies_hip_handle;
 #define SPCIES_VARIANT_MFMA 2   /* 16 instances per wavefront on v_mfma_f64_16x16x4, state in registers          */
 #define SPCIES_VARIANT_MFMA4 3  /* same on v_mfma_f64_4x4x4 (4 blocks): no row padding, zero blocks skipped      */
 #define SPCIES_VARIANT_MFMA4G 4 /* v_mfma_f64_4x4x4 with a rolled stage loop: any N, state streamed through HBM   */
+#define SPCIES_VARIANT_TILE 5   /* sparse-KKT solvers: 4-16 lanes per instance, LDL right-hand side in LDS          */
 
 typedef struct {
     int formulation, method, submethod;

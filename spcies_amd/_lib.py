@@ -17,9 +17,9 @@ EXPORTS = (
     "spcies_hip_get_sol_layout", "spcies_hip_solve_batch_ex", "spcies_hip_solve_batch_device_ex",
 )
 
-VARIANT_AUTO, VARIANT_STREAM, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4G = 0, 1, 2, 3, 4
+VARIANT_AUTO, VARIANT_STREAM, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4G, VARIANT_TILE = 0, 1, 2, 3, 4, 5
 VARIANTS = {"auto": VARIANT_AUTO, "stream": VARIANT_STREAM, "mfma": VARIANT_MFMA, "mfma4": VARIANT_MFMA4,
-            "mfma4g": VARIANT_MFMA4G}
+            "mfma4g": VARIANT_MFMA4G, "tile": VARIANT_TILE}
 
 
 class SpciesHipError(RuntimeError):

@@ -12,6 +12,7 @@
 #include "eadmm_mfma4g.hpp"
 #include "soc_stream.hpp"
 #include "hmpc_stream.hpp"
+#include "sparse_tile.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -67,6 +68,9 @@ struct Solver {
     MfmaPlan mfma;
     Mfma4Plan mfma4;
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
+    tile::TileDev tdev{};          // TILE (soc, HMPC): step streams of the sparse operations
+    std::vector<tile::Rec> tile_recs;
+    int4 *d_recs = nullptr;
     // scratch of the STREAM variant (grown on demand)
     double *d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -174,6 +178,21 @@ static int parse_soc(const uint8_t *blob, size_t bytes, const spcies_blob_header
             for (int j = Lc[i]; j < Lc[i + 1]; j++)
                 if (Lr[j] <= i) return fail(SPCIES_HIP_EINVAL, "L - I is not strictly lower triangular");
     }
+    {  // TILE variant: step streams (sparse_tile.hpp)
+        const int *I = s.soc_i32.data();
+        const double *F = s.soc_f64.data();
+        const int lpi = tile::pick_lpi((long)nr + 2L * np, I + d.L_col, nr);
+        s.tdev = tile::TileDev{};
+        s.tdev.lpi = lpi;
+        if (lpi) {
+            s.tdev.lds_bytes = (size_t)(nr + 2 * np) * (64 / lpi) * sizeof(double);
+            tile::build_ldl_streams(nr, I + d.L_col, I + d.L_row, F + d.L_val, lpi, s.tile_recs, s.tdev.fwd, s.tdev.bwd);
+            tile::build_spmv_stream(nr, I + d.GhHhi_row, I + d.GhHhi_col, F + d.GhHhi_val, nr, nullptr, nullptr, nullptr, 0, lpi,
+                                    s.tile_recs, s.tdev.rhs);
+            tile::build_spmv_stream(np, I + d.Hhi_row, I + d.Hhi_col, F + d.Hhi_val, nr, I + d.HhiGh_row, I + d.HhiGh_col,
+                                    F + d.HhiGh_val, 0, lpi, s.tile_recs, s.tdev.prim);
+        }
+    }
     return 0;
 }
 
@@ -229,6 +248,15 @@ static int parse_hmpc(const uint8_t *blob, size_t bytes, const spcies_blob_heade
     for (int i = 0; i < d.nrow_M; i++)
         for (int j = Lc[i]; j < Lc[i + 1]; j++)
             if (Lr[j] <= i) return fail(SPCIES_HIP_EINVAL, "L - I is not strictly lower triangular");
+    {  // TILE variant: step streams (sparse_tile.hpp)
+        const int lpi = tile::pick_lpi((long)d.nrow_M, Lc, d.nrow_M);
+        s.tdev = tile::TileDev{};
+        s.tdev.lpi = lpi;
+        if (lpi) {
+            s.tdev.lds_bytes = (size_t)d.nrow_M * (64 / lpi) * sizeof(double);
+            tile::build_ldl_streams(d.nrow_M, Lc, Lr, s.soc_f64.data() + d.L_val, lpi, s.tile_recs, s.tdev.fwd, s.tdev.bwd);
+        }
+    }
     return 0;
 }
 
@@ -308,6 +336,10 @@ static int upload_consts(Solver &s) {
         SPCIES_HIP_CHECK(hipMemcpy(s.d_consts, s.soc_f64.data(), s.soc_f64.size() * sizeof(double), hipMemcpyHostToDevice));
         SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_idx, s.soc_i32.size() * sizeof(int)));
         SPCIES_HIP_CHECK(hipMemcpy(s.d_idx, s.soc_i32.data(), s.soc_i32.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (!s.tile_recs.empty()) {
+            SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_recs, s.tile_recs.size() * sizeof(tile::Rec)));
+            SPCIES_HIP_CHECK(hipMemcpy(s.d_recs, s.tile_recs.data(), s.tile_recs.size() * sizeof(tile::Rec), hipMemcpyHostToDevice));
+        }
         return 0;
     }
     std::vector<const std::vector<double> *> arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Hi, &a.Hi_0, &a.Hi_N,
@@ -349,7 +381,7 @@ static bool stream_shape_built(int n, int m) {
 
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
-    if (s.is_soc()) return SPCIES_VARIANT_STREAM;
+    if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
     if (s.mfma.ok) return SPCIES_VARIANT_MFMA;
@@ -546,13 +578,73 @@ static int launch_hmpc(Solver &s, const double *x0, const double *xr, const doub
     return 0;
 }
 
+static size_t tile_scratch_bytes(const Solver &s, long B) {
+    if (!s.tdev.lpi) return 0;
+    const long T = 64 / s.tdev.lpi, tiles = (B + T - 1) / T;
+    const long np = s.soc_dim() + s.soc_ns();
+    const long rows = s.is_hmpc() ? 3 * np + (s.hdev.n_eq + s.hdev.n_s) + s.hdev.dim : 3 * np + (s.sdev.n_eq + s.sdev.n_s) + s.sdev.dim;
+    return (size_t)tiles * rows * T * sizeof(double);
+}
+
+// TILE variant of the two sparse-KKT solvers; record fields and u are row slices of PR / PH / DU
+static int launch_tile(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, const double *r,
+                       int r_stride, long B, double *u, int *k, int *e, double *const *f, hipStream_t st) {
+    const int lpi = s.tdev.lpi, T = 64 / lpi;
+    const long tiles = (B + T - 1) / T;
+    const long np = s.soc_dim() + s.soc_ns();
+    const long rows = s.is_hmpc() ? 3 * np + (s.hdev.n_eq + s.hdev.n_s) + s.hdev.dim : 3 * np + (s.sdev.n_eq + s.sdev.n_s) + s.sdev.dim;
+    double *S = s.d_scratch;
+    const size_t shmem = s.tdev.lds_bytes;
+    dim3 grid((unsigned)tiles), block(64);
+#define SPCIES_TILE_LAUNCH(LPI)                                                                                            \
+    do {                                                                                                                   \
+        if (s.is_hmpc()) {                                                                                                 \
+            auto kern = tile::hmpc_tile_kernel<LPI>;                                                                       \
+            SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            hipLaunchKernelGGL(kern, grid, block, shmem, st, s.hdev, s.tdev, s.d_consts, s.d_idx, s.d_recs, x0, xr, ur,    \
+                               ref_stride, B, S, k, e);                                                                    \
+        } else {                                                                                                           \
+            auto kern = tile::soc_tile_kernel<LPI>;                                                                        \
+            SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            hipLaunchKernelGGL(kern, grid, block, shmem, st, s.sdev, s.tdev, s.d_consts, s.d_recs, x0, xr, ur, ref_stride, r, \
+                               r_stride, B, S, k, e);                                                                      \
+        }                                                                                                                  \
+    } while (0)
+    if (lpi == 4) SPCIES_TILE_LAUNCH(4);
+    else if (lpi == 8) SPCIES_TILE_LAUNCH(8);
+    else SPCIES_TILE_LAUNCH(16);
+#undef SPCIES_TILE_LAUNCH
+    SPCIES_HIP_CHECK(hipGetLastError());
+    const int dim = s.soc_dim(), n_s = s.soc_ns();
+    auto gather = [&](int row0, int nrows, double *out) {
+        const long total = B * (long)nrows;
+        hipLaunchKernelGGL(tile::tile_rows_to_aos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, rows, T,
+                           row0, nrows, B, out);
+    };
+    gather(0, s.host.m, u);  // u = first m entries of z (:283-285)
+    // z, s | z_hat, s_hat | lambda, mu  =  PR | PH | DU
+    const long base[3] = {0, 2 * np, np};
+    for (int i = 0; i < 6; i++)
+        if (f[i]) gather((int)(base[i / 2] + ((i % 2) ? dim : 0)), (i % 2) ? n_s : dim, f[i]);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int solve_device(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                         double *u, int *k, int *e, double *const *f, const double *extra, int extra_stride,
                         hipStream_t st) {
     if (B <= 0) return 0;
+    if (s.is_soc() && !s.is_hmpc() && !extra)
+        return fail(SPCIES_HIP_EINVAL, "ellipMPC soc solvers take a 4th input r (extra): Spcies:ellipMPC:nrhs:r");
+    if (s.is_soc() && resolve_variant(s) == SPCIES_VARIANT_TILE) {
+        if (!s.tdev.lpi) return fail(SPCIES_HIP_ENOSUP, "TILE variant not available: the LDL right-hand side does not fit the LDS");
+        int rc = ensure_scratch(s, tile_scratch_bytes(s, B));
+        if (rc) return rc;
+        return launch_tile(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, f, st);
+    }
     if (s.is_hmpc()) {
         if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
-            return fail(SPCIES_HIP_ENOSUP, "HMPC: only the STREAM variant is built");
+            return fail(SPCIES_HIP_ENOSUP, "HMPC: variants STREAM and TILE are built");
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
         if (rc) return rc;
         return launch_hmpc(s, x0, xr, ur, ref_stride, B, u, k, e, f, st);
@@ -560,7 +652,7 @@ static int solve_device(Solver &s, const double *x0, const double *xr, const dou
     if (s.is_soc()) {
         if (!extra) return fail(SPCIES_HIP_EINVAL, "ellipMPC soc solvers take a 4th input r (extra): Spcies:ellipMPC:nrhs:r");
         if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
-            return fail(SPCIES_HIP_ENOSUP, "ellipMPC soc: only the STREAM variant is built");
+            return fail(SPCIES_HIP_ENOSUP, "ellipMPC soc: variants STREAM and TILE are built");
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
         if (rc) return rc;
         return launch_soc(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, f, st);
@@ -677,6 +769,7 @@ int spcies_hip_destroy(spcies_hip_handle h) {
     if (s->d_scratch) hipFree(s->d_scratch);
     if (s->d_io) hipFree(s->d_io);
     if (s->d_idx) hipFree(s->d_idx);
+    if (s->d_recs) hipFree(s->d_recs);
     mfma_plan_free(s->mfma);
     mfma4_plan_free(s->mfma4);
     g4::plan_free(s->g4plan);
@@ -702,7 +795,9 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
 int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_MFMA4G) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_TILE) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant == SPCIES_VARIANT_TILE && !(s->is_soc() && s->tdev.lpi))
+        return fail(SPCIES_HIP_ENOSUP, "TILE variant: built for the sparse-KKT solvers (ellipMPC soc, HMPC) whose LDL right-hand side fits the LDS");
     if (variant == SPCIES_VARIANT_MFMA4G && !s->g4plan.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available for this solver: %s", s->g4plan.why.c_str());
     if (variant == SPCIES_VARIANT_MFMA4 && !s->mfma4.ok)
@@ -731,6 +826,7 @@ int spcies_hip_reserve(spcies_hip_handle h, long B) {
     SPCIES_HIP_CHECK(hipSetDevice(s->device));
     size_t need = stream_scratch_bytes(*s, B, true);
     if (s->g4plan.ok && s->method == SPCIES_FISTA) need = std::max(need, g4::fista_state_bytes(s->g4plan, s->host, B));
+    need = std::max(need, tile_scratch_bytes(*s, B));
     if (s->g4plan.ok && s->method == SPCIES_EADMM) need = std::max(need, g4::eadmm_state_bytes(s->g4plan, s->host, B));
     return ensure_scratch(*s, need);
 }

@@ -356,13 +356,34 @@ def test_mpct_vs_reference_template_fixture(variant, golden_dir):
 # ellipMPC ADMM soc: STREAM variant (CSR SpMV + CSC-LDL solve + SOC projection) -> bit-exact
 # ----------------------------------------------------------------------------------------------
 _SOC_FIELDS = ("z", "s", "z_hat", "s_hat", "lam", "mu")
+SPARSE_VARIANTS = ["stream", "tile"]  # TILE: LDS-resident LDL solve, sums in another order -> 1e-10
 
 
-def test_soc_reference_test_instance(golden_dir):
+def _compare_sparse(variant, got, O):
+    u, k, e, sol = got
+    if variant == "stream":
+        assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+        for name, ref in zip(_SOC_FIELDS, O[3:]):
+            assert np.array_equal(getattr(sol, name), ref), name
+        return
+    dk = np.abs(np.asarray(k).astype(int) - O[1].astype(int))
+    assert dk.max() <= 1 and (dk > 0).mean() <= 1e-3 + 1.0 / max(len(dk), 1) * (len(dk) < 1000)
+    same = dk == 0
+    assert np.array_equal(np.asarray(e)[same], O[2][same])
+    assert np.abs(u - O[0])[same].max() <= TOL_SPCIES
+    if sol.z is None:
+        return
+    for name, ref in zip(_SOC_FIELDS, O[3:]):
+        scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True)) if name in ("lam", "mu") else 1.0
+        assert (np.abs(getattr(sol, name) - ref) / scale)[same].max() <= TOL_SPCIES, name
+
+
+@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+def test_soc_reference_test_instance(variant, golden_dir):
     from oracle import oracle
     from spcies_amd import benchmarks
     from spcies_amd.solver import SpciesArgError
-    cfg, v, s = _fista_solver("C1_soc")
+    cfg, v, s = _fista_solver("C1_soc", variant)
     assert [f for f, _ in s.sol_fields] == ["z", "s", "z_hat", "s_hat", "lambda", "mu"]  # header_ellipMPC_ADMM_soc_C.h:14-24
     st = benchmarks.tester_status(cfg.sys)
     with pytest.raises(SpciesArgError):
@@ -372,32 +393,28 @@ def test_soc_reference_test_instance(golden_dir):
         z_opt = np.array(json.load(f)["test_ellipMPC_ADMM_soc"])
     assert e == 1 and np.abs(sol.z[:-1] - z_opt).max() <= TOL_OPT
     O = oracle.admm_soc_batch(v, st.x[None], st.xr, st.ur, cfg.param.r)
-    assert k == O[1][0] and np.array_equal(u, O[0][0])
-    for name, ref in zip(_SOC_FIELDS, O[3:]):
-        assert np.array_equal(getattr(sol, name), ref[0]), name
+    got = (u[None], np.array([k]), np.array([e]), type(sol)(**{f: getattr(sol, f)[None] for f in _SOC_FIELDS}))
+    _compare_sparse(variant, got, O)
 
 
 @pytest.mark.parametrize("cfg_name,B,overrides", [("C1_soc", 70, {}), ("C5_soc", 130, {}),
                                                   ("C5_soc", 40, dict(tol_p=1e-6, tol_d=1e-6, k_max=3000))])
-def test_soc_seeded_batch_vs_oracle(cfg_name, B, overrides):
+@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+def test_soc_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
-    cfg, v, s = _fista_solver(cfg_name, **overrides)
+    cfg, v, s = _fista_solver(cfg_name, variant, **overrides)
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
     r = cfg.param.r + 0.3 * np.random.default_rng(3).random(B)  # one radius per instance
-    u, k, e, sol = s(x0, xr, ur, r)
-    O = oracle.admm_soc_batch(v, x0, xr, ur, r)
-    assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
-    for name, ref in zip(_SOC_FIELDS, O[3:]):
-        assert np.array_equal(getattr(sol, name), ref), name
+    _compare_sparse(variant, s(x0, xr, ur, r), oracle.admm_soc_batch(v, x0, xr, ur, r))
     shared = s(x0[:20], xr[:20], ur[:20], 0.4, want_sol=False)  # shared scalar radius
-    Os = oracle.admm_soc_batch(v, x0[:20], xr[:20], ur[:20], 0.4, want_sol=False)
-    assert np.array_equal(shared[0], Os[0]) and np.array_equal(shared[1], Os[1])
+    _compare_sparse(variant, shared, oracle.admm_soc_batch(v, x0[:20], xr[:20], ur[:20], 0.4, want_sol=False))
 
 
-def test_soc_vs_reference_template_fixture(golden_dir):
+@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+def test_soc_vs_reference_template_fixture(variant, golden_dir):
     g = np.load(os.path.join(golden_dir, "template_C5_soc.npz"))
-    cfg, v, s = _fista_solver("C5_soc")
+    cfg, v, s = _fista_solver("C5_soc", variant)
     u, k, e, sol = s(g["x0"], g["xr"], g["ur"], g["r"])
     assert np.array_equal(e, g["e_flag"]) and np.array_equal(k, g["k"])
     assert np.abs(u - g["u"]).max() <= 1e-9 and np.abs(sol.z - g["z"]).max() <= 1e-9 and np.abs(sol.s - g["s"]).max() <= 1e-9
@@ -411,27 +428,26 @@ def test_soc_vs_reference_template_fixture(golden_dir):
     ("C5_HMPC_SADMM", 65, {}),                                  # BASELINE config 5 shape, 200 fixed iterations
     ("C5_HMPC_SADMM", 12, dict(tol_p=1e-5, tol_d=1e-5, k_max=2500)),
 ])
-def test_hmpc_seeded_batch_vs_oracle(cfg_name, B, overrides):
+@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+def test_hmpc_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
-    cfg, v, s = _fista_solver(cfg_name, **overrides)
+    cfg, v, s = _fista_solver(cfg_name, variant, **overrides)
     assert [f for f, _ in s.sol_fields] == ["z", "s", "z_hat", "s_hat", "lambda", "mu"]  # header_HMPC_ADMM_split_C.h:14-24
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
     if cfg_name.startswith("C1"):
         st = benchmarks.tester_status(cfg.sys)
         x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
-    u, k, e, sol = s(x0, xr, ur)
-    O = oracle.admm_hmpc_batch(v, x0, xr, ur)
-    assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
-    for name, ref in zip(_SOC_FIELDS, O[3:]):
-        assert np.array_equal(getattr(sol, name), ref), name
+    got = s(x0, xr, ur)
+    _compare_sparse(variant, got, oracle.admm_hmpc_batch(v, x0, xr, ur))
     nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
-    assert np.array_equal(nosol[0], O[0][:9]) and np.array_equal(nosol[1], O[1][:9])
+    assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
 
 
-def test_hmpc_vs_reference_template_fixture(golden_dir):
+@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+def test_hmpc_vs_reference_template_fixture(variant, golden_dir):
     g = np.load(os.path.join(golden_dir, "template_C1_HMPC_SADMM.npz"))
-    cfg, v, s = _fista_solver("C1_HMPC_SADMM")
+    cfg, v, s = _fista_solver("C1_HMPC_SADMM", variant)
     u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
     assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
     same = k == g["k"]

@@ -19,8 +19,8 @@ from spcies_amd.solver import HipSolver
 
 def run(name, B, variant=None, reps=3):
     cfg = benchmarks.config(name)
-    if cfg.formulation == "ellipMPC":
-        return run_ex(cfg, name, B)
+    if cfg.formulation in ("ellipMPC", "HMPC"):
+        return run_ex(cfg, name, B, variant)
     v = benchmarks.ingredients(cfg)
     s = HipSolver(v)
     if variant:
@@ -43,13 +43,16 @@ def run(name, B, variant=None, reps=3):
     s.close()
 
 
-def run_ex(cfg, name, B):
-    """Solvers that need the _ex entry point (extra input): host-buffer call, kernel time from the timing record."""
+def run_ex(cfg, name, B, variant=None):
+    """Solvers with a 6-field record (_ex entry points): host-buffer call, kernel time from the timing record."""
     v = benchmarks.ingredients(cfg)
     s = HipSolver(v)
+    if variant:
+        s.set_variant(variant)
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
-    s(x0[:256], xr[:256], ur[:256], cfg.param.r, want_sol=False)
-    u, k, e, sol = s(x0, xr, ur, cfg.param.r, want_sol=False)
+    extra = (cfg.param.r,) if cfg.formulation == "ellipMPC" else ()
+    s(x0[:256], xr[:256], ur[:256], *extra, want_sol=False)
+    u, k, e, sol = s(x0, xr, ur, *extra, want_sol=False)
     print(json.dumps(dict(config=name, formulation=cfg.formulation, method=cfg.method, n=cfg.sys.n, m=cfg.sys.m,
                           N=cfg.param.N, B=B, variant=s.variant, kernel_ms=round(sol.solve_time, 3),
                           solves_per_s=round(B / sol.solve_time * 1e3), k_unique=np.unique(k).tolist()[:4])), flush=True)
@@ -60,7 +63,8 @@ if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = [("C2", 65536, "mfma4"), ("C2", 65536, "mfma"), ("C2", 65536, "stream"), ("C2_equ", 65536, "mfma4"),
             ("C3", 262144, "mfma4g"), ("C3", 262144, "stream"), ("C2_lax_FISTA", 65536, "mfma4g"),
-            ("C4", 131072, "mfma4g"), ("C4", 131072, "stream"), ("C5_soc", 65536, None)]
+            ("C4", 131072, "mfma4g"), ("C4", 131072, "stream"), ("C5_soc", 65536, "tile"), ("C5_soc", 65536, "stream"),
+            ("C5_HMPC_SADMM", 65536, "tile"), ("C5_HMPC_SADMM", 16384, "stream")]
     for name, B, var in jobs:
         if only and name not in only:
             continue
