@@ -21,6 +21,8 @@
 //   * SpMV (CSR, :152-160 / :193-205): lane group g owns row r0 + g of a group of LPI rows, a step is
 //     one nonzero of each of them: acc += val * IN[col]; the last step of a group stores acc.
 #pragma once
+#include <cstdlib>
+
 #include "hmpc_stream.hpp"
 #include "soc_stream.hpp"
 
@@ -35,7 +37,12 @@ struct Rec {  // one lane group's share of a step
     double v;  // value (0 in padding)
 };
 static_assert(sizeof(Rec) == 16, "Rec");
-constexpr int BS = 8;  // steps per prefetch block; streams are padded to whole blocks
+#ifndef SPCIES_TILE_BS
+#define SPCIES_TILE_BS 8
+#endif
+constexpr int BS = SPCIES_TILE_BS;  // steps per prefetch block; streams are padded to whole blocks
+constexpr int WAVES = 4;        // wavefronts (tiles) per workgroup: they read the same streams and share them through L1
+constexpr int SYNC_BLOCKS = 2;  // a workgroup barrier every SYNC_BLOCKS blocks keeps them within a few KB of each other
 
 struct Stream {
     int off = 0;    // first record (in Rec units) inside the device stream allocation
@@ -129,10 +136,14 @@ inline void build_spmv_stream(int nrows, const int *p1, const int *c1, const dou
 inline int pick_lpi(long lds_rows, const int *col_ptr, int nrow) {
     int best = 0;
     double best_score = -1.0;
-    for (int lpi = 4; lpi <= 16; lpi *= 2) {
+    if (const char *ev = getenv("SPCIES_TILE_LPI")) {  // experiments: force the lane split
+        const int lpi = atoi(ev);
+        if ((lpi == 4 || lpi == 8 || lpi == 16 || lpi == 32 || lpi == 64) && lds_rows * (64 / lpi) * 8 * WAVES <= 160 * 1024 - 2048) return lpi;
+    }
+    for (int lpi = 4; lpi <= 64; lpi *= 2) {
         const long bytes = lds_rows * (64 / lpi) * 8;
-        if (bytes > 160 * 1024 - 1024) continue;
-        const int waves = (int)std::min<long>(12, (160 * 1024) / (bytes + 256));
+        if (bytes * WAVES > 160 * 1024 - 2048) continue;
+        const int waves = (int)std::min<long>(16, WAVES * ((160 * 1024) / (bytes * WAVES + 256)));  // 16: what ~128 VGPRs allow
         long steps = 0;
         for (int i = 0; i < nrow; i++) steps += (col_ptr[i + 1] - col_ptr[i] + lpi - 1) / lpi;
         const double score = (double)waves * (64 / lpi) / (double)std::max<long>(steps, 1);
@@ -158,16 +169,18 @@ template <int LPI>
 __device__ __forceinline__ void scatter_stream(double *V, const int4 *__restrict__ recs, int steps, int g, int cc) {
     constexpr int T = 64 / LPI;
     const int nblk = steps / BS;
-    Blk cur, nxt;
+    // (fetching two blocks ahead was measured slower: the extra registers cost a wavefront per SIMD)
+    Blk cur, n1;
     if (nblk > 0) cur.load(recs, 0, LPI, g);
     for (int b = 0; b < nblk; b++) {
-        if (b + 1 < nblk) nxt.load(recs, b + 1, LPI, g);
+        if (b + 1 < nblk) n1.load(recs, b + 1, LPI, g);
+        if ((b & (SYNC_BLOCKS - 1)) == 0) __syncthreads();  // keep the workgroup's wavefronts on the same stream lines (L1)
 #pragma unroll
         for (int s = 0; s < BS; s++) {
             const double x = V[cur.r[s].y * T + cc];
             V[cur.r[s].x * T + cc] -= rec_val(cur.r[s]) * x;
         }
-        cur = nxt;
+        cur = n1;
     }
 }
 
@@ -177,22 +190,26 @@ __device__ __forceinline__ void spmv_stream(const double *IN, double *OUT, int n
                                             int g, int cc) {
     constexpr int T = 64 / LPI;
     const int nblk = steps / BS;
-    Blk cur, nxt;
+    Blk cur, n1;
     if (nblk > 0) cur.load(recs, 0, LPI, g);
     double acc = 0.0;
     int row = g;
     for (int b = 0; b < nblk; b++) {
-        if (b + 1 < nblk) nxt.load(recs, b + 1, LPI, g);
+        if (b + 1 < nblk) n1.load(recs, b + 1, LPI, g);
+        if ((b & (SYNC_BLOCKS - 1)) == 0) __syncthreads();
+        double x[BS];
+#pragma unroll
+        for (int s = 0; s < BS; s++) x[s] = IN[cur.r[s].x * T + cc];
 #pragma unroll
         for (int s = 0; s < BS; s++) {
-            acc += rec_val(cur.r[s]) * IN[cur.r[s].x * T + cc];
-            if (cur.r[s].y) {
+            acc += rec_val(cur.r[s]) * x[s];
+            if (__builtin_amdgcn_readfirstlane(cur.r[s].y)) {  // (the flag is the same in every lane)
                 if (row < nrows) OUT[row * T + cc] = acc;
                 acc = 0.0;
                 row += LPI;
             }
         }
-        cur = nxt;
+        cur = n1;
     }
 }
 
@@ -227,15 +244,16 @@ struct TileDev {
 // scratch rows per tile: PR (np) | DU (np) | PH (np) | BH (nr) | QV (dim);  LDS rows: RH (nr) | QH (np) | PL (np)
 // ---------------------------------------------------------------------------------------------------------
 template <int LPI>
-__global__ __launch_bounds__(64) void soc_tile_kernel(SocDev c, TileDev td, const double *__restrict__ C,
+__global__ __launch_bounds__(64 * WAVES) void soc_tile_kernel(SocDev c, TileDev td, const double *__restrict__ C,
                                                       const int4 *__restrict__ recs, const double *__restrict__ x0g,
                                                       const double *__restrict__ xrg, const double *__restrict__ urg,
                                                       int ref_stride, const double *__restrict__ rg, int r_stride, long B,
                                                       double *__restrict__ S, int *__restrict__ k_out, int *__restrict__ e_out) {
-    constexpr int T = 64 / LPI;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int lane = threadIdx.x, g = lane / T, cc = lane % T;
-    const long tile = blockIdx.x;
+    constexpr int T = 64 / LPI, U = 4;
+    extern __shared__ __attribute__((aligned(16))) double lds_wg[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / T, cc = lane % T;
+    double *lds = lds_wg + (size_t)wave * td.lds_bytes / sizeof(double);  // each wavefront's own vectors
+    const long tile = (long)blockIdx.x * WAVES + wave;  // (tiles past the batch run on instance 0's inputs, store nothing)
     const long t = tile * T + cc;
     const bool valid = t < B;
     const int n = c.n, m = c.m, nm = n + m, N = c.N, dim = c.dim, n_s = c.n_s, n_eq = c.n_eq;
@@ -293,11 +311,32 @@ __global__ __launch_bounds__(64) void soc_tile_kernel(SocDev c, TileDev td, cons
     while (true) {
         k += 1;
         // q_hat = [q + lambda - sigma z; mu - rho s]  (:144-149)
-        for (int j = g; j < np; j += LPI)
-            QH[j * T + cc] = (j < dim) ? AT(QV, j) + AT(DU, j) - sigma * AT(PR, j) : AT(DU, j) - rho * AT(PR, j);
+        // (element-wise loops: U row groups per pass, all global loads of a pass issued before they are used)
+        for (int j0 = g; j0 < np; j0 += U * LPI) {
+            double q[U], du[U], pr[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = j0 + u * LPI;
+                q[u] = (j < dim) ? AT(QV, j) : 0.0;
+                du[u] = (j < np) ? AT(DU, j) : 0.0;
+                pr[u] = (j < np) ? AT(PR, j) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = j0 + u * LPI;
+                if (j < np) QH[j * T + cc] = (j < dim) ? q[u] + du[u] - sigma * pr[u] : du[u] - rho * pr[u];
+            }
+        }
         // rhs = (-Gh Hh^-1) q_hat - bh  (:152-160)
         spmv_stream<LPI>(lds, RH, nr, recs + td.rhs.off, td.rhs.steps, g, cc);
-        for (int i = g; i < nr; i += LPI) RH[i * T + cc] -= AT(BH, i);
+        for (int i0 = g; i0 < nr; i0 += U * LPI) {
+            double bh[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) bh[u] = (i0 + u * LPI < nr) ? AT(BH, i0 + u * LPI) : 0.0;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (i0 + u * LPI < nr) RH[(i0 + u * LPI) * T + cc] -= bh[u];
+        }
         // W mu = rhs through L D L' (:166-188)
         scatter_stream<LPI>(RH, recs + td.fwd.off, td.fwd.steps, g, cc);
         for (int i = g; i < nr; i += LPI) RH[i * T + cc] *= Dinv[i];
@@ -307,16 +346,31 @@ __global__ __launch_bounds__(64) void soc_tile_kernel(SocDev c, TileDev td, cons
         double s_norm = 0.0;
         bool res = false;
         // z: box (:209-217), lambda (:246-248), residuals (:256-267)
-        for (int i = g; i < dim; i += LPI) {
-            const double zh = PL[i * T + cc], lam = AT(DU, i), zo = AT(PR, i);
-            double z = zh + sigma_i * lam;
-            if (i < dim - n - 1) z = fmin(fmax(z, cLB[i]), cUB[i]);
-            if (active) {
-                AT(PH, i) = zh;
-                AT(PR, i) = z;
-                AT(DU, i) = lam + sigma * (zh - z);
+        for (int i0 = g; i0 < dim; i0 += U * LPI) {
+            double lam[U], zo[U], lb[U], ub[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * LPI;
+                lam[u] = (i < dim) ? AT(DU, i) : 0.0;
+                zo[u] = (i < dim) ? AT(PR, i) : 0.0;
+                lb[u] = (i < dim - n - 1) ? cLB[i] : 0.0;
+                ub[u] = (i < dim - n - 1) ? cUB[i] : 0.0;
             }
-            res |= (fabs(zo - z) > c.tol_d) | (fabs(z - zh) > c.tol_p);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * LPI;
+                if (i < dim) {
+                    const double zh = PL[i * T + cc];
+                    double z = zh + sigma_i * lam[u];
+                    if (i < dim - n - 1) z = fmin(fmax(z, lb[u]), ub[u]);
+                    if (active) {
+                        AT(PH, i) = zh;
+                        AT(PR, i) = z;
+                        AT(DU, i) = lam[u] + sigma * (zh - z);
+                    }
+                    res |= (fabs(zo[u] - z) > c.tol_d) | (fabs(z - zh) > c.tol_p);
+                }
+            }
         }
         // un-projected s = s_hat + mu / rho into QH's tail (free now), then the SOC projection (:220-242), mu (:251-253)
         for (int i = dim + (g + LPI - dim % LPI) % LPI; i < np; i += LPI) QH[i * T + cc] = PL[i * T + cc] + rho_i * AT(DU, i);
@@ -352,7 +406,7 @@ __global__ __launch_bounds__(64) void soc_tile_kernel(SocDev c, TileDev td, cons
             }
             active = false;
         }
-        if (!__any(active)) break;
+        if (!__syncthreads_or(active ? 1 : 0)) break;
     }
 #undef AT
 }
@@ -363,15 +417,16 @@ __global__ __launch_bounds__(64) void soc_tile_kernel(SocDev c, TileDev td, cons
 // scratch rows per tile: PR (np) | DU (np) | PH (np) | BH (nc) | QV (dim);  LDS rows: RH (nrow_M)
 // ---------------------------------------------------------------------------------------------------------
 template <int LPI>
-__global__ __launch_bounds__(64) void hmpc_tile_kernel(HmpcDev c, TileDev td, const double *__restrict__ C,
+__global__ __launch_bounds__(64 * WAVES) void hmpc_tile_kernel(HmpcDev c, TileDev td, const double *__restrict__ C,
                                                        const int *__restrict__ I, const int4 *__restrict__ recs,
                                                        const double *__restrict__ x0g, const double *__restrict__ xrg,
                                                        const double *__restrict__ urg, int ref_stride, long B,
                                                        double *__restrict__ S, int *__restrict__ k_out, int *__restrict__ e_out) {
-    constexpr int T = 64 / LPI;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int lane = threadIdx.x, g = lane / T, cc = lane % T;
-    const long tile = blockIdx.x;
+    constexpr int T = 64 / LPI, U = 4;
+    extern __shared__ __attribute__((aligned(16))) double lds_wg[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / T, cc = lane % T;
+    double *lds = lds_wg + (size_t)wave * td.lds_bytes / sizeof(double);  // each wavefront's own vectors
+    const long tile = (long)blockIdx.x * WAVES + wave;  // (tiles past the batch run on instance 0's inputs, store nothing)
     const long t = tile * T + cc;
     const bool valid = t < B;
     const int n = c.n, m = c.m, nm = n + m, N = c.N, dim = c.dim, n_s = c.n_s, n_eq = c.n_eq, nrow = c.nrow_M;
@@ -427,7 +482,19 @@ __global__ __launch_bounds__(64) void hmpc_tile_kernel(HmpcDev c, TileDev td, co
     while (true) {
         k += 1;
         // rhs = [sigma z - q - lambda; rho s - mu; bh]  (:156-165)
-        for (int j = g; j < dim; j += LPI) RH[j * T + cc] = sigma * AT(PR, j) - AT(QV, j) - AT(DU, j);
+        for (int j0 = g; j0 < dim; j0 += U * LPI) {
+            double q[U], du[U], pr[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = j0 + u * LPI;
+                q[u] = (j < dim) ? AT(QV, j) : 0.0;
+                du[u] = (j < dim) ? AT(DU, j) : 0.0;
+                pr[u] = (j < dim) ? AT(PR, j) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (j0 + u * LPI < dim) RH[(j0 + u * LPI) * T + cc] = sigma * pr[u] - q[u] - du[u];
+        }
         for (int j = g; j < triples; j += LPI)
             for (int r = 0; r < 3; r++) RH[(dim + 3 * j + r) * T + cc] = rho * AT(PR, dim + 3 * j + r) - AT(DU, dim + 3 * j + r);
         for (int j = g; j < nc; j += LPI) RH[(np + j) * T + cc] = AT(BH, j);
@@ -437,18 +504,33 @@ __global__ __launch_bounds__(64) void hmpc_tile_kernel(HmpcDev c, TileDev td, co
         scatter_stream<LPI>(RH, recs + td.bwd.off, td.bwd.steps, g, cc);
         bool res = false;
         // z (:215-238, 288-312, 318-333)
-        for (int j = g; j < dim; j += LPI) {
-            const double zh = RH[j * T + cc], zo = AT(PR, j);
-            double lam = AT(DU, j);
-            if (c.symmetric) lam += as * (zh - zo);
-            double z = zh + sigma_i * lam;
-            if (j < dim - 3 * nm) z = fmin(fmax(z, cLB[j]), cUB[j]);
-            if (active) {
-                AT(PH, j) = zh;
-                AT(PR, j) = z;
-                AT(DU, j) = lam + gz * (zh - z);
+        for (int j0 = g; j0 < dim; j0 += U * LPI) {
+            double lm[U], zo[U], lb[U], ub[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = j0 + u * LPI;
+                lm[u] = (j < dim) ? AT(DU, j) : 0.0;
+                zo[u] = (j < dim) ? AT(PR, j) : 0.0;
+                lb[u] = (j < dim - 3 * nm) ? cLB[j] : 0.0;
+                ub[u] = (j < dim - 3 * nm) ? cUB[j] : 0.0;
             }
-            res |= (fabs(zo - z) > c.tol_d) | (fabs(z - zh) > c.tol_p);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = j0 + u * LPI;
+                if (j < dim) {
+                    const double zh = RH[j * T + cc];
+                    double lam = lm[u];
+                    if (c.symmetric) lam += as * (zh - zo[u]);
+                    double z = zh + sigma_i * lam;
+                    if (j < dim - 3 * nm) z = fmin(fmax(z, lb[u]), ub[u]);
+                    if (active) {
+                        AT(PH, j) = zh;
+                        AT(PR, j) = z;
+                        AT(DU, j) = lam + gz * (zh - z);
+                    }
+                    res |= (fabs(zo[u] - z) > c.tol_d) | (fabs(z - zh) > c.tol_p);
+                }
+            }
         }
         // s in triples (:241-259)
         for (int j = g; j < triples; j += LPI) {
@@ -486,7 +568,7 @@ __global__ __launch_bounds__(64) void hmpc_tile_kernel(HmpcDev c, TileDev td, co
             }
             active = false;
         }
-        if (!__any(active)) break;
+        if (!__syncthreads_or(active ? 1 : 0)) break;
     }
 #undef AT
 }

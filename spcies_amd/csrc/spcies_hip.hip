@@ -580,7 +580,7 @@ static int launch_hmpc(Solver &s, const double *x0, const double *xr, const doub
 
 static size_t tile_scratch_bytes(const Solver &s, long B) {
     if (!s.tdev.lpi) return 0;
-    const long T = 64 / s.tdev.lpi, tiles = (B + T - 1) / T;
+    const long T = 64 / s.tdev.lpi, tiles = ((B + T - 1) / T + tile::WAVES - 1) / tile::WAVES * tile::WAVES;
     const long np = s.soc_dim() + s.soc_ns();
     const long rows = s.is_hmpc() ? 3 * np + (s.hdev.n_eq + s.hdev.n_s) + s.hdev.dim : 3 * np + (s.sdev.n_eq + s.sdev.n_s) + s.sdev.dim;
     return (size_t)tiles * rows * T * sizeof(double);
@@ -590,29 +590,33 @@ static size_t tile_scratch_bytes(const Solver &s, long B) {
 static int launch_tile(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, const double *r,
                        int r_stride, long B, double *u, int *k, int *e, double *const *f, hipStream_t st) {
     const int lpi = s.tdev.lpi, T = 64 / lpi;
-    const long tiles = (B + T - 1) / T;
+    const long tiles = ((B + T - 1) / T + tile::WAVES - 1) / tile::WAVES * tile::WAVES;
     const long np = s.soc_dim() + s.soc_ns();
     const long rows = s.is_hmpc() ? 3 * np + (s.hdev.n_eq + s.hdev.n_s) + s.hdev.dim : 3 * np + (s.sdev.n_eq + s.sdev.n_s) + s.sdev.dim;
     double *S = s.d_scratch;
-    const size_t shmem = s.tdev.lds_bytes;
-    dim3 grid((unsigned)tiles), block(64);
+    const size_t shmem = s.tdev.lds_bytes * tile::WAVES;
+    dim3 grid((unsigned)(tiles / tile::WAVES)), block(64 * tile::WAVES);
 #define SPCIES_TILE_LAUNCH(LPI)                                                                                            \
     do {                                                                                                                   \
         if (s.is_hmpc()) {                                                                                                 \
             auto kern = tile::hmpc_tile_kernel<LPI>;                                                                       \
-            SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            if (shmem > 48 * 1024)                                                                                         \
+                SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
             hipLaunchKernelGGL(kern, grid, block, shmem, st, s.hdev, s.tdev, s.d_consts, s.d_idx, s.d_recs, x0, xr, ur,    \
                                ref_stride, B, S, k, e);                                                                    \
         } else {                                                                                                           \
             auto kern = tile::soc_tile_kernel<LPI>;                                                                        \
-            SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            if (shmem > 48 * 1024)                                                                                         \
+                SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
             hipLaunchKernelGGL(kern, grid, block, shmem, st, s.sdev, s.tdev, s.d_consts, s.d_recs, x0, xr, ur, ref_stride, r, \
                                r_stride, B, S, k, e);                                                                      \
         }                                                                                                                  \
     } while (0)
     if (lpi == 4) SPCIES_TILE_LAUNCH(4);
     else if (lpi == 8) SPCIES_TILE_LAUNCH(8);
-    else SPCIES_TILE_LAUNCH(16);
+    else if (lpi == 16) SPCIES_TILE_LAUNCH(16);
+    else if (lpi == 32) SPCIES_TILE_LAUNCH(32);
+    else SPCIES_TILE_LAUNCH(64);
 #undef SPCIES_TILE_LAUNCH
     SPCIES_HIP_CHECK(hipGetLastError());
     const int dim = s.soc_dim(), n_s = s.soc_ns();
