@@ -107,7 +107,13 @@ enum spcies_array_id {
     SPCIES_A_TE = 41, SPCIES_A_SE = 42,      /* [n][n], [m][m]                                      */
     SPCIES_A_LBY = 43, SPCIES_A_UBY = 44,    /* [n+m]                                               */
     SPCIES_A_IDX_X0 = 45,                    /* i32 [n]: rows of bh that hold -A x0                 */
-    SPCIES_A_BH = 46                         /* [n_eq + n_s]                                        */
+    SPCIES_A_BH = 46,                        /* [n_eq + n_s]                                        */
+    /* time-varying lax/equ MPC ADMM (header flags bit2; cons_laxMPC_ADMM_C.m:97-109): the blob holds only T (9)
+     * and T_rho_i = inv(T + rho I); A, B, Q, R, LB, UB arrive with every call through the `extra` argument of
+     * the _ex entry points, packed per instance as A [n*n] and B [n*m] COLUMN-major, Q [n], R [m], LB [n+m],
+     * UB [n+m] (the six extra inputs of the 9-argument mex gateway, struct_laxMPC_ADMM_C_Matlab.c:57-103);
+     * extra_stride = n*n + n*m + n + m + 2(n+m) for one model per instance, 0 for one shared model          */
+    SPCIES_A_T_RHO_I = 47                    /* [n][n]                                              */
 };
 
 typedef struct {
@@ -117,7 +123,7 @@ typedef struct {
     uint32_t formulation;  /* enum spcies_formulation                        */
     uint32_t method;       /* enum spcies_method                             */
     uint32_t submethod;    /* 0 = none                                       */
-    uint32_t flags;        /* bit0: scalar rho                               */
+    uint32_t flags;        /* bit0: scalar rho, bit1: use_soc, bit2: time-varying */
     uint32_t n, m, N, k_max;
     uint32_t n_arrays;
     uint32_t reserved0;

@@ -16,6 +16,7 @@
  * optimum (tests/test_laxMPC_ADMM.m:35, tests/test_equMPC_ADMM.m:33; tolerance 1e-4 as
  * tests/spcies_tester.m:261) and against tests/golden/ vectors.
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -274,4 +275,143 @@ int oracle_admm_banded_batch(const admm_banded_data *d, long B, const double *x0
         if (rc) return rc;
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * TIME_VARYING == 1: the update phase that computes the solver's ingredients from the model handed in
+ * with every call (code_laxMPC_ADMM_C.c:117-279, code_equMPC_ADMM_C.c:117-265), then the same iteration.
+ * Inputs as the 9-argument mex gateway (struct_laxMPC_ADMM_C_Matlab.c:57-103): A [n][n] and B [n][m]
+ * COLUMN-major, Q [n], R [m] diagonals, LB / UB [n+m].  T_rho_i = inv(T + rho I) and T (negated) are the
+ * only controller constants (cons_laxMPC_ADMM_C.m:107-109).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    double *AB, *Alpha, *Beta, *Hi, *Hi_0, *Q, *R; /* outputs, sized as in admm_banded_data */
+} admm_tv_out;
+
+void oracle_admm_tv_update(int n, int m, int N, int terminal, double rho, const double *A_in, const double *B_in,
+                           const double *Q_in, const double *R_in, const double *T_rho_i, admm_tv_out *o) {
+    const int nm = n + m;
+    double *Q_rho_i = (double *)calloc((size_t)n, sizeof(double));
+    double *R_rho_i = (double *)calloc((size_t)m, sizeof(double));
+    double *AQiAt = (double *)calloc((size_t)n * n, sizeof(double));
+    double *BRiBt = (double *)calloc((size_t)n * n, sizeof(double));
+#define TAB(i, j) (o->AB[(size_t)(i) * nm + (j)])
+#define TALPHA(l, i, j) (o->Alpha[((size_t)(l) * n + (i)) * n + (j)])
+#define TBETA(l, i, j) (o->Beta[((size_t)(l) * n + (i)) * n + (j)])
+    memset(o->Alpha, 0, sizeof(double) * (size_t)(N - 1) * n * n);
+    memset(o->Beta, 0, sizeof(double) * (size_t)N * n * n);
+    /* :117-145 */
+    for (int i = 0; i < n; i++) {
+        o->Q[i] = Q_in[i];
+        Q_rho_i[i] = 1 / (o->Q[i] + rho);
+        for (int j = 0; j < n; j++) TAB(i, j) = A_in[i + j * n];
+        for (int j = 0; j < m; j++) TAB(i, n + j) = B_in[i + j * n];
+    }
+    for (int j = 0; j < m; j++) {
+        o->R[j] = R_in[j];
+        R_rho_i[j] = 1 / (o->R[j] + rho);
+        o->Hi_0[j] = R_rho_i[j];
+    }
+    for (int i = 0; i < N - 1; i++)
+        for (int j = 0; j < nm; j++) o->Hi[(size_t)i * nm + j] = (j < n) ? Q_rho_i[j] : R_rho_i[j - n];
+    /* :151-161 */
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            for (int k = 0; k < n; k++) AQiAt[i * n + j] += A_in[i + k * n] * Q_rho_i[k] * A_in[j + k * n];
+            for (int k = 0; k < m; k++) BRiBt[i * n + j] += B_in[i + k * n] * R_rho_i[k] * B_in[j + k * n];
+        }
+    /* Beta{0} :164-181, Alpha{0} :184-197 */
+    for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++) {
+            TBETA(0, i, j) = BRiBt[i * n + j];
+            for (int l = 1; l <= i; l++) TBETA(0, i, j) -= TBETA(0, l - 1, i) * TBETA(0, l - 1, j);
+            if (i == j) {
+                TBETA(0, i, i) += Q_rho_i[i];
+                TBETA(0, i, i) = 1 / sqrt(TBETA(0, i, i));
+            } else {
+                TBETA(0, i, j) = TBETA(0, i, j) * TBETA(0, i, i);
+            }
+        }
+    for (int h = 0; h < N - 1; h++) {
+        if (h >= 1) { /* Beta{h} :200-222 */
+            for (int i = 0; i < n; i++)
+                for (int j = i; j < n; j++) {
+                    TBETA(h, i, j) = AQiAt[i * n + j] + BRiBt[i * n + j];
+                    for (int k = 0; k < n; k++) TBETA(h, i, j) -= TALPHA(h - 1, k, i) * TALPHA(h - 1, k, j);
+                    for (int l = 1; l <= i; l++) TBETA(h, i, j) -= TBETA(h, l - 1, i) * TBETA(h, l - 1, j);
+                    if (i == j) {
+                        TBETA(h, i, i) += Q_rho_i[i];
+                        TBETA(h, i, i) = 1 / sqrt(TBETA(h, i, i));
+                    } else {
+                        TBETA(h, i, j) = TBETA(h, i, j) * TBETA(h, i, i);
+                    }
+                }
+        }
+        /* Alpha{h} :184-197, :225-238 */
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                TALPHA(h, i, j) = -Q_rho_i[i] * TAB(j, i);
+                for (int l = 1; l <= i; l++) TALPHA(h, i, j) -= TBETA(h, l - 1, i) * TALPHA(h, l - 1, j);
+                TALPHA(h, i, j) = TALPHA(h, i, j) * TBETA(h, i, i);
+            }
+    }
+    /* Beta{N-1} :244-267 (laxMPC adds the dense T_rho_i; equMPC: code_equMPC_ADMM_C.c:234-255) */
+    for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++) {
+            TBETA(N - 1, i, j) = AQiAt[i * n + j] + BRiBt[i * n + j];
+            for (int k = 0; k < n; k++) TBETA(N - 1, i, j) -= TALPHA(N - 2, k, i) * TALPHA(N - 2, k, j);
+            for (int l = 1; l <= i; l++) TBETA(N - 1, i, j) -= TBETA(N - 1, l - 1, i) * TBETA(N - 1, l - 1, j);
+            if (terminal) TBETA(N - 1, i, j) += T_rho_i[(size_t)i * n + j];
+            if (i == j) TBETA(N - 1, i, i) = 1 / sqrt(TBETA(N - 1, i, i));
+            else TBETA(N - 1, i, j) = TBETA(N - 1, i, j) * TBETA(N - 1, i, i);
+        }
+    /* :271-276 */
+    for (int i = 0; i < n; i++) o->Q[i] = -o->Q[i];
+    for (int i = 0; i < m; i++) o->R[i] = -o->R[i];
+#undef TAB
+#undef TALPHA
+#undef TBETA
+    free(Q_rho_i); free(R_rho_i); free(AQiAt); free(BRiBt);
+}
+
+/* Batch driver of the time-varying solver.  model is [B][n*n + n*m + n + m + 2(n+m)] = (A, B, Q, R, LB, UB) per
+ * instance when model_stride != 0, else one shared model.  fac_out (optional) receives instance 0's
+ * Alpha ((N-1) n n) then Beta (N n n) for the tests. */
+int oracle_admm_tv_batch(int n, int m, int N, int k_max, int terminal, double tol, double rho, const double *T,
+                         const double *T_rho_i, long B, const double *x0, const double *xr, const double *ur,
+                         int ref_stride, const double *model, int model_stride, double *u, int *k, int *e_flag,
+                         double *z, double *v, double *lam, double *fac_out) {
+    const int nm = n + m;
+    const size_t dim = (size_t)N * nm - (terminal ? 0 : (size_t)n);
+    const size_t msz = (size_t)n * n + (size_t)n * m + n + m + 2 * (size_t)nm;
+    admm_tv_out o;
+    o.AB = (double *)calloc((size_t)n * nm, sizeof(double));
+    o.Alpha = (double *)calloc((size_t)(N - 1) * n * n, sizeof(double));
+    o.Beta = (double *)calloc((size_t)N * n * n, sizeof(double));
+    o.Hi = (double *)calloc((size_t)(N - 1) * nm, sizeof(double));
+    o.Hi_0 = (double *)calloc((size_t)m, sizeof(double));
+    o.Q = (double *)calloc((size_t)n, sizeof(double));
+    o.R = (double *)calloc((size_t)m, sizeof(double));
+    int rc = 0;
+    for (long i = 0; i < B && !rc; i++) {
+        const double *mi = model_stride ? model + (size_t)i * msz : model;
+        const double *A_in = mi, *B_in = A_in + (size_t)n * n, *Q_in = B_in + (size_t)n * m, *R_in = Q_in + n,
+                     *LB = R_in + m, *UB = LB + nm;
+        oracle_admm_tv_update(n, m, N, terminal, rho, A_in, B_in, Q_in, R_in, T_rho_i, &o);
+        if (i == 0 && fac_out) {
+            memcpy(fac_out, o.Alpha, sizeof(double) * (size_t)(N - 1) * n * n);
+            memcpy(fac_out + (size_t)(N - 1) * n * n, o.Beta, sizeof(double) * (size_t)N * n * n);
+        }
+        admm_banded_data d;
+        d.n = n; d.m = m; d.N = N; d.k_max = k_max; d.terminal = terminal; d.tol = tol; d.rho = rho; d.rho_i = 1.0 / rho;
+        d.AB = o.AB; d.Alpha = o.Alpha; d.Beta = o.Beta; d.Hi = o.Hi; d.Hi_0 = o.Hi_0; d.Hi_N = T_rho_i;
+        d.Q = o.Q; d.R = o.R; d.T = T; d.LB = LB; d.UB = UB;
+        const double *xri = ref_stride ? xr + (size_t)i * n : xr;
+        const double *uri = ref_stride ? ur + (size_t)i * m : ur;
+        rc = oracle_admm_banded_solve(&d, x0 + (size_t)i * n, xri, uri, u + (size_t)i * m, k + i, e_flag + i,
+                                      z ? z + (size_t)i * dim : NULL, v ? v + (size_t)i * dim : NULL,
+                                      lam ? lam + (size_t)i * dim : NULL);
+    }
+    free(o.AB); free(o.Alpha); free(o.Beta); free(o.Hi); free(o.Hi_0); free(o.Q); free(o.R);
+    return rc;
 }

@@ -44,6 +44,57 @@ def quantize_like_reference(a):
     return np.array([float("%1.15f" % x) for x in a.ravel()]).reshape(a.shape)
 
 
+def pack_tv_model(A, Bm, Q, R, LB, UB):
+    """(A, B, Q, R, LB, UB) -> the packed per-instance model rows of the time-varying solvers
+    (A, B column-major as MATLAB hands them to the mex).  Inputs may carry a leading batch axis."""
+    A, Bm = np.asarray(A, float), np.asarray(Bm, float)
+    batched = A.ndim == 3
+    rows = A.shape[0] if batched else 1
+    parts = []
+    for a, nd in ((A, 2), (Bm, 2), (Q, 1), (R, 1), (LB, 1), (UB, 1)):
+        a = np.asarray(a, float)
+        a = np.broadcast_to(a, (rows,) + a.shape[-nd:]) if a.ndim == nd else a
+        if nd == 2:
+            a = np.transpose(a, (0, 2, 1))
+        parts.append(np.reshape(a, (rows, -1)))
+    return np.ascontiguousarray(np.hstack(parts)), batched
+
+
+def admm_tv_batch(v, x0, xr, ur, model, per_instance, want_sol=True, want_factors=False):
+    """Time-varying lax/equ MPC ADMM (update phase + iteration).  ``v``: the time-varying ingredients
+    (n, m, N, T, T_rho_i, rho, tol, k_max, terminal); ``model``: rows from :func:`pack_tv_model`."""
+    n, m, N = int(v["n"]), int(v["m"]), int(v["N"])
+    terminal = bool(v.get("terminal", True))
+    x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
+    B = x0.shape[0]
+    xr = np.ascontiguousarray(np.asarray(xr, dtype=float))
+    ur = np.ascontiguousarray(np.asarray(ur, dtype=float))
+    stride = 1 if xr.ndim == 2 else 0
+    T = np.ascontiguousarray(np.asarray(v["T"], float))
+    Tri = np.ascontiguousarray(np.asarray(v["T_rho_i"], float))
+    model = np.ascontiguousarray(model)
+    dim = N * (n + m) - (0 if terminal else n)
+    u = np.zeros((B, m)); k = np.zeros(B, dtype=np.int32); e = np.zeros(B, dtype=np.int32)
+    z = np.zeros((B, dim)) if want_sol else None
+    vv = np.zeros((B, dim)) if want_sol else None
+    lam = np.zeros((B, dim)) if want_sol else None
+    fac = np.zeros((2 * N - 1) * n * n) if want_factors else None
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    lib = _lib()
+    lib.oracle_admm_tv_batch.restype = C.c_int
+    rc = lib.oracle_admm_tv_batch(C.c_int(n), C.c_int(m), C.c_int(N), C.c_int(int(v["k_max"])), C.c_int(int(terminal)),
+                                  C.c_double(float(v["tol"])), C.c_double(float(v["rho"])), _dp(T), _dp(Tri), C.c_long(B),
+                                  _dp(x0), _dp(xr), _dp(ur), C.c_int(stride), _dp(model), C.c_int(1 if per_instance else 0),
+                                  _dp(u), ip(k), ip(e), _dp(z) if want_sol else None, _dp(vv) if want_sol else None,
+                                  _dp(lam) if want_sol else None, _dp(fac) if want_factors else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle_admm_tv_batch failed rc={rc}")
+    out = (u, k, e, z, vv, lam)
+    if want_factors:
+        return out + (fac[:(N - 1) * n * n].reshape(N - 1, n, n), fac[(N - 1) * n * n:].reshape(N, n, n))
+    return out
+
+
 def admm_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     """Run the C oracle on a batch.  ``v`` is the ingredients dict of
     ``spcies_amd.formulations.laxMPC.compute_*_ADMM_ingredients``.  Returns ``u, k, e_flag, z, v, lam``."""

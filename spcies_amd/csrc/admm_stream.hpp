@@ -48,10 +48,65 @@ __device__ __forceinline__ bool above(double a, double b, double tol) {
     return r > tol;
 }
 
+// A controller constant array: shared by all instances (pointer into the constants allocation, fetched with
+// scalar loads) or, for the time-varying solvers, per instance in the structure-of-arrays scratch [row][Bp].
+template <bool TV>
+struct KArr;
+template <>
+struct KArr<false> {
+    const double *p;
+    __device__ __forceinline__ double operator[](long i) const { return p[i]; }
+    __device__ __forceinline__ KArr operator+(long off) const { return KArr{p + off}; }
+};
+// Per-instance rows are read through a buffer resource (SGPR descriptor over the whole scratch, SGPR row
+// offset, one VGPR lane offset): with flat addressing hipcc materialises one 64-bit VGPR pointer per
+// constant of the unrolled sweeps and spills hundreds of them.  The scratch of one launch stays below 4 GB
+// (the host splits larger batches).
+template <>
+struct KArr<true> {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t r;
+    unsigned row, bp8, voff;  // first row, Bp * 8, 8 * instance
+    __device__ __forceinline__ double operator[](long i) const {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, (row + (unsigned)i) * bp8, 0));
+    }
+    __device__ __forceinline__ KArr operator+(long off) const { return KArr{r, row + (unsigned)off, bp8, voff}; }
+};
+
+// Row offsets of the per-instance constants of the time-varying solvers inside their scratch (tv_layout()).
+struct TvLayout {
+    int AB, Alpha, Beta, Hi, Hi_0, Q, R, LB, UB, AQiAt, BRiBt, rows;
+};
+__host__ __device__ inline TvLayout tv_layout(int n, int m, int N) {
+    TvLayout L;
+    const int nm = n + m;
+    int r = 0;
+    L.AB = r; r += n * nm;
+    L.Alpha = r; r += (N - 1) * n * n;
+    L.Beta = r; r += N * n * n;
+    L.Hi = r; r += (N - 1) * nm;
+    L.Hi_0 = r; r += m;
+    L.Q = r; r += n;
+    L.R = r; r += m;
+    L.LB = r; r += nm;
+    L.UB = r; r += nm;
+    L.AQiAt = r; r += n * n;
+    L.BRiBt = r; r += n * n;
+    L.rows = r;
+    return L;
+}
+
 // Scratch: V, LAM are [dim][Bp], Y is [N*n][Bp], ZS (optional, only when the caller wants
 // z / v / lambda back) is [dim][Bp].  Element order inside dim = the reference's flattened order
 // (code_laxMPC_ADMM_C.c:659-684): m head entries, N-1 rows of n+m, n tail entries.
-template <int n, int m, bool TERMINAL, bool EXACT>
+// time-varying instantiation: every constant is a per-lane global load; a compiler barrier per row keeps hipcc
+// from hoisting a whole sweep's loads to the top (510 spilled registers without it)
+#define SPCIES_TV_ROW_BARRIER()                          \
+    do {                                                 \
+        if constexpr (TV) asm volatile("" ::: "memory"); \
+    } while (0)
+
+template <int n, int m, bool TERMINAL, bool EXACT, bool TV = false>
 __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double *__restrict__ C,
                                                          const double *__restrict__ x0g,
                                                          const double *__restrict__ xrg,
@@ -59,14 +114,27 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                                                          long Bp, double *__restrict__ V,
                                                          double *__restrict__ LAM, double *__restrict__ Y,
                                                          double *__restrict__ ZS, double *__restrict__ u_out,
-                                                         int *__restrict__ k_out, int *__restrict__ e_out) {
+                                                         int *__restrict__ k_out, int *__restrict__ e_out,
+                                                         const double *__restrict__ TVS = nullptr) {
     constexpr int nm = n + m;
     const long t = (long)blockIdx.x * 64 + threadIdx.x;
     if (t >= B) return;
     const int N = c.N;
     const double rho = c.rho, rho_i = c.rho_i, tol = c.tol;
-    const double *cAB = C + c.AB, *cAlpha = C + c.Alpha, *cBeta = C + c.Beta, *cHi = C + c.Hi, *cHi_0 = C + c.Hi_0,
-                 *cHi_N = C + c.Hi_N, *cQ = C + c.Q, *cR = C + c.R, *cT = C + c.T, *cLB = C + c.LB, *cUB = C + c.UB;
+    // time-varying: everything but Hi_N (= T_rho_i) and T comes from the instance's own rows (written by
+    // admm_tv_update_kernel); otherwise from the shared constants
+    const TvLayout tl = tv_layout(n, m, N);
+    auto K = [&](int shared_off, int tv_row) {
+        if constexpr (TV) {
+            return KArr<true>{__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(TVS), 0, -1, 0x00020000), (unsigned)tv_row,
+                              (unsigned)(Bp * 8), (unsigned)(t * 8)};
+        } else {
+            return KArr<false>{C + shared_off};
+        }
+    };
+    const KArr<TV> cAB = K(c.AB, tl.AB), cAlpha = K(c.Alpha, tl.Alpha), cBeta = K(c.Beta, tl.Beta), cHi = K(c.Hi, tl.Hi),
+                   cHi_0 = K(c.Hi_0, tl.Hi_0), cQ = K(c.Q, tl.Q), cR = K(c.R, tl.R), cLB = K(c.LB, tl.LB), cUB = K(c.UB, tl.UB);
+    const double *cHi_N = C + c.Hi_N, *cT = C + c.T;
 
     // ---- per-instance setup (code_laxMPC_ADMM_C.c:282-299)
     double xr[n], b[n], q[nm], qT[n];
@@ -146,6 +214,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
             double y[n];
 #pragma unroll
             for (int j = 0; j < n; j++) {
+                SPCIES_TV_ROW_BARRIER();
                 double acc;
                 if (l == 0) {
                     acc = cHi[j] * qc[j] - b[j];
@@ -170,10 +239,11 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                 y[j] = acc;
             }
             // forward substitution (:388-417)
-            const double *Bl = cBeta + (long)l * n * n;
-            const double *Al = cAlpha + (long)(l - 1) * n * n;
+            const KArr<TV> Bl = cBeta + (long)l * n * n;
+            const KArr<TV> Al = cAlpha + (long)(l - 1) * n * n;
 #pragma unroll
             for (int j = 0; j < n; j++) {
+                SPCIES_TV_ROW_BARRIER();
                 double acc = y[j];
                 if (l > 0) {
 #pragma unroll
@@ -196,13 +266,14 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
         bool res = false;
         double mun[n];  // mu of block l+1
         for (int l = N - 1; l >= 0; l--) {
-            const double *Bl = cBeta + (long)l * n * n;
-            const double *Al = cAlpha + (long)l * n * n;
+            const KArr<TV> Bl = cBeta + (long)l * n * n;
+            const KArr<TV> Al = cAlpha + (long)l * n * n;
             double mu[n];
 #pragma unroll
             for (int j = 0; j < n; j++) mu[j] = (l == N - 1) ? yp[j] : Yt[((long)l * n + j) * Bp];
 #pragma unroll
             for (int j = n - 1; j >= 0; j--) {
+                SPCIES_TV_ROW_BARRIER();
                 double acc = mu[j];
                 if (l < N - 1) {
 #pragma unroll
@@ -241,6 +312,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                 // reference block l: z[l] = -Hi[l] (q_hat - [mu_l; 0] + AB' mu_{l+1})  (:464-474)
 #pragma unroll
                 for (int j = 0; j < nm; j++) {
+                    SPCIES_TV_ROW_BARRIER();
                     long e = off_mid + (long)l * nm + j;
                     double lam = first ? 0.0 : Lt[e * Bp];
                     double vold = first ? 0.0 : Vt[e * Bp];
@@ -263,6 +335,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
         // head: z_0 = -Hi_0 (q_hat_0 + B' mu_0)  (:456-461)
 #pragma unroll
         for (int j = 0; j < m; j++) {
+            SPCIES_TV_ROW_BARRIER();
             double lam = first ? 0.0 : Lt[(long)j * Bp];
             double vold = first ? 0.0 : Vt[(long)j * Bp];
             double zz = q[n + j] + lam - rho * vold;
@@ -291,6 +364,113 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
     for (int j = 0; j < m; j++) u_out[t * m + j] = u0[j];
     k_out[t] = k;
     e_out[t] = flag;
+}
+
+// Update phase of the time-varying solvers (TIME_VARYING == 1, code_laxMPC_ADMM_C.c:117-279, equMPC:
+// code_equMPC_ADMM_C.c:117-265): from the model handed in with the call - A [n][n], B [n][m] column-major, Q, R
+// diagonals, LB, UB, packed per instance in `model` (one shared model when model_stride == 0) - to AB, Hi, Hi_0,
+// the banded Cholesky factors Alpha / Beta, and the negated Q, R, in the instance's rows of the scratch.
+// One lane per instance, the reference's operation order.
+template <int n, int m, bool TERMINAL>
+__global__ __launch_bounds__(64) void admm_tv_update_kernel(int N, double rho, const double *__restrict__ T_rho_i,
+                                                            const double *__restrict__ model, long model_stride, long B,
+                                                            long Bp, double *__restrict__ TVS) {
+    constexpr int nm = n + m;
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    if (t >= B) return;
+    const TvLayout tl = tv_layout(n, m, N);
+    const double *A_in = model + t * model_stride, *B_in = A_in + n * n, *Q_in = B_in + n * m, *R_in = Q_in + n,
+                 *LB_in = R_in + m, *UB_in = LB_in + nm;
+    double *S = TVS + t;
+#define ROW(base, i) S[(long)((base) + (i)) * Bp]
+#define TBETA(h, i, j) ROW(tl.Beta, ((h) * n + (i)) * n + (j))
+#define TALPHA(h, i, j) ROW(tl.Alpha, ((h) * n + (i)) * n + (j))
+    double Q_rho_i[n], R_rho_i[m];
+    for (int i = 0; i < (N - 1) * n * n; i++) ROW(tl.Alpha, i) = 0.0;
+    for (int i = 0; i < N * n * n; i++) ROW(tl.Beta, i) = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        Q_rho_i[i] = 1 / (Q_in[i] + rho);
+        for (int j = 0; j < n; j++) ROW(tl.AB, i * nm + j) = A_in[i + j * n];
+        for (int j = 0; j < m; j++) ROW(tl.AB, i * nm + n + j) = B_in[i + j * n];
+    }
+#pragma unroll
+    for (int j = 0; j < m; j++) {
+        R_rho_i[j] = 1 / (R_in[j] + rho);
+        ROW(tl.Hi_0, j) = R_rho_i[j];
+    }
+    for (int i = 0; i < N - 1; i++) {
+#pragma unroll
+        for (int j = 0; j < nm; j++) ROW(tl.Hi, i * nm + j) = (j < n) ? Q_rho_i[j < n ? j : 0] : R_rho_i[j >= n ? j - n : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < nm; j++) {
+        ROW(tl.LB, j) = LB_in[j];
+        ROW(tl.UB, j) = UB_in[j];
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int k = 0; k < n; k++) a += A_in[i + k * n] * Q_rho_i[k] * A_in[j + k * n];
+#pragma unroll
+            for (int k = 0; k < m; k++) b += B_in[i + k * n] * R_rho_i[k] * B_in[j + k * n];
+            ROW(tl.AQiAt, i * n + j) = a;
+            ROW(tl.BRiBt, i * n + j) = b;
+        }
+    // Beta{0}
+    for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++) {
+            double v = ROW(tl.BRiBt, i * n + j);
+            for (int l = 1; l <= i; l++) v -= TBETA(0, l - 1, i) * TBETA(0, l - 1, j);
+            if (i == j) {
+                v += Q_rho_i[i];
+                v = 1 / sqrt(v);
+            } else {
+                v = v * TBETA(0, i, i);
+            }
+            TBETA(0, i, j) = v;
+        }
+    for (int h = 0; h < N - 1; h++) {
+        if (h >= 1) {
+            for (int i = 0; i < n; i++)
+                for (int j = i; j < n; j++) {
+                    double v = ROW(tl.AQiAt, i * n + j) + ROW(tl.BRiBt, i * n + j);
+                    for (int k = 0; k < n; k++) v -= TALPHA(h - 1, k, i) * TALPHA(h - 1, k, j);
+                    for (int l = 1; l <= i; l++) v -= TBETA(h, l - 1, i) * TBETA(h, l - 1, j);
+                    if (i == j) {
+                        v += Q_rho_i[i];
+                        v = 1 / sqrt(v);
+                    } else {
+                        v = v * TBETA(h, i, i);
+                    }
+                    TBETA(h, i, j) = v;
+                }
+        }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                double v = -Q_rho_i[i] * ROW(tl.AB, j * nm + i);
+                for (int l = 1; l <= i; l++) v -= TBETA(h, l - 1, i) * TALPHA(h, l - 1, j);
+                TALPHA(h, i, j) = v * TBETA(h, i, i);
+            }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++) {
+            double v = ROW(tl.AQiAt, i * n + j) + ROW(tl.BRiBt, i * n + j);
+            for (int k = 0; k < n; k++) v -= TALPHA(N - 2, k, i) * TALPHA(N - 2, k, j);
+            for (int l = 1; l <= i; l++) v -= TBETA(N - 1, l - 1, i) * TBETA(N - 1, l - 1, j);
+            if constexpr (TERMINAL) v += T_rho_i[i * n + j];
+            if (i == j) v = 1 / sqrt(v);
+            else v = v * TBETA(N - 1, i, i);
+            TBETA(N - 1, i, j) = v;
+        }
+#pragma unroll
+    for (int i = 0; i < n; i++) ROW(tl.Q, i) = -Q_in[i];
+#pragma unroll
+    for (int i = 0; i < m; i++) ROW(tl.R, i) = -R_in[i];
+#undef ROW
+#undef TBETA
+#undef TALPHA
 }
 
 // [rows][Bp] structure-of-arrays scratch -> [B][rows] instance-contiguous output (the layout the

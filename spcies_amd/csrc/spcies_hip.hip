@@ -29,6 +29,8 @@ struct Solver {
     AdmmDev dev{};
     FistaDev fdev{};
     std::vector<double> QRi, Td, Ti;  // FISTA-only ingredients
+    bool tv = false;                  // time-varying lax/equ ADMM: model arrives with every call (extra)
+    int tv_model_size() const { return host.n * host.n + host.n * host.m + host.n + host.m + 2 * (host.n + host.m); }
     SocDev sdev{};
     HmpcDev hdev{};
     std::vector<double> soc_f64;   // ellipMPC-soc: all FP64 constants, concatenated
@@ -294,11 +296,17 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     std::vector<Want> want = {{SPCIES_A_AB, n * nm, &a.AB},       {SPCIES_A_ALPHA, (N - 1) * n * n, &a.Alpha},
                               {SPCIES_A_BETA, N * n * n, &a.Beta}, {SPCIES_A_LB, nm, &a.LB},
                               {SPCIES_A_UB, nm, &a.UB}};
-    if (h.method != SPCIES_EADMM) {
+    s.tv = (h.flags & 4u) != 0;
+    if (s.tv) {
+        if (h.method != SPCIES_ADMM || !banded) return fail(SPCIES_HIP_ENOSUP, "time-varying: built for laxMPC / equMPC ADMM only");
+        want = {{SPCIES_A_T, n * n, &a.T}, {SPCIES_A_T_RHO_I, n * n, &a.Hi_N}};  // Hi_N = T_rho_i (code_laxMPC_ADMM_C.c:123)
+    }
+    if (h.method != SPCIES_EADMM && !s.tv) {
         want.push_back({SPCIES_A_Q, n, &a.Q});
         want.push_back({SPCIES_A_R, m, &a.R});
     }
-    if (h.method == SPCIES_EADMM) {
+    if (s.tv) {
+    } else if (h.method == SPCIES_EADMM) {
         want.push_back({SPCIES_A_T, n * n, &a.T});
         want.push_back({SPCIES_A_S, m * m, &s.e_S});
         want.push_back({SPCIES_A_RHO_MAT, (N + 1) * nm, &s.e_rho});
@@ -381,6 +389,7 @@ static bool stream_shape_built(int n, int m) {
 
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
+    if (s.tv) return SPCIES_VARIANT_STREAM;
     if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
@@ -516,6 +525,55 @@ static int launch_eadmm(Solver &s, const double *x0, const double *xr, const dou
     SPCIES_CASE(20, 2)
 #undef SPCIES_CASE
     return fail(SPCIES_HIP_ENOSUP, "EADMM STREAM variant not instantiated for n=%d m=%d", n, m);
+}
+
+static bool tv_shape_built(int n, int m) { return m == 2 && (n == 6 || n == 12); }
+
+// Time-varying lax/equ ADMM: update phase (per-instance banded Cholesky) + the STREAM iteration reading the
+// instance's own constants.  Large batches are split so that one launch's constants stay below the 4 GB a
+// buffer resource can address.
+template <int n, int m>
+static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, const double *model,
+                        int model_stride, long B, double *u, int *k, int *e, double *z, double *v, double *lam,
+                        hipStream_t st) {
+    const int N = s.host.N;
+    const TvLayout tl = tv_layout(n, m, N);
+    const bool want_sol = (z || v || lam);
+    const size_t dim = (size_t)s.host.dim();
+    const size_t rows_stream = 2 * dim + (size_t)N * n + (want_sol ? dim : 0);
+    long chunk = (long)((3900ull << 20) / ((size_t)tl.rows * 8)) / 64 * 64;
+    if (chunk > B) chunk = (B + 63) / 64 * 64;
+    int rc = ensure_scratch(s, (rows_stream + (size_t)tl.rows) * (size_t)chunk * sizeof(double));
+    if (rc) return rc;
+    for (long b0 = 0; b0 < B; b0 += chunk) {
+        const long Bc = std::min(chunk, B - b0), Bp = (Bc + 63) / 64 * 64;
+        double *V = s.d_scratch, *LAM = V + dim * Bp, *Y = LAM + dim * Bp;
+        double *ZS = want_sol ? Y + (size_t)N * n * Bp : nullptr;
+        double *TVS = s.d_scratch + rows_stream * Bp;
+        const double *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
+        const double *mc = model_stride ? model + b0 * (long)model_stride : model;
+        dim3 grid((unsigned)(Bp / 64)), block(64);
+        if (s.host.terminal) {
+            hipLaunchKernelGGL((admm_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
+                               (long)model_stride, Bc, Bp, TVS);
+            hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true, true>), grid, block, 0, st, s.dev, s.d_consts, x0 + b0 * n,
+                               xrc, urc, ref_stride, Bc, Bp, V, LAM, Y, ZS, u + b0 * m, k + b0, e + b0, TVS);
+        } else {
+            hipLaunchKernelGGL((admm_tv_update_kernel<n, m, false>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N,
+                               mc, (long)model_stride, Bc, Bp, TVS);
+            hipLaunchKernelGGL((admm_stream_kernel<n, m, false, true, true>), grid, block, 0, st, s.dev, s.d_consts, x0 + b0 * n,
+                               xrc, urc, ref_stride, Bc, Bp, V, LAM, Y, ZS, u + b0 * m, k + b0, e + b0, TVS);
+        }
+        SPCIES_HIP_CHECK(hipGetLastError());
+        if (want_sol) {
+            dim3 tg((unsigned)(Bp / 64), (unsigned)((dim + 63) / 64));
+            if (z) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, ZS, Bp, Bc, (int)dim, z + b0 * dim);
+            if (v) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, V, Bp, Bc, (int)dim, v + b0 * dim);
+            if (lam) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, LAM, Bp, Bc, (int)dim, lam + b0 * dim);
+            SPCIES_HIP_CHECK(hipGetLastError());
+        }
+    }
+    return 0;
 }
 
 static int launch_stream(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
@@ -692,6 +750,16 @@ static int solve_device(Solver &s, const double *x0, const double *xr, const dou
         if (rc) return rc;
         return launch_fista(s, x0, xr, ur, ref_stride, B, u, k, e, z, lam, st);
     }
+    if (s.tv) {
+        if (!extra) return fail(SPCIES_HIP_EINVAL, "time-varying solvers take A, B, Q, R, LB, UB with every call (extra): Spcies:laxMPC:nrhs:number");
+        if (extra_stride != 0 && extra_stride != s.tv_model_size())
+            return fail(SPCIES_HIP_EINVAL, "time-varying: extra_stride must be 0 (shared model) or %d", s.tv_model_size());
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
+            return fail(SPCIES_HIP_ENOSUP, "time-varying: only the STREAM variant is built");
+        if (s.host.n == 6 && s.host.m == 2) return launch_tv_nm<6, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
+        if (s.host.n == 12 && s.host.m == 2) return launch_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
+        return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
+    }
     const int variant = resolve_variant(s);
     if (variant == SPCIES_VARIANT_MFMA4) {
         if (!s.mfma4.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s.mfma4.why.c_str());
@@ -745,7 +813,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     SPCIES_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     rc = upload_consts(*s);
     if (rc) return rc;
-    if (s->method == SPCIES_ADMM && (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC)) {
+    if (s->method == SPCIES_ADMM && (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC) && !s->tv) {
         rc = mfma_plan_build(s->mfma, s->host);
         if (rc) return rc;
         rc = mfma4_plan_build(s->mfma4, s->host);
@@ -906,7 +974,8 @@ int spcies_hip_solve_batch_ex(spcies_hip_handle h, const double *x0, const doubl
     const size_t n = s->host.n, m = s->host.m;
     const size_t nref = ref_stride ? (size_t)B : 1;
     // device staging: x0 | xr | ur | u | extra | fields... | k | e   (doubles first, ints last)
-    const size_t nex = extra ? (extra_stride ? (size_t)B : 1) : 0;
+    const size_t ex_w = s->tv ? (size_t)s->tv_model_size() : 1;  // doubles per instance in `extra`
+    const size_t nex = extra ? (extra_stride ? (size_t)B : 1) * ex_w : 0;
     size_t nd = (size_t)B * n + nref * n + nref * m + (size_t)B * m + nex;
     const size_t o_x0 = 0, o_xr = (size_t)B * n, o_ur = o_xr + nref * n, o_u = o_ur + nref * m, o_ex = o_u + (size_t)B * m;
     size_t o_f[6] = {0, 0, 0, 0, 0, 0};

@@ -66,11 +66,18 @@ def compute_laxMPC_ADMM_ingredients(controller, opt, terminal=True):
     rho = opt.solver["rho"]
     if np.ndim(rho) != 0 or opt.solver.get("force_vector_rho", False):
         raise NotImplementedError("HIP platform: vector rho is not built yet (scalar rho only)")
-    if opt.time_varying:
-        raise NotImplementedError("HIP platform: time_varying solvers are not built yet")
     rho = float(rho)
     nm = n + m
     dim = N * nm if terminal else N * nm - n
+    if opt.time_varying:
+        # compute_laxMPC_ADMM_ingredients.m:89-117, cons_laxMPC_ADMM_C.m:97-109: the generated solver receives
+        # A, B, Q, R, LB, UB with every call and factorises on line; only T and inv(T + rho I) are constants
+        v = dict(n=n, m=m, N=N, formulation="laxMPC" if terminal else "equMPC", method="ADMM", terminal=bool(terminal),
+                 time_varying=True, rho=rho, rho_i=1.0 / rho, rho_is_scalar=True, k_max=int(opt.solver["k_max"]),
+                 tol=float(opt.solver["tol"]), dim=dim)
+        v["T"] = -T if terminal else np.zeros((n, n))
+        v["T_rho_i"] = np.linalg.inv(T + rho * np.eye(n)) if terminal else np.zeros((n, n))
+        return v
 
     H = np.zeros((dim, dim))
     H[:m, :m] = R

@@ -56,6 +56,7 @@ class HipSolver:
         self.device = info.device
         self.formulation = {v: k for k, v in _blob.FORMULATION.items()}[info.formulation]
         self.name = name or self.formulation
+        self.time_varying = bool(int.from_bytes(self.blob[28:32], "little") & 4)  # header flags bit2
         self.debug = bool(debug)  # reference option `debug`: copy z, v, lambda out (Spcies_options.m:121)
 
     # -- lifecycle
@@ -114,6 +115,35 @@ class HipSolver:
             raise SpciesArgError(f"Spcies:{f}:nrhs:ur", f"ur must be of dimension {self.m}")
         return x0, xr, ur, B, per, single
 
+    def _pack_model(self, extra_in, B):
+        """Time-varying solvers: ``solver(x0, xr, ur, A, B, Q, R, LB, UB)`` as the 9-input mex gateway
+        (``struct_laxMPC_ADMM_C_Matlab.c:29-31, 57-103``).  Each of the six may carry a leading batch axis
+        (one model per instance).  Packed per instance as the C-ABI's ``extra``: A, B column-major, Q, R, LB, UB."""
+        f, n, m = self.formulation, self.n, self.m
+        if len(extra_in) != 6:
+            raise SpciesArgError(f"Spcies:{f}:nrhs:number", "Nine inputs are required")
+        names, shapes = ("A", "B", "Q", "R", "LB", "UB"), ((n, n), (n, m), (n,), (m,), (n + m,), (n + m,))
+        arrs, per = [], False
+        for name, shp, a in zip(names, shapes, extra_in):
+            a = np.asarray(a, dtype=np.float64)
+            if a.size == int(np.prod(shp)):
+                a = a.reshape(shp)
+            elif a.size == B * int(np.prod(shp)) and a.shape[0] == B:
+                a = a.reshape((B,) + shp)
+                per = True
+            else:
+                raise SpciesArgError(f"Spcies:{f}:nrhs:{name}", f"{name} must be of dimension {' by '.join(map(str, shp))}")
+            arrs.append(a)
+        rows = B if per else 1
+        cols = []
+        for shp, a in zip(shapes, arrs):
+            a = np.broadcast_to(a, (rows,) + shp) if a.ndim == len(shp) else a
+            if len(shp) == 2:
+                a = np.transpose(a, (0, 2, 1))  # column-major, as MATLAB hands it to the mex
+            cols.append(np.reshape(a, (rows, -1)))
+        model = np.ascontiguousarray(np.hstack(cols))
+        return model, (model.shape[1] if per else 0)
+
     def __call__(self, x0, xr, ur, *extra_in, want_sol=None):
         """``u, k, e_flag, sol = solver(x0, xr, ur)``; host (numpy) buffers in and out.  The ellipMPC soc
         solver takes the ellipsoid radius as a 4th input, ``solver(x0, xr, ur, r)``
@@ -127,6 +157,8 @@ class HipSolver:
             if extra.size not in (1, B):
                 raise SpciesArgError("Spcies:ellipMPC:nrhs:r", "r must be a scalar (or one value per instance)")
             extra_stride = 1 if (extra.size == B and B > 1) else 0
+        elif self.time_varying:
+            extra, extra_stride = self._pack_model(extra_in, B)
         elif extra_in:
             raise SpciesArgError(f"Spcies:{self.formulation}:nrhs:number", "Three inputs are required")
         want_sol = self.debug if want_sol is None else want_sol

@@ -1,0 +1,100 @@
+"""Time-varying lax/equ MPC ADMM (TIME_VARYING == 1 in
+formulations/+laxMPC/code_laxMPC_ADMM_C.c:117-279, code_equMPC_ADMM_C.c:117-265, tutorial
+examples/t01_time_varying_MPC.m): the model (A, B, Q, R, LB, UB) arrives with every call and the banded
+Cholesky factors are computed on line.
+
+Oracle pin (CPU): the on-line factors equal the off-line ones of compute_laxMPC_ADMM_ingredients.m (chol of
+W) to rounding, and a time-varying solve handed the design model reproduces the ordinary solver - hence the
+reference tests' z_opt.  GPU: the HIP path against the oracle, bit for bit (STREAM operation order), with one
+model per instance.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+def _setup(name):
+    from spcies_amd import benchmarks
+    cfg = benchmarks.config(name)
+    v = benchmarks.ingredients(cfg)
+    vt = benchmarks.ingredients(cfg, time_varying=True)
+    sys, prm = cfg.sys, cfg.param
+    LB = np.concatenate([np.ravel(sys.LBx), np.ravel(sys.LBu)])
+    UB = np.concatenate([np.ravel(sys.UBx), np.ravel(sys.UBu)])
+    return cfg, v, vt, (np.asarray(sys.A, float), np.asarray(sys.B, float), np.diag(prm.Q).copy(), np.diag(prm.R).copy(), LB, UB)
+
+
+def _perturbed_models(design, B, seed=5):
+    """One model per instance: the design model with every entry of A, B and the weights moved by up to 2 %,
+    bounds by up to 5 %."""
+    rng = np.random.default_rng(seed)
+    A, Bm, Q, R, LB, UB = design
+    j = lambda a, s: a[None] * (1.0 + s * (2 * rng.random((B,) + a.shape) - 1))
+    return j(A, 0.02), j(Bm, 0.02), j(Q, 0.02), j(R, 0.02), j(LB, 0.05), j(UB, 0.05)
+
+
+@pytest.mark.parametrize("name,test_name", [("C1_lax", "test_laxMPC_ADMM"), ("C1_equ", "test_equMPC_ADMM"), ("C2_lax", None)])
+def test_oracle_time_varying_matches_offline(name, test_name, golden_dir):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, vt, design = _setup(name)
+    assert vt["time_varying"] and "Alpha" not in vt and vt["T_rho_i"].shape == (cfg.sys.n, cfg.sys.n)
+    model, per = oracle.pack_tv_model(*design)
+    x0, xr, ur = benchmarks.sample_batch(cfg, 12)
+    if test_name:
+        st = benchmarks.tester_status(cfg.sys)
+        x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
+    out = oracle.admm_tv_batch(vt, x0, xr, ur, model, per, want_factors=True)
+    ref = oracle.admm_banded_batch(v, x0, xr, ur)
+    assert np.abs(out[6] - v["Alpha"]).max() <= 1e-12
+    assert np.abs(np.triu(out[7]) - np.triu(v["Beta"])).max() <= 1e-11
+    assert np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2])
+    lscale = np.maximum(1.0, np.abs(ref[5]).max(axis=1, keepdims=True) / 100.0)
+    assert (np.abs(out[0] - ref[0]) / lscale).max() <= 1e-10 and (np.abs(out[3] - ref[3]) / lscale).max() <= 1e-9
+    if test_name:
+        with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
+            z_opt = np.array(json.load(f)[test_name])
+        assert out[2][0] == 1 and np.abs(out[3][0] - z_opt).max() <= 1e-4
+
+
+def test_blob_roundtrip_time_varying():
+    from spcies_amd import blob
+    cfg, v, vt, design = _setup("C1_lax")
+    b = blob.pack(vt)
+    w = blob.unpack(b)
+    assert w["time_varying"] and np.array_equal(w["T_rho_i"], vt["T_rho_i"]) and "AB" not in w
+    assert not blob.unpack(blob.pack(v))["time_varying"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,overrides", [("C1_lax", 70, {}), ("C1_equ", 40, {}), ("C2_lax", 130, {}),
+                                              ("C2_lax", 50, dict(tol=1e-6, k_max=3000))])
+def test_hip_time_varying_vs_oracle(name, B, overrides):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver, SpciesArgError
+    cfg, v, vt, design = _setup(name)
+    vt = benchmarks.ingredients(cfg, time_varying=True, **overrides)
+    s = HipSolver(vt)
+    assert s.time_varying and s.variant == "stream"
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    with pytest.raises(SpciesArgError):
+        s(x0, xr, ur)  # nine inputs are required (struct_laxMPC_ADMM_C_Matlab.c:29-31)
+    # one shared model (the design model)
+    model, per = oracle.pack_tv_model(*design)
+    O = oracle.admm_tv_batch(vt, x0, xr, ur, model, per)
+    u, k, e, sol = s(x0, xr, ur, *design)
+    assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+    assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.v, O[4]) and np.array_equal(sol.lam, O[5])
+    # one model per instance
+    models = _perturbed_models(design, B)
+    model, per = oracle.pack_tv_model(*models)
+    O = oracle.admm_tv_batch(vt, x0, xr, ur, model, per)
+    u, k, e, sol = s(x0, xr, ur, *models)
+    assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+    assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.v, O[4]) and np.array_equal(sol.lam, O[5])
+    nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)
+    assert np.array_equal(nosol[0], O[0][:9]) and np.array_equal(nosol[1], O[1][:9])
+    s.close()
