@@ -219,6 +219,16 @@ int spcies_hip_time_device(spcies_hip_handle h, const double *x0, const double *
                            int ref_stride, long B, double *u, int *k, int *e_flag, void *stream, int reps,
                            double *ms_per_launch);
 
+/* Closed-loop batch simulation on the device (examples/cl_in_C/main_cl_in_C.c:98-117: solve, then
+ * x+ = A x + B u with the plant AB [n][n+m] row-major, `steps` times) for B independent plants, without a
+ * host round trip between sample times.  Host buffers: x0 [B][n] initial states, xr / ur as in solve_batch;
+ * outputs (each may be NULL): x_traj [steps+1][B][n] (x_traj[0] = x0), u_traj [steps][B][m],
+ * k_traj / e_traj [steps][B].  Solvers with extra inputs (ellipMPC radius, time-varying model) are not driven
+ * by this entry point.                                                                                      */
+int spcies_hip_closed_loop(spcies_hip_handle h, const double *AB_plant, const double *x0, const double *xr, const double *ur,
+                           int ref_stride, long B, int steps, double *x_traj, double *u_traj, int *k_traj, int *e_traj,
+                           spcies_hip_timing *timing);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ EXPORTS = (
     "spcies_hip_destroy", "spcies_hip_get_info", "spcies_hip_set_variant", "spcies_hip_set_exit",
     "spcies_hip_reserve", "spcies_hip_solve_batch", "spcies_hip_solve_batch_device", "spcies_hip_time_device",
     "spcies_hip_get_sol_layout", "spcies_hip_solve_batch_ex", "spcies_hip_solve_batch_device_ex",
+    "spcies_hip_closed_loop",
 )
 
 VARIANT_AUTO, VARIANT_STREAM, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4G, VARIANT_TILE = 0, 1, 2, 3, 4, 5

@@ -776,6 +776,21 @@ static int solve_device(Solver &s, const double *x0, const double *xr, const dou
     return launch_stream(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
 }
 
+#pragma clang fp contract(off)
+// x+ = A x + B u in the operation order of examples/cl_in_C/main_cl_in_C.c:106-116, one instance per thread
+__global__ __launch_bounds__(256) void plant_step_kernel(const double *__restrict__ AB, int n, int m, const double *__restrict__ x,
+                                                         const double *__restrict__ u, long B, double *__restrict__ xn) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= B) return;
+    const int nm = n + m;
+    for (int i = 0; i < n; i++) {
+        double acc = 0.0;
+        for (int j = 0; j < n; j++) acc += AB[i * nm + j] * x[t * n + j];
+        for (int j = 0; j < m; j++) acc += AB[i * nm + n + j] * u[t * m + j];
+        xn[t * n + i] = acc;
+    }
+}
+
 }  // namespace spcies
 
 using namespace spcies;
@@ -1057,6 +1072,70 @@ int spcies_hip_time_device(spcies_hip_handle h, const double *x0, const double *
     hipEventDestroy(b);
     *ms_per_launch = (double)ms / reps;
     return 0;
+}
+
+int spcies_hip_closed_loop(spcies_hip_handle h, const double *AB_plant, const double *x0, const double *xr, const double *ur,
+                           int ref_stride, long B, int steps, double *x_traj, double *u_traj, int *k_traj, int *e_traj,
+                           spcies_hip_timing *timing) {
+    if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
+    if (B < 0 || steps < 0) return fail(SPCIES_HIP_EINVAL, "negative batch / steps");
+    if (timing) *timing = spcies_hip_timing{0, 0, 0, 0};
+    if (B == 0 || steps == 0) return 0;
+    if (!AB_plant || !x0 || !xr || !ur) return fail(SPCIES_HIP_EINVAL, "NULL buffer");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    if (s->tv || (s->is_soc() && !s->is_hmpc()))
+        return fail(SPCIES_HIP_ENOSUP, "closed loop: solvers with extra inputs (ellipMPC r, time-varying model) are not driven here");
+    std::lock_guard<std::mutex> lk(s->mu);
+    SPCIES_HIP_CHECK(hipSetDevice(s->device));
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    const size_t n = s->host.n, m = s->host.m, nm = n + m, nref = ref_stride ? (size_t)B : 1;
+    // device buffers: AB | xr | ur | x_traj [steps+1][B][n] | u_traj [steps][B][m] | k_traj, e_traj [steps][B]
+    const size_t o_ab = 0, o_xr = n * nm, o_ur = o_xr + nref * n, o_x = o_ur + nref * m, o_u = o_x + (size_t)(steps + 1) * B * n;
+    const size_t nd = o_u + (size_t)steps * B * m;
+    const size_t need = nd * sizeof(double) + 2 * (size_t)steps * B * sizeof(int);
+    double *d = nullptr;
+    SPCIES_HIP_CHECK(hipMalloc((void **)&d, need));
+    int *dk = reinterpret_cast<int *>(d + nd), *de = dk + (size_t)steps * B;
+    hipStream_t st = s->stream;
+    auto cleanup = [&](int rc) { hipFree(d); return rc; };
+#define SPCIES_CL_CHECK(expr)                                                                                   \
+    do {                                                                                                        \
+        hipError_t e__ = (expr);                                                                                \
+        if (e__ != hipSuccess) return cleanup(fail(SPCIES_HIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e__))); \
+    } while (0)
+    SPCIES_CL_CHECK(hipMemcpyAsync(d + o_ab, AB_plant, n * nm * 8, hipMemcpyHostToDevice, st));
+    SPCIES_CL_CHECK(hipMemcpyAsync(d + o_xr, xr, nref * n * 8, hipMemcpyHostToDevice, st));
+    SPCIES_CL_CHECK(hipMemcpyAsync(d + o_ur, ur, nref * m * 8, hipMemcpyHostToDevice, st));
+    SPCIES_CL_CHECK(hipMemcpyAsync(d + o_x, x0, (size_t)B * n * 8, hipMemcpyHostToDevice, st));
+    SPCIES_CL_CHECK(hipStreamSynchronize(st));
+    auto t1 = clk::now();
+    double *f[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int t = 0; t < steps; t++) {
+        double *xt = d + o_x + (size_t)t * B * n, *ut = d + o_u + (size_t)t * B * m;
+        int rc = solve_device(*s, xt, d + o_xr, d + o_ur, ref_stride, B, ut, dk + (size_t)t * B, de + (size_t)t * B, f, nullptr, 0, st);
+        if (rc) return cleanup(rc);
+        hipLaunchKernelGGL(plant_step_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, d + o_ab, (int)n, (int)m, xt, ut, B,
+                           xt + (size_t)B * n);
+        SPCIES_CL_CHECK(hipGetLastError());
+    }
+    SPCIES_CL_CHECK(hipStreamSynchronize(st));
+    auto t2 = clk::now();
+    if (x_traj) SPCIES_CL_CHECK(hipMemcpyAsync(x_traj, d + o_x, (size_t)(steps + 1) * B * n * 8, hipMemcpyDeviceToHost, st));
+    if (u_traj) SPCIES_CL_CHECK(hipMemcpyAsync(u_traj, d + o_u, (size_t)steps * B * m * 8, hipMemcpyDeviceToHost, st));
+    if (k_traj) SPCIES_CL_CHECK(hipMemcpyAsync(k_traj, dk, (size_t)steps * B * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (e_traj) SPCIES_CL_CHECK(hipMemcpyAsync(e_traj, de, (size_t)steps * B * sizeof(int), hipMemcpyDeviceToHost, st));
+    SPCIES_CL_CHECK(hipStreamSynchronize(st));
+#undef SPCIES_CL_CHECK
+    auto t3 = clk::now();
+    if (timing) {
+        auto ms = [](clk::duration x) { return std::chrono::duration<double, std::milli>(x).count(); };
+        timing->update_time = ms(t1 - t0);
+        timing->solve_time = ms(t2 - t1);
+        timing->polish_time = ms(t3 - t2);
+        timing->run_time = ms(t3 - t0);
+    }
+    return cleanup(0);
 }
 
 }  // extern "C"

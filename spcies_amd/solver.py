@@ -91,7 +91,7 @@ class HipSolver:
         _lib.check(self._lib.spcies_hip_set_exit(self._h, int(k_max), float(tol)))
 
     def reserve(self, B):
-        _lib.check(self._lib.spcies_hip_reserve(self._h, int(B)))
+        _lib.check(self._lib.spcies_hip_reserve(self._h, C.c_long(int(B))))
 
     # -- the generated-solver call
     def _check_args(self, x0, xr, ur):
@@ -170,7 +170,8 @@ class HipSolver:
         ptrs = (dp * len(self.sol_fields))(*[_dp(a) for a in arrays]) if want_sol else None
         t = _lib.Timing()
         _lib.check(self._lib.spcies_hip_solve_batch_ex(
-            self._h, _dp(x0), _dp(xr), _dp(ur), int(per), _dp(extra) if extra is not None else None, extra_stride, B,
+            self._h, _dp(x0), _dp(xr), _dp(ur), C.c_int(int(per)), _dp(extra) if extra is not None else None,
+            C.c_int(int(extra_stride)), C.c_long(B),
             _dp(u), _ip(k), _ip(e), ptrs, len(self.sol_fields), C.byref(t)))
         fields = {name: (arrays[i] if want_sol else None) for i, (name, _) in enumerate(self.sol_fields)}
         if single:
@@ -184,13 +185,29 @@ class HipSolver:
             return u[0], int(k[0]), int(e[0]), sol
         return u, k, e, sol
 
+    def closed_loop(self, AB, x0, xr, ur, steps):
+        """Closed-loop simulation of B plants on the device (``examples/cl_in_C/main_cl_in_C.c:98-117``): at every
+        sample time solve, then ``x+ = A x + B u`` with the plant ``AB = [A B]``.  Returns
+        ``x_traj (steps+1, B, n), u_traj (steps, B, m), k_traj, e_traj (steps, B), timing``."""
+        x0, xr, ur, B, per, single = self._check_args(x0, xr, ur)
+        AB = np.ascontiguousarray(np.asarray(AB, dtype=np.float64))
+        if AB.shape != (self.n, self.n + self.m):
+            raise SpciesArgError(f"Spcies:{self.formulation}:closed_loop:AB", f"AB must be {self.n} by {self.n + self.m}")
+        steps = int(steps)
+        xt = np.zeros((steps + 1, B, self.n)); ut = np.zeros((steps, B, self.m))
+        kt = np.zeros((steps, B), dtype=np.int32); et = np.zeros((steps, B), dtype=np.int32)
+        t = _lib.Timing()
+        _lib.check(self._lib.spcies_hip_closed_loop(self._h, _dp(AB), _dp(x0), _dp(xr), _dp(ur), C.c_int(int(per)), C.c_long(B), C.c_int(steps), _dp(xt),
+                                                    _dp(ut), _ip(kt), _ip(et), C.byref(t)))
+        return xt, ut, kt, et, t
+
     def solve_device(self, x0, xr, ur, u, k, e_flag, z=None, v=None, lam=None, stream=0):
         """Device-resident call: arguments are objects with ``data_ptr()`` (torch tensors on this GPU)
         or raw integer device addresses; asynchronous on ``stream`` (a raw ``hipStream_t`` value)."""
         ptr = lambda a: None if a is None else C.c_void_p(a if isinstance(a, int) else a.data_ptr())
         B = x0.shape[0]
         per = 1 if xr.dim() == 2 else 0
-        _lib.check(self._lib.spcies_hip_solve_batch_device(self._h, ptr(x0), ptr(xr), ptr(ur), per, B, ptr(u), ptr(k),
+        _lib.check(self._lib.spcies_hip_solve_batch_device(self._h, ptr(x0), ptr(xr), ptr(ur), C.c_int(per), C.c_long(B), ptr(u), ptr(k),
                                                           ptr(e_flag), ptr(z), ptr(v), ptr(lam), C.c_void_p(stream)))
 
     def time_device(self, x0, xr, ur, u, k, e_flag, stream=0, reps=1):
@@ -198,6 +215,6 @@ class HipSolver:
         ptr = lambda a: C.c_void_p(a.data_ptr())
         ms = C.c_double(0)
         per = 1 if xr.dim() == 2 else 0
-        _lib.check(self._lib.spcies_hip_time_device(self._h, ptr(x0), ptr(xr), ptr(ur), per, x0.shape[0], ptr(u),
+        _lib.check(self._lib.spcies_hip_time_device(self._h, ptr(x0), ptr(xr), ptr(ur), C.c_int(per), C.c_long(x0.shape[0]), ptr(u),
                                                    ptr(k), ptr(e_flag), C.c_void_p(stream), int(reps), C.byref(ms)))
         return ms.value

@@ -452,3 +452,49 @@ def test_hmpc_vs_reference_template_fixture(variant, golden_dir):
     assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
     same = k == g["k"]
     assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-8
+
+
+# ----------------------------------------------------------------------------------------------
+# Closed-loop batch simulation on the device (examples/cl_in_C/main_cl_in_C.c:98-117)
+# ----------------------------------------------------------------------------------------------
+def _plant_step_ref(AB, x, u):
+    """x+ = A x + B u accumulated in the order of main_cl_in_C.c:106-116."""
+    n = x.shape[1]
+    xn = np.zeros_like(x)
+    for i in range(n):
+        acc = np.zeros(x.shape[0])
+        for j in range(n):
+            acc = acc + AB[i, j] * x[:, j]
+        for j in range(u.shape[1]):
+            acc = acc + AB[i, n + j] * u[:, j]
+        xn[:, i] = acc
+    return xn
+
+
+@pytest.mark.parametrize("cfg_name,variant,steps,B", [("C1_lax", "stream", 12, 40), ("C1_lax", "mfma4", 12, 40),
+                                                       ("C2_lax", "stream", 4, 70), ("C1_lax_FISTA", "stream", 6, 33)])
+def test_closed_loop_vs_oracle_loop(cfg_name, variant, steps, B):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    fista = cfg_name.endswith("FISTA")
+    cfg, v, s = _fista_solver(cfg_name, variant) if fista else _solver(cfg_name, variant)
+    AB = np.hstack([cfg.sys.A, cfg.sys.B])
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    st = benchmarks.tester_status(cfg.sys)
+    if cfg_name.startswith("C1"):
+        x0[0], xr[0], ur[0] = 0.0, st.xr, st.ur  # the tutorial's run: from the origin to the reference
+    xt, ut, kt, et, timing = s.closed_loop(AB, x0, xr, ur, steps)
+    assert np.array_equal(xt[0], x0) and timing.solve_time > 0
+    x = x0.copy()
+    for t in range(steps):
+        O = (oracle.fista_banded_batch if fista else oracle.admm_banded_batch)(v, x, xr, ur, want_sol=False)
+        if variant == "stream":
+            assert np.array_equal(ut[t], O[0]) and np.array_equal(kt[t], O[1]) and np.array_equal(et[t], O[2])
+            x = _plant_step_ref(AB, x, O[0])
+            assert np.array_equal(xt[t + 1], x)
+        else:  # re-associated sums: follow the device trajectory, compare every sample time to 1e-10
+            assert np.abs(ut[t] - O[0]).max() <= TOL_SPCIES and np.abs(kt[t].astype(int) - O[1]).max() <= 1
+            assert np.abs(xt[t + 1] - _plant_step_ref(AB, x, ut[t])).max() <= 1e-13
+            x = xt[t + 1].copy()
+    if cfg_name.startswith("C1") and steps >= 12:  # the tutorial's plant moves towards the reference
+        assert np.linalg.norm(xt[-1][0] - st.xr) < np.linalg.norm(xt[0][0] - st.xr)
