@@ -113,7 +113,15 @@ enum spcies_array_id {
      * the _ex entry points, packed per instance as A [n*n] and B [n*m] COLUMN-major, Q [n], R [m], LB [n+m],
      * UB [n+m] (the six extra inputs of the 9-argument mex gateway, struct_laxMPC_ADMM_C_Matlab.c:57-103);
      * extra_stride = n*n + n*m + n + m + 2(n+m) for one model per instance, 0 for one shared model          */
-    SPCIES_A_T_RHO_I = 47                    /* [n][n]                                              */
+    SPCIES_A_T_RHO_I = 47,                   /* [n][n]                                              */
+    /* option in_engineering (header flags bit3; cons_laxMPC_ADMM_C.m:110-116): the solver's arguments are in
+     * engineering units: x = scaling_x o (x_in - OpPoint_x) for x0 and xr, ur likewise with scaling_u / OpPoint_u,
+     * u_out = v_0 o scaling_i_u + OpPoint_u (code_laxMPC_ADMM_C.c:83-100, 642-646)                          */
+    SPCIES_A_SCALING_X = 48,                 /* [n]                                                 */
+    SPCIES_A_SCALING_U = 49,                 /* [m]                                                 */
+    SPCIES_A_SCALING_I_U = 50,               /* [m]                                                 */
+    SPCIES_A_OPPOINT_X = 51,                 /* [n]                                                 */
+    SPCIES_A_OPPOINT_U = 52                  /* [m]                                                 */
 };
 
 typedef struct {
@@ -123,7 +131,7 @@ typedef struct {
     uint32_t formulation;  /* enum spcies_formulation                        */
     uint32_t method;       /* enum spcies_method                             */
     uint32_t submethod;    /* 0 = none                                       */
-    uint32_t flags;        /* bit0: scalar rho, bit1: use_soc, bit2: time-varying */
+    uint32_t flags;        /* bit0: scalar rho, bit1: use_soc, bit2: time-varying, bit3: in_engineering */
     uint32_t n, m, N, k_max;
     uint32_t n_arrays;
     uint32_t reserved0;

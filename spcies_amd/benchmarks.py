@@ -139,4 +139,4 @@ def ingredients(cfg, **solver_overrides):
           ("ellipMPC", "ADMM"): ellipMPC.compute_ellipMPC_ADMM_soc_ingredients,
           ("HMPC", "ADMM"): HMPC.compute_HMPC_ADMM_split_ingredients,
           ("HMPC", "SADMM"): HMPC.compute_HMPC_ADMM_split_ingredients}
-    return fn[(cfg.formulation, cfg.method)](ctrl, opt)
+    return laxMPC.add_engineering(fn[(cfg.formulation, cfg.method)](ctrl, opt), cfg.sys, opt)

@@ -29,6 +29,10 @@ struct Solver {
     AdmmDev dev{};
     FistaDev fdev{};
     std::vector<double> QRi, Td, Ti;  // FISTA-only ingredients
+    bool eng = false;                 // in_engineering: arguments scaled on the way in, u on the way out
+    std::vector<double> eng_v;        // scaling_x [n] | OpPoint_x [n] | scaling_u [m] | OpPoint_u [m] | scaling_i_u [m]
+    double *d_eng = nullptr, *d_eng_in = nullptr;
+    size_t eng_in_bytes = 0;
     bool tv = false;                  // time-varying lax/equ ADMM: model arrives with every call (extra)
     int tv_model_size() const { return host.n * host.n + host.n * host.m + host.n + host.m + 2 * (host.n + host.m); }
     SocDev sdev{};
@@ -276,6 +280,8 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
                         (h.formulation == SPCIES_LAXMPC || h.formulation == SPCIES_EQUMPC);
     const bool mpct = (h.method == SPCIES_EADMM && h.formulation == SPCIES_MPCT);
     const bool soc = (h.method == SPCIES_ADMM && h.formulation == SPCIES_ELLIPMPC && h.submethod == 1);
+    if ((h.flags & 8u) && (h.formulation == SPCIES_ELLIPMPC || h.formulation == SPCIES_HMPC))
+        return fail(SPCIES_HIP_ENOSUP, "in_engineering is built for the lax/equ MPC and MPCT solvers only");
     if (soc) return parse_soc(blob, bytes, h, s);
     if (h.formulation == SPCIES_HMPC && (h.method == SPCIES_ADMM || h.method == SPCIES_SADMM) && h.submethod == 2)
         return parse_hmpc(blob, bytes, h, s);
@@ -289,6 +295,17 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     AdmmHost &a = s.host;
     a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max;
     a.terminal = (h.formulation != SPCIES_EQUMPC);
+    s.eng = (h.flags & 8u) != 0;
+    if (s.eng) {
+        const uint32_t ids[5] = {SPCIES_A_SCALING_X, SPCIES_A_OPPOINT_X, SPCIES_A_SCALING_U, SPCIES_A_OPPOINT_U, SPCIES_A_SCALING_I_U};
+        const uint64_t cnt[5] = {h.n, h.n, h.m, h.m, h.m};
+        s.eng_v.clear();
+        for (int i = 0; i < 5; i++) {
+            const double *p = find_array(blob, bytes, h, ids[i], cnt[i]);
+            if (!p) return fail(SPCIES_HIP_EINVAL, "in_engineering: blob array id %u missing or mis-sized", ids[i]);
+            s.eng_v.insert(s.eng_v.end(), p, p + cnt[i]);
+        }
+    }
     a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
     if (a.k_max <= 0 || (h.method == SPCIES_ADMM && !(a.rho > 0))) return fail(SPCIES_HIP_EINVAL, "bad rho / k_max");
     const uint64_t n = h.n, m = h.m, N = h.N, nm = n + m;
@@ -692,9 +709,59 @@ static int launch_tile(Solver &s, const double *x0, const double *xr, const doub
     return 0;
 }
 
+static int solve_device_scaled(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
+                               double *u, int *k, int *e, double *const *f, const double *extra, int extra_stride,
+                               hipStream_t st);
+
+#pragma clang fp contract(off)  // the reference's mul-then-add, not an FMA
+// out[i][j] = scale[j] * (in[i][j] - op[j])  (code_laxMPC_ADMM_C.c:84-91)
+__global__ __launch_bounds__(256) void eng_in_kernel(const double *__restrict__ in, long rows, int w, const double *__restrict__ scale,
+                                                     const double *__restrict__ op, double *__restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * w) return;
+    const int j = (int)(i % w);
+    out[i] = scale[j] * (in[i] - op[j]);
+}
+// u[i][j] = u[i][j] * scaling_i_u[j] + OpPoint_u[j]  (:642-646)
+__global__ __launch_bounds__(256) void eng_out_kernel(double *__restrict__ u, long rows, int w, const double *__restrict__ sc,
+                                                      const double *__restrict__ op) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * w) return;
+    const int j = (int)(i % w);
+    u[i] = u[i] * sc[j] + op[j];
+}
+
+// Option in_engineering wraps every solver: scale the arguments, solve, un-scale the control action.
 static int solve_device(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                         double *u, int *k, int *e, double *const *f, const double *extra, int extra_stride,
                         hipStream_t st) {
+    if (B <= 0) return 0;
+    if (!s.eng) return solve_device_scaled(s, x0, xr, ur, ref_stride, B, u, k, e, f, extra, extra_stride, st);
+    const long n = s.host.n, m = s.host.m, nref = ref_stride ? B : 1;
+    const size_t need = (size_t)(B * n + nref * (n + m)) * sizeof(double);
+    if (need > s.eng_in_bytes) {
+        if (s.d_eng_in) SPCIES_HIP_CHECK(hipFree(s.d_eng_in));
+        s.d_eng_in = nullptr; s.eng_in_bytes = 0;
+        SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_eng_in, need));
+        s.eng_in_bytes = need;
+    }
+    double *sx0 = s.d_eng_in, *sxr = sx0 + B * n, *sur = sxr + nref * n;
+    const double *scx = s.d_eng, *opx = scx + n, *scu = opx + n, *opu = scu + m, *sciu = opu + m;
+    auto blocks = [](long cnt) { return dim3((unsigned)((cnt + 255) / 256)); };
+    hipLaunchKernelGGL(eng_in_kernel, blocks(B * n), dim3(256), 0, st, x0, B, (int)n, scx, opx, sx0);
+    hipLaunchKernelGGL(eng_in_kernel, blocks(nref * n), dim3(256), 0, st, xr, nref, (int)n, scx, opx, sxr);
+    hipLaunchKernelGGL(eng_in_kernel, blocks(nref * m), dim3(256), 0, st, ur, nref, (int)m, scu, opu, sur);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    int rc = solve_device_scaled(s, sx0, sxr, sur, ref_stride, B, u, k, e, f, extra, extra_stride, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(eng_out_kernel, blocks(B * m), dim3(256), 0, st, u, B, (int)m, sciu, opu);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int solve_device_scaled(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
+                               double *u, int *k, int *e, double *const *f, const double *extra, int extra_stride,
+                               hipStream_t st) {
     if (B <= 0) return 0;
     if (s.is_soc() && !s.is_hmpc() && !extra)
         return fail(SPCIES_HIP_EINVAL, "ellipMPC soc solvers take a 4th input r (extra): Spcies:ellipMPC:nrhs:r");
@@ -828,6 +895,11 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     SPCIES_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     rc = upload_consts(*s);
     if (rc) return rc;
+    if (s->eng) {
+        if (s->tv) return fail(SPCIES_HIP_ENOSUP, "in_engineering with time_varying is not built");
+        SPCIES_HIP_CHECK(hipMalloc((void **)&s->d_eng, s->eng_v.size() * sizeof(double)));
+        SPCIES_HIP_CHECK(hipMemcpy(s->d_eng, s->eng_v.data(), s->eng_v.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (s->method == SPCIES_ADMM && (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC) && !s->tv) {
         rc = mfma_plan_build(s->mfma, s->host);
         if (rc) return rc;
@@ -857,6 +929,8 @@ int spcies_hip_destroy(spcies_hip_handle h) {
     if (s->d_io) hipFree(s->d_io);
     if (s->d_idx) hipFree(s->d_idx);
     if (s->d_recs) hipFree(s->d_recs);
+    if (s->d_eng) hipFree(s->d_eng);
+    if (s->d_eng_in) hipFree(s->d_eng_in);
     mfma_plan_free(s->mfma);
     mfma4_plan_free(s->mfma4);
     g4::plan_free(s->g4plan);

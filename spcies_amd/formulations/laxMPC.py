@@ -22,6 +22,24 @@ def _is_diag(M):
     return np.count_nonzero(M - np.diag(np.diag(M))) == 0
 
 
+def add_engineering(v, sys, opt):
+    """Scaling vectors and operating point the generated solver applies to its arguments when the option
+    ``in_engineering`` is set (``compute_laxMPC_ADMM_ingredients.m:136-165``, printed by
+    ``cons_laxMPC_ADMM_C.m:110-116``): ``x = scaling_x o (x_in - OpPoint_x)``, ``u_out = v_0 o scaling_i_u + OpPoint_u``
+    (``code_laxMPC_ADMM_C.c:83-100, 642-646``).  Missing fields default to ones / zeros as there."""
+    if not getattr(opt, "in_engineering", False):
+        return v
+    n, m = int(v["n"]), int(v["m"])
+    get = lambda name, default: np.ravel(np.asarray(_get(sys, name, default), dtype=float))
+    v["scaling_x"] = get("Nx", np.ones(n))
+    v["scaling_u"] = get("Nu", np.ones(m))
+    v["scaling_i_u"] = 1.0 / get("Nu", np.ones(m))
+    v["OpPoint_x"] = get("x0", np.zeros(n))
+    v["OpPoint_u"] = get("u0", np.zeros(m))
+    v["in_engineering"] = True
+    return v
+
+
 def build_G(A, B, N, terminal=True):
     """Equality-constraint matrix of the lax (``terminal=True``) / equ (``False``) formulation.
 

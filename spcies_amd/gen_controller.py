@@ -19,38 +19,43 @@ from .options import SpciesOptions
 from .solver import HipSolver
 
 
+def _eng(v, recipe):
+    """Option ``in_engineering``: scaling vectors and operating point travel with the controller constants."""
+    return _lax.add_engineering(v, _lax._get(recipe.controller, "sys"), recipe.options)
+
+
 def cons_laxMPC_ADMM_HIP(recipe, device=0):
-    v = _lax.compute_laxMPC_ADMM_ingredients(recipe.controller, recipe.options)
+    v = _eng(_lax.compute_laxMPC_ADMM_ingredients(recipe.controller, recipe.options), recipe)
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 
 def cons_equMPC_ADMM_HIP(recipe, device=0):
-    v = _lax.compute_equMPC_ADMM_ingredients(recipe.controller, recipe.options)
+    v = _eng(_lax.compute_equMPC_ADMM_ingredients(recipe.controller, recipe.options), recipe)
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 
 def cons_laxMPC_FISTA_HIP(recipe, device=0):
-    v = _lax.compute_laxMPC_FISTA_ingredients(recipe.controller, recipe.options)
+    v = _eng(_lax.compute_laxMPC_FISTA_ingredients(recipe.controller, recipe.options), recipe)
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 
 def cons_equMPC_FISTA_HIP(recipe, device=0):
-    v = _lax.compute_equMPC_FISTA_ingredients(recipe.controller, recipe.options)
+    v = _eng(_lax.compute_equMPC_FISTA_ingredients(recipe.controller, recipe.options), recipe)
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 
 def cons_MPCT_EADMM_HIP(recipe, device=0):
-    v = _mpct.compute_MPCT_EADMM_ingredients(recipe.controller, recipe.options)
+    v = _eng(_mpct.compute_MPCT_EADMM_ingredients(recipe.controller, recipe.options), recipe)
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 
 def cons_ellipMPC_ADMM_soc_HIP(recipe, device=0):
-    v = _ellip.compute_ellipMPC_ADMM_soc_ingredients(recipe.controller, recipe.options)
+    v = _eng(_ellip.compute_ellipMPC_ADMM_soc_ingredients(recipe.controller, recipe.options), recipe)
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 
 def cons_HMPC_ADMM_split_HIP(recipe, device=0):
-    v = _hmpc.compute_HMPC_ADMM_split_ingredients(recipe.controller, recipe.options)
+    v = _eng(_hmpc.compute_HMPC_ADMM_split_ingredients(recipe.controller, recipe.options), recipe)
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 

@@ -98,3 +98,62 @@ def test_hip_time_varying_vs_oracle(name, B, overrides):
     nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)
     assert np.array_equal(nosol[0], O[0][:9]) and np.array_equal(nosol[1], O[1][:9])
     s.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# option in_engineering (first switch): arguments in engineering units
+# ----------------------------------------------------------------------------------------------
+def _eng_cfg(name, seed=11):
+    import copy
+    from types import SimpleNamespace
+    from spcies_amd import benchmarks
+    cfg = copy.copy(benchmarks.config(name))
+    rng = np.random.default_rng(seed)
+    n, m = cfg.sys.n, cfg.sys.m
+    sysd = dict(vars(cfg.sys))
+    sysd.update(Nx=0.5 + rng.random(n), Nu=0.5 + rng.random(m), x0=0.1 * rng.standard_normal(n), u0=0.1 * rng.standard_normal(m))
+    cfg.sys = SimpleNamespace(**sysd)
+    return cfg
+
+
+def _oracle_eng(fn, v, x0, xr, ur, **kw):
+    """The oracle in scaled units wrapped by the reference's argument scaling (code_laxMPC_ADMM_C.c:83-100, 642-646)."""
+    sx, ox, su, ou, siu = (v[k] for k in ("scaling_x", "OpPoint_x", "scaling_u", "OpPoint_u", "scaling_i_u"))
+    O = list(fn({k: val for k, val in v.items()}, sx * (x0 - ox), sx * (xr - ox), su * (ur - ou), **kw))
+    O[0] = O[0] * siu + ou
+    return O
+
+
+def test_blob_roundtrip_in_engineering():
+    from spcies_amd import benchmarks, blob
+    cfg = _eng_cfg("C1_lax")
+    v = benchmarks.ingredients(cfg, in_engineering=True)
+    w = blob.unpack(blob.pack(v))
+    assert w["in_engineering"] and np.array_equal(w["scaling_i_u"], 1.0 / cfg.sys.Nu) and np.array_equal(w["OpPoint_x"], cfg.sys.x0)
+    assert not blob.unpack(blob.pack(benchmarks.ingredients(cfg)))["in_engineering"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,variant,B", [("C1_lax", "stream", 60), ("C2_lax", "mfma4", 100), ("C1_equ_FISTA", "stream", 40),
+                                            ("C1_MPCT", "stream", 30)])
+def test_hip_in_engineering_vs_oracle(name, variant, B):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _eng_cfg(name)
+    v = benchmarks.ingredients(cfg, in_engineering=True)
+    s = HipSolver(v)
+    s.set_variant(variant)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    x0, xr, ur = x0 / v["scaling_x"] + v["OpPoint_x"], xr / v["scaling_x"] + v["OpPoint_x"], ur / v["scaling_u"] + v["OpPoint_u"]
+    fn = {"ADMM": oracle.admm_banded_batch, "FISTA": oracle.fista_banded_batch, "EADMM": oracle.eadmm_mpct_batch}[cfg.method]
+    O = _oracle_eng(fn, v, x0, xr, ur)
+    u, k, e, sol = s(x0, xr, ur)
+    if variant == "stream":
+        assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+        z = sol.z1 if cfg.method == "EADMM" else sol.z
+        assert np.array_equal(z, O[3])  # the record stays in scaled units, as the reference's
+    else:
+        assert np.array_equal(e, O[2]) and np.abs(k.astype(int) - O[1]).max() <= 1
+        assert np.abs(u - O[0]).max() <= 1e-10 and np.abs(sol.z - O[3]).max() <= 1e-10
+    s.close()
