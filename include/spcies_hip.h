@@ -121,7 +121,17 @@ enum spcies_array_id {
     SPCIES_A_SCALING_U = 49,                 /* [m]                                                 */
     SPCIES_A_SCALING_I_U = 50,               /* [m]                                                 */
     SPCIES_A_OPPOINT_X = 51,                 /* [n]                                                 */
-    SPCIES_A_OPPOINT_U = 52                  /* [m]                                                 */
+    SPCIES_A_OPPOINT_U = 52,                 /* [m]                                                 */
+    /* ellipMPC ADMM with the P-projection onto the terminal ellipsoid (formulation 4, submethod 0;
+     * cons_ellipMPC_ADMM_C.m:74-110): the lax arrays 1-9 (no LB / UB) plus these; r in header reserved[4]   */
+    SPCIES_A_P = 53,                         /* [n][n]                                              */
+    SPCIES_A_P_HALF = 54,                    /* [n][n] sqrtm(P)                                     */
+    SPCIES_A_PINV_HALF = 55,                 /* [n][n] P^-1 P_half                                  */
+    SPCIES_A_C_ELL = 56,                     /* [n] centre of the ellipsoid                         */
+    SPCIES_A_LBZ = 57,                       /* [N-1][n+m]                                          */
+    SPCIES_A_UBZ = 58,                       /* [N-1][n+m]                                          */
+    SPCIES_A_LBU0 = 59,                      /* [m]                                                 */
+    SPCIES_A_UBU0 = 60                       /* [m]                                                 */
 };
 
 typedef struct {

@@ -34,6 +34,14 @@ typedef struct {
     const double *Q, *R;  /* NEGATED diagonals of Q, R ([n], [m])                          */
     const double *T;      /* [n][n] NEGATED terminal cost (terminal only)                  */
     const double *LB, *UB;/* [n+m] state bounds first, then input bounds                   */
+    /* ellipMPC ADMM (formulations/+ellipMPC/code_ellipMPC_ADMM_C.c, `ellip = 1`): terminal ellipsoid
+     * (x_N - c)' P (x_N - c) <= r^2 imposed by a P-projection, stage-wise bounds                     */
+    int ellip;
+    const double *P, *P_half, *Pinv_half; /* [n][n]                                          */
+    const double *c;                      /* [n]                                             */
+    double r;
+    const double *LBz, *UBz;              /* [N-1][n+m]                                      */
+    const double *LBu0, *UBu0;            /* [m]                                             */
 } admm_banded_data;
 
 /* Workspace layout mirrors the reference's split of every vector into a `_0` head (m inputs of
@@ -65,7 +73,13 @@ static void form_qhat(const admm_banded_data *d, const double *q, const double *
     for (int j = 0; j < m; j++) z->h[j] = q[n + j] + lam->h[j] - d->rho * v->h[j];
     for (int l = 0; l < N - 1; l++)
         for (int j = 0; j < nm; j++) MID(*z, l, j) = q[j] + MID(*lam, l, j) - d->rho * MID(*v, l, j);
-    if (d->terminal)
+    if (d->ellip) { /* code_ellipMPC_ADMM_C.c:146-156 */
+        for (int j = 0; j < n; j++) {
+            z->t[j] = qT[j];
+            for (int i = 0; i < n; i++)
+                z->t[j] = z->t[j] + d->P_half[(size_t)j * n + i] * lam->t[i] - d->P[(size_t)j * n + i] * d->rho * v->t[i];
+        }
+    } else if (d->terminal)
         for (int j = 0; j < n; j++) z->t[j] = qT[j] + lam->t[j] - d->rho * v->t[j];
 }
 
@@ -150,6 +164,37 @@ static inline double clampd(double x, double lo, double hi) {
 }
 
 /* v = clamp(z + lambda/rho), lambda += rho (z - v)   (code_laxMPC_ADMM_C.c:490-568). */
+/* ellipMPC: stage-wise boxes, P-projection of the terminal block, P_half in its dual update
+ * (code_ellipMPC_ADMM_C.c:292-386). */
+static void update_v_lambda_ellip(const admm_banded_data *d, const split_vec *z, split_vec *v, split_vec *lam, double *aux) {
+    const int n = d->n, m = d->m, nm = n + m, N = d->N;
+    for (int j = 0; j < m; j++) v->h[j] = clampd(z->h[j] + d->rho_i * lam->h[j], d->LBu0[j], d->UBu0[j]);
+    for (int l = 0; l < N - 1; l++)
+        for (int j = 0; j < nm; j++)
+            MID(*v, l, j) = clampd(MID(*z, l, j) + d->rho_i * MID(*lam, l, j), d->LBz[(size_t)l * nm + j], d->UBz[(size_t)l * nm + j]);
+    for (int j = 0; j < n; j++) {
+        v->t[j] = z->t[j];
+        for (int i = 0; i < n; i++) v->t[j] = v->t[j] + d->Pinv_half[(size_t)j * n + i] * d->rho_i * lam->t[i];
+    }
+    for (int j = 0; j < n; j++) {
+        aux[j] = 0.0;
+        for (int i = 0; i < n; i++) aux[j] = aux[j] + d->P[(size_t)j * n + i] * (v->t[i] - d->c[i]);
+    }
+    double vPv = 0.0;
+    for (int j = 0; j < n; j++) vPv = vPv + (v->t[j] - d->c[j]) * aux[j];
+    if (vPv > d->r * d->r) {
+        vPv = d->r / sqrt(vPv);
+        for (int j = 0; j < n; j++) v->t[j] = vPv * (v->t[j] - d->c[j]) + d->c[j];
+    }
+    for (int j = 0; j < m; j++) lam->h[j] = lam->h[j] + d->rho * (z->h[j] - v->h[j]);
+    for (int l = 0; l < N - 1; l++)
+        for (int j = 0; j < nm; j++)
+            MID(*lam, l, j) = MID(*lam, l, j) + d->rho * (MID(*z, l, j) - MID(*v, l, j));
+    for (int j = 0; j < n; j++) aux[j] = d->rho * (z->t[j] - v->t[j]);
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) lam->t[j] = lam->t[j] + d->P_half[(size_t)j * n + i] * aux[i];
+}
+
 static void update_v_lambda(const admm_banded_data *d, const split_vec *z, split_vec *v, split_vec *lam) {
     const int n = d->n, m = d->m, nm = n + m, N = d->N;
     for (int j = 0; j < m; j++)
@@ -238,7 +283,8 @@ int oracle_admm_banded_solve(const admm_banded_data *d, const double *x0, const 
         form_rhs(d, b, xr, &z, mu);
         solve_W(d, mu);
         form_z(d, mu, &z, aux);
-        update_v_lambda(d, &z, &v, &lam);
+        if (d->ellip) update_v_lambda_ellip(d, &z, &v, &lam, aux);
+        else update_v_lambda(d, &z, &v, &lam);
         if (!residual_flag(d, &z, &v, &v1)) {
             done = 1;
             flag = 1;
@@ -406,6 +452,7 @@ int oracle_admm_tv_batch(int n, int m, int N, int k_max, int terminal, double to
         d.n = n; d.m = m; d.N = N; d.k_max = k_max; d.terminal = terminal; d.tol = tol; d.rho = rho; d.rho_i = 1.0 / rho;
         d.AB = o.AB; d.Alpha = o.Alpha; d.Beta = o.Beta; d.Hi = o.Hi; d.Hi_0 = o.Hi_0; d.Hi_N = T_rho_i;
         d.Q = o.Q; d.R = o.R; d.T = T; d.LB = LB; d.UB = UB;
+        d.ellip = 0;
         const double *xri = ref_stride ? xr + (size_t)i * n : xr;
         const double *uri = ref_stride ? ur + (size_t)i * m : ur;
         rc = oracle_admm_banded_solve(&d, x0 + (size_t)i * n, xri, uri, u + (size_t)i * m, k + i, e_flag + i,

@@ -51,9 +51,12 @@ def main():
                                ("C1_lax_FISTA", 16, {}), ("C1_equ_FISTA", 16, dict(k_max=500)),
                                ("C2_lax_FISTA", 32, {}), ("C2_lax_FISTA", 32, dict(tol=1e-6, k_max=2000)),
                                ("C2_equ_FISTA", 32, {}), ("C1_MPCT", 16, {}), ("C4", 8, {}),
+                               ("C1_ellip", 12, {}), ("C2_ellip", 8, {}),
                                ("C1_soc", 12, {}), ("C5_soc", 8, {}),
                                ("C1_HMPC", 6, {}), ("C1_HMPC_SADMM", 6, {}), ("C1_HMPC_soc", 4, {}),
                                ("C1_HMPC_SADMM_soc", 4, {}), ("C5_HMPC_SADMM", 4, {})):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:  # `python -m oracle.make_golden C1_ellip ...`: only these
+            continue
         cfg = benchmarks.config(name)
         v = benchmarks.ingredients(cfg, **overrides)
         x0, xr, ur = benchmarks.sample_batch(cfg, B)

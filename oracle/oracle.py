@@ -23,7 +23,11 @@ class _Data(C.Structure):
     _fields_ = [("n", C.c_int), ("m", C.c_int), ("N", C.c_int), ("k_max", C.c_int), ("terminal", C.c_int),
                 ("tol", C.c_double), ("rho", C.c_double), ("rho_i", C.c_double)] + [
         (name, C.POINTER(C.c_double))
-        for name in ("AB", "Alpha", "Beta", "Hi", "Hi_0", "Hi_N", "Q", "R", "T", "LB", "UB")]
+        for name in ("AB", "Alpha", "Beta", "Hi", "Hi_0", "Hi_N", "Q", "R", "T", "LB", "UB")] + [
+        ("ellip", C.c_int), ("P", C.POINTER(C.c_double)), ("P_half", C.POINTER(C.c_double)),
+        ("Pinv_half", C.POINTER(C.c_double)), ("c", C.POINTER(C.c_double)), ("r", C.c_double),
+        ("LBz", C.POINTER(C.c_double)), ("UBz", C.POINTER(C.c_double)), ("LBu0", C.POINTER(C.c_double)),
+        ("UBu0", C.POINTER(C.c_double))]
 
 
 def _lib():
@@ -101,12 +105,16 @@ def admm_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     n, m, N = int(v["n"]), int(v["m"]), int(v["N"])
     terminal = bool(v.get("terminal", True))
     qz = quantize_like_reference if quantize else (lambda a: a)
-    keep = {name: np.ascontiguousarray(qz(np.asarray(v[name], dtype=float)))
-            for name in ("AB", "Alpha", "Beta", "Hi", "Hi_0", "Hi_N", "Q", "R", "T", "LB", "UB")}
+    ellip = v.get("formulation") == "ellipMPC"
+    names = ("AB", "Alpha", "Beta", "Hi", "Hi_0", "Hi_N", "Q", "R", "T") + (
+        ("P", "P_half", "Pinv_half", "c", "LBz", "UBz", "LBu0", "UBu0") if ellip else ("LB", "UB"))
+    keep = {name: np.ascontiguousarray(qz(np.asarray(v[name], dtype=float))) for name in names}
     if quantize:  # +-inf -> +-1e20 as dec_var.m:245-248
-        for nm_ in ("LB", "UB"):
-            keep[nm_] = np.clip(keep[nm_], -1e20, 1e20)
-    d = _Data(n=n, m=m, N=N, k_max=int(v["k_max"]), terminal=int(terminal),
+        for nm_ in ("LB", "UB", "LBz", "UBz", "LBu0", "UBu0"):
+            if nm_ in keep:
+                keep[nm_] = np.clip(keep[nm_], -1e20, 1e20)
+    d = _Data(n=n, m=m, N=N, k_max=int(v["k_max"]), terminal=int(terminal), ellip=int(ellip),
+              r=float(v.get("r", 0.0)),
               tol=float(qz(v["tol"])) if quantize else float(v["tol"]),
               rho=float(v["rho"]), rho_i=float(qz(v["rho_i"])) if quantize else float(v["rho_i"]),
               **{k_: _dp(a) for k_, a in keep.items()})

@@ -98,7 +98,14 @@ def build_admm(v, name):
     defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
             "#define IS_DIAG 1", f"#define nn_ {n}", f"#define mm_ {m}", f"#define nm_ {n + m}", f"#define NN_ {N}",
             f"#define k_max {int(v['k_max'])}", f"#define tol {_fmt(v['tol'])}"]
-    if method == "ADMM":  # cons_laxMPC_ADMM_C.m:72-130
+    variables = ""
+    if method == "ADMM" and form == "ellipMPC":  # cons_ellipMPC_ADMM_C.m:74-110
+        defs += ["#define SCALAR_RHO", f"#define rho {_fmt(v['rho'])}", f"#define rho_i {_fmt(v['rho_i'])}"]
+        order = [(k, k) for k in ["LBu0", "UBu0", "LBz", "UBz", "Hi", "Hi_0", "Hi_N", "AB", "P", "P_half", "Pinv_half",
+                                  "Alpha", "Beta", "Q", "R", "T"]]
+        variables = _decl("c", np.asarray(v["c"], float)).replace("const static ", "") \
+            + f"double r = {_fmt(v['r'])};\n"
+    elif method == "ADMM":  # cons_laxMPC_ADMM_C.m:72-130
         defs += ["#define SCALAR_RHO", f"#define rho {_fmt(v['rho'])}", f"#define rho_i {_fmt(v['rho_i'])}"]
         order = [(k, k) for k in ["LB", "UB", "Hi", "Hi_0"] + (["Hi_N"] if v["terminal"] else [])
                  + ["Q", "R", "AB", "Alpha", "Beta"] + (["T"] if v["terminal"] else [])]
@@ -116,7 +123,7 @@ def build_admm(v, name):
         code = code.replace("$INSERT_SOLVER$", f.read())
     with open(os.path.join(fdir, f"header_{form}_{method}_C.h")) as f:
         header = f.read()
-    code = code.replace("$INSERT_CONSTANTS$", consts)
+    code = code.replace("$INSERT_CONSTANTS$", consts).replace("$INSERT_VARIABLES$", variables)
     header = header.replace("$INSERT_DEFINES$", "\n".join(defs))
     code, header = _snippets(code, "c"), _snippets(header, "h")
     code = _unescape(code.replace("$INSERT_NAME$", name))
@@ -218,7 +225,7 @@ def _build_soc(v, name):
         code = code.replace("$INSERT_SOLVER$", f.read())
     with open(os.path.join(fdir, "header_ellipMPC_ADMM_soc_C.h")) as f:
         header = f.read()
-    code = code.replace("$INSERT_CONSTANTS$", consts)
+    code = code.replace("$INSERT_CONSTANTS$", consts).replace("$INSERT_VARIABLES$", variables)
     header = header.replace("$INSERT_DEFINES$", "\n".join(defs))
     code, header = _snippets(code, "c"), _snippets(header, "h")
     code = _unescape(code.replace("$INSERT_NAME$", name))
@@ -288,7 +295,7 @@ def _build_hmpc(v, name):
         code = code.replace("$INSERT_SOLVER$", f.read())
     with open(os.path.join(fdir, "header_HMPC_ADMM_split_C.h")) as f:
         header = f.read()
-    code = code.replace("$INSERT_CONSTANTS$", consts).replace("$INSERT_VARIABLES$", variables)
+    code = code.replace("$INSERT_CONSTANTS$", consts).replace("$INSERT_VARIABLES$", variables).replace("$INSERT_VARIABLES$", variables)
     header = header.replace("$INSERT_DEFINES$", "\n".join(defs))
     code, header = _snippets(code, "c"), _snippets(header, "h")
     code = _unescape(code.replace("$INSERT_NAME$", name))

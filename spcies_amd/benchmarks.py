@@ -78,6 +78,20 @@ def config(name):
             c.param.N, c.B, c.seed = 20, 1048576, 1204
             c.solver_options.update(k_max=200, tol=0.0)
         return c
+    if name in ("C1_ellip", "C2_ellip"):  # tests/test_ellipMPC_ADMM.m:6-21; C2: 12-state, N = 15, r = 0.5, 200 fixed iterations
+        sys = sp_utils.oscillating_masses_sys(3 if name == "C1_ellip" else 6)
+        Q, R, T = _weights(sys, "diag")
+        st = tester_status(sys)
+        c = SimpleNamespace(name=name, sys=sys, param=SimpleNamespace(Q=Q, R=R, T=T, N=10, P=np.eye(sys.n), c=st.xr, r=0.0),
+                            formulation="ellipMPC", method="ADMM", submethod="",
+                            solver_options=dict(rho=15, k_max=5000, tol=1e-7), B=1, seed=1206)
+        if name == "C2_ellip":
+            rng = np.random.default_rng(3)
+            M = rng.standard_normal((sys.n, sys.n))
+            c.param.N, c.param.r, c.B = 15, 0.5, 65536
+            c.param.P = np.eye(sys.n) + 0.05 * (M @ M.T)  # a genuine (non-spherical) ellipsoid
+            c.solver_options.update(k_max=200, tol=0.0)
+        return c
     if name in ("C1_soc", "C5_soc"):  # tests/test_ellipMPC_ADMM_soc.m:8-25; C5: 12-state, N = 15, 200 fixed iterations
         sys = sp_utils.oscillating_masses_sys(3 if name == "C1_soc" else 6)
         Q, R, T = _weights(sys, "diag")
@@ -136,7 +150,8 @@ def ingredients(cfg, **solver_overrides):
           ("laxMPC", "FISTA"): laxMPC.compute_laxMPC_FISTA_ingredients,
           ("equMPC", "FISTA"): laxMPC.compute_equMPC_FISTA_ingredients,
           ("MPCT", "EADMM"): MPCT.compute_MPCT_EADMM_ingredients,
-          ("ellipMPC", "ADMM"): ellipMPC.compute_ellipMPC_ADMM_soc_ingredients,
+          ("ellipMPC", "ADMM"): (ellipMPC.compute_ellipMPC_ADMM_soc_ingredients if getattr(cfg, "submethod", "") == "soc"
+                                 else ellipMPC.compute_ellipMPC_ADMM_ingredients),
           ("HMPC", "ADMM"): HMPC.compute_HMPC_ADMM_split_ingredients,
           ("HMPC", "SADMM"): HMPC.compute_HMPC_ADMM_split_ingredients}
     return laxMPC.add_engineering(fn[(cfg.formulation, cfg.method)](ctrl, opt), cfg.sys, opt)

@@ -106,7 +106,7 @@ __host__ __device__ inline TvLayout tv_layout(int n, int m, int N) {
         if constexpr (TV) asm volatile("" ::: "memory"); \
     } while (0)
 
-template <int n, int m, bool TERMINAL, bool EXACT, bool TV = false>
+template <int n, int m, bool TERMINAL, bool EXACT, bool TV = false, bool ELLIP = false>
 __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double *__restrict__ C,
                                                          const double *__restrict__ x0g,
                                                          const double *__restrict__ xrg,
@@ -135,6 +135,10 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
     const KArr<TV> cAB = K(c.AB, tl.AB), cAlpha = K(c.Alpha, tl.Alpha), cBeta = K(c.Beta, tl.Beta), cHi = K(c.Hi, tl.Hi),
                    cHi_0 = K(c.Hi_0, tl.Hi_0), cQ = K(c.Q, tl.Q), cR = K(c.R, tl.R), cLB = K(c.LB, tl.LB), cUB = K(c.UB, tl.UB);
     const double *cHi_N = C + c.Hi_N, *cT = C + c.T;
+    // ellipMPC ADMM (code_ellipMPC_ADMM_C.c): terminal ellipsoid constants and stage-wise bounds
+    const double *cP = C + c.P, *cPh = C + c.P_half, *cPih = C + c.Pinv_half, *cCe = C + c.c_ell, *cLBz = C + c.LBz,
+                 *cUBz = C + c.UBz, *cLBu0 = C + c.LBu0, *cUBu0 = C + c.UBu0;
+    static_assert(!ELLIP || (TERMINAL && !TV), "ellipMPC ADMM: terminal block, constant model");
 
     // ---- per-instance setup (code_laxMPC_ADMM_C.c:282-299)
     double xr[n], b[n], q[nm], qT[n];
@@ -167,6 +171,20 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
         for (int j = 0; j < m; j++) q[n + j] = cR[j] * urp[j];
     }
 
+    // q_hat of the terminal block: qT + lambda - rho v (lax, :343-349) or qT + P_half lambda - P rho v (ellip, :146-156)
+    auto qhat_tail = [&](const double (&lamv)[n], const double (&vold)[n], double (&out)[n]) {
+#pragma unroll
+        for (int j = 0; j < n; j++) {
+            if constexpr (ELLIP) {
+                double acc = qT[j];
+#pragma unroll
+                for (int i = 0; i < n; i++) acc = acc + cPh[j * n + i] * lamv[i] - cP[j * n + i] * rho * vold[i];
+                out[j] = acc;
+            } else {
+                out[j] = qT[j] + lamv[j] - rho * vold[j];
+            }
+        }
+    };
     const long off_mid = (long)m;                       // element offset of the middle rows
     const long off_tail = (long)m + (long)(N - 1) * nm; // element offset of the tail
     double *Vt = V + t, *Lt = LAM + t, *Yt = Y + t;
@@ -202,13 +220,16 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                     qc[j] = q[j] + lam - rho * vv;
                 }
             } else if constexpr (TERMINAL) {
+                double lamN[n], vN[n], qN[n];
 #pragma unroll
                 for (int j = 0; j < n; j++) {
                     long e = off_tail + j;
-                    double lam = first ? 0.0 : Lt[e * Bp];
-                    double vv = first ? 0.0 : Vt[e * Bp];
-                    qc[j] = qT[j] + lam - rho * vv;
+                    lamN[j] = first ? 0.0 : Lt[e * Bp];
+                    vN[j] = first ? 0.0 : Vt[e * Bp];
                 }
+                qhat_tail(lamN, vN, qN);
+#pragma unroll
+                for (int j = 0; j < n; j++) qc[j] = qN[j];
             }
             // right-hand side (:355-381)
             double y[n];
@@ -292,20 +313,69 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                         long e = off_tail + j;
                         lamv[j] = first ? 0.0 : Lt[e * Bp];
                         vold[j] = first ? 0.0 : Vt[e * Bp];
-                        aux[j] = (qT[j] + lamv[j] - rho * vold[j]) - mu[j];
                     }
+                    qhat_tail(lamv, vold, aux);
 #pragma unroll
-                    for (int j = 0; j < n; j++) {
-                        double zz = 0.0;
+                    for (int j = 0; j < n; j++) aux[j] = aux[j] - mu[j];
+                    if constexpr (ELLIP) {
+                        // z_N, then the P-projection onto the ellipsoid (:318-352) and lambda_N through P_half (:374-386)
+                        double zN[n], vn[n], pv[n];
 #pragma unroll
-                        for (int i = 0; i < n; i++) zz = msub<EXACT>(zz, cHi_N[j * n + i], aux[i]);
-                        double vn = clamp_ref(zz + rho_i * lamv[j], cLB[j], cUB[j]);
-                        double ln = lamv[j] + rho * (zz - vn);
-                        res = res || above(vold[j], vn, tol) || above(zz, vn, tol);
-                        long e = off_tail + j;
-                        Vt[e * Bp] = vn;
-                        Lt[e * Bp] = ln;
-                        if (Zt) Zt[e * Bp] = zz;
+                        for (int j = 0; j < n; j++) {
+                            double zz = 0.0;
+#pragma unroll
+                            for (int i = 0; i < n; i++) zz = msub<EXACT>(zz, cHi_N[j * n + i], aux[i]);
+                            zN[j] = zz;
+                        }
+#pragma unroll
+                        for (int j = 0; j < n; j++) {
+                            double acc = zN[j];
+#pragma unroll
+                            for (int i = 0; i < n; i++) acc = acc + cPih[j * n + i] * rho_i * lamv[i];
+                            vn[j] = acc;
+                        }
+#pragma unroll
+                        for (int j = 0; j < n; j++) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int i = 0; i < n; i++) acc = acc + cP[j * n + i] * (vn[i] - cCe[i]);
+                            pv[j] = acc;
+                        }
+                        double vPv = 0.0;
+#pragma unroll
+                        for (int j = 0; j < n; j++) vPv = vPv + (vn[j] - cCe[j]) * pv[j];
+                        if (vPv > c.r_ell * c.r_ell) {
+                            vPv = c.r_ell / sqrt(vPv);
+#pragma unroll
+                            for (int j = 0; j < n; j++) vn[j] = vPv * (vn[j] - cCe[j]) + cCe[j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < n; j++) pv[j] = rho * (zN[j] - vn[j]);
+#pragma unroll
+                        for (int j = 0; j < n; j++) {
+                            double ln = lamv[j];
+#pragma unroll
+                            for (int i = 0; i < n; i++) ln = ln + cPh[j * n + i] * pv[i];
+                            res = res || above(vold[j], vn[j], tol) || above(zN[j], vn[j], tol);
+                            long e = off_tail + j;
+                            Vt[e * Bp] = vn[j];
+                            Lt[e * Bp] = ln;
+                            if (Zt) Zt[e * Bp] = zN[j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < n; j++) {
+                            double zz = 0.0;
+#pragma unroll
+                            for (int i = 0; i < n; i++) zz = msub<EXACT>(zz, cHi_N[j * n + i], aux[i]);
+                            double vn = clamp_ref(zz + rho_i * lamv[j], cLB[j], cUB[j]);
+                            double ln = lamv[j] + rho * (zz - vn);
+                            res = res || above(vold[j], vn, tol) || above(zz, vn, tol);
+                            long e = off_tail + j;
+                            Vt[e * Bp] = vn;
+                            Lt[e * Bp] = ln;
+                            if (Zt) Zt[e * Bp] = zz;
+                        }
                     }
                 }
             } else {
@@ -321,7 +391,8 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
 #pragma unroll
                     for (int i = 0; i < n; i++) zz = madd<EXACT>(zz, cAB[i * nm + j], mun[i]);
                     zz = -cHi[l * nm + j] * zz;
-                    double vn = clamp_ref(zz + rho_i * lam, cLB[j], cUB[j]);
+                    double vn = ELLIP ? clamp_ref(zz + rho_i * lam, cLBz[l * nm + j], cUBz[l * nm + j])
+                                      : clamp_ref(zz + rho_i * lam, cLB[j], cUB[j]);
                     double ln = lam + rho * (zz - vn);
                     res = res || above(vold, vn, tol) || above(zz, vn, tol);
                     Vt[e * Bp] = vn;
@@ -342,7 +413,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
 #pragma unroll
             for (int i = 0; i < n; i++) zz = madd<EXACT>(zz, cAB[i * nm + n + j], mun[i]);
             zz = -cHi_0[j] * zz;
-            double vn = clamp_ref(zz + rho_i * lam, cLB[n + j], cUB[n + j]);
+            double vn = ELLIP ? clamp_ref(zz + rho_i * lam, cLBu0[j], cUBu0[j]) : clamp_ref(zz + rho_i * lam, cLB[n + j], cUB[n + j]);
             double ln = lam + rho * (zz - vn);
             res = res || above(vold, vn, tol) || above(zz, vn, tol);
             Vt[(long)j * Bp] = vn;

@@ -38,6 +38,10 @@ struct AdmmHost {
     bool terminal = true;
     double tol = 0, rho = 0, rho_i = 0;
     std::vector<double> AB, Alpha, Beta, Hi, Hi_0, Hi_N, Q, R, T, LB, UB;
+    // ellipMPC ADMM (code_ellipMPC_ADMM_C.c): terminal ellipsoid (P, c, r) and stage-wise bounds
+    bool ellip = false;
+    double r_ell = 0;
+    std::vector<double> P, P_half, Pinv_half, c_ell, LBz, UBz, LBu0, UBu0;
     int dim() const { return N * (n + m) - (terminal ? 0 : n); }
 };
 
@@ -48,6 +52,8 @@ struct AdmmDev {
     int AB, Alpha, Beta, Hi, Hi_0, Hi_N, Q, R, T, LB, UB;
     int N, k_max;
     double tol, rho, rho_i;
+    int P = 0, P_half = 0, Pinv_half = 0, c_ell = 0, LBz = 0, UBz = 0, LBu0 = 0, UBu0 = 0;  // ellipMPC ADMM only
+    double r_ell = 0;
 };
 
 }  // namespace spcies

@@ -42,7 +42,7 @@ struct Solver {
     int *d_idx = nullptr;
     EadmmDev edev{};
     std::vector<double> e_rho, e_rho0, e_rhos, e_LB0, e_UB0, e_LBs, e_UBs, e_S, e_H1i, e_W2, e_H3i;  // EADMM-only
-    bool is_soc() const { return formulation == SPCIES_ELLIPMPC || formulation == SPCIES_HMPC; }  // 6-field (z, s, ...) record
+    bool is_soc() const { return (formulation == SPCIES_ELLIPMPC && submethod == 1) || formulation == SPCIES_HMPC; }  // 6-field (z, s, ...) record
     bool is_hmpc() const { return formulation == SPCIES_HMPC; }
     int soc_dim() const { return is_hmpc() ? hdev.dim : sdev.dim; }
     int soc_ns() const { return is_hmpc() ? hdev.n_s : sdev.n_s; }
@@ -276,11 +276,12 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         return fail(SPCIES_HIP_EINVAL, "blob version/size mismatch");
     if ((size_t)h.header_bytes + (size_t)h.n_arrays * sizeof(spcies_blob_entry) > bytes)
         return fail(SPCIES_HIP_EINVAL, "blob directory out of range");
-    const bool banded = (h.method == SPCIES_ADMM || h.method == SPCIES_FISTA) &&
-                        (h.formulation == SPCIES_LAXMPC || h.formulation == SPCIES_EQUMPC);
+    const bool ellip_admm = (h.method == SPCIES_ADMM && h.formulation == SPCIES_ELLIPMPC && h.submethod == 0);
+    const bool banded = ((h.method == SPCIES_ADMM || h.method == SPCIES_FISTA) &&
+                         (h.formulation == SPCIES_LAXMPC || h.formulation == SPCIES_EQUMPC)) || ellip_admm;
     const bool mpct = (h.method == SPCIES_EADMM && h.formulation == SPCIES_MPCT);
     const bool soc = (h.method == SPCIES_ADMM && h.formulation == SPCIES_ELLIPMPC && h.submethod == 1);
-    if ((h.flags & 8u) && (h.formulation == SPCIES_ELLIPMPC || h.formulation == SPCIES_HMPC))
+    if ((h.flags & 8u) && ((h.formulation == SPCIES_ELLIPMPC && h.submethod != 0) || h.formulation == SPCIES_HMPC))
         return fail(SPCIES_HIP_ENOSUP, "in_engineering is built for the lax/equ MPC and MPCT solvers only");
     if (soc) return parse_soc(blob, bytes, h, s);
     if (h.formulation == SPCIES_HMPC && (h.method == SPCIES_ADMM || h.method == SPCIES_SADMM) && h.submethod == 2)
@@ -313,6 +314,15 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     std::vector<Want> want = {{SPCIES_A_AB, n * nm, &a.AB},       {SPCIES_A_ALPHA, (N - 1) * n * n, &a.Alpha},
                               {SPCIES_A_BETA, N * n * n, &a.Beta}, {SPCIES_A_LB, nm, &a.LB},
                               {SPCIES_A_UB, nm, &a.UB}};
+    a.ellip = ellip_admm;
+    if (ellip_admm) {  // no LB / UB: stage-wise bounds and the ellipsoid instead (cons_ellipMPC_ADMM_C.m:74-110)
+        want = {{SPCIES_A_AB, n * nm, &a.AB}, {SPCIES_A_ALPHA, (N - 1) * n * n, &a.Alpha}, {SPCIES_A_BETA, N * n * n, &a.Beta},
+                {SPCIES_A_P, n * n, &a.P}, {SPCIES_A_P_HALF, n * n, &a.P_half}, {SPCIES_A_PINV_HALF, n * n, &a.Pinv_half},
+                {SPCIES_A_C_ELL, n, &a.c_ell}, {SPCIES_A_LBZ, (N - 1) * nm, &a.LBz}, {SPCIES_A_UBZ, (N - 1) * nm, &a.UBz},
+                {SPCIES_A_LBU0, m, &a.LBu0}, {SPCIES_A_UBU0, m, &a.UBu0}};
+        a.r_ell = h.reserved[4];
+        if (!(a.r_ell >= 0)) return fail(SPCIES_HIP_EINVAL, "ellipMPC: bad ellipsoid radius");
+    }
     s.tv = (h.flags & 4u) != 0;
     if (s.tv) {
         if (h.method != SPCIES_ADMM || !banded) return fail(SPCIES_HIP_ENOSUP, "time-varying: built for laxMPC / equMPC ADMM only");
@@ -369,6 +379,8 @@ static int upload_consts(Solver &s) {
     }
     std::vector<const std::vector<double> *> arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Hi, &a.Hi_0, &a.Hi_N,
                                                      &a.Q,  &a.R,     &a.T,    &a.LB, &a.UB};
+    if (a.ellip)
+        for (auto *v : {&a.P, &a.P_half, &a.Pinv_half, &a.c_ell, &a.LBz, &a.UBz, &a.LBu0, &a.UBu0}) arrs.push_back(v);
     if (s.method == SPCIES_FISTA) arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Q, &a.R, &s.QRi, &s.Td, &s.Ti, &a.LB, &a.UB};
     if (s.method == SPCIES_EADMM)
         arrs = {&s.e_rho, &s.e_rho0, &s.e_rhos, &a.LB,    &a.UB,   &s.e_LB0, &s.e_UB0, &s.e_LBs, &s.e_UBs,
@@ -396,6 +408,11 @@ static int upload_consts(Solver &s) {
     s.dev = AdmmDev{(int)offs[0], (int)offs[1], (int)offs[2], (int)offs[3], (int)offs[4], (int)offs[5],
                     (int)offs[6], (int)offs[7], (int)offs[8], (int)offs[9], (int)offs[10],
                     a.N,          a.k_max,      a.tol,        a.rho,        a.rho_i};
+    if (a.ellip) {
+        s.dev.P = (int)offs[11]; s.dev.P_half = (int)offs[12]; s.dev.Pinv_half = (int)offs[13]; s.dev.c_ell = (int)offs[14];
+        s.dev.LBz = (int)offs[15]; s.dev.UBz = (int)offs[16]; s.dev.LBu0 = (int)offs[17]; s.dev.UBu0 = (int)offs[18];
+        s.dev.r_ell = a.r_ell;
+    }
     return 0;
 }
 
@@ -406,7 +423,7 @@ static bool stream_shape_built(int n, int m) {
 
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
-    if (s.tv) return SPCIES_VARIANT_STREAM;
+    if (s.tv || s.host.ellip) return SPCIES_VARIANT_STREAM;
     if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
@@ -436,7 +453,7 @@ static int ensure_scratch(Solver &s, size_t need) {
     return 0;
 }
 
-template <int n, int m>
+template <int n, int m, bool ELLIP = false>
 static int launch_stream_nm(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                             double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
     const bool want_sol = (z || v || lam);
@@ -447,7 +464,10 @@ static int launch_stream_nm(Solver &s, const double *x0, const double *xr, const
     double *Y = LAM + dim * Bp;
     double *ZS = want_sol ? Y + (size_t)s.host.N * n * Bp : nullptr;
     dim3 grid((unsigned)(Bp / 64)), block(64);
-    if (s.host.terminal)
+    if constexpr (ELLIP)
+        hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true, false, true>), grid, block, 0, st, s.dev, s.d_consts, x0, xr, ur,
+                           ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e, nullptr);
+    else if (s.host.terminal)
         hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true>), grid, block, 0, st, s.dev, s.d_consts, x0, xr, ur,
                            ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e);
     else
@@ -827,6 +847,15 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (s.host.n == 12 && s.host.m == 2) return launch_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
     }
+    if (s.host.ellip) {
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
+            return fail(SPCIES_HIP_ENOSUP, "ellipMPC ADMM: only the STREAM variant is built");
+        int rc = ensure_scratch(s, stream_scratch_bytes(s, B, z || v || lam));
+        if (rc) return rc;
+        if (s.host.n == 6 && s.host.m == 2) return launch_stream_nm<6, 2, true>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
+        if (s.host.n == 12 && s.host.m == 2) return launch_stream_nm<12, 2, true>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
+        return fail(SPCIES_HIP_ENOSUP, "ellipMPC ADMM STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
+    }
     const int variant = resolve_variant(s);
     if (variant == SPCIES_VARIANT_MFMA4) {
         if (!s.mfma4.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s.mfma4.why.c_str());
@@ -900,7 +929,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         SPCIES_HIP_CHECK(hipMalloc((void **)&s->d_eng, s->eng_v.size() * sizeof(double)));
         SPCIES_HIP_CHECK(hipMemcpy(s->d_eng, s->eng_v.data(), s->eng_v.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    if (s->method == SPCIES_ADMM && (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC) && !s->tv) {
+    if (s->method == SPCIES_ADMM && (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC) && !s->tv && !s->host.ellip) {
         rc = mfma_plan_build(s->mfma, s->host);
         if (rc) return rc;
         rc = mfma4_plan_build(s->mfma4, s->host);

@@ -81,3 +81,71 @@ def compute_ellipMPC_ADMM_soc_ingredients(controller, opt):
     v["rho_is_scalar"] = True
     v["r_default"] = r
     return v
+
+
+def compute_ellipMPC_ADMM_ingredients(controller, opt):
+    """ellipMPC, ADMM with the P-projection onto the terminal ellipsoid (no submethod) - SURVEY section 8f
+    rank 2.  Reference: ``formulations/+ellipMPC/compute_ellipMPC_ADMM_ingredients.m:60-247``: the lax
+    ingredients with ``H = Hz + rho blkdiag(I, P)``, stage-wise bounds ``LBu0/UBu0, LBz/UBz`` and the terminal
+    constants ``P, P_half = sqrtm(P), Pinv_half = P^-1 P_half, c, r``.  Scalar ``rho`` only."""
+    sys, param = _get(controller, "sys"), _get(controller, "param")
+    A = np.asarray(_get(sys, "A"), dtype=float)
+    B = np.asarray(_get(sys, "B"), dtype=float)
+    n, m = B.shape
+    nm = n + m
+    N = int(_get(param, "N"))
+    Q = np.asarray(_get(param, "Q"), dtype=float)
+    R = np.asarray(_get(param, "R"), dtype=float)
+    T = np.asarray(_get(param, "T"), dtype=float)
+    P = np.asarray(_get(param, "P"), dtype=float)
+    c = np.ravel(np.asarray(_get(param, "c"), dtype=float))
+    r = float(_get(param, "r", 1.0))
+    if not (_is_diag(Q) and _is_diag(R)):
+        raise ValueError("Spcies:ellipMPC:ADMM:non_diagonal - matrices Q and R must be diagonal")
+    rho = opt.solver["rho"]
+    if np.ndim(rho) != 0 or opt.solver.get("force_vector_rho", False):
+        raise NotImplementedError("HIP platform: vector rho is not built yet (scalar rho only)")
+    rho = float(rho)
+    dim = N * nm
+    Hz = np.zeros((dim, dim))
+    Hz[:m, :m] = R
+    for l in range(N - 1):
+        o = m + l * nm
+        Hz[o:o + n, o:o + n] = Q
+        Hz[o + n:o + nm, o + n:o + nm] = R
+    Hz[dim - n:, dim - n:] = T
+    P_half = np.real(sla.sqrtm(P))
+    E = np.eye(dim)
+    E[dim - n:, dim - n:] = P
+    H = Hz + rho * E
+    G = build_G(A, B, N, terminal=True)
+    Hinv = np.linalg.inv(H)
+    W = G @ Hinv @ G.T
+    Wc = np.linalg.cholesky(W).T
+    incBx = np.asarray(_get(param, "incBx", np.zeros((n, N + 1))), dtype=float).reshape(n, N + 1)
+    incBu = np.asarray(_get(param, "incBu", np.zeros((m, N + 1))), dtype=float).reshape(m, N + 1)
+    LBx, UBx = np.ravel(_get(sys, "LBx")).astype(float), np.ravel(_get(sys, "UBx")).astype(float)
+    LBu, UBu = np.ravel(_get(sys, "LBu")).astype(float), np.ravel(_get(sys, "UBu")).astype(float)
+    LBz = np.array([np.concatenate([LBx + incBx[:, i], LBu + incBu[:, i]]) for i in range(1, N)])
+    UBz = np.array([np.concatenate([UBx - incBx[:, i], UBu - incBu[:, i]]) for i in range(1, N)])
+    v = dict(n=n, m=m, N=N, formulation="ellipMPC", method="ADMM", submethod="", terminal=True, dim=dim)
+    v["Hi_0"] = np.diag(Hinv)[:m].copy()
+    v["Hi"] = np.diag(Hinv)[m:m + (N - 1) * nm].reshape(N - 1, nm).copy()
+    v["Hi_N"] = Hinv[dim - n:, dim - n:].copy()
+    v["AB"] = np.hstack([A, B])
+    v["LBu0"], v["UBu0"], v["LBz"], v["UBz"] = LBu.copy(), UBu.copy(), LBz, UBz
+    v["P"], v["P_half"], v["Pinv_half"] = P.copy(), P_half, np.linalg.inv(P) @ P_half
+    v["Q"], v["R"], v["T"] = -np.diag(Q).copy(), -np.diag(R).copy(), -T
+    v["c"], v["r"] = c.copy(), r
+    v["rho"], v["rho_i"], v["rho_is_scalar"] = rho, 1.0 / rho, True
+    Beta = np.zeros((N, n, n))
+    Alpha = np.zeros((N - 1, n, n))
+    for i in range(N):
+        Beta[i] = Wc[i * n:(i + 1) * n, i * n:(i + 1) * n]
+        Beta[i][np.diag_indices(n)] = 1.0 / np.diag(Beta[i])
+    for i in range(N - 1):
+        Alpha[i] = Wc[i * n:(i + 1) * n, (i + 1) * n:(i + 2) * n]
+    v["Alpha"], v["Beta"] = Alpha, Beta
+    v["k_max"] = int(opt.solver["k_max"])
+    v["tol"] = float(opt.solver["tol"])
+    return v

@@ -50,6 +50,8 @@ _DEF_SOLVER = {
     ("laxMPC", "FISTA", ""): dict(tol=1e-4, k_max=1000),
     ("equMPC", "FISTA", ""): dict(tol=1e-4, k_max=1000),
     # formulations/+MPCT/def_options_MPCT_EADMM.m
+    # formulations/+ellipMPC/def_options_ellipMPC_ADMM.m
+    ("ellipMPC", "ADMM", ""): dict(rho=1e-2, tol=1e-4, tol_p=1e-4, tol_d=1e-4, k_max=1000, force_vector_rho=False),
     # formulations/+ellipMPC/def_options_ellipMPC_ADMM_soc.m
     ("ellipMPC", "ADMM", "soc"): dict(rho=5, sigma=5, tol_p=1e-4, tol_d=1e-4, k_max=1000),
     # formulations/+HMPC/def_options_HMPC_ADMM.m / def_options_HMPC_SADMM.m

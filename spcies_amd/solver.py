@@ -55,6 +55,7 @@ class HipSolver:
         self.sol_fields = [(names[i].decode(), int(dims[i])) for i in range(nf.value)]
         self.device = info.device
         self.formulation = {v: k for k, v in _blob.FORMULATION.items()}[info.formulation]
+        self.submethod = int(info.submethod)  # 1 = soc, 2 = split (include/spcies_hip.h)
         self.name = name or self.formulation
         self.time_varying = bool(int.from_bytes(self.blob[28:32], "little") & 4)  # header flags bit2
         self.debug = bool(debug)  # reference option `debug`: copy z, v, lambda out (Spcies_options.m:121)
@@ -150,7 +151,7 @@ class HipSolver:
         (``struct_ellipMPC_ADMM_soc_C_Matlab.c:24``), scalar or one value per instance."""
         x0, xr, ur, B, per, single = self._check_args(x0, xr, ur)
         extra, extra_stride = None, 0
-        if self.formulation == "ellipMPC":
+        if self.formulation == "ellipMPC" and self.submethod == 1:
             if len(extra_in) != 1:
                 raise SpciesArgError("Spcies:ellipMPC:nrhs:number", "Four inputs are required")
             extra = np.ascontiguousarray(np.atleast_1d(np.asarray(extra_in[0], dtype=np.float64)).ravel())

@@ -498,3 +498,52 @@ def test_closed_loop_vs_oracle_loop(cfg_name, variant, steps, B):
             x = xt[t + 1].copy()
     if cfg_name.startswith("C1") and steps >= 12:  # the tutorial's plant moves towards the reference
         assert np.linalg.norm(xt[-1][0] - st.xr) < np.linalg.norm(xt[0][0] - st.xr)
+
+
+# ----------------------------------------------------------------------------------------------
+# ellipMPC ADMM with the P-projection onto the terminal ellipsoid (SURVEY section 8f rank 2;
+# formulations/+ellipMPC/code_ellipMPC_ADMM_C.c): STREAM variant -> bit-exact
+# ----------------------------------------------------------------------------------------------
+def test_ellip_admm_reference_test_instance(golden_dir):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _solver("C1_ellip", "stream")
+    assert [f for f, _ in s.sol_fields] == ["z", "v", "lambda"]  # header_ellipMPC_ADMM_C.h
+    st = benchmarks.tester_status(cfg.sys)
+    u, k, e, sol = s(st.x, st.xr, st.ur)
+    with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
+        z_opt = np.array(json.load(f)["test_ellipMPC_ADMM"])
+    assert e == 1 and np.abs(sol.z - z_opt).max() <= TOL_OPT
+    O = oracle.admm_banded_batch(v, st.x[None], st.xr, st.ur)
+    assert k == O[1][0] and np.array_equal(u, O[0][0]) and np.array_equal(sol.z, O[3][0])
+    assert np.array_equal(sol.v, O[4][0]) and np.array_equal(sol.lam, O[5][0])
+
+
+@pytest.mark.parametrize("cfg_name,B,overrides", [("C1_ellip", 70, {}), ("C2_ellip", 130, {}),
+                                                  ("C2_ellip", 40, dict(tol=1e-6, k_max=3000))])
+def test_ellip_admm_seeded_batch_vs_oracle(cfg_name, B, overrides):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _solver(cfg_name, "stream", **overrides)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    got = s(x0, xr, ur)
+    _compare("stream", got, oracle.admm_banded_batch(v, x0, xr, ur), v)
+    if cfg_name == "C2_ellip":  # v_N lies in the ellipsoid; before convergence some instances sit on its boundary
+        n = cfg.sys.n
+        d = got[3].v[:, -n:] - cfg.param.c
+        q = np.einsum("bi,ij,bj->b", d, cfg.param.P, d)
+        assert (q <= cfg.param.r ** 2 * (1 + 1e-9)).all()
+        if not overrides:
+            assert (q >= cfg.param.r ** 2 * (1 - 1e-9)).any()
+    nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
+    assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
+
+
+@pytest.mark.parametrize("tag", ["C1_ellip", "C2_ellip"])
+def test_ellip_admm_vs_reference_template_fixture(tag, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"template_{tag}.npz"))
+    cfg, v, s = _solver(tag, "stream")
+    u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
+    assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
+    same = k == g["k"]
+    assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-9
