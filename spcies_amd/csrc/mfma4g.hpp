@@ -177,12 +177,14 @@ inline int pick_wgs(long groups, int num_cu, int max_wgs) {
 template <int KI, int KJ, int PAT>
 __device__ __forceinline__ void prod(double (&acc)[KI], const double (&x)[KJ], const double *blk, int ao, int &tix,
                                      double2 &cur) {
+    bool fresh = true;  // a product may start on the second block of a pair: fetch the pair then too
 #pragma unroll
     for (int J = 0; J < KJ; J++)
 #pragma unroll
         for (int I = 0; I < KI; I++)
             if (blk_nz(I, J, PAT)) {
-                if (tix % 2 == 0) cur = *reinterpret_cast<const double2 *>(blk + (tix / 2) * 32 + 2 * ao);
+                if (tix % 2 == 0 || fresh) cur = *reinterpret_cast<const double2 *>(blk + (tix / 2) * 32 + 2 * ao);
+                fresh = false;
                 SPCIES_G4_MFMA(acc[I], (tix % 2 == 0) ? cur.x : cur.y, x[J]);
                 tix++;
             }

@@ -8,6 +8,7 @@
 #include "admm_stream.hpp"
 #include "fista_stream.hpp"
 #include "fista_mfma4g.hpp"
+#include "admm_mfma4g.hpp"
 #include "eadmm_stream.hpp"
 #include "eadmm_mfma4g.hpp"
 #include "soc_stream.hpp"
@@ -428,6 +429,7 @@ static int resolve_variant(const Solver &s) {
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
     if (s.mfma.ok) return SPCIES_VARIANT_MFMA;
+    if (s.g4plan.ok) return SPCIES_VARIANT_MFMA4G;
     return SPCIES_VARIANT_STREAM;
 }
 
@@ -861,6 +863,13 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (!s.mfma4.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s.mfma4.why.c_str());
         return launch_mfma4(s.mfma4, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
     }
+    if (variant == SPCIES_VARIANT_MFMA4G) {
+        if (!s.g4plan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available: %s", s.g4plan.why.c_str());
+        int rc = ensure_scratch(s, g4::admm_state_bytes(s.g4plan, s.host, B));
+        if (rc) return rc;
+        return g4::launch_admm_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, s.d_consts + s.dev.LB,
+                                 s.d_consts + s.dev.UB, u, k, e, z, v, lam, st);
+    }
     if (variant == SPCIES_VARIANT_MFMA) {
         if (!s.mfma.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA variant not available for this shape: %s", s.mfma.why.c_str());
         return launch_mfma(s.mfma, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
@@ -933,6 +942,8 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         rc = mfma_plan_build(s->mfma, s->host);
         if (rc) return rc;
         rc = mfma4_plan_build(s->mfma4, s->host);
+        if (rc) return rc;
+        rc = g4::admm_plan_build(s->g4plan, s->host);
         if (rc) return rc;
     }
     if (s->method == SPCIES_EADMM) {
@@ -1016,6 +1027,7 @@ int spcies_hip_reserve(spcies_hip_handle h, long B) {
     SPCIES_HIP_CHECK(hipSetDevice(s->device));
     size_t need = stream_scratch_bytes(*s, B, true);
     if (s->g4plan.ok && s->method == SPCIES_FISTA) need = std::max(need, g4::fista_state_bytes(s->g4plan, s->host, B));
+    if (s->g4plan.ok && s->method == SPCIES_ADMM && !s->is_soc()) need = std::max(need, g4::admm_state_bytes(s->g4plan, s->host, B));
     need = std::max(need, tile_scratch_bytes(*s, B));
     if (s->g4plan.ok && s->method == SPCIES_EADMM) need = std::max(need, g4::eadmm_state_bytes(s->g4plan, s->host, B));
     return ensure_scratch(*s, need);

@@ -55,7 +55,7 @@ def _compare(variant, got, ref, v):
         assert (np.abs(sol.lam - lo) / (tol * (1.0 + lscale)))[same].max() <= 1.0
 
 
-VARIANTS = ["stream", "mfma", "mfma4"]
+VARIANTS = ["stream", "mfma", "mfma4", "mfma4g"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -547,3 +547,42 @@ def test_ellip_admm_vs_reference_template_fixture(tag, golden_dir):
     assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
     same = k == g["k"]
     assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-9
+
+
+# ----------------------------------------------------------------------------------------------
+# MFMA4G ADMM on shapes no other variant is instantiated for (any N, n + m <= 24)
+# ----------------------------------------------------------------------------------------------
+def _random_cfg(n, m, N, seed):
+    from types import SimpleNamespace
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, n))
+    A *= 0.95 / max(abs(np.linalg.eigvals(A)))  # stable, well inside the unit circle
+    Bm = rng.standard_normal((n, m))
+    sys = SimpleNamespace(A=A, B=Bm, n=n, m=m, LBx=-1.0 - rng.random(n), UBx=1.0 + rng.random(n), LBu=-0.5 - rng.random(m),
+                          UBu=0.5 + rng.random(m))
+    param = SimpleNamespace(Q=np.diag(1.0 + 4 * rng.random(n)), R=np.diag(0.1 + rng.random(m)), N=N)
+    M = rng.standard_normal((n, n))
+    param.T = np.diag(np.diag(param.Q)) * 3 + 0.1 * (M @ M.T)  # dense terminal weight
+    return SimpleNamespace(name=f"rand_{n}_{m}_{N}", sys=sys, param=param, formulation="laxMPC", method="ADMM",
+                           solver_options=dict(rho=8.0, tol=1e-6, k_max=400), B=1, seed=seed)
+
+
+@pytest.mark.parametrize("n,m,N,formulation", [(4, 1, 7, "laxMPC"), (10, 3, 9, "laxMPC"), (8, 2, 12, "equMPC"), (16, 4, 6, "laxMPC"),
+                                               (20, 2, 20, "laxMPC"), (23, 1, 5, "laxMPC"), (3, 3, 33, "equMPC")])
+def test_mfma4g_admm_arbitrary_shapes(n, m, N, formulation):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=100 + n)
+    cfg.formulation = formulation
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    s.set_variant("mfma4g")
+    rng = np.random.default_rng(n)
+    B = 50
+    x0 = 0.6 * rng.standard_normal((B, n))
+    xr = 0.2 * rng.standard_normal((B, n))
+    ur = 0.1 * rng.standard_normal((B, m))
+    got = s(x0, xr, ur)
+    _compare("mfma4g", got, oracle.admm_banded_batch(v, x0, xr, ur), v)
+    s.close()
