@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void eadmm_g_pack_lambda_kernel(const double *
     out[i] = v;
 }
 
-#define SPCIES_G4_EADMM_SHAPES(X) X(2, 2) X(3, 4) X(5, 6)
+#define SPCIES_G4_EADMM_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 3) X(3, 4) X(4, 4) X(4, 5) X(5, 5) X(5, 6) X(6, 6)
 
 inline int eadmm_plan_build(Plan &p, const AdmmHost &a, const EadmmGHost &h) {
     p.ok = false;

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
     }
 }
 
-#define SPCIES_G4_FISTA_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 4) X(5, 6)
+#define SPCIES_G4_FISTA_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 3) X(3, 4) X(4, 4) X(4, 5) X(5, 5) X(5, 6) X(6, 6)
 
 inline int fista_plan_build(Plan &p, const AdmmHost &a, const FistaGHost &f) {
     p.ok = false;
