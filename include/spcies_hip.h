@@ -131,7 +131,17 @@ enum spcies_array_id {
     SPCIES_A_LBZ = 57,                       /* [N-1][n+m]                                          */
     SPCIES_A_UBZ = 58,                       /* [N-1][n+m]                                          */
     SPCIES_A_LBU0 = 59,                      /* [m]                                                 */
-    SPCIES_A_UBU0 = 60                       /* [m]                                                 */
+    SPCIES_A_UBU0 = 60,                      /* [m]                                                 */
+    /* lax/equ MPC ADMM switches.  Vector rho (header flags bit0 clear; cons_laxMPC_ADMM_C.m:123-129): rho_0 (17)
+     * [m], these, and Hi computed with them.  VAR_BOUNDS (flags bit4; :82-90): LB0 / UB0 (19, 20) [m], LB / UB
+     * (10, 11) become [N-1][n+m], LBN / UBN [n]                                                             */
+    SPCIES_A_RHO_V = 61,                     /* [N-1][n+m]                                          */
+    SPCIES_A_RHO_N = 62,                     /* [n]                                                 */
+    SPCIES_A_RHO_I_V = 63,                   /* [N-1][n+m] reciprocals as the generator prints them */
+    SPCIES_A_RHO_I_0 = 64,                   /* [m]                                                 */
+    SPCIES_A_RHO_I_N = 65,                   /* [n]                                                 */
+    SPCIES_A_LBN = 66,                       /* [n]                                                 */
+    SPCIES_A_UBN = 67                        /* [n]                                                 */
 };
 
 typedef struct {
@@ -141,7 +151,7 @@ typedef struct {
     uint32_t formulation;  /* enum spcies_formulation                        */
     uint32_t method;       /* enum spcies_method                             */
     uint32_t submethod;    /* 0 = none                                       */
-    uint32_t flags;        /* bit0: scalar rho, bit1: use_soc, bit2: time-varying, bit3: in_engineering */
+    uint32_t flags;        /* bit0: scalar rho, bit1: use_soc, bit2: time-varying, bit3: in_engineering, bit4: VAR_BOUNDS */
     uint32_t n, m, N, k_max;
     uint32_t n_arrays;
     uint32_t reserved0;

@@ -42,7 +42,17 @@ typedef struct {
     double r;
     const double *LBz, *UBz;              /* [N-1][n+m]                                      */
     const double *LBu0, *UBu0;            /* [m]                                             */
+    /* lax/equ MPC switches (code_laxMPC_ADMM_C.c:323-348, 490-568): NULL = scalar rho / constant bounds       */
+    const double *rho_0, *rho_v, *rho_N;       /* vector rho: [m], [N-1][n+m], [n]   (no SCALAR_RHO)          */
+    const double *rho_i_0, *rho_i_v, *rho_i_N; /* their printed reciprocals                                    */
+    const double *LB0, *UB0, *LBN, *UBN;       /* VAR_BOUNDS: [m], [n] and LB / UB become [N-1][n+m]          */
 } admm_banded_data;
+#define RHO_H(j) (d->rho_0 ? d->rho_0[j] : d->rho)
+#define RHO_M(l, j) (d->rho_v ? d->rho_v[(size_t)(l) * nm + (j)] : d->rho)
+#define RHO_T(j) (d->rho_N ? d->rho_N[j] : d->rho)
+#define RHOI_H(j) (d->rho_i_0 ? d->rho_i_0[j] : d->rho_i)
+#define RHOI_M(l, j) (d->rho_i_v ? d->rho_i_v[(size_t)(l) * nm + (j)] : d->rho_i)
+#define RHOI_T(j) (d->rho_i_N ? d->rho_i_N[j] : d->rho_i)
 
 /* Workspace layout mirrors the reference's split of every vector into a `_0` head (m inputs of
  * stage 0), N-1 middle rows of n+m and a `_N` tail (n terminal states).                     */
@@ -70,9 +80,9 @@ static void split_free(split_vec *s) { free(s->h); free(s->mid); free(s->t); }
 static void form_qhat(const admm_banded_data *d, const double *q, const double *qT,
                       const split_vec *lam, const split_vec *v, split_vec *z) {
     const int n = d->n, m = d->m, nm = n + m, N = d->N;
-    for (int j = 0; j < m; j++) z->h[j] = q[n + j] + lam->h[j] - d->rho * v->h[j];
+    for (int j = 0; j < m; j++) z->h[j] = q[n + j] + lam->h[j] - RHO_H(j) * v->h[j];
     for (int l = 0; l < N - 1; l++)
-        for (int j = 0; j < nm; j++) MID(*z, l, j) = q[j] + MID(*lam, l, j) - d->rho * MID(*v, l, j);
+        for (int j = 0; j < nm; j++) MID(*z, l, j) = q[j] + MID(*lam, l, j) - RHO_M(l, j) * MID(*v, l, j);
     if (d->ellip) { /* code_ellipMPC_ADMM_C.c:146-156 */
         for (int j = 0; j < n; j++) {
             z->t[j] = qT[j];
@@ -80,7 +90,7 @@ static void form_qhat(const admm_banded_data *d, const double *q, const double *
                 z->t[j] = z->t[j] + d->P_half[(size_t)j * n + i] * lam->t[i] - d->P[(size_t)j * n + i] * d->rho * v->t[i];
         }
     } else if (d->terminal)
-        for (int j = 0; j < n; j++) z->t[j] = qT[j] + lam->t[j] - d->rho * v->t[j];
+        for (int j = 0; j < n; j++) z->t[j] = qT[j] + lam->t[j] - RHO_T(j) * v->t[j];
 }
 
 /* Right-hand side  -G*Hhat^{-1}*q_hat - b  of the W system, stored in mu
@@ -197,20 +207,23 @@ static void update_v_lambda_ellip(const admm_banded_data *d, const split_vec *z,
 
 static void update_v_lambda(const admm_banded_data *d, const split_vec *z, split_vec *v, split_vec *lam) {
     const int n = d->n, m = d->m, nm = n + m, N = d->N;
+    const int vb = d->LB0 != NULL; /* VAR_BOUNDS */
     for (int j = 0; j < m; j++)
-        v->h[j] = clampd(z->h[j] + d->rho_i * lam->h[j], d->LB[n + j], d->UB[n + j]);
+        v->h[j] = clampd(z->h[j] + RHOI_H(j) * lam->h[j], vb ? d->LB0[j] : d->LB[n + j], vb ? d->UB0[j] : d->UB[n + j]);
     for (int l = 0; l < N - 1; l++)
         for (int j = 0; j < nm; j++)
-            MID(*v, l, j) = clampd(MID(*z, l, j) + d->rho_i * MID(*lam, l, j), d->LB[j], d->UB[j]);
+            MID(*v, l, j) = clampd(MID(*z, l, j) + RHOI_M(l, j) * MID(*lam, l, j), vb ? d->LB[(size_t)l * nm + j] : d->LB[j],
+                                   vb ? d->UB[(size_t)l * nm + j] : d->UB[j]);
     if (d->terminal)
-        for (int j = 0; j < n; j++) v->t[j] = clampd(z->t[j] + d->rho_i * lam->t[j], d->LB[j], d->UB[j]);
+        for (int j = 0; j < n; j++)
+            v->t[j] = clampd(z->t[j] + RHOI_T(j) * lam->t[j], vb ? d->LBN[j] : d->LB[j], vb ? d->UBN[j] : d->UB[j]);
 
-    for (int j = 0; j < m; j++) lam->h[j] = lam->h[j] + d->rho * (z->h[j] - v->h[j]);
+    for (int j = 0; j < m; j++) lam->h[j] = lam->h[j] + RHO_H(j) * (z->h[j] - v->h[j]);
     for (int l = 0; l < N - 1; l++)
         for (int j = 0; j < nm; j++)
-            MID(*lam, l, j) = MID(*lam, l, j) + d->rho * (MID(*z, l, j) - MID(*v, l, j));
+            MID(*lam, l, j) = MID(*lam, l, j) + RHO_M(l, j) * (MID(*z, l, j) - MID(*v, l, j));
     if (d->terminal)
-        for (int j = 0; j < n; j++) lam->t[j] = lam->t[j] + d->rho * (z->t[j] - v->t[j]);
+        for (int j = 0; j < n; j++) lam->t[j] = lam->t[j] + RHO_T(j) * (z->t[j] - v->t[j]);
 }
 
 static inline int exceeds(double a, double b, double tol) {
@@ -453,6 +466,8 @@ int oracle_admm_tv_batch(int n, int m, int N, int k_max, int terminal, double to
         d.AB = o.AB; d.Alpha = o.Alpha; d.Beta = o.Beta; d.Hi = o.Hi; d.Hi_0 = o.Hi_0; d.Hi_N = T_rho_i;
         d.Q = o.Q; d.R = o.R; d.T = T; d.LB = LB; d.UB = UB;
         d.ellip = 0;
+        d.rho_0 = d.rho_v = d.rho_N = d.rho_i_0 = d.rho_i_v = d.rho_i_N = NULL;
+        d.LB0 = d.UB0 = d.LBN = d.UBN = NULL;
         const double *xri = ref_stride ? xr + (size_t)i * n : xr;
         const double *uri = ref_stride ? ur + (size_t)i * m : ur;
         rc = oracle_admm_banded_solve(&d, x0 + (size_t)i * n, xri, uri, u + (size_t)i * m, k + i, e_flag + i,

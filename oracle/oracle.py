@@ -27,7 +27,9 @@ class _Data(C.Structure):
         ("ellip", C.c_int), ("P", C.POINTER(C.c_double)), ("P_half", C.POINTER(C.c_double)),
         ("Pinv_half", C.POINTER(C.c_double)), ("c", C.POINTER(C.c_double)), ("r", C.c_double),
         ("LBz", C.POINTER(C.c_double)), ("UBz", C.POINTER(C.c_double)), ("LBu0", C.POINTER(C.c_double)),
-        ("UBu0", C.POINTER(C.c_double))]
+        ("UBu0", C.POINTER(C.c_double))] + [
+        (name, C.POINTER(C.c_double)) for name in ("rho_0", "rho_v", "rho_N", "rho_i_0", "rho_i_v", "rho_i_N",
+                                                   "LB0", "UB0", "LBN", "UBN")]
 
 
 def _lib():
@@ -108,9 +110,13 @@ def admm_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     ellip = v.get("formulation") == "ellipMPC"
     names = ("AB", "Alpha", "Beta", "Hi", "Hi_0", "Hi_N", "Q", "R", "T") + (
         ("P", "P_half", "Pinv_half", "c", "LBz", "UBz", "LBu0", "UBu0") if ellip else ("LB", "UB"))
+    if not v.get("rho_is_scalar", True):
+        names += ("rho_0", "rho_v", "rho_N", "rho_i_0", "rho_i_v", "rho_i_N")
+    if v.get("var_bounds", False):
+        names += ("LB0", "UB0", "LBN", "UBN")
     keep = {name: np.ascontiguousarray(qz(np.asarray(v[name], dtype=float))) for name in names}
     if quantize:  # +-inf -> +-1e20 as dec_var.m:245-248
-        for nm_ in ("LB", "UB", "LBz", "UBz", "LBu0", "UBu0"):
+        for nm_ in ("LB", "UB", "LBz", "UBz", "LBu0", "UBu0", "LB0", "UB0", "LBN", "UBN"):
             if nm_ in keep:
                 keep[nm_] = np.clip(keep[nm_], -1e20, 1e20)
     d = _Data(n=n, m=m, N=N, k_max=int(v["k_max"]), terminal=int(terminal), ellip=int(ellip),

@@ -106,9 +106,16 @@ def build_admm(v, name):
         variables = _decl("c", np.asarray(v["c"], float)).replace("const static ", "") \
             + f"double r = {_fmt(v['r'])};\n"
     elif method == "ADMM":  # cons_laxMPC_ADMM_C.m:72-130
-        defs += ["#define SCALAR_RHO", f"#define rho {_fmt(v['rho'])}", f"#define rho_i {_fmt(v['rho_i'])}"]
         order = [(k, k) for k in ["LB", "UB", "Hi", "Hi_0"] + (["Hi_N"] if v["terminal"] else [])
                  + ["Q", "R", "AB", "Alpha", "Beta"] + (["T"] if v["terminal"] else [])]
+        if v.get("var_bounds", False):  # :82-90
+            defs += ["#define VAR_BOUNDS 1"]
+            order = [("LB0", "LB0"), ("UB0", "UB0")] + order + ([("LBN", "LBN"), ("UBN", "UBN")] if v["terminal"] else [])
+        if v.get("rho_is_scalar", True):
+            defs += ["#define SCALAR_RHO", f"#define rho {_fmt(v['rho'])}", f"#define rho_i {_fmt(v['rho_i'])}"]
+        else:  # :123-129
+            order += [("rho", "rho_v"), ("rho_0", "rho_0"), ("rho_i", "rho_i_v"), ("rho_i_0", "rho_i_0")] \
+                + ([("rho_N", "rho_N"), ("rho_i_N", "rho_i_N")] if v["terminal"] else [])
     elif method == "FISTA":  # cons_laxMPC_FISTA_C.m:94-107 / cons_equMPC_FISTA_C.m
         order = [(k, k) for k in ["LB", "UB", "AB", "Alpha", "Beta", "Q", "R", "QRi"]] \
             + ([("T", "Tdiag"), ("Ti", "Ti")] if v["terminal"] else [])

@@ -54,6 +54,18 @@ def config(name):
         c = config("C2")
         c.name, c.formulation = name, "equMPC"
         return c
+    if name.endswith("_gen"):  # C1_lax_gen, C1_equ_gen, C2_lax_gen: vector rho + one bound column per prediction step
+        c = config(name[:-4])
+        c.name = name
+        rng = np.random.default_rng(77)
+        n, m, N = c.sys.n, c.sys.m, c.param.N
+        sysd = dict(vars(c.sys))
+        wide = lambda a, sc: np.tile(np.ravel(a)[:, None], (1, N + 1)) * (1.0 + sc * rng.random((np.size(a), N + 1)))
+        sysd.update(LBx=wide(c.sys.LBx, 0.2), UBx=wide(c.sys.UBx, 0.2), LBu=wide(c.sys.LBu, 0.3), UBu=wide(c.sys.UBu, 0.3))
+        c.sys = SimpleNamespace(**sysd)
+        dim = N * (n + m) - (0 if c.formulation == "laxMPC" else n)
+        c.solver_options = dict(c.solver_options, rho=15.0 * (0.5 + rng.random(dim)))
+        return c
     if name in ("C1_lax_FISTA", "C1_equ_FISTA"):  # tests/test_laxMPC_FISTA.m:6-15, tests/test_equMPC_FISTA.m:6-13
         c = config("C1")
         c.name, c.method, c.solver_options = name, "FISTA", dict(k_max=5000, tol=1e-7)

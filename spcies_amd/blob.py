@@ -26,7 +26,8 @@ ARRAY_ID = {"AB": 1, "Alpha": 2, "Beta": 3, "Hi": 4, "Hi_0": 5, "Hi_N": 6, "Q": 
             "GhHhi_row": 34, "HhiGh_val": 35, "HhiGh_col": 36, "HhiGh_row": 37, "Hhi_val": 38, "Hhi_col": 39,
             "Hhi_row": 40, "Te": 41, "Se": 42, "LBy": 43, "UBy": 44, "idx_x0": 45, "bh": 46, "T_rho_i": 47,
             "scaling_x": 48, "scaling_u": 49, "scaling_i_u": 50, "OpPoint_x": 51, "OpPoint_u": 52,
-            "P": 53, "P_half": 54, "Pinv_half": 55, "c": 56, "LBz": 57, "UBz": 58, "LBu0": 59, "UBu0": 60}
+            "P": 53, "P_half": 54, "Pinv_half": 55, "c": 56, "LBz": 57, "UBz": 58, "LBu0": 59, "UBu0": 60,
+            "rho_v": 61, "rho_N": 62, "rho_i_v": 63, "rho_i_0": 64, "rho_i_N": 65, "LBN": 66, "UBN": 67}
 INT_ARRAYS = {"L_col", "L_row", "GhHhi_col", "GhHhi_row", "HhiGh_col", "HhiGh_row", "Hhi_col", "Hhi_row", "idx_x0"}
 SUBMETHOD = {"": 0, "soc": 1, "split": 2, "cs": 3, "semiband": 4}
 _ID_NAME = {v: k for k, v in ARRAY_ID.items()}
@@ -51,7 +52,7 @@ def pack(v):
             arrays.append((k, np.ascontiguousarray(np.asarray(v[k], dtype="<i4"))))
             continue
         a = np.ascontiguousarray(np.asarray(v[k], dtype="<f8"))
-        if k in ("LB", "UB", "LB0", "UB0", "LBs", "UBs", "LBy", "UBy", "LBz", "UBz", "LBu0", "UBu0"):
+        if k in ("LB", "UB", "LB0", "UB0", "LBs", "UBs", "LBy", "UBy", "LBz", "UBz", "LBu0", "UBu0", "LBN", "UBN"):
             a = np.clip(a, -INF_VALUE, INF_VALUE)
         arrays.append((k, a))
     off = _align(HEADER_BYTES + ENTRY_BYTES * len(arrays))
@@ -63,7 +64,7 @@ def pack(v):
         off = _align(off + a.nbytes)
     total = off
     flags = (1 if v.get("rho_is_scalar", True) else 0) | (2 if v.get("use_soc", False) else 0) | (
-        4 if v.get("time_varying", False) else 0) | (8 if v.get("in_engineering", False) else 0)
+        4 if v.get("time_varying", False) else 0) | (8 if v.get("in_engineering", False) else 0) | (16 if v.get("var_bounds", False) else 0)
     res = [float(v.get("sigma", 0.0)), float(v.get("sigma_i", 0.0)), float(v.get("tol_d", 0.0)), float(v.get("alpha", 0.0)), float(v.get("r", 0.0))]
     hdr = struct.pack(_HDR, MAGIC, VERSION, HEADER_BYTES, FORMULATION[v["formulation"]], METHOD[v["method"]],
                       SUBMETHOD[v.get("submethod", "")], flags, int(v["n"]), int(v["m"]), int(v["N"]), int(v["k_max"]),
@@ -88,7 +89,7 @@ def unpack(blob):
     inv = lambda d, x: next(k for k, val in d.items() if val == x)
     v = dict(formulation=inv(FORMULATION, form), method=inv(METHOD, meth), n=n, m=m, N=N, k_max=k_max, tol=tol,
              rho=rho, rho_i=rho_i, rho_is_scalar=bool(flags & 1), time_varying=bool(flags & 4),
-             in_engineering=bool(flags & 8))
+             in_engineering=bool(flags & 8), var_bounds=bool(flags & 16))
     v["terminal"] = v["formulation"] != "equMPC"
     for i in range(n_arr):
         aid, dtype, off, count, d0, d1, d2, d3, _p0, _p1 = struct.unpack_from(_ENT, blob, HEADER_BYTES + i * ENTRY_BYTES)

@@ -26,20 +26,50 @@ struct AdmmGLayout {
     // stage-invariant blocks: -AB (KX x KS), AB' (KS x KX), Hi_N (KX x KX), T (KX x KX, negated weight)
     static constexpr int T_NAB = 0, T_ABT = KX * KS, T_HIN = 2 * KX * KS, T_T = 2 * KX * KS + KX * KX;
     static constexpr int INV_TILES = (2 * KX * KS + 2 * KX * KX + 1) / 2 * 2;
-    enum { C_HD0, C_LB0, C_UB0, C_QR, C_COUNT };  // Hd of stage 0 (u rows only), its bounds, [Q; R] (negated)
+    enum { C_HD0, C_LB0, C_UB0, C_QR, C_RHO0, C_COUNT };  // Hd of stage 0 (u rows only), its bounds, [Q; R] (negated), rho
     static constexpr int INV_D = INV_TILES * 16 + C_COUNT * RC;
     static constexpr int NT = blk_count(KX, KX, LOWER) + KX * KX, NT_PAD = (NT + 1) / 2 * 2;
-    enum { K_HD, K_LB, K_UB, K_COUNT };  // of stage l + 1 (both sweeps)
+    enum { K_HD, K_LB, K_UB, K_RHO, K_COUNT };  // of stage l + 1 (both sweeps)
     static constexpr int CHD = NT_PAD * 16 + K_COUNT * RC;
     static constexpr int LDS_D = INV_D + 2 * CHD;
-    static size_t table_doubles(int N) { return (size_t)INV_D + (size_t)2 * N * CHD; }
+    static size_t chunks_end(int N) { return (size_t)INV_D + (size_t)2 * N * CHD; }
+    // after the chunks: stage-wise lb, ub, rho ([N+1][n+m] each) for the record kernel
+    static size_t table_doubles(int N, int nm) { return chunks_end(N) + (size_t)3 * (N + 1) * nm; }
 };
+
+// bounds and penalty of every stage t = 0..N and row, from the scalar / constant form or the stage-wise one
+// (vector rho, VAR_BOUNDS); rows that do not exist (x of stage 0, u of stage N) get lb = ub = 0, rho = 1
+inline void admm_stage_arrays(const AdmmHost &a, std::vector<double> &lb, std::vector<double> &ub, std::vector<double> &rho) {
+    const int n = a.n, m = a.m, N = a.N, nm = n + m;
+    lb.assign((size_t)(N + 1) * nm, 0.0);
+    ub.assign((size_t)(N + 1) * nm, 0.0);
+    rho.assign((size_t)(N + 1) * nm, 1.0);
+    for (int t = 0; t <= N; t++)
+        for (int j = 0; j < nm; j++) {
+            const bool exists = (t == 0) ? (j >= n) : (t == N ? (a.terminal && j < n) : true);
+            if (!exists) continue;
+            double l, u, r;
+            if (a.gen) {
+                if (t == 0) { l = a.LBu0[j - n]; u = a.UBu0[j - n]; r = a.rho_0[j - n]; }
+                else if (t == N) { l = a.LBN[j]; u = a.UBN[j]; r = a.rho_N[j]; }
+                else { l = a.LBz[(size_t)(t - 1) * nm + j]; u = a.UBz[(size_t)(t - 1) * nm + j]; r = a.rho_v[(size_t)(t - 1) * nm + j]; }
+            } else {
+                l = a.LB[j]; u = a.UB[j]; r = a.rho;
+            }
+            lb[(size_t)t * nm + j] = l; ub[(size_t)t * nm + j] = u; rho[(size_t)t * nm + j] = r;
+        }
+}
 
 template <int KX, int KS>
 inline int admm_plan_build_shape(Plan &p, const AdmmHost &a) {
     using LY = AdmmGLayout<KX, KS>;
     const int n = a.n, m = a.m, N = a.N, nm = n + m;
-    std::vector<double> tab(LY::table_doubles(N), 0.0);
+    std::vector<double> tab(LY::table_doubles(N, nm), 0.0);
+    std::vector<double> lbS, ubS, rhoS;
+    admm_stage_arrays(a, lbS, ubS, rhoS);
+    std::copy(lbS.begin(), lbS.end(), tab.begin() + LY::chunks_end(N));
+    std::copy(ubS.begin(), ubS.end(), tab.begin() + LY::chunks_end(N) + lbS.size());
+    std::copy(rhoS.begin(), rhoS.end(), tab.begin() + LY::chunks_end(N) + 2 * lbS.size());
     DM AB(n, nm), HiN(n, n), T(n, n);
     for (int i = 0; i < n; i++)
         for (int j = 0; j < nm; j++) AB(i, j) = a.AB[(size_t)i * nm + j];
@@ -59,9 +89,12 @@ inline int admm_plan_build_shape(Plan &p, const AdmmHost &a) {
         double *rc = tab.data() + LY::INV_TILES * 16;
         for (int j = 0; j < m; j++) {
             rc[LY::C_HD0 * LY::RC + n + j] = a.Hi_0[j];
-            rc[LY::C_LB0 * LY::RC + n + j] = a.LB[n + j];
-            rc[LY::C_UB0 * LY::RC + n + j] = a.UB[n + j];
             rc[LY::C_QR * LY::RC + n + j] = a.R[j];
+        }
+        for (int j = 0; j < nm; j++) {
+            rc[LY::C_LB0 * LY::RC + j] = lbS[j];
+            rc[LY::C_UB0 * LY::RC + j] = ubS[j];
+            rc[LY::C_RHO0 * LY::RC + j] = rhoS[j];
         }
         for (int j = 0; j < n; j++) rc[LY::C_QR * LY::RC + j] = a.Q[j];
     }
@@ -88,17 +121,11 @@ inline int admm_plan_build_shape(Plan &p, const AdmmHost &a) {
         ok = ok && w.structure_ok && w.cursor == LY::NT;
         double *rc = tab.data() + base + LY::NT_PAD * 16;
         const int t = l + 1;  // constants of stage l + 1: Hd (diagonal; stage N: x rows only, the dense Hi_N is a block)
-        if (t < N) {
-            for (int j = 0; j < nm; j++) {
-                rc[LY::K_HD * LY::RC + j] = a.Hi[(size_t)(t - 1) * nm + j];
-                rc[LY::K_LB * LY::RC + j] = a.LB[j];
-                rc[LY::K_UB * LY::RC + j] = a.UB[j];
-            }
-        } else if (a.terminal) {
-            for (int j = 0; j < n; j++) {
-                rc[LY::K_LB * LY::RC + j] = a.LB[j];
-                rc[LY::K_UB * LY::RC + j] = a.UB[j];
-            }
+        for (int j = 0; j < nm; j++) {
+            if (t < N) rc[LY::K_HD * LY::RC + j] = a.Hi[(size_t)(t - 1) * nm + j];
+            rc[LY::K_LB * LY::RC + j] = lbS[(size_t)t * nm + j];
+            rc[LY::K_UB * LY::RC + j] = ubS[(size_t)t * nm + j];
+            rc[LY::K_RHO * LY::RC + j] = rhoS[(size_t)t * nm + j];
         }
     }
     if (!ok) { p.why = "MFMA4G packer: block structure mismatch"; return 0; }
@@ -136,7 +163,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void admm_g_kernel(AdmmGArgs pa, co
     const int g = lane >> 4, c = lane & 15;
     const int ao = g * 4 + (lane & 3);
     const long n_tiles = (p.B + 15) / 16, n_groups = (n_tiles + 3) / 4;
-    const double tol = p.tol, rho = pa.rho;
+    const double tol = p.tol;
     const int dim = TERMINAL ? N * nm : N * nm - n;
     Stager<LY::CHD> stg;
 #define SPCIES_RC(K, which, s) (K)[(which) * LY::RC + 4 * (s) + g]
@@ -193,25 +220,25 @@ __global__ __launch_bounds__(256, WG_PER_CU) void admm_g_kernel(AdmmGArgs pa, co
         bool active = valid;
         int kk = 0;
         // q_hat of a stage from its w; cw = clamp(w)
-        auto qhat = [&](const double (&w)[KS], const double *K, int which_lb, int which_ub, bool lastt, double rf, double (&cw)[KS],
-                        double (&qh)[KS]) {
+        auto qhat = [&](const double (&w)[KS], const double *K, int which_lb, int which_ub, int which_rho, bool lastt, double fz,
+                        double (&cw)[KS], double (&qh)[KS]) {
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 cw[s] = fmin(fmax(w[s], SPCIES_RC(K, which_lb, s)), SPCIES_RC(K, which_ub, s));
                 const double q = lastt ? ((s < KX) ? qT[s < KX ? s : 0] : 0.0) : qm[s];
-                qh[s] = q + rf * (w[s] - 2.0 * cw[s]);
+                qh[s] = q + fz * SPCIES_RC(K, which_rho, s) * (w[s] - 2.0 * cw[s]);
             }
         };
         while (true) {
             kk += 1;
-            const double fz = (kk == 1) ? 0.0 : 1.0, rf = rho * fz;  // cold start: v = lambda = 0 in iteration 1
+            const double fz = (kk == 1) ? 0.0 : 1.0;  // cold start: v = lambda = 0 in iteration 1
             // ======================= forward sweep =======================
             double wc[KS], cw[KS], qc[KS], yprev[KX];
 #pragma unroll
             for (int s = 0; s < KS; s++) wc[s] = Wt.ld(s, voff);
 #pragma unroll
             for (int s = 0; s < KX; s++) yprev[s] = 0.0;
-            qhat(wc, inv_rc, LY::C_LB0, LY::C_UB0, false, rf, cw, qc);  // stage 0
+            qhat(wc, inv_rc, LY::C_LB0, LY::C_UB0, LY::C_RHO0, false, fz, cw, qc);  // stage 0
             double hdc[KS];  // Hd of the current stage
 #pragma unroll
             for (int s = 0; s < KS; s++) hdc[s] = SPCIES_RC(inv_rc, LY::C_HD0, s);
@@ -230,7 +257,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void admm_g_kernel(AdmmGArgs pa, co
                     wn[s] = wpre[s];
                     wpre[s] = (l + 2 <= N) ? Wt.ld((l + 2) * KS + s, voff) : 0.0;
                 }
-                qhat(wn, K, LY::K_LB, LY::K_UB, lastt, rf, cwn, qn);
+                qhat(wn, K, LY::K_LB, LY::K_UB, LY::K_RHO, lastt, fz, cwn, qn);
                 // right-hand side (:355-381)
                 double r[KX], t1[KS];
 #pragma unroll
@@ -350,7 +377,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void admm_g_kernel(AdmmGArgs pa, co
                 const int t = l + 1;
                 const bool lastt = (t == N);
                 double cwo[KS], qh[KS], z[KS], vn[KS];
-                qhat(wt, K, LY::K_LB, LY::K_UB, lastt, rf, cwo, qh);
+                qhat(wt, K, LY::K_LB, LY::K_UB, LY::K_RHO, lastt, fz, cwo, qh);
                 if (lastt) {
 #pragma unroll
                     for (int s = 0; s < KS; s++) z[s] = 0.0;
@@ -382,7 +409,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void admm_g_kernel(AdmmGArgs pa, co
                 for (int s = 0; s < KX; s++) mun[s] = mu[s];
                 if (l == 0) {  // stage 0: z_0 = -Hd_0 (q_hat_0 + AB' mu_0)  (:456-461)
                     double cw0[KS], qh0[KS], acc[KS], z0[KS];
-                    qhat(wfp, inv_rc, LY::C_LB0, LY::C_UB0, false, rf, cw0, qh0);
+                    qhat(wfp, inv_rc, LY::C_LB0, LY::C_UB0, LY::C_RHO0, false, fz, cw0, qh0);
 #pragma unroll
                     for (int s = 0; s < KS; s++) acc[s] = qh0[s];
                     int tix = LY::T_ABT;
@@ -419,9 +446,9 @@ __global__ __launch_bounds__(256, WG_PER_CU) void admm_g_kernel(AdmmGArgs pa, co
 
 // v = clamp(w), lambda = rho (w - v) from the frozen w, in the reference's flattened order (:659-684)
 __global__ __launch_bounds__(256) void admm_g_record_kernel(const double *__restrict__ W, long B, int N, int KS, int n, int m,
-                                                            int terminal, double rho, const double *__restrict__ LB,
-                                                            const double *__restrict__ UB, double *__restrict__ v_out,
-                                                            double *__restrict__ lam_out) {
+                                                            int terminal, const double *__restrict__ lbS,
+                                                            const double *__restrict__ ubS, const double *__restrict__ rhoS,
+                                                            double *__restrict__ v_out, double *__restrict__ lam_out) {
     const int nm = n + m;
     const long dim = (long)N * nm - (terminal ? 0 : n);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -438,9 +465,9 @@ __global__ __launch_bounds__(256) void admm_g_record_kernel(const double *__rest
     }
     const long tile = inst / 16;
     const double w = W[((tile * (N + 1) + t) * KS + row / 4) * 64 + 16 * (row % 4) + (inst % 16)];
-    const double v = fmin(fmax(w, LB[row]), UB[row]);
+    const double v = fmin(fmax(w, lbS[t * nm + row]), ubS[t * nm + row]);
     if (v_out) v_out[i] = v;
-    if (lam_out) lam_out[i] = rho * (w - v);
+    if (lam_out) lam_out[i] = rhoS[t * nm + row] * (w - v);
 }
 
 #define SPCIES_G4_ADMM_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 3) X(3, 4) X(4, 4) X(4, 5) X(5, 5) X(5, 6) X(6, 6)
@@ -466,8 +493,8 @@ inline size_t admm_state_bytes(const Plan &p, const AdmmHost &a, long B) {
 
 template <int KX, int KS>
 static int launch_admm_g_shape(Plan &pl, const AdmmHost &a, const Args &args, const double *x0, const double *xr,
-                               const double *ur, double *state, const double *d_LB, const double *d_UB, double *u, int *k,
-                               int *e, double *z, double *v, double *lam, hipStream_t st) {
+                               const double *ur, double *state, double *u, int *k, int *e, double *z, double *v, double *lam,
+                               hipStream_t st) {
     using LY = AdmmGLayout<KX, KS>;
     constexpr int WGS = (KS >= 4) ? 2 : 3;
     const long tiles = padded_tiles(args.B);
@@ -489,22 +516,23 @@ static int launch_admm_g_shape(Plan &pl, const AdmmHost &a, const Args &args, co
     SPCIES_HIP_CHECK(hipGetLastError());
     if (v || lam) {
         const long total = args.B * (long)a.dim();
+        const double *lbS = pl.d_table + LY::chunks_end(N), *ubS = lbS + (size_t)(N + 1) * (a.n + a.m),
+                     *rhoS = ubS + (size_t)(N + 1) * (a.n + a.m);
         hipLaunchKernelGGL(admm_g_record_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, args.B, N, KS, a.n,
-                           a.m, a.terminal ? 1 : 0, a.rho, d_LB, d_UB, v, lam);
+                           a.m, a.terminal ? 1 : 0, lbS, ubS, rhoS, v, lam);
         SPCIES_HIP_CHECK(hipGetLastError());
     }
     return 0;
 }
 
 inline int launch_admm_g(Plan &pl, const AdmmHost &a, const double *x0, const double *xr, const double *ur, int ref_stride,
-                         long B, double *state, const double *d_LB, const double *d_UB, double *u, int *k, int *e, double *z,
-                         double *v, double *lam, hipStream_t st) {
+                         long B, double *state, double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
     if (!pl.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant unavailable: %s", pl.why.c_str());
     if ((v || lam) && !z) {}  // (v, lambda come from the frozen state: they do not need the in-loop z stores)
     Args args{a.n, a.m, a.N, a.k_max, a.tol, B, ref_stride};
 #define X(KKX, KKS)                   \
     if (pl.KX == KKX && pl.KS == KKS) \
-        return launch_admm_g_shape<KKX, KKS>(pl, a, args, x0, xr, ur, state, d_LB, d_UB, u, k, e, z, v, lam, st);
+        return launch_admm_g_shape<KKX, KKS>(pl, a, args, x0, xr, ur, state, u, k, e, z, v, lam, st);
     SPCIES_G4_ADMM_SHAPES(X)
 #undef X
     return fail(SPCIES_HIP_ENOSUP, "MFMA4G ADMM kernel not instantiated for KX=%d KS=%d", pl.KX, pl.KS);

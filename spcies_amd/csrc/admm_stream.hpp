@@ -106,7 +106,7 @@ __host__ __device__ inline TvLayout tv_layout(int n, int m, int N) {
         if constexpr (TV) asm volatile("" ::: "memory"); \
     } while (0)
 
-template <int n, int m, bool TERMINAL, bool EXACT, bool TV = false, bool ELLIP = false>
+template <int n, int m, bool TERMINAL, bool EXACT, bool TV = false, bool ELLIP = false, bool GEN = false>
 __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double *__restrict__ C,
                                                          const double *__restrict__ x0g,
                                                          const double *__restrict__ xrg,
@@ -139,6 +139,16 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
     const double *cP = C + c.P, *cPh = C + c.P_half, *cPih = C + c.Pinv_half, *cCe = C + c.c_ell, *cLBz = C + c.LBz,
                  *cUBz = C + c.UBz, *cLBu0 = C + c.LBu0, *cUBu0 = C + c.UBu0;
     static_assert(!ELLIP || (TERMINAL && !TV), "ellipMPC ADMM: terminal block, constant model");
+    static_assert(!GEN || (!ELLIP && !TV), "vector rho / VAR_BOUNDS: lax and equ MPC with a constant model");
+    // GEN: stage-wise penalty and bounds (no SCALAR_RHO / VAR_BOUNDS, code_laxMPC_ADMM_C.c:323-348, 490-568)
+    const double *gR0 = C + c.rho_0, *gRv = C + c.rho_v, *gRN = C + c.rho_N, *gRi0 = C + c.rho_i_0, *gRiv = C + c.rho_i_v,
+                 *gRiN = C + c.rho_i_N, *gLBN = C + c.LBN, *gUBN = C + c.UBN;
+    auto RH = [&](int j) { return GEN ? gR0[j] : rho; };
+    auto RM = [&](int l, int j) { return GEN ? gRv[l * nm + j] : rho; };
+    auto RT = [&](int j) { return GEN ? gRN[j] : rho; };
+    auto RIH = [&](int j) { return GEN ? gRi0[j] : rho_i; };
+    auto RIM = [&](int l, int j) { return GEN ? gRiv[l * nm + j] : rho_i; };
+    auto RIT = [&](int j) { return GEN ? gRiN[j] : rho_i; };
 
     // ---- per-instance setup (code_laxMPC_ADMM_C.c:282-299)
     double xr[n], b[n], q[nm], qT[n];
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                 for (int i = 0; i < n; i++) acc = acc + cPh[j * n + i] * lamv[i] - cP[j * n + i] * rho * vold[i];
                 out[j] = acc;
             } else {
-                out[j] = qT[j] + lamv[j] - rho * vold[j];
+                out[j] = qT[j] + lamv[j] - RT(j) * vold[j];
             }
         }
     };
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
         for (int j = 0; j < m; j++) {
             double lam = first ? 0.0 : Lt[(long)j * Bp];
             double vv = first ? 0.0 : Vt[(long)j * Bp];
-            h0[j] = q[n + j] + lam - rho * vv;
+            h0[j] = q[n + j] + lam - RH(j) * vv;
         }
         for (int l = 0; l < N; l++) {
             // q_hat of reference block l  (= z[l][.] for l < N-1, z_N[.] for l = N-1)
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                     long e = off_mid + (long)l * nm + j;
                     double lam = first ? 0.0 : Lt[e * Bp];
                     double vv = first ? 0.0 : Vt[e * Bp];
-                    qc[j] = q[j] + lam - rho * vv;
+                    qc[j] = q[j] + lam - RM(l, j) * vv;
                 }
             } else if constexpr (TERMINAL) {
                 double lamN[n], vN[n], qN[n];
@@ -368,8 +378,9 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                             double zz = 0.0;
 #pragma unroll
                             for (int i = 0; i < n; i++) zz = msub<EXACT>(zz, cHi_N[j * n + i], aux[i]);
-                            double vn = clamp_ref(zz + rho_i * lamv[j], cLB[j], cUB[j]);
-                            double ln = lamv[j] + rho * (zz - vn);
+                            double vn = GEN ? clamp_ref(zz + RIT(j) * lamv[j], gLBN[j], gUBN[j])
+                                            : clamp_ref(zz + rho_i * lamv[j], cLB[j], cUB[j]);
+                            double ln = lamv[j] + RT(j) * (zz - vn);
                             res = res || above(vold[j], vn, tol) || above(zz, vn, tol);
                             long e = off_tail + j;
                             Vt[e * Bp] = vn;
@@ -386,14 +397,14 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                     long e = off_mid + (long)l * nm + j;
                     double lam = first ? 0.0 : Lt[e * Bp];
                     double vold = first ? 0.0 : Vt[e * Bp];
-                    double zz = q[j] + lam - rho * vold;
+                    double zz = q[j] + lam - RM(l, j) * vold;
                     if (j < n) zz = zz - mu[j];
 #pragma unroll
                     for (int i = 0; i < n; i++) zz = madd<EXACT>(zz, cAB[i * nm + j], mun[i]);
                     zz = -cHi[l * nm + j] * zz;
-                    double vn = ELLIP ? clamp_ref(zz + rho_i * lam, cLBz[l * nm + j], cUBz[l * nm + j])
-                                      : clamp_ref(zz + rho_i * lam, cLB[j], cUB[j]);
-                    double ln = lam + rho * (zz - vn);
+                    double vn = (ELLIP || GEN) ? clamp_ref(zz + RIM(l, j) * lam, cLBz[l * nm + j], cUBz[l * nm + j])
+                                               : clamp_ref(zz + rho_i * lam, cLB[j], cUB[j]);
+                    double ln = lam + RM(l, j) * (zz - vn);
                     res = res || above(vold, vn, tol) || above(zz, vn, tol);
                     Vt[e * Bp] = vn;
                     Lt[e * Bp] = ln;
@@ -409,12 +420,13 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
             SPCIES_TV_ROW_BARRIER();
             double lam = first ? 0.0 : Lt[(long)j * Bp];
             double vold = first ? 0.0 : Vt[(long)j * Bp];
-            double zz = q[n + j] + lam - rho * vold;
+            double zz = q[n + j] + lam - RH(j) * vold;
 #pragma unroll
             for (int i = 0; i < n; i++) zz = madd<EXACT>(zz, cAB[i * nm + n + j], mun[i]);
             zz = -cHi_0[j] * zz;
-            double vn = ELLIP ? clamp_ref(zz + rho_i * lam, cLBu0[j], cUBu0[j]) : clamp_ref(zz + rho_i * lam, cLB[n + j], cUB[n + j]);
-            double ln = lam + rho * (zz - vn);
+            double vn = (ELLIP || GEN) ? clamp_ref(zz + RIH(j) * lam, cLBu0[j], cUBu0[j])
+                                       : clamp_ref(zz + rho_i * lam, cLB[n + j], cUB[n + j]);
+            double ln = lam + RH(j) * (zz - vn);
             res = res || above(vold, vn, tol) || above(zz, vn, tol);
             Vt[(long)j * Bp] = vn;
             Lt[(long)j * Bp] = ln;

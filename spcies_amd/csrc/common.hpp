@@ -42,6 +42,11 @@ struct AdmmHost {
     bool ellip = false;
     double r_ell = 0;
     std::vector<double> P, P_half, Pinv_half, c_ell, LBz, UBz, LBu0, UBu0;
+    // lax/equ switches: vector rho (no SCALAR_RHO) and VAR_BOUNDS (code_laxMPC_ADMM_C.c:323-348, 490-568).  When
+    // either is set (`gen`), the stage-wise form of BOTH is kept: rho_0 [m], rho_v [N-1][n+m], rho_N [n] and their
+    // reciprocals, bounds in LBu0/UBu0 [m], LBz/UBz [N-1][n+m], LBN/UBN [n]
+    bool gen = false;
+    std::vector<double> rho_0, rho_v, rho_N, rho_i_0, rho_i_v, rho_i_N, LBN, UBN;
     int dim() const { return N * (n + m) - (terminal ? 0 : n); }
 };
 
@@ -52,8 +57,9 @@ struct AdmmDev {
     int AB, Alpha, Beta, Hi, Hi_0, Hi_N, Q, R, T, LB, UB;
     int N, k_max;
     double tol, rho, rho_i;
-    int P = 0, P_half = 0, Pinv_half = 0, c_ell = 0, LBz = 0, UBz = 0, LBu0 = 0, UBu0 = 0;  // ellipMPC ADMM only
+    int P = 0, P_half = 0, Pinv_half = 0, c_ell = 0, LBz = 0, UBz = 0, LBu0 = 0, UBu0 = 0;  // ellipMPC ADMM / gen
     double r_ell = 0;
+    int rho_0 = 0, rho_v = 0, rho_N = 0, rho_i_0 = 0, rho_i_v = 0, rho_i_N = 0, LBN = 0, UBN = 0;  // gen only
 };
 
 }  // namespace spcies

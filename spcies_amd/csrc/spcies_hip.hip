@@ -289,7 +289,10 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         return parse_hmpc(blob, bytes, h, s);
     if (!banded && !mpct)
         return fail(SPCIES_HIP_ENOSUP, "formulation %u / method %u not built in this library", h.formulation, h.method);
-    if (h.method == SPCIES_ADMM && !(h.flags & 1u)) return fail(SPCIES_HIP_ENOSUP, "vector rho not built");
+    const bool vec_rho = (h.method == SPCIES_ADMM && !(h.flags & 1u)), var_b = (h.flags & 16u) != 0;
+    if ((vec_rho || var_b) && !(h.method == SPCIES_ADMM && (h.formulation == SPCIES_LAXMPC || h.formulation == SPCIES_EQUMPC)))
+        return fail(SPCIES_HIP_ENOSUP, "vector rho / stage-wise bounds are built for the lax/equ MPC ADMM solvers only");
+    if ((vec_rho || var_b) && (h.flags & 4u)) return fail(SPCIES_HIP_EINVAL, "time-varying solvers take a scalar rho and constant bounds");
     if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.N > 100000) return fail(SPCIES_HIP_EINVAL, "bad n/m/N");
     s.formulation = (int)h.formulation;
     s.method = (int)h.method;
@@ -309,7 +312,7 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         }
     }
     a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
-    if (a.k_max <= 0 || (h.method == SPCIES_ADMM && !(a.rho > 0))) return fail(SPCIES_HIP_EINVAL, "bad rho / k_max");
+    if (a.k_max <= 0 || (h.method == SPCIES_ADMM && !vec_rho && !(a.rho > 0))) return fail(SPCIES_HIP_EINVAL, "bad rho / k_max");
     const uint64_t n = h.n, m = h.m, N = h.N, nm = n + m;
     struct Want { uint32_t id; uint64_t count; std::vector<double> *dst; };
     std::vector<Want> want = {{SPCIES_A_AB, n * nm, &a.AB},       {SPCIES_A_ALPHA, (N - 1) * n * n, &a.Alpha},
@@ -357,10 +360,53 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         want.push_back({SPCIES_A_TDIAG, n, &s.Td});
         want.push_back({SPCIES_A_TI, n, &s.Ti});
     }
+    if (var_b) {  // LB / UB are [N-1][n+m] here
+        for (auto &w : want)
+            if (w.id == SPCIES_A_LB || w.id == SPCIES_A_UB) w.count = (N - 1) * nm;
+        want.push_back({SPCIES_A_LB_0, m, &a.LBu0});
+        want.push_back({SPCIES_A_UB_0, m, &a.UBu0});
+        if (a.terminal) {
+            want.push_back({SPCIES_A_LBN, n, &a.LBN});
+            want.push_back({SPCIES_A_UBN, n, &a.UBN});
+        }
+    }
+    if (vec_rho) {
+        want.push_back({SPCIES_A_RHO_0, m, &a.rho_0});
+        want.push_back({SPCIES_A_RHO_V, (N - 1) * nm, &a.rho_v});
+        want.push_back({SPCIES_A_RHO_I_0, m, &a.rho_i_0});
+        want.push_back({SPCIES_A_RHO_I_V, (N - 1) * nm, &a.rho_i_v});
+        if (a.terminal) {
+            want.push_back({SPCIES_A_RHO_N, n, &a.rho_N});
+            want.push_back({SPCIES_A_RHO_I_N, n, &a.rho_i_N});
+        }
+    }
     for (auto &w : want) {
         const double *p = find_array(blob, bytes, h, w.id, w.count);
         if (!p) return fail(SPCIES_HIP_EINVAL, "blob array id %u missing or mis-sized", w.id);
         w.dst->assign(p, p + w.count);
+    }
+    a.gen = vec_rho || var_b;
+    if (a.gen) {  // keep the stage-wise form of both switches
+        if (var_b) {
+            a.LBz = a.LB; a.UBz = a.UB;
+        } else {
+            a.LBu0.assign(a.LB.begin() + n, a.LB.end()); a.UBu0.assign(a.UB.begin() + n, a.UB.end());
+            a.LBN.assign(a.LB.begin(), a.LB.begin() + n); a.UBN.assign(a.UB.begin(), a.UB.begin() + n);
+            a.LBz.clear(); a.UBz.clear();
+            for (uint64_t l = 0; l + 1 < N; l++) {
+                a.LBz.insert(a.LBz.end(), a.LB.begin(), a.LB.end());
+                a.UBz.insert(a.UBz.end(), a.UB.begin(), a.UB.end());
+            }
+        }
+        if (!a.terminal) { a.LBN.assign(n, 0.0); a.UBN.assign(n, 0.0); }
+        if (!vec_rho) {
+            a.rho_0.assign(m, a.rho); a.rho_v.assign((N - 1) * nm, a.rho); a.rho_N.assign(n, a.rho);
+            a.rho_i_0.assign(m, a.rho_i); a.rho_i_v.assign((N - 1) * nm, a.rho_i); a.rho_i_N.assign(n, a.rho_i);
+        } else if (!a.terminal) {
+            a.rho_N.assign(n, 1.0); a.rho_i_N.assign(n, 1.0);
+        }
+        for (double r : a.rho_0) if (!(r > 0)) return fail(SPCIES_HIP_EINVAL, "bad rho");
+        for (double r : a.rho_v) if (!(r > 0)) return fail(SPCIES_HIP_EINVAL, "bad rho");
     }
     return 0;
 }
@@ -382,6 +428,10 @@ static int upload_consts(Solver &s) {
                                                      &a.Q,  &a.R,     &a.T,    &a.LB, &a.UB};
     if (a.ellip)
         for (auto *v : {&a.P, &a.P_half, &a.Pinv_half, &a.c_ell, &a.LBz, &a.UBz, &a.LBu0, &a.UBu0}) arrs.push_back(v);
+    if (a.gen)
+        for (auto *v : {&a.LBz, &a.UBz, &a.LBu0, &a.UBu0, &a.LBN, &a.UBN, &a.rho_0, &a.rho_v, &a.rho_N, &a.rho_i_0, &a.rho_i_v,
+                        &a.rho_i_N})
+            arrs.push_back(v);
     if (s.method == SPCIES_FISTA) arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Q, &a.R, &s.QRi, &s.Td, &s.Ti, &a.LB, &a.UB};
     if (s.method == SPCIES_EADMM)
         arrs = {&s.e_rho, &s.e_rho0, &s.e_rhos, &a.LB,    &a.UB,   &s.e_LB0, &s.e_UB0, &s.e_LBs, &s.e_UBs,
@@ -413,6 +463,11 @@ static int upload_consts(Solver &s) {
         s.dev.P = (int)offs[11]; s.dev.P_half = (int)offs[12]; s.dev.Pinv_half = (int)offs[13]; s.dev.c_ell = (int)offs[14];
         s.dev.LBz = (int)offs[15]; s.dev.UBz = (int)offs[16]; s.dev.LBu0 = (int)offs[17]; s.dev.UBu0 = (int)offs[18];
         s.dev.r_ell = a.r_ell;
+    }
+    if (a.gen) {
+        s.dev.LBz = (int)offs[11]; s.dev.UBz = (int)offs[12]; s.dev.LBu0 = (int)offs[13]; s.dev.UBu0 = (int)offs[14];
+        s.dev.LBN = (int)offs[15]; s.dev.UBN = (int)offs[16]; s.dev.rho_0 = (int)offs[17]; s.dev.rho_v = (int)offs[18];
+        s.dev.rho_N = (int)offs[19]; s.dev.rho_i_0 = (int)offs[20]; s.dev.rho_i_v = (int)offs[21]; s.dev.rho_i_N = (int)offs[22];
     }
     return 0;
 }
@@ -455,7 +510,7 @@ static int ensure_scratch(Solver &s, size_t need) {
     return 0;
 }
 
-template <int n, int m, bool ELLIP = false>
+template <int n, int m, bool ELLIP = false, bool GEN = false>
 static int launch_stream_nm(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                             double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
     const bool want_sol = (z || v || lam);
@@ -469,7 +524,14 @@ static int launch_stream_nm(Solver &s, const double *x0, const double *xr, const
     if constexpr (ELLIP)
         hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true, false, true>), grid, block, 0, st, s.dev, s.d_consts, x0, xr, ur,
                            ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e, nullptr);
-    else if (s.host.terminal)
+    else if constexpr (GEN) {
+        if (s.host.terminal)
+            hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true, false, false, true>), grid, block, 0, st, s.dev, s.d_consts, x0,
+                               xr, ur, ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e, nullptr);
+        else
+            hipLaunchKernelGGL((admm_stream_kernel<n, m, false, true, false, false, true>), grid, block, 0, st, s.dev, s.d_consts, x0,
+                               xr, ur, ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e, nullptr);
+    } else if (s.host.terminal)
         hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true>), grid, block, 0, st, s.dev, s.d_consts, x0, xr, ur,
                            ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e);
     else
@@ -867,12 +929,18 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (!s.g4plan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available: %s", s.g4plan.why.c_str());
         int rc = ensure_scratch(s, g4::admm_state_bytes(s.g4plan, s.host, B));
         if (rc) return rc;
-        return g4::launch_admm_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, s.d_consts + s.dev.LB,
-                                 s.d_consts + s.dev.UB, u, k, e, z, v, lam, st);
+        return g4::launch_admm_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, z, v, lam, st);
     }
     if (variant == SPCIES_VARIANT_MFMA) {
         if (!s.mfma.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA variant not available for this shape: %s", s.mfma.why.c_str());
         return launch_mfma(s.mfma, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
+    }
+    if (s.host.gen) {
+        int rc = ensure_scratch(s, stream_scratch_bytes(s, B, z || v || lam));
+        if (rc) return rc;
+        if (s.host.n == 6 && s.host.m == 2) return launch_stream_nm<6, 2, false, true>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
+        if (s.host.n == 12 && s.host.m == 2) return launch_stream_nm<12, 2, false, true>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
+        return fail(SPCIES_HIP_ENOSUP, "STREAM variant with vector rho / stage-wise bounds not instantiated for n=%d m=%d", s.host.n, s.host.m);
     }
     if (!stream_shape_built(s.host.n, s.host.m))
         return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
@@ -939,10 +1007,14 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         SPCIES_HIP_CHECK(hipMemcpy(s->d_eng, s->eng_v.data(), s->eng_v.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (s->method == SPCIES_ADMM && (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC) && !s->tv && !s->host.ellip) {
-        rc = mfma_plan_build(s->mfma, s->host);
-        if (rc) return rc;
-        rc = mfma4_plan_build(s->mfma4, s->host);
-        if (rc) return rc;
+        if (s->host.gen) {
+            s->mfma.why = s->mfma4.why = "vector rho / stage-wise bounds: use MFMA4G or STREAM";
+        } else {
+            rc = mfma_plan_build(s->mfma, s->host);
+            if (rc) return rc;
+            rc = mfma4_plan_build(s->mfma4, s->host);
+            if (rc) return rc;
+        }
         rc = g4::admm_plan_build(s->g4plan, s->host);
         if (rc) return rc;
     }

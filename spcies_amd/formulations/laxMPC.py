@@ -82,11 +82,17 @@ def compute_laxMPC_ADMM_ingredients(controller, opt, terminal=True):
     if not (_is_diag(Q) and _is_diag(R)):
         raise ValueError("Spcies:laxMPC:ADMM:non_diagonal - matrices Q and R must be diagonal")
     rho = opt.solver["rho"]
-    if np.ndim(rho) != 0 or opt.solver.get("force_vector_rho", False):
-        raise NotImplementedError("HIP platform: vector rho is not built yet (scalar rho only)")
-    rho = float(rho)
     nm = n + m
     dim = N * nm if terminal else N * nm - n
+    # vector rho (compute_laxMPC_ADMM_ingredients.m:53-64, 123-133): one penalty per decision variable
+    rho_vec = None
+    if np.ndim(rho) != 0 or opt.solver.get("force_vector_rho", False):
+        rho_vec = np.ravel(np.asarray(rho, dtype=float)) * np.ones(dim)
+        if opt.time_varying:
+            raise ValueError("LaxMPC ADMM time varying solver only allows the use of a scalar rho")  # cons_laxMPC_ADMM_C.m:50-52
+        rho = float("nan")
+    else:
+        rho = float(rho)
     if opt.time_varying:
         # compute_laxMPC_ADMM_ingredients.m:89-117, cons_laxMPC_ADMM_C.m:97-109: the generated solver receives
         # A, B, Q, R, LB, UB with every call and factorises on line; only T and inv(T + rho I) are constants
@@ -105,7 +111,7 @@ def compute_laxMPC_ADMM_ingredients(controller, opt, terminal=True):
         H[o + n:o + nm, o + n:o + nm] = R
     if terminal:
         H[dim - n:, dim - n:] = T
-    Hhat = H + rho * np.eye(dim)
+    Hhat = H + (np.diag(rho_vec) if rho_vec is not None else rho * np.eye(dim))
     G = build_G(A, B, N, terminal=terminal)
     Hinv = np.linalg.inv(Hhat)
     W = G @ Hinv @ G.T
@@ -124,11 +130,30 @@ def compute_laxMPC_ADMM_ingredients(controller, opt, terminal=True):
     v["AB"] = np.hstack([A, B])
     v["Q"] = -np.diag(Q).copy()
     v["R"] = -np.diag(R).copy()
-    v["LB"] = np.concatenate([np.ravel(_get(sys, "LBx")), np.ravel(_get(sys, "LBu"))]).astype(float)
-    v["UB"] = np.concatenate([np.ravel(_get(sys, "UBx")), np.ravel(_get(sys, "UBu"))]).astype(float)
-    v["rho"] = rho
-    v["rho_i"] = 1.0 / rho
-    v["rho_is_scalar"] = True
+    LBx, UBx = np.asarray(_get(sys, "LBx"), dtype=float), np.asarray(_get(sys, "UBx"), dtype=float)
+    LBu, UBu = np.asarray(_get(sys, "LBu"), dtype=float), np.asarray(_get(sys, "UBu"), dtype=float)
+    if LBx.ndim == 2 and LBx.shape[1] > 1:
+        # one column per prediction step 0..N (cons_laxMPC_ADMM_C.m:82-90, `VAR_BOUNDS`)
+        LB, UB = np.vstack([LBx, LBu.reshape(m, -1)]), np.vstack([UBx, UBu.reshape(m, -1)])
+        if LB.shape != (nm, N + 1) or UB.shape != (nm, N + 1):
+            raise ValueError("stage-wise bounds must have one column per prediction step 0..N")
+        v["var_bounds"] = True
+        v["LB0"], v["UB0"] = LB[n:, 0].copy(), UB[n:, 0].copy()
+        v["LB"], v["UB"] = LB[:, 1:N].T.copy(), UB[:, 1:N].T.copy()
+        v["LBN"], v["UBN"] = LB[:n, N].copy(), UB[:n, N].copy()
+    else:
+        v["LB"] = np.concatenate([np.ravel(LBx), np.ravel(LBu)])
+        v["UB"] = np.concatenate([np.ravel(UBx), np.ravel(UBu)])
+    if rho_vec is None:
+        v["rho"] = rho
+        v["rho_i"] = 1.0 / rho
+        v["rho_is_scalar"] = True
+    else:
+        tail = dim - (n if terminal else 0)
+        v["rho"], v["rho_i"], v["rho_is_scalar"] = 0.0, 0.0, False
+        v["rho_0"], v["rho_v"] = rho_vec[:m].copy(), rho_vec[m:tail].reshape(N - 1, nm).copy()
+        v["rho_N"] = rho_vec[tail:].copy() if terminal else np.ones(n)
+        v["rho_i_0"], v["rho_i_v"], v["rho_i_N"] = 1.0 / v["rho_0"], 1.0 / v["rho_v"], 1.0 / v["rho_N"]
     Beta = np.zeros((N, n, n))
     Alpha = np.zeros((N - 1, n, n))
     for i in range(N):

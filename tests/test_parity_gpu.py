@@ -627,3 +627,54 @@ def test_mfma4g_eadmm_arbitrary_shapes(n, m, N):
     x0, xr, ur = 0.5 * rng.standard_normal((B, n)), 0.2 * rng.standard_normal((B, n)), 0.1 * rng.standard_normal((B, m))
     _compare_mpct("mfma4g", s(x0, xr, ur), oracle.eadmm_mpct_batch(v, x0, xr, ur))
     s.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# lax/equ MPC ADMM with vector rho and stage-wise bounds (no SCALAR_RHO, VAR_BOUNDS)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["stream", "mfma4g"])
+@pytest.mark.parametrize("cfg_name,B,overrides", [("C1_lax_gen", 60, {}), ("C1_equ_gen", 40, dict(k_max=3000)), ("C2_lax_gen", 100, {}),
+                                                  ("C2_lax_gen", 40, dict(tol=1e-6, k_max=3000))])
+def test_vector_rho_and_var_bounds_vs_oracle(variant, cfg_name, B, overrides):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _solver(cfg_name, variant, **overrides)
+    assert not v["rho_is_scalar"] and v["var_bounds"] and s.variant == variant
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    _compare(variant, s(x0, xr, ur), oracle.admm_banded_batch(v, x0, xr, ur), v)
+    with pytest.raises(Exception):
+        s.set_variant("mfma4")  # the register-resident kernels take a scalar rho and constant bounds
+
+
+@pytest.mark.parametrize("which", ["rho", "bounds"])
+def test_one_switch_at_a_time(which):
+    """Only vector rho, or only VAR_BOUNDS: the other one is expanded from its scalar / constant form."""
+    import copy
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    gen = benchmarks.config("C1_lax_gen")
+    cfg = copy.copy(benchmarks.config("C1_lax"))
+    if which == "rho":
+        v = benchmarks.ingredients(cfg, rho=gen.solver_options["rho"])
+    else:
+        cfg.sys = gen.sys
+        v = benchmarks.ingredients(cfg)
+    assert v["rho_is_scalar"] == (which == "bounds") and bool(v.get("var_bounds", False)) == (which == "bounds")
+    x0, xr, ur = benchmarks.sample_batch(cfg, 30)
+    ref = oracle.admm_banded_batch(v, x0, xr, ur)
+    for variant in ("stream", "mfma4g"):
+        s = HipSolver(v)
+        s.set_variant(variant)
+        _compare(variant, s(x0, xr, ur), ref, v)
+        s.close()
+
+
+@pytest.mark.parametrize("tag", ["C1_lax_gen", "C2_lax_gen"])
+def test_vector_rho_vs_reference_template_fixture(tag, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"template_{tag}.npz"))
+    cfg, v, s = _solver(tag, "stream")
+    u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
+    assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
+    same = k == g["k"]
+    assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-9
