@@ -141,7 +141,12 @@ enum spcies_array_id {
     SPCIES_A_RHO_I_0 = 64,                   /* [m]                                                 */
     SPCIES_A_RHO_I_N = 65,                   /* [n]                                                 */
     SPCIES_A_LBN = 66,                       /* [n]                                                 */
-    SPCIES_A_UBN = 67                        /* [n]                                                 */
+    SPCIES_A_UBN = 67,                       /* [n]                                                 */
+    /* HMPC split, NON_SPARSE path (the reference's default option sparse = false; compute_HMPC_ADMM_split_
+     * ingredients.m:236-239, code_HMPC_ADMM_split_C.c:174-190): optional, enable the GEMM variant                */
+    SPCIES_A_M1 = 68,                        /* [dim + n_s][dim + n_s]                              */
+    SPCIES_A_M2 = 69,                        /* [dim + n_s][n_eq + n_s]                             */
+    SPCIES_A_BH_NAT = 70                     /* [n_eq + n_s] bh in natural order (x0 rows first)    */
 };
 
 typedef struct {
@@ -178,7 +183,8 @@ typedef struct spcies_hip_solver_s *spcies_hip_handle;
 #define SPCIES_VARIANT_MFMA 2   /* 16 instances per wavefront on v_mfma_f64_16x16x4, state in registers          */
 #define SPCIES_VARIANT_MFMA4 3  /* same on v_mfma_f64_4x4x4 (4 blocks): no row padding, zero blocks skipped      */
 #define SPCIES_VARIANT_MFMA4G 4 /* v_mfma_f64_4x4x4 with a rolled stage loop: any N, state streamed through HBM   */
-#define SPCIES_VARIANT_TILE 5   /* sparse-KKT solvers: 4-16 lanes per instance, LDL right-hand side in LDS          */
+#define SPCIES_VARIANT_TILE 5   /* sparse-KKT solvers: 4-64 lanes per instance, LDL right-hand side in LDS          */
+#define SPCIES_VARIANT_GEMM 6   /* HMPC split, NON_SPARSE path: one dgemm per iteration for the whole batch         */
 
 typedef struct {
     int formulation, method, submethod;

@@ -31,6 +31,12 @@ typedef struct {
     const double *L_val; const int *L_col, *L_row; const double *Dinv;  /* CSC of L - I, nrow_M columns */
     const int *idx_x0;    /* [n] position of the x0 rows inside bh */
     const double *bh;     /* [n_eq + n_s] (copied: its x0 rows are rewritten per call) */
+    /* NON_SPARSE (option sparse = false, the reference's default: def_options_HMPC_ADMM.m:31):
+     * primal_hat = M2 bh - M1 q_hat (code_HMPC_ADMM_split_C.c:174-190) instead of the L D L' sweeps       */
+    int non_sparse, dim_M2;   /* dim_M2 = n (diamond: only the x0 rows of bh are non-zero) or n_eq + n_s (use_soc)     */
+    const double *M1;         /* [dim + n_s][dim + n_s]                                               */
+    const double *M2;         /* [dim + n_s][dim_M2]                                                  */
+    const double *bh_nat;     /* [n_eq + n_s] bh in its natural order (x0 rows first)                 */
 } admm_hmpc_data;
 
 static inline double absd(double x) { return (x > 0.0) ? x : -x; }
@@ -61,11 +67,12 @@ int oracle_admm_hmpc_solve(const admm_hmpc_data *d, const double *x0, const doub
     double *primal = (double *)calloc((size_t)np_, sizeof(double)), *primal_ant = (double *)calloc((size_t)np_, sizeof(double));
     double *dual = (double *)calloc((size_t)np_, sizeof(double)), *bh = (double *)malloc(sizeof(double) * (size_t)(n_eq + n_s));
     double *z = primal, *s = primal + dim, *lambda = dual, *mu = dual + dim, *z_hat = rhs, *s_hat = rhs + dim;
-    memcpy(bh, d->bh, sizeof(double) * (size_t)(n_eq + n_s));
-    /* setup (:106-129) */
+    memcpy(bh, d->non_sparse ? d->bh_nat : d->bh, sizeof(double) * (size_t)(n_eq + n_s));
+    /* setup (:97-129) */
     for (int j = 0; j < n; j++) {
-        bh[d->idx_x0[j]] = 0.0;
-        for (int i = 0; i < n; i++) bh[d->idx_x0[j]] -= d->A[(size_t)j * n + i] * x0[i];
+        const int at = d->non_sparse ? j : d->idx_x0[j];
+        bh[at] = 0.0;
+        for (int i = 0; i < n; i++) bh[at] -= d->A[(size_t)j * n + i] * x0[i];
     }
     for (int j = 0; j < n; j++)
         for (int i = 0; i < n; i++) q[(N - 1) * nm + m + j] -= d->Te[(size_t)j * n + i] * xr[i] + d->QQ[(size_t)j * n + i] * x0[i];
@@ -81,12 +88,23 @@ int oracle_admm_hmpc_solve(const admm_hmpc_data *d, const double *x0, const doub
         memcpy(primal_ant, primal, sizeof(double) * (size_t)np_);
         for (int j = 0; j < dim; j++) rhs[j] = d->sigma * z[j] - q[j] - lambda[j];
         for (int j = 0; j < n_s; j++) rhs[j + dim] = d->rho * s[j] - mu[j];
+        if (d->non_sparse) { /* (:174-190): q_hat sits in rhs[0..np), the result replaces it */
+            double *qh = (double *)malloc(sizeof(double) * (size_t)np_);
+            memcpy(qh, rhs, sizeof(double) * (size_t)np_);
+            for (int i = 0; i < np_; i++) rhs[i] = 0.0;
+            for (int i = 0; i < np_; i++)
+                for (int j = 0; j < d->dim_M2; j++) rhs[i] += d->M2[(size_t)i * d->dim_M2 + j] * bh[j];
+            for (int i = 0; i < np_; i++)
+                for (int j = 0; j < np_; j++) rhs[i] -= d->M1[(size_t)i * np_ + j] * qh[j];
+            free(qh);
+        } else {
         for (int j = 0; j < n_s + n_eq; j++) rhs[dim + n_s + j] = bh[j];
         for (int i = 0; i < nrow; i++)
             for (int j = d->L_col[i]; j < d->L_col[i + 1]; j++) rhs[d->L_row[j]] -= d->L_val[j] * rhs[i];
         for (int j = 0; j < nrow; j++) rhs[j] *= d->Dinv[j];
         for (int i = nrow - 1; i >= 0; i--)
             for (int j = d->L_col[i]; j < d->L_col[i + 1]; j++) rhs[i] -= d->L_val[j] * rhs[d->L_row[j]];
+        }
         if (d->symmetric) { /* (:215-225) alpha_SADMM*sigma*(...) evaluates left to right */
             for (int j = 0; j < dim; j++) lambda[j] += as * (z_hat[j] - z[j]);
             for (int j = 0; j < n_s; j++) mu[j] += ar * (s_hat[j] - s[j]);

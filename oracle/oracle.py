@@ -287,11 +287,14 @@ class _HmpcData(C.Structure):
                 + [(k_, C.c_double) for k_ in ("tol_p", "tol_d", "rho", "rho_i", "sigma", "sigma_i", "alpha")]
                 + [(k_, C.POINTER(C.c_double)) for k_, _ in _HMPC_F64]
                 + [("L_val", C.POINTER(C.c_double)), ("L_col", C.POINTER(C.c_int)), ("L_row", C.POINTER(C.c_int)),
-                   ("Dinv", C.POINTER(C.c_double)), ("idx_x0", C.POINTER(C.c_int)), ("bh", C.POINTER(C.c_double))])
+                   ("Dinv", C.POINTER(C.c_double)), ("idx_x0", C.POINTER(C.c_int)), ("bh", C.POINTER(C.c_double)),
+                   ("non_sparse", C.c_int), ("dim_M2", C.c_int), ("M1", C.POINTER(C.c_double)), ("M2", C.POINTER(C.c_double)),
+                   ("bh_nat", C.POINTER(C.c_double))])
 
 
-def admm_hmpc_batch(v, x0, xr, ur, want_sol=True, quantize=False):
-    """C oracle of HMPC ADMM / SADMM split.  Returns ``u, k, e_flag, z, s, z_hat, s_hat, lam, mu``."""
+def admm_hmpc_batch(v, x0, xr, ur, want_sol=True, quantize=False, sparse=True):
+    """C oracle of HMPC ADMM / SADMM split.  Returns ``u, k, e_flag, z, s, z_hat, s_hat, lam, mu``.
+    ``sparse=False``: the reference's NON_SPARSE path (dense ``M1``, ``M2``; its default option)."""
     n, m = int(v["n"]), int(v["m"])
     qz = quantize_like_reference if quantize else (lambda a: a)
     keep, fields = {}, {}
@@ -305,6 +308,12 @@ def admm_hmpc_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     for k_ in ("L_col", "L_row", "idx_x0"):
         keep[k_] = np.ascontiguousarray(np.asarray(v[k_], dtype=np.int32))
         fields[k_] = ipt(keep[k_])
+    dim_M2 = (int(v["n_eq"]) + int(v["n_s"])) if v["use_soc"] else n  # cons_HMPC_ADMM_split_C.m:143-150
+    if not sparse:
+        keep["M1"] = np.ascontiguousarray(qz(np.asarray(v["M1"], dtype=float)))
+        keep["M2"] = np.ascontiguousarray(qz(np.asarray(v["M2"], dtype=float)[:, :dim_M2]))
+        keep["bh_nat"] = np.ascontiguousarray(qz(np.asarray(v["bh_nat"], dtype=float)))
+        fields.update(M1=_dp(keep["M1"]), M2=_dp(keep["M2"]), bh_nat=_dp(keep["bh_nat"]), non_sparse=1, dim_M2=dim_M2)
     sc = {k_: (float(qz(v[k_])) if quantize else float(v[k_])) for k_ in ("tol_p", "tol_d", "rho", "rho_i", "sigma", "sigma_i")}
     d = _HmpcData(n=n, m=m, N=int(v["N"]), dim=int(v["dim"]), n_s=int(v["n_s"]), n_eq=int(v["n_eq"]), n_soc=int(v["n_soc"]),
                   nrow_M=int(v["nrow_M"]), k_max=int(v["k_max"]), use_soc=int(v["use_soc"]),

@@ -92,7 +92,7 @@ def build_admm(v, name):
     if v.get("submethod") == "soc":
         return _build_soc(v, name)
     if v.get("submethod") == "split":
-        return _build_hmpc(v, name)
+        return _build_hmpc(v, name, sparse=v.get("_template_sparse", True))
     fdir = os.path.join(REF, "formulations", f"+{form}")
     n, m, N = v["n"], v["m"], v["N"]
     defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
@@ -277,25 +277,32 @@ def run_soc(so, v, x0, xr, ur, r):
     return (u, k, e, out["z"], out["s"], out["z_hat"], out["s_hat"], out["lam"], out["mu"])
 
 
-def _build_hmpc(v, name):
-    """HMPC ADMM / SADMM split, sparse + box constraints: cons_HMPC_ADMM_split_C.m:88-181.  (`bh` goes to
-    $INSERT_VARIABLES$ as a non-const array; scalars rho.. carry no 'array' flag.)"""
+def _build_hmpc(v, name, sparse=True):
+    """HMPC ADMM / SADMM split, box constraints, sparse (L D L') or NON_SPARSE (dense M1, M2: the reference's
+    default option): cons_HMPC_ADMM_split_C.m:88-181.  (`bh` goes to $INSERT_VARIABLES$ as a non-const array;
+    scalars rho.. carry no 'array' flag.)"""
     fdir = os.path.join(REF, "formulations", "+HMPC")
     n, m, N = v["n"], v["m"], v["N"]
     defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
             "#define IS_DIAG 1", f"#define nn_ {n}", f"#define mm_ {m}", f"#define nm_ {n + m}", f"#define NN_ {N}",
             f"#define dim {v['dim']}", f"#define n_s {v['n_s']}", f"#define n_eq {v['n_eq']}", f"#define n_soc {v['n_soc']}",
-            f"#define nrow_M {v['nrow_M']}", f"#define k_max {int(v['k_max'])}", f"#define tol_p {_fmt(v['tol_p'])}",
-            f"#define tol_d {_fmt(v['tol_d'])}"]
+            f"#define k_max {int(v['k_max'])}", f"#define tol_p {_fmt(v['tol_p'])}", f"#define tol_d {_fmt(v['tol_d'])}"]
+    dim_M2 = (v["n_eq"] + v["n_s"]) if v["use_soc"] else n
+    defs += [f"#define nrow_M {v['nrow_M']}"] if sparse else ["#define NON_SPARSE 1", f"#define dim_M2 {dim_M2}"]
     if v["method"] == "SADMM":
         defs += [f"#define alpha_SADMM {_fmt(v['alpha'])}", "#define IS_SYMMETRIC 1"]
     if v["use_soc"]:
         defs += ["#define USE_SOC 1"]
     consts = "".join(_decl_scalar(k, v[k]) for k in ("rho", "rho_i", "sigma", "sigma_i"))
     consts += "".join(_decl(cn, v[k]) for cn, k in (("A", "A"), ("QQ", "Q"), ("Te", "Te"), ("Se", "Se"), ("LB", "LB"),
-                                                    ("UB", "UB"), ("LBy", "LBy"), ("UBy", "UBy"), ("L_val", "L_val")))
-    consts += _decl_int("L_col", v["L_col"]) + _decl_int("L_row", v["L_row"]) + _decl("Dinv", v["Dinv"]) + _decl_int("idx_x0", v["idx_x0"])
-    variables = _decl("bh", v["bh"]).replace("const static ", "")
+                                                    ("UB", "UB"), ("LBy", "LBy"), ("UBy", "UBy")))
+    if sparse:
+        consts += _decl("L_val", v["L_val"]) + _decl_int("L_col", v["L_col"]) + _decl_int("L_row", v["L_row"]) \
+            + _decl("Dinv", v["Dinv"]) + _decl_int("idx_x0", v["idx_x0"])
+        variables = _decl("bh", v["bh"]).replace("const static ", "")
+    else:
+        consts += _decl("M1", v["M1"]) + _decl("M2", np.asarray(v["M2"])[:, :dim_M2])
+        variables = _decl("bh", v["bh_nat"]).replace("const static ", "")
     with open(os.path.join(REF, "platforms", "+C_code", "generic_solver_struct.c")) as f:
         code = f.read()
     with open(os.path.join(fdir, "code_HMPC_ADMM_split_C.c")) as f:

@@ -14,6 +14,7 @@
 #include "soc_stream.hpp"
 #include "hmpc_stream.hpp"
 #include "sparse_tile.hpp"
+#include "hmpc_gemm.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -75,6 +76,8 @@ struct Solver {
     MfmaPlan mfma;
     Mfma4Plan mfma4;
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
+    hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
+    std::vector<double> h_M1, h_M2, h_bh_nat;
     tile::TileDev tdev{};          // TILE (soc, HMPC): step streams of the sparse operations
     std::vector<tile::Rec> tile_recs;
     int4 *d_recs = nullptr;
@@ -255,6 +258,17 @@ static int parse_hmpc(const uint8_t *blob, size_t bytes, const spcies_blob_heade
     for (int i = 0; i < d.nrow_M; i++)
         for (int j = Lc[i]; j < Lc[i + 1]; j++)
             if (Lr[j] <= i) return fail(SPCIES_HIP_EINVAL, "L - I is not strictly lower triangular");
+    {  // optional dense matrices of the NON_SPARSE path (GEMM variant)
+        const int np = d.dim + d.n_s;
+        const double *pM1 = find_array(blob, bytes, h, SPCIES_A_M1, (uint64_t)np * np);
+        const double *pM2 = find_array(blob, bytes, h, SPCIES_A_M2, (uint64_t)np * nc);
+        const double *pbh = find_array(blob, bytes, h, SPCIES_A_BH_NAT, (uint64_t)nc);
+        if (pM1 && pM2 && pbh) {
+            s.h_M1.assign(pM1, pM1 + (size_t)np * np);
+            s.h_M2.assign(pM2, pM2 + (size_t)np * nc);
+            s.h_bh_nat.assign(pbh, pbh + nc);
+        }
+    }
     {  // TILE variant: step streams (sparse_tile.hpp)
         const int lpi = tile::pick_lpi((long)d.nrow_M, Lc, d.nrow_M);
         s.tdev = tile::TileDev{};
@@ -480,6 +494,7 @@ static bool stream_shape_built(int n, int m) {
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
     if (s.tv || s.host.ellip) return SPCIES_VARIANT_STREAM;
+    if (s.is_hmpc() && s.hgemm.ok) return SPCIES_VARIANT_GEMM;
     if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
@@ -849,6 +864,13 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
     if (B <= 0) return 0;
     if (s.is_soc() && !s.is_hmpc() && !extra)
         return fail(SPCIES_HIP_EINVAL, "ellipMPC soc solvers take a 4th input r (extra): Spcies:ellipMPC:nrhs:r");
+    if (s.is_hmpc() && resolve_variant(s) == SPCIES_VARIANT_GEMM) {
+        if (!s.hgemm.ok) return fail(SPCIES_HIP_ENOSUP, "GEMM variant not available: %s", s.hgemm.why.c_str());
+        int rc = ensure_scratch(s, hgemm::scratch_bytes(s.hgemm.dev, B));
+        if (rc) return rc;
+        s.hgemm.dev.k_max = s.hdev.k_max; s.hgemm.dev.tol_p = s.hdev.tol_p; s.hgemm.dev.tol_d = s.hdev.tol_d;  // set_exit overrides
+        return hgemm::launch(s.hgemm, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f, st);
+    }
     if (s.is_soc() && resolve_variant(s) == SPCIES_VARIANT_TILE) {
         if (!s.tdev.lpi) return fail(SPCIES_HIP_ENOSUP, "TILE variant not available: the LDL right-hand side does not fit the LDS");
         int rc = ensure_scratch(s, tile_scratch_bytes(s, B));
@@ -1001,6 +1023,13 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     SPCIES_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     rc = upload_consts(*s);
     if (rc) return rc;
+    if (s->is_hmpc() && !s->h_M1.empty()) {
+        const HmpcDev &hd = s->hdev;
+        const double *F = s->soc_f64.data();
+        rc = hgemm::plan_build(s->hgemm, hd, s->h_M1, s->h_M2, s->h_bh_nat, F + hd.A, F + hd.QQ, F + hd.Te, F + hd.Se, F + hd.LB,
+                               hd.dim - 3 * (hd.n + hd.m), F + hd.UB, F + hd.LBy, F + hd.UBy);
+        if (rc) return rc;
+    }
     if (s->eng) {
         if (s->tv) return fail(SPCIES_HIP_ENOSUP, "in_engineering with time_varying is not built");
         SPCIES_HIP_CHECK(hipMalloc((void **)&s->d_eng, s->eng_v.size() * sizeof(double)));
@@ -1041,6 +1070,7 @@ int spcies_hip_destroy(spcies_hip_handle h) {
     if (s->d_io) hipFree(s->d_io);
     if (s->d_idx) hipFree(s->d_idx);
     if (s->d_recs) hipFree(s->d_recs);
+    hgemm::plan_free(s->hgemm);
     if (s->d_eng) hipFree(s->d_eng);
     if (s->d_eng_in) hipFree(s->d_eng_in);
     mfma_plan_free(s->mfma);
@@ -1068,7 +1098,9 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
 int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_TILE) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_GEMM) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant == SPCIES_VARIANT_GEMM && !(s->is_hmpc() && s->hgemm.ok))
+        return fail(SPCIES_HIP_ENOSUP, "GEMM variant: built for HMPC split solvers whose blob carries M1, M2 (%s)", s->hgemm.why.c_str());
     if (variant == SPCIES_VARIANT_TILE && !(s->is_soc() && s->tdev.lpi))
         return fail(SPCIES_HIP_ENOSUP, "TILE variant: built for the sparse-KKT solvers (ellipMPC soc, HMPC) whose LDL right-hand side fits the LDS");
     if (variant == SPCIES_VARIANT_MFMA4G && !s->g4plan.ok)
@@ -1101,6 +1133,7 @@ int spcies_hip_reserve(spcies_hip_handle h, long B) {
     if (s->g4plan.ok && s->method == SPCIES_FISTA) need = std::max(need, g4::fista_state_bytes(s->g4plan, s->host, B));
     if (s->g4plan.ok && s->method == SPCIES_ADMM && !s->is_soc()) need = std::max(need, g4::admm_state_bytes(s->g4plan, s->host, B));
     need = std::max(need, tile_scratch_bytes(*s, B));
+    if (s->hgemm.ok) need = std::max(need, hgemm::scratch_bytes(s->hgemm.dev, B));
     if (s->g4plan.ok && s->method == SPCIES_EADMM) need = std::max(need, g4::eadmm_state_bytes(s->g4plan, s->host, B));
     return ensure_scratch(*s, need);
 }

@@ -141,6 +141,13 @@ def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
     v["L_val"], v["L_row"], v["L_col"], v["Dinv"] = Lv, Lr, Lc, 1.0 / D
     v["idx_x0"] = inv[:n].astype(np.int32)       # where the first n equality rows (x0 rows) sit in the permuted tail
     v["bh"] = bh[perm2]
+    # NON_SPARSE path (option sparse = false, the reference's default): primal_hat = M2 bh - M1 q_hat (:236-239)
+    Hhi = np.linalg.inv(Hh)
+    Wi = np.linalg.inv(Gh @ Hhi @ Gh.T)
+    v["M1"] = Hhi @ Gh.T @ Wi @ Gh @ Hhi - Hhi
+    v["M2"] = Hhi @ Gh.T @ Wi
+    v["bh_nat"] = bh.copy()
+    v["sparse"] = bool(so.get("sparse", False))
     v["rho"], v["rho_i"], v["sigma"], v["sigma_i"] = rho, 1.0 / rho, sigma, 1.0 / sigma
     v["alpha"] = float(so.get("alpha", 0.95))
     v["k_max"] = int(so["k_max"])

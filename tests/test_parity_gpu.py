@@ -431,7 +431,7 @@ def test_soc_vs_reference_template_fixture(variant, golden_dir):
     ("C5_HMPC_SADMM", 65, {}),                                  # BASELINE config 5 shape, 200 fixed iterations
     ("C5_HMPC_SADMM", 12, dict(tol_p=1e-5, tol_d=1e-5, k_max=2500)),
 ])
-@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+@pytest.mark.parametrize("variant", SPARSE_VARIANTS + ["gemm"])  # GEMM: the reference's NON_SPARSE path (dense M1, M2)
 def test_hmpc_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
@@ -442,7 +442,7 @@ def test_hmpc_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
         st = benchmarks.tester_status(cfg.sys)
         x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
     got = s(x0, xr, ur)
-    _compare_sparse(variant, got, oracle.admm_hmpc_batch(v, x0, xr, ur))
+    _compare_sparse(variant, got, oracle.admm_hmpc_batch(v, x0, xr, ur, sparse=(variant != "gemm")))
     nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
     assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
 
