@@ -52,6 +52,7 @@ def run_ex(cfg, name, B, variant=None):
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
     extra = (cfg.param.r,) if cfg.formulation == "ellipMPC" else ()
     s(x0[:256], xr[:256], ur[:256], *extra, want_sol=False)
+    s(x0, xr, ur, *extra, want_sol=False)  # first full-size call: scratch allocation, rocBLAS kernel selection for this shape
     u, k, e, sol = s(x0, xr, ur, *extra, want_sol=False)
     print(json.dumps(dict(config=name, formulation=cfg.formulation, method=cfg.method, n=cfg.sys.n, m=cfg.sys.m,
                           N=cfg.param.N, B=B, variant=s.variant, kernel_ms=round(sol.solve_time, 3),
