@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma_kernel(MfmaArgs p, const dou
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const long n_tiles = (p.B + 15) / 16;
-    const double rho = p.rho, rho_i = p.rho_i, tol = p.tol;
+    const double rho = p.rho, tol = p.tol;
     const int dim = TERMINAL ? N * nm : N * nm - n;
 
     // LDS reads of the tiles are loop-invariant; left alone, LICM hoists all of them out of the

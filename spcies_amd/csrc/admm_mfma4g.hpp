@@ -528,7 +528,7 @@ static int launch_admm_g_shape(Plan &pl, const AdmmHost &a, const Args &args, co
 inline int launch_admm_g(Plan &pl, const AdmmHost &a, const double *x0, const double *xr, const double *ur, int ref_stride,
                          long B, double *state, double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
     if (!pl.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant unavailable: %s", pl.why.c_str());
-    if ((v || lam) && !z) {}  // (v, lambda come from the frozen state: they do not need the in-loop z stores)
+    // (v, lambda come from the frozen state: they do not need the in-loop z stores)
     Args args{a.n, a.m, a.N, a.k_max, a.tol, B, ref_stride};
 #define X(KKX, KKS)                   \
     if (pl.KX == KKX && pl.KS == KKS) \

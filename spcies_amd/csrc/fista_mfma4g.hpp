@@ -127,7 +127,6 @@ __global__ __launch_bounds__(256, WG_PER_CU) void fista_g_kernel(Args p, const d
     const double *inv_rc = lds + LY::INV_TILES * 16;
 
     const int lane = threadIdx.x & 63;
-    const unsigned ulane = lane;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: state addresses are SGPR base + lane offset
     const int g = lane >> 4, c = lane & 15;
     const int ao = g * 4 + (lane & 3);

@@ -77,7 +77,6 @@ inline int plan_build(Plan &p, const HmpcDev &h, const std::vector<double> &M1, 
                       const double *LB, int n_lb, const double *UB, const double *LBy, const double *UBy) {
     const int n = h.n, m = h.m, nm = n + m, np = h.dim + h.n_s, nc = h.n_eq + h.n_s;
     if ((int)M1.size() != np * np || (int)M2.size() != np * nc || (int)bh_nat.size() != nc) { p.why = "M1 / M2 / bh missing"; return 0; }
-    if (h.dim % 3 != 0 && h.dim % CHUNK != 0) {}
     std::vector<double> flat;
     auto put = [&](const double *src, size_t cnt) {
         const int off = (int)flat.size();

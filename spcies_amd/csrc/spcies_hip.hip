@@ -643,8 +643,6 @@ static int launch_eadmm(Solver &s, const double *x0, const double *xr, const dou
     return fail(SPCIES_HIP_ENOSUP, "EADMM STREAM variant not instantiated for n=%d m=%d", n, m);
 }
 
-static bool tv_shape_built(int n, int m) { return m == 2 && (n == 6 || n == 12); }
-
 // Time-varying lax/equ ADMM: update phase (per-instance banded Cholesky) + the STREAM iteration reading the
 // instance's own constants.  Large batches are split so that one launch's constants stay below the 4 GB a
 // buffer resource can address.
