@@ -62,3 +62,17 @@ def test_mex_gateway_source_is_valid_c(tmp_path):
     f.write_text(src)
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                            "-I", os.path.join(ROOT, "tests", "mex_stub"), str(f)])
+
+
+def test_generic_mex_gateway_source_is_valid_c(tmp_path):
+    """The generic gateway (all solvers; 0, 1 or 6 extra inputs) is valid C against the real spcies_hip.h."""
+    import subprocess
+    src0 = open(os.path.join(ROOT, "matlab", "+HIP", "struct_generic_HIP_Matlab.c")).read()
+    for n_extra, debug in ((0, 1), (1, 0), (6, 1)):
+        defs = "\n".join((["#define DEBUG 1"] if debug else []) + ["#define nn_ 12", "#define mm_ 2", f"#define N_EXTRA_ {n_extra}",
+                                                                  '#define BLOB_PATH "solver.spcb"'])
+        src = src0.replace("$INSERT_DEFINES$", defs).replace("$FORM$", "laxMPC").replace("$INSERT_NAME$", "laxMPC")
+        f = tmp_path / f"gateway_{n_extra}.c"
+        f.write_text(src)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                               "-I", os.path.join(ROOT, "tests", "mex_stub"), str(f)])
