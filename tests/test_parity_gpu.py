@@ -678,3 +678,19 @@ def test_vector_rho_vs_reference_template_fixture(tag, golden_dir):
     assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
     same = k == g["k"]
     assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-9
+
+
+@pytest.mark.parametrize("lpi", [4, 8, 16, 64])
+@pytest.mark.parametrize("cfg_name", ["C1_soc", "C1_HMPC_SADMM"])
+def test_tile_every_lane_split(cfg_name, lpi, monkeypatch):
+    """TILE kernels are compiled for 4..64 lanes per instance; AUTO picks one from the problem's size - force the others."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    monkeypatch.setenv("SPCIES_TILE_LPI", str(lpi))  # read when the solver is created
+    cfg, v, s = _fista_solver(cfg_name, "tile")
+    x0, xr, ur = benchmarks.sample_batch(cfg, 37)
+    if cfg.formulation == "ellipMPC":
+        r = cfg.param.r + 0.3 * np.random.default_rng(3).random(37)
+        _compare_sparse("tile", s(x0, xr, ur, r), oracle.admm_soc_batch(v, x0, xr, ur, r))
+    else:
+        _compare_sparse("tile", s(x0, xr, ur), oracle.admm_hmpc_batch(v, x0, xr, ur))
