@@ -26,7 +26,9 @@
 
 namespace spcies {
 
+// [rtc-begin]  (regions between these markers are also compiled at run time: mfma4_rtc.hpp, gen_rtc_src.py)
 typedef double d4 __attribute__((ext_vector_type(4)));
+// [rtc-end]
 
 // ---------------------------------------------------------------------------------------------
 // Tile table layout (shared by the host packer and the kernel).  A "tile" is one MFMA A-operand:
@@ -249,6 +251,7 @@ inline int mfma_plan_build(MfmaPlan &p, const AdmmHost &a) {
 // ---------------------------------------------------------------------------------------------
 // Device
 // ---------------------------------------------------------------------------------------------
+// [rtc-begin]
 struct MfmaArgs {
     int n, m, k_max;
     double tol, rho, rho_i;
@@ -257,6 +260,7 @@ struct MfmaArgs {
 };
 
 #define LAUNDER4(x) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
+// [rtc-end]
 #define SPCIES_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (acc), 0, 0, 0)
 
 template <int N, int KX, int KS, bool TERMINAL, bool WANT_SOL>

@@ -23,6 +23,7 @@
 
 namespace spcies {
 
+// [rtc-begin]
 // Shapes of the block products.  pattern: 0 dense, 1 lower (J <= I), 2 upper (J >= I).
 struct Prod4 {
     int I0, I1, J0, J1, pat;
@@ -71,9 +72,11 @@ struct Mfma4Layout {
     __host__ __device__ constexpr int rc_off(int i) const { return n_tiles() * 16 + i * 16; }
     __host__ __device__ constexpr int total_doubles() const { return n_tiles() * 16 + RC_COUNT * 16; }
 };
+// [rtc-end]
 
 struct Mfma4Plan {
     bool ok = false;
+    bool needs_rtc = false;  // tables are packed, but no kernel of this shape was instantiated at build time (mfma4_rtc.hpp)
     std::string why = "not built";
     Mfma4Layout lay{};
     double *d_table = nullptr;
@@ -96,7 +99,9 @@ inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
     Mfma4Layout L{N, (n + 3) / 4, (nm + 3) / 4, a.terminal};
     if (n / 4 != L.KS - 1) { p.why = "u rows must sit inside the last slab (n % 4 + m <= 4)"; return 0; }
     if (N < 3) { p.why = "N < 3"; return 0; }
-    if (!mfma4_shape_instantiated(N, L.KX, L.KS)) { p.why = "MFMA4 kernel not instantiated for this (N, n, m)"; return 0; }
+    p.needs_rtc = !mfma4_shape_instantiated(N, L.KX, L.KS);
+    // registers: one slab (2 VGPRs) per stage vector and block of y / mu; 109 slabs at C2 leave ~35 registers of working set
+    if (p.needs_rtc && (N + 1) * L.KS + N * L.KX > 112) { p.why = "state does not fit the register file (use MFMA4G)"; p.needs_rtc = false; return 0; }
     for (int l = 1; l < N - 1; l++)
         for (int j = 0; j < nm; j++)
             if (a.Hi[(size_t)l * nm + j] != a.Hi[j]) { p.why = "Hi differs between stages (vector rho?)"; return 0; }
@@ -215,6 +220,10 @@ inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
     SPCIES_HIP_CHECK(hipGetDevice(&dev));
     SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     p.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (p.needs_rtc) {
+        p.why = "MFMA4 kernel not instantiated for this (N, n, m): select the MFMA4 variant (or set SPCIES_HIP_RTC=1) to compile it at run time";
+        return 0;
+    }
     p.ok = true;
     p.why.clear();
     return 0;
@@ -223,6 +232,7 @@ inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
 // ---------------------------------------------------------------------------------------------
 // Device
 // ---------------------------------------------------------------------------------------------
+// [rtc-begin]
 template <int N, int KX, int KS, bool TERMINAL, bool WANT_SOL>
 __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const double *__restrict__ table_g,
                                                             const double *__restrict__ x0g,
@@ -231,9 +241,13 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
                                                             int *__restrict__ k_out, int *__restrict__ e_out,
                                                             double *__restrict__ z_out, double *__restrict__ v_out,
                                                             double *__restrict__ lam_out, double *__restrict__ dump) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int n = p.n, m = p.m, nm = n + m;
     constexpr Mfma4Layout LL{N, KX, KS, TERMINAL};
+#ifdef SPCIES_RTC_STATIC_LDS  // run-time compiled for one shape: the table size is a constant
+    __shared__ __attribute__((aligned(16))) double lds[LL.total_doubles()];
+#else
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+#endif
+    const int n = p.n, m = p.m, nm = n + m;
     {
         constexpr int total = LL.total_doubles();
         const double2 *src = reinterpret_cast<const double2 *>(table_g);
@@ -508,6 +522,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
     }
 #undef MFMA4
 }
+// [rtc-end]
 
 #define SPCIES_MFMA4_SHAPES(X) X(10, 2, 2) X(15, 3, 4)
 

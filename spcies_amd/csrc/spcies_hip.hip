@@ -5,6 +5,7 @@
 
 #include "admm_mfma.hpp"
 #include "admm_mfma4.hpp"
+#include "mfma4_rtc.hpp"
 #include "admm_stream.hpp"
 #include "fista_stream.hpp"
 #include "fista_mfma4g.hpp"
@@ -75,6 +76,7 @@ struct Solver {
     // MFMA-variant packing
     MfmaPlan mfma;
     Mfma4Plan mfma4;
+    rtc::Mfma4Module mfma4_rtc;  // run-time compiled MFMA4 kernel when the shape was not instantiated at build time
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
     std::vector<double> h_M1, h_M2, h_bh_nat;
@@ -489,6 +491,18 @@ static int upload_consts(Solver &s) {
 static bool stream_shape_built(int n, int m) {
     return (m == 2 && (n == 6 || n == 12 || n == 20)) || (n == 4 && m == 1) || (n == 8 && m == 2) ||
            (n == 2 && m == 1);
+}
+
+// compile the MFMA4 kernel for this controller's shape (tens of seconds, once)
+static int ensure_mfma4_rtc(Solver &s) {
+    if (s.mfma4.ok) return 0;
+    if (!s.mfma4.needs_rtc) return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s.mfma4.why.c_str());
+    const Mfma4Layout &L = s.mfma4.lay;
+    int rc = rtc::compile_mfma4(s.mfma4_rtc, L.N, L.KX, L.KS, L.terminal);
+    if (rc) return rc;
+    s.mfma4.ok = true;
+    s.mfma4.why.clear();
+    return 0;
 }
 
 static int resolve_variant(const Solver &s) {
@@ -943,6 +957,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
     const int variant = resolve_variant(s);
     if (variant == SPCIES_VARIANT_MFMA4) {
         if (!s.mfma4.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s.mfma4.why.c_str());
+        if (s.mfma4_rtc.ok) return rtc::launch_mfma4(s.mfma4_rtc, s.mfma4, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
         return launch_mfma4(s.mfma4, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
     }
     if (variant == SPCIES_VARIANT_MFMA4G) {
@@ -1044,6 +1059,12 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         }
         rc = g4::admm_plan_build(s->g4plan, s->host);
         if (rc) return rc;
+        // no build-time MFMA4 kernel of this shape: specialise one now (hiprtc, about a second; SPCIES_HIP_RTC=0 turns it
+        // off).  A failure is not an error: AUTO then runs MFMA4G, and the reason is reported if MFMA4 is asked for.
+        const char *ev = getenv("SPCIES_HIP_RTC");
+        if (s->mfma4.needs_rtc && !(ev && ev[0] == '0')) {
+            if (ensure_mfma4_rtc(*s) != 0) s->mfma4.why = g_last_error;
+        }
     }
     if (s->method == SPCIES_EADMM) {
         g4::EadmmGHost eh{&s->e_rho, &s->e_rho0, &s->e_rhos, &s->e_LB0, &s->e_UB0, &s->e_LBs, &s->e_UBs, &s->e_S, &s->e_H1i, &s->e_W2, &s->e_H3i};
@@ -1073,6 +1094,7 @@ int spcies_hip_destroy(spcies_hip_handle h) {
     if (s->d_eng_in) hipFree(s->d_eng_in);
     mfma_plan_free(s->mfma);
     mfma4_plan_free(s->mfma4);
+    rtc::module_free(s->mfma4_rtc);
     g4::plan_free(s->g4plan);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
@@ -1103,8 +1125,11 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
         return fail(SPCIES_HIP_ENOSUP, "TILE variant: built for the sparse-KKT solvers (ellipMPC soc, HMPC) whose LDL right-hand side fits the LDS");
     if (variant == SPCIES_VARIANT_MFMA4G && !s->g4plan.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available for this solver: %s", s->g4plan.why.c_str());
-    if (variant == SPCIES_VARIANT_MFMA4 && !s->mfma4.ok)
-        return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s->mfma4.why.c_str());
+    if (variant == SPCIES_VARIANT_MFMA4 && !s->mfma4.ok) {
+        SPCIES_HIP_CHECK(hipSetDevice(s->device));
+        int rc = ensure_mfma4_rtc(*s);
+        if (rc) return rc;
+    }
     if (variant == SPCIES_VARIANT_MFMA && !s->mfma.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA variant not available for this shape: %s", s->mfma.why.c_str());
     if (variant == SPCIES_VARIANT_STREAM && !stream_shape_built(s->host.n, s->host.m))

@@ -694,3 +694,26 @@ def test_tile_every_lane_split(cfg_name, lpi, monkeypatch):
         _compare_sparse("tile", s(x0, xr, ur, r), oracle.admm_soc_batch(v, x0, xr, ur, r))
     else:
         _compare_sparse("tile", s(x0, xr, ur), oracle.admm_hmpc_batch(v, x0, xr, ur))
+
+
+@pytest.mark.parametrize("n,m,N,formulation", [(6, 2, 20, "laxMPC"), (9, 3, 8, "equMPC"), (4, 1, 12, "laxMPC")])
+def test_mfma4_run_time_specialisation(n, m, N, formulation):
+    """A shape no MFMA4 kernel was instantiated for at build time: selecting the variant compiles one with hiprtc
+    (mfma4_rtc.hpp); same bar as the built-in instantiations."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=400 + n)
+    cfg.formulation = formulation
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    assert s.variant == "mfma4"    # AUTO: specialised at create time (about a second)
+    s.set_variant("mfma4")
+    rng = np.random.default_rng(n)
+    B = 50
+    x0, xr, ur = 0.6 * rng.standard_normal((B, n)), 0.2 * rng.standard_normal((B, n)), 0.1 * rng.standard_normal((B, m))
+    got = s(x0, xr, ur)
+    _compare("mfma4", got, oracle.admm_banded_batch(v, x0, xr, ur), v)
+    nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
+    assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
+    s.close()
