@@ -146,7 +146,14 @@ enum spcies_array_id {
      * ingredients.m:236-239, code_HMPC_ADMM_split_C.c:174-190): optional, enable the GEMM variant                */
     SPCIES_A_M1 = 68,                        /* [dim + n_s][dim + n_s]                              */
     SPCIES_A_M2 = 69,                        /* [dim + n_s][n_eq + n_s]                             */
-    SPCIES_A_BH_NAT = 70                     /* [n_eq + n_s] bh in natural order (x0 rows first)    */
+    SPCIES_A_BH_NAT = 70,                    /* [n_eq + n_s] bh in natural order (x0 rows first)    */
+    /* HMPC ADMM / SADMM WITHOUT the splitting (formulation 5, submethod 0 - the reference's default HMPC solver;
+     * cons_HMPC_ADMM_C.m:88-131): A (26), QQ as Q (7), Te, Se, LBy, UBy (41-44), LB / UB (10, 11) with
+     * n_box = dim - 3(n+m) entries, M1 (68) [dim][dim], M2 (69) [dim][n], and these; n_s = n_box + 3 n_soc;
+     * header flags bit1 = use_soc, reserved = {-, -, tol_d, alpha_SADMM}.  Record: z [dim], s [n_s], lambda [n_s] */
+    SPCIES_A_C_VAL = 71, SPCIES_A_C_COL = 72, SPCIES_A_C_ROW = 73,    /* CSR of C  [n_s x dim] (0-based)  */
+    SPCIES_A_CT_VAL = 74, SPCIES_A_CT_COL = 75, SPCIES_A_CT_ROW = 76, /* CSR of C' [dim x n_s]            */
+    SPCIES_A_D = 77                          /* [n_s] d (read with use_soc only)                    */
 };
 
 typedef struct {
@@ -184,7 +191,7 @@ typedef struct spcies_hip_solver_s *spcies_hip_handle;
 #define SPCIES_VARIANT_MFMA4 3  /* same on v_mfma_f64_4x4x4 (4 blocks): no row padding, zero blocks skipped      */
 #define SPCIES_VARIANT_MFMA4G 4 /* v_mfma_f64_4x4x4 with a rolled stage loop: any N, state streamed through HBM   */
 #define SPCIES_VARIANT_TILE 5   /* sparse-KKT solvers: 4-64 lanes per instance, LDL right-hand side in LDS          */
-#define SPCIES_VARIANT_GEMM 6   /* HMPC split, NON_SPARSE path: one dgemm per iteration for the whole batch         */
+#define SPCIES_VARIANT_GEMM 6   /* HMPC (split NON_SPARSE path; no-split solver): one dgemm per iteration for the batch */
 
 typedef struct {
     int formulation, method, submethod;

@@ -55,7 +55,9 @@ def main():
                                ("C1_lax_gen", 12, {}), ("C1_equ_gen", 12, dict(k_max=3000)), ("C2_lax_gen", 8, {}),
                                ("C1_soc", 12, {}), ("C5_soc", 8, {}),
                                ("C1_HMPC", 6, {}), ("C1_HMPC_SADMM", 6, {}), ("C1_HMPC_soc", 4, {}),
-                               ("C1_HMPC_SADMM_soc", 4, {}), ("C5_HMPC_SADMM", 4, {})):
+                               ("C1_HMPC_SADMM_soc", 4, {}), ("C5_HMPC_SADMM", 4, {}),
+                               ("C1_HMPC_nosplit", 6, {}), ("C1_HMPC_SADMM_nosplit", 6, {}), ("C1_HMPC_soc_nosplit", 4, {}),
+                               ("C1_HMPC_SADMM_soc_nosplit", 4, {}), ("C5_HMPC_SADMM_nosplit", 4, {})):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:  # `python -m oracle.make_golden C1_ellip ...`: only these
             continue
         cfg = benchmarks.config(name)
@@ -66,6 +68,14 @@ def main():
             x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
         tag = name + ("_conv" if overrides else "")
         so = ref_template.build_admm(v, "golden_" + tag)
+        if v["formulation"] == "HMPC" and v.get("submethod") != "split":
+            T = ref_template.run_hmpc_nosplit(so, v, x0, xr, ur)
+            O = oracle.hmpc_dense_batch(v, x0, xr, ur)
+            print(tag, "template-vs-oracle(full doubles): z %.2e s %.2e dk %d" % (
+                np.abs(T[3] - O[3]).max(), np.abs(T[4] - O[4]).max(), np.abs(T[1] - O[1]).max()))
+            np.savez_compressed(os.path.join(OUT, f"template_{tag}.npz"), x0=x0, xr=xr, ur=ur, u=T[0], k=T[1],
+                                e_flag=T[2], z=T[3], s=T[4], lam=T[5], solver_overrides=json.dumps(overrides))
+            continue
         if v.get("submethod") == "split":
             T = ref_template.run_hmpc(so, v, x0, xr, ur)
             O = oracle.admm_hmpc_batch(v, x0, xr, ur)

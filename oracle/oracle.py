@@ -13,7 +13,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c", "eadmm_mpct_oracle.c", "admm_soc_oracle.c", "admm_hmpc_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c", "eadmm_mpct_oracle.c", "admm_soc_oracle.c", "admm_hmpc_oracle.c", "admm_hmpc_dense_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return so
@@ -335,3 +335,51 @@ def admm_hmpc_batch(v, x0, xr, ur, want_sol=True, quantize=False, sparse=True):
     if rc != 0:
         raise RuntimeError(f"oracle_admm_hmpc_batch failed rc={rc}")
     return u, k, e, z, s, zh, sh, lam, mu
+
+
+class _HmpcDenseData(C.Structure):
+    _fields_ = ([(k_, C.c_int) for k_ in ("n", "m", "N", "dim", "n_s", "n_box", "n_soc", "k_max", "use_soc", "symmetric")]
+                + [(k_, C.c_double) for k_ in ("tol_p", "tol_d", "rho", "rho_i", "alpha")]
+                + [(k_, C.POINTER(C.c_double)) for k_ in ("A", "QQ", "Te", "Se", "LB", "UB", "LBy", "UBy", "d")]
+                + [("C_val", C.POINTER(C.c_double)), ("C_col", C.POINTER(C.c_int)), ("C_row", C.POINTER(C.c_int)),
+                   ("Ct_val", C.POINTER(C.c_double)), ("Ct_col", C.POINTER(C.c_int)), ("Ct_row", C.POINTER(C.c_int)),
+                   ("M1", C.POINTER(C.c_double)), ("M2", C.POINTER(C.c_double))])
+
+
+def hmpc_dense_batch(v, x0, xr, ur, want_sol=True, quantize=False):
+    """C oracle of the non-split HMPC ADMM / SADMM solver.  Returns ``u, k, e_flag, z, s, lam``."""
+    n, m = int(v["n"]), int(v["m"])
+    qz = quantize_like_reference if quantize else (lambda a: a)
+    keep, fields = {}, {}
+    ipt = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    for k_, s_ in (("A", "A"), ("QQ", "Q"), ("Te", "Te"), ("Se", "Se"), ("LB", "LB"), ("UB", "UB"), ("LBy", "LBy"), ("UBy", "UBy"),
+                   ("d", "d"), ("C_val", "C_val"), ("Ct_val", "Ct_val"), ("M1", "M1"), ("M2", "M2")):
+        a = np.ascontiguousarray(qz(np.asarray(v[s_], dtype=float)))
+        if quantize and k_ in ("LB", "UB", "LBy", "UBy"):
+            a = np.clip(a, -1e20, 1e20)
+        keep[k_] = a
+        fields[k_] = _dp(a)
+    for k_ in ("C_col", "C_row", "Ct_col", "Ct_row"):
+        keep[k_] = np.ascontiguousarray(np.asarray(v[k_], dtype=np.int32))
+        fields[k_] = ipt(keep[k_])
+    sc = {k_: (float(qz(v[k_])) if quantize else float(v[k_])) for k_ in ("tol_p", "tol_d", "rho", "rho_i")}
+    d = _HmpcDenseData(n=n, m=m, N=int(v["N"]), dim=int(v["dim"]), n_s=int(v["n_s"]), n_box=int(v["n_box"]), n_soc=int(v["n_soc"]),
+                       k_max=int(v["k_max"]), use_soc=int(v["use_soc"]), symmetric=int(v["method"] == "SADMM"),
+                       alpha=float(v["alpha"]), **sc, **fields)
+    x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
+    B = x0.shape[0]
+    xr = np.ascontiguousarray(np.asarray(xr, dtype=float))
+    ur = np.ascontiguousarray(np.asarray(ur, dtype=float))
+    stride = 1 if xr.ndim == 2 else 0
+    dim, n_s = int(v["dim"]), int(v["n_s"])
+    u = np.zeros((B, m)); k = np.zeros(B, dtype=np.int32); e = np.zeros(B, dtype=np.int32)
+    mk = lambda w: np.zeros((B, w)) if want_sol else None
+    z, s, lam = mk(dim), mk(n_s), mk(n_s)
+    o = lambda a: _dp(a) if a is not None else None
+    lib = _lib()
+    lib.oracle_hmpc_dense_batch.restype = C.c_int
+    rc = lib.oracle_hmpc_dense_batch(C.byref(d), C.c_long(B), _dp(x0), _dp(xr), _dp(ur), C.c_int(stride), _dp(u), ipt(k), ipt(e),
+                                     o(z), o(s), o(lam))
+    if rc != 0:
+        raise RuntimeError(f"oracle_hmpc_dense_batch failed rc={rc}")
+    return u, k, e, z, s, lam

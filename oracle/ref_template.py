@@ -93,6 +93,8 @@ def build_admm(v, name):
         return _build_soc(v, name)
     if v.get("submethod") == "split":
         return _build_hmpc(v, name, sparse=v.get("_template_sparse", True))
+    if form == "HMPC":
+        return _build_hmpc_nosplit(v, name)
     fdir = os.path.join(REF, "formulations", f"+{form}")
     n, m, N = v["n"], v["m"], v["N"]
     defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
@@ -350,3 +352,72 @@ def run_hmpc(so, v, x0, xr, ur):
         for f in out:
             out[f][i] = np.frombuffer(getattr(sol, f))
     return (u, k, e, out["z"], out["s"], out["z_hat"], out["s_hat"], out["lam"], out["mu"])
+
+
+def _build_hmpc_nosplit(v, name):
+    """HMPC ADMM / SADMM without the splitting (the reference's default HMPC solver): cons_HMPC_ADMM_C.m:88-151."""
+    fdir = os.path.join(REF, "formulations", "+HMPC")
+    n, m, N = v["n"], v["m"], v["N"]
+    defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
+            "#define IS_DIAG 1", f"#define nn_ {n}", f"#define mm_ {m}", f"#define nm_ {n + m}", f"#define NN_ {N}",
+            f"#define dim {v['dim']}", f"#define n_s {v['n_s']}", f"#define n_eq {v['n_eq']}", f"#define n_soc {v['n_soc']}",
+            f"#define n_y {n + m}", f"#define n_box {v['n_box']}", f"#define nrow_C {v['n_s']}", f"#define nrow_Ct {v['dim']}",
+            f"#define k_max {int(v['k_max'])}", f"#define tol_p {_fmt(v['tol_p'])}", f"#define tol_d {_fmt(v['tol_d'])}"]
+    if v["method"] == "SADMM":
+        defs += [f"#define alpha_SADMM {_fmt(v['alpha'])}", "#define IS_SYMMETRIC 1"]
+    if v["use_soc"]:
+        defs += ["#define USE_SOC 1"]
+    consts = "".join(_decl_scalar(k, v[k]) for k in ("rho", "rho_i")) + _decl("A", v["A"])
+    consts += _decl("C_val", v["C_val"]) + _decl_int("C_col", v["C_col"]) + _decl_int("C_row", v["C_row"])
+    consts += _decl("Ct_val", v["Ct_val"]) + _decl_int("Ct_col", v["Ct_col"]) + _decl_int("Ct_row", v["Ct_row"])
+    consts += "".join(_decl(cn, v[k]) for cn, k in (("QQ", "Q"), ("Te", "Te"), ("Se", "Se"), ("LB", "LB"), ("UB", "UB"),
+                                                    ("LBy", "LBy"), ("UBy", "UBy")))
+    if v["use_soc"]:
+        consts += _decl("d", v["d"])
+    consts += _decl("M1", v["M1"]) + _decl("M2", v["M2"])
+    with open(os.path.join(REF, "platforms", "+C_code", "generic_solver_struct.c")) as f:
+        code = f.read()
+    with open(os.path.join(fdir, "code_HMPC_ADMM_C.c")) as f:
+        code = code.replace("$INSERT_SOLVER$", f.read())
+    with open(os.path.join(fdir, "header_HMPC_ADMM_C.h")) as f:
+        header = f.read()
+    code = code.replace("$INSERT_CONSTANTS$", consts).replace("$INSERT_VARIABLES$", "")
+    header = header.replace("$INSERT_DEFINES$", "\n".join(defs))
+    code, header = _snippets(code, "c"), _snippets(header, "h")
+    code = _unescape(code.replace("$INSERT_NAME$", name))
+    header = _unescape(header.replace("$INSERT_NAME$", name))
+    os.makedirs(OUT, exist_ok=True)
+    so = os.path.join(OUT, f"lib{name}.so")
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, f"{name}.c"), "w") as f:
+            f.write(code)
+        with open(os.path.join(td, f"{name}.h"), "w") as f:
+            f.write(header)
+        subprocess.check_call(["gcc", "-O3", "-fPIC", "-shared", "-w", "-o", so, os.path.join(td, f"{name}.c"), "-lm"])
+    return so
+
+
+def run_hmpc_nosplit(so, v, x0, xr, ur):
+    """``HMPC_ADMM(x0, xr, ur, u, &k, &e, &sol)`` of the non-split solver; returns u, k, e, z, s, lam."""
+    n, m, dim, n_s = v["n"], v["m"], v["dim"], v["n_s"]
+    lib = C.CDLL(so)
+    fn = lib.HMPC_ADMM
+
+    class Sol(C.Structure):
+        _fields_ = [("z", C.c_double * dim), ("s", C.c_double * n_s), ("lam", C.c_double * n_s), ("t", C.c_double * 4)]
+    x0 = np.atleast_2d(np.asarray(x0, float))
+    B = x0.shape[0]
+    per = np.ndim(xr) == 2
+    u = np.zeros((B, m)); k = np.zeros(B, np.int32); e = np.zeros(B, np.int32)
+    out = {f: np.zeros((B, w)) for f, w in (("z", dim), ("s", n_s), ("lam", n_s))}
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for i in range(B):
+        sol = Sol()
+        xi = np.ascontiguousarray(x0[i]); xri = np.ascontiguousarray(xr[i] if per else xr)
+        uri = np.ascontiguousarray(ur[i] if per else ur)
+        ui = np.zeros(m); ki = C.c_int(0); ei = C.c_int(0)
+        fn(dp(xi), dp(xri), dp(uri), dp(ui), C.byref(ki), C.byref(ei), C.byref(sol))
+        u[i] = ui; k[i] = ki.value; e[i] = ei.value
+        for f in out:
+            out[f][i] = np.frombuffer(getattr(sol, f))
+    return (u, k, e, out["z"], out["s"], out["lam"])

@@ -121,7 +121,7 @@ def config(name):
         Q, R, _ = _weights(sys, "diag")
         N = 10 if name.startswith("C1") else 15
         c = SimpleNamespace(name=name, sys=sys, formulation="HMPC", method="SADMM" if "SADMM" in name else "ADMM",
-                            submethod="split",
+                            submethod="" if "nosplit" in name else "split",  # "": code_HMPC_ADMM_C.c (the default)
                             param=SimpleNamespace(N=N, w=3 * 1.627 * 0.2, Q=Q, R=R, Te=10 * N * Q, Th=10 * N * Q, Se=R,
                                                   Sh=0.5 * R),
                             solver_options=dict(rho=2, sigma=20, k_max=5000, tol_p=1e-7, tol_d=1e-7, sparse=True,
@@ -157,6 +157,8 @@ def ingredients(cfg, **solver_overrides):
     so.update(solver_overrides)
     opt = SpciesOptions(formulation=cfg.formulation, method=cfg.method, submethod=getattr(cfg, "submethod", ""), options=so)
     ctrl = SimpleNamespace(sys=cfg.sys, param=cfg.param)
+    hmpc = (HMPC.compute_HMPC_ADMM_split_ingredients if getattr(cfg, "submethod", "") == "split"
+            else HMPC.compute_HMPC_ADMM_ingredients)
     fn = {("laxMPC", "ADMM"): laxMPC.compute_laxMPC_ADMM_ingredients,
           ("equMPC", "ADMM"): laxMPC.compute_equMPC_ADMM_ingredients,
           ("laxMPC", "FISTA"): laxMPC.compute_laxMPC_FISTA_ingredients,
@@ -164,6 +166,5 @@ def ingredients(cfg, **solver_overrides):
           ("MPCT", "EADMM"): MPCT.compute_MPCT_EADMM_ingredients,
           ("ellipMPC", "ADMM"): (ellipMPC.compute_ellipMPC_ADMM_soc_ingredients if getattr(cfg, "submethod", "") == "soc"
                                  else ellipMPC.compute_ellipMPC_ADMM_ingredients),
-          ("HMPC", "ADMM"): HMPC.compute_HMPC_ADMM_split_ingredients,
-          ("HMPC", "SADMM"): HMPC.compute_HMPC_ADMM_split_ingredients}
+          ("HMPC", "ADMM"): hmpc, ("HMPC", "SADMM"): hmpc}
     return laxMPC.add_engineering(fn[(cfg.formulation, cfg.method)](ctrl, opt), cfg.sys, opt)

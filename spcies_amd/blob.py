@@ -27,8 +27,10 @@ ARRAY_ID = {"AB": 1, "Alpha": 2, "Beta": 3, "Hi": 4, "Hi_0": 5, "Hi_N": 6, "Q": 
             "Hhi_row": 40, "Te": 41, "Se": 42, "LBy": 43, "UBy": 44, "idx_x0": 45, "bh": 46, "T_rho_i": 47,
             "scaling_x": 48, "scaling_u": 49, "scaling_i_u": 50, "OpPoint_x": 51, "OpPoint_u": 52,
             "P": 53, "P_half": 54, "Pinv_half": 55, "c": 56, "LBz": 57, "UBz": 58, "LBu0": 59, "UBu0": 60,
-            "rho_v": 61, "rho_N": 62, "rho_i_v": 63, "rho_i_0": 64, "rho_i_N": 65, "LBN": 66, "UBN": 67, "M1": 68, "M2": 69, "bh_nat": 70}
-INT_ARRAYS = {"L_col", "L_row", "GhHhi_col", "GhHhi_row", "HhiGh_col", "HhiGh_row", "Hhi_col", "Hhi_row", "idx_x0"}
+            "rho_v": 61, "rho_N": 62, "rho_i_v": 63, "rho_i_0": 64, "rho_i_N": 65, "LBN": 66, "UBN": 67, "M1": 68, "M2": 69, "bh_nat": 70,
+            "C_val": 71, "C_col": 72, "C_row": 73, "Ct_val": 74, "Ct_col": 75, "Ct_row": 76, "d": 77}
+INT_ARRAYS = {"L_col", "L_row", "GhHhi_col", "GhHhi_row", "HhiGh_col", "HhiGh_row", "Hhi_col", "Hhi_row", "idx_x0",
+              "C_col", "C_row", "Ct_col", "Ct_row"}
 SUBMETHOD = {"": 0, "soc": 1, "split": 2, "cs": 3, "semiband": 4}
 _ID_NAME = {v: k for k, v in ARRAY_ID.items()}
 _HDR = "<8sIIIIIIIIIIIIQddd5d"
@@ -45,7 +47,7 @@ def _align(x, a=64):
 
 def pack(v):
     """Pack an ingredients dict (``compute_*_ingredients``) into blob bytes."""
-    names = [k for k in ARRAY_ID if k in v and not (v["formulation"] == "HMPC" and k in ("H", "G", "C", "d"))]
+    names = [k for k in ARRAY_ID if k in v and not (k == "d" and v.get("submethod") != "")]  # d: HMPC without the splitting
     arrays = []
     for k in names:
         if k in INT_ARRAYS:

@@ -16,6 +16,7 @@
 #include "hmpc_stream.hpp"
 #include "sparse_tile.hpp"
 #include "hmpc_gemm.hpp"
+#include "hmpc_dense.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -45,11 +46,13 @@ struct Solver {
     int *d_idx = nullptr;
     EadmmDev edev{};
     std::vector<double> e_rho, e_rho0, e_rhos, e_LB0, e_UB0, e_LBs, e_UBs, e_S, e_H1i, e_W2, e_H3i;  // EADMM-only
-    bool is_soc() const { return (formulation == SPCIES_ELLIPMPC && submethod == 1) || formulation == SPCIES_HMPC; }  // 6-field (z, s, ...) record
-    bool is_hmpc() const { return formulation == SPCIES_HMPC; }
+    bool is_soc() const { return (formulation == SPCIES_ELLIPMPC && submethod == 1) || is_hmpc(); }  // 6-field (z, s, ...) record
+    bool is_hmpc() const { return formulation == SPCIES_HMPC && submethod == 2; }    // split (code_HMPC_ADMM_split_C.c)
+    bool is_hdense() const { return formulation == SPCIES_HMPC && submethod == 0; }  // no splitting (code_HMPC_ADMM_C.c)
     int soc_dim() const { return is_hmpc() ? hdev.dim : sdev.dim; }
     int soc_ns() const { return is_hmpc() ? hdev.n_s : sdev.n_s; }
     int lam_dim() const {
+        if (is_hdense()) return hd_host.n_s;
         if (method == SPCIES_FISTA) return host.N * host.n;
         if (method == SPCIES_EADMM) return (host.N + 3) * (host.n + host.m);
         return host.dim();
@@ -59,10 +62,12 @@ struct Solver {
     //   FISTA : z, lambda               (header_laxMPC_FISTA_C.h:14-21)
     //   EADMM : z1, z2, z3, lambda      (header_MPCT_EADMM_C.h:14-23)
     //   soc   : z, s, z_hat, s_hat, lambda, mu   (header_ellipMPC_ADMM_soc_C.h:14-24)
+    //   HMPC (no splitting): z, s, lambda        (header_HMPC_ADMM_C.h:14-22)
     int n_fields() const { return is_soc() ? 6 : (method == SPCIES_FISTA ? 2 : (method == SPCIES_EADMM ? 4 : 3)); }
     int field_dim(int i) const {
         const int nm = host.n + host.m;
         if (is_soc()) return (i % 2 == 0) ? soc_dim() : soc_ns();
+        if (is_hdense()) return i == 0 ? hd_host.dim : hd_host.n_s;
         if (method == SPCIES_FISTA) return i == 0 ? host.dim() : lam_dim();
         if (method == SPCIES_EADMM) return i == 1 ? nm : (i == 3 ? lam_dim() : (host.N + 1) * nm);
         return host.dim();
@@ -70,7 +75,9 @@ struct Solver {
     const char *field_name(int i) const {
         static const char *admm[] = {"z", "v", "lambda"}, *fista[] = {"z", "lambda"}, *eadmm[] = {"z1", "z2", "z3", "lambda"};
         static const char *soc[] = {"z", "s", "z_hat", "s_hat", "lambda", "mu"};
+        static const char *hdn[] = {"z", "s", "lambda"};
         if (is_soc()) return soc[i];
+        if (is_hdense()) return hdn[i];
         return method == SPCIES_FISTA ? fista[i] : (method == SPCIES_EADMM ? eadmm[i] : admm[i]);
     }
     // MFMA-variant packing
@@ -80,6 +87,8 @@ struct Solver {
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
     std::vector<double> h_M1, h_M2, h_bh_nat;
+    hdense::Host hd_host;          // HMPC without the splitting: blob contents, and its GEMM plan
+    hdense::Plan hd_plan;
     tile::TileDev tdev{};          // TILE (soc, HMPC): step streams of the sparse operations
     std::vector<tile::Rec> tile_recs;
     int4 *d_recs = nullptr;
@@ -283,6 +292,57 @@ static int parse_hmpc(const uint8_t *blob, size_t bytes, const spcies_blob_heade
     return 0;
 }
 
+// HMPC ADMM / SADMM without the splitting, box constraints (cons_HMPC_ADMM_C.m:88-131)
+static int parse_hmpc_dense(const uint8_t *blob, size_t bytes, const spcies_blob_header &h, Solver &s) {
+    s.formulation = (int)h.formulation; s.method = (int)h.method; s.submethod = (int)h.submethod;
+    AdmmHost &a = s.host;
+    a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max; a.terminal = true;
+    a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
+    if (h.n == 0 || h.m == 0 || h.N < 3 || h.n > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0))
+        return fail(SPCIES_HIP_EINVAL, "bad n/m/N/k_max/rho");
+    const int n = a.n, m = a.m, N = a.N, nm = n + m;
+    hdense::Host &d = s.hd_host;
+    d.n = n; d.m = m; d.N = N; d.use_soc = (h.flags & 2u) ? 1 : 0; d.symmetric = (h.method == SPCIES_SADMM);
+    d.dim = (N - 1) * nm + m + 3 * nm; d.n_eq = (N + 3) * n; d.n_soc = d.use_soc ? 2 * nm : nm; d.n_box = d.dim - 3 * nm;
+    d.n_s = d.n_box + 3 * d.n_soc; d.k_max = a.k_max;
+    if ((long)d.dim * d.dim > (1L << 28)) return fail(SPCIES_HIP_EINVAL, "HMPC: dim too large for the dense M1");
+    d.tol_p = h.tol; d.tol_d = h.reserved[2]; d.rho = h.rho; d.rho_i = h.rho_i;
+    d.alpha = d.symmetric ? h.reserved[3] : 1.0;
+    struct F { uint32_t id; uint64_t want; std::vector<double> *dst; bool optional; };
+    F fs[] = {{SPCIES_A_A, (uint64_t)n * n, &d.A, false}, {SPCIES_A_Q, (uint64_t)n * n, &d.QQ, false},
+              {SPCIES_A_TE, (uint64_t)n * n, &d.Te, false}, {SPCIES_A_SE, (uint64_t)m * m, &d.Se, false},
+              {SPCIES_A_LB, (uint64_t)d.n_box, &d.LB, false}, {SPCIES_A_UB, (uint64_t)d.n_box, &d.UB, false},
+              {SPCIES_A_LBY, (uint64_t)nm, &d.LBy, false}, {SPCIES_A_UBY, (uint64_t)nm, &d.UBy, false},
+              {SPCIES_A_D, (uint64_t)d.n_s, &d.d, !d.use_soc}, {SPCIES_A_C_VAL, 0, &d.C_val, false},
+              {SPCIES_A_CT_VAL, 0, &d.Ct_val, false}, {SPCIES_A_M1, (uint64_t)d.dim * d.dim, &d.M1, false},
+              {SPCIES_A_M2, (uint64_t)d.dim * n, &d.M2, false}};
+    for (auto &f : fs) {
+        uint64_t cnt = 0;
+        const double *p = find_farray_any(blob, bytes, h, f.id, &cnt);
+        if (!p && f.optional) continue;
+        if (!p || (f.want && cnt != f.want)) return fail(SPCIES_HIP_EINVAL, "blob array id %u missing or mis-sized", f.id);
+        f.dst->assign(p, p + cnt);
+    }
+    if (d.C_val.size() != d.Ct_val.size() || d.C_val.size() > (size_t)d.n_s * d.dim)
+        return fail(SPCIES_HIP_EINVAL, "C and C' hold different numbers of non-zeros");
+    const int nnz = (int)d.C_val.size();
+    struct G { uint32_t id; uint64_t want; std::vector<int> *dst; int maxval; bool is_ptr; };
+    G gs[] = {{SPCIES_A_C_ROW, (uint64_t)d.n_s + 1, &d.C_row, nnz, true}, {SPCIES_A_C_COL, (uint64_t)nnz, &d.C_col, d.dim - 1, false},
+              {SPCIES_A_CT_ROW, (uint64_t)d.dim + 1, &d.Ct_row, nnz, true}, {SPCIES_A_CT_COL, (uint64_t)nnz, &d.Ct_col, d.n_s - 1, false}};
+    for (auto &g : gs) {
+        uint64_t cnt = 0;
+        const int *p = find_iarray(blob, bytes, h, g.id, &cnt);
+        if (!p || cnt != g.want) return fail(SPCIES_HIP_EINVAL, "blob index array id %u missing or mis-sized", g.id);
+        for (uint64_t i = 0; i < cnt; i++) {
+            if (p[i] < 0 || p[i] > g.maxval) return fail(SPCIES_HIP_EINVAL, "blob index array id %u: value out of range", g.id);
+            if (g.is_ptr && i > 0 && p[i] < p[i - 1]) return fail(SPCIES_HIP_EINVAL, "blob pointer array id %u not monotone", g.id);
+        }
+        if (g.is_ptr && (p[0] != 0 || p[cnt - 1] != g.maxval)) return fail(SPCIES_HIP_EINVAL, "blob pointer array id %u: bad ends", g.id);
+        g.dst->assign(p, p + cnt);
+    }
+    return 0;
+}
+
 static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     const uint8_t *blob = static_cast<const uint8_t *>(blobv);
     if (!blob || bytes < sizeof(spcies_blob_header)) return fail(SPCIES_HIP_EINVAL, "blob too small");
@@ -303,6 +363,8 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     if (soc) return parse_soc(blob, bytes, h, s);
     if (h.formulation == SPCIES_HMPC && (h.method == SPCIES_ADMM || h.method == SPCIES_SADMM) && h.submethod == 2)
         return parse_hmpc(blob, bytes, h, s);
+    if (h.formulation == SPCIES_HMPC && (h.method == SPCIES_ADMM || h.method == SPCIES_SADMM) && h.submethod == 0)
+        return parse_hmpc_dense(blob, bytes, h, s);
     if (!banded && !mpct)
         return fail(SPCIES_HIP_ENOSUP, "formulation %u / method %u not built in this library", h.formulation, h.method);
     const bool vec_rho = (h.method == SPCIES_ADMM && !(h.flags & 1u)), var_b = (h.flags & 16u) != 0;
@@ -429,6 +491,7 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
 
 static int upload_consts(Solver &s) {
     AdmmHost &a = s.host;
+    if (s.is_hdense()) return hdense::plan_build(s.hd_plan, s.hd_host);
     if (s.is_soc()) {
         SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_consts, s.soc_f64.size() * sizeof(double)));
         SPCIES_HIP_CHECK(hipMemcpy(s.d_consts, s.soc_f64.data(), s.soc_f64.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -508,6 +571,7 @@ static int ensure_mfma4_rtc(Solver &s) {
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
     if (s.tv || s.host.ellip) return SPCIES_VARIANT_STREAM;
+    if (s.is_hdense()) return SPCIES_VARIANT_GEMM;
     if (s.is_hmpc() && s.hgemm.ok) return SPCIES_VARIANT_GEMM;
     if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
@@ -876,6 +940,15 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
     if (B <= 0) return 0;
     if (s.is_soc() && !s.is_hmpc() && !extra)
         return fail(SPCIES_HIP_EINVAL, "ellipMPC soc solvers take a 4th input r (extra): Spcies:ellipMPC:nrhs:r");
+    if (s.is_hdense()) {
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_GEMM)
+            return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variant GEMM is built");
+        int rc = ensure_scratch(s, hdense::scratch_bytes(s.hd_plan.dev, B));
+        if (rc) return rc;
+        hdense::Dev &hd = s.hd_plan.dev;
+        hd.k_max = s.hd_host.k_max; hd.tol_p = s.hd_host.tol_p; hd.tol_d = s.hd_host.tol_d;  // set_exit overrides
+        return hdense::launch(s.hd_plan, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f, st);
+    }
     if (s.is_hmpc() && resolve_variant(s) == SPCIES_VARIANT_GEMM) {
         if (!s.hgemm.ok) return fail(SPCIES_HIP_ENOSUP, "GEMM variant not available: %s", s.hgemm.why.c_str());
         int rc = ensure_scratch(s, hgemm::scratch_bytes(s.hgemm.dev, B));
@@ -1090,6 +1163,7 @@ int spcies_hip_destroy(spcies_hip_handle h) {
     if (s->d_idx) hipFree(s->d_idx);
     if (s->d_recs) hipFree(s->d_recs);
     hgemm::plan_free(s->hgemm);
+    hdense::plan_free(s->hd_plan);
     if (s->d_eng) hipFree(s->d_eng);
     if (s->d_eng_in) hipFree(s->d_eng_in);
     mfma_plan_free(s->mfma);
@@ -1107,7 +1181,7 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
     info->formulation = s->formulation;
     info->method = s->method;
     info->submethod = s->submethod;
-    info->n = s->host.n; info->m = s->host.m; info->N = s->host.N; info->dim = s->is_soc() ? s->sdev.dim : s->host.dim();
+    info->n = s->host.n; info->m = s->host.m; info->N = s->host.N; info->dim = s->is_soc() ? s->soc_dim() : (s->is_hdense() ? s->hd_host.dim : s->host.dim());
     info->k_max = s->host.k_max; info->tol = s->host.tol; info->rho = s->host.rho;
     info->variant = resolve_variant(*s);
     info->dim_lambda = s->lam_dim();
@@ -1119,6 +1193,12 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
     if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_GEMM) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (s->is_hdense()) {
+        if (variant != SPCIES_VARIANT_AUTO && variant != SPCIES_VARIANT_GEMM)
+            return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variant GEMM is built");
+        s->variant = variant;
+        return 0;
+    }
     if (variant == SPCIES_VARIANT_GEMM && !(s->is_hmpc() && s->hgemm.ok))
         return fail(SPCIES_HIP_ENOSUP, "GEMM variant: built for HMPC split solvers whose blob carries M1, M2 (%s)", s->hgemm.why.c_str());
     if (variant == SPCIES_VARIANT_TILE && !(s->is_soc() && s->tdev.lpi))
@@ -1141,9 +1221,9 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
 int spcies_hip_set_exit(spcies_hip_handle h, int k_max, double tol) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (k_max > 0) s->host.k_max = s->dev.k_max = s->fdev.k_max = s->edev.k_max = s->sdev.k_max = s->hdev.k_max = k_max;
+    if (k_max > 0) s->host.k_max = s->dev.k_max = s->fdev.k_max = s->edev.k_max = s->sdev.k_max = s->hdev.k_max = s->hd_host.k_max = k_max;
     if (tol >= 0)
-        s->host.tol = s->dev.tol = s->fdev.tol = s->edev.tol = s->sdev.tol_p = s->sdev.tol_d = s->hdev.tol_p = s->hdev.tol_d = tol;
+        s->hd_host.tol_p = s->hd_host.tol_d = s->host.tol = s->dev.tol = s->fdev.tol = s->edev.tol = s->sdev.tol_p = s->sdev.tol_d = s->hdev.tol_p = s->hdev.tol_d = tol;
     return 0;
 }
 
@@ -1152,6 +1232,7 @@ int spcies_hip_reserve(spcies_hip_handle h, long B) {
     Solver *s = reinterpret_cast<Solver *>(h);
     std::lock_guard<std::mutex> lk(s->mu);
     SPCIES_HIP_CHECK(hipSetDevice(s->device));
+    if (s->is_hdense()) return ensure_scratch(*s, hdense::scratch_bytes(s->hd_plan.dev, B));
     size_t need = stream_scratch_bytes(*s, B, true);
     if (s->g4plan.ok && s->method == SPCIES_FISTA) need = std::max(need, g4::fista_state_bytes(s->g4plan, s->host, B));
     if (s->g4plan.ok && s->method == SPCIES_ADMM && !s->is_soc()) need = std::max(need, g4::admm_state_bytes(s->g4plan, s->host, B));

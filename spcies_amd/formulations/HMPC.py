@@ -18,6 +18,8 @@ import numpy as np
 import scipy.sparse as sp
 from scipy.sparse.csgraph import reverse_cuthill_mckee
 
+from types import SimpleNamespace
+
 from .. import sp_utils
 from .laxMPC import _get
 
@@ -37,7 +39,9 @@ def _ldl_nopivot(M):
     return L, D
 
 
-def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
+def _hmpc_problem(controller, opt):
+    """H, G, the cone rows C_aux / dsoc and the bounds of the HMPC problem (box-constraint case) - common to the split and
+    the non-split solver (``compute_HMPC_ADMM_split_ingredients.m:60-218`` = ``compute_HMPC_ADMM_ingredients.m:60-230``)."""
     sys, param = _get(controller, "sys"), _get(controller, "param")
     A = np.asarray(_get(sys, "A"), dtype=float)
     B = np.asarray(_get(sys, "B"), dtype=float)
@@ -46,8 +50,6 @@ def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
     so = opt.solver
     if so.get("box_constraints") is False or _get(sys, "E") is not None:
         raise NotImplementedError("HIP platform: HMPC with coupled output constraints (E, F) is not built")
-    if not so.get("sparse", False):
-        raise NotImplementedError("HIP platform: HMPC split is built for the sparse KKT path (options.sparse = true)")
     use_soc = bool(so.get("use_soc", False))
     LBx, UBx = np.ravel(_get(sys, "LBx")).astype(float), np.ravel(_get(sys, "UBx")).astype(float)
     LBu, UBu = np.ravel(_get(sys, "LBu")).astype(float), np.ravel(_get(sys, "UBu")).astype(float)
@@ -58,7 +60,6 @@ def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
     Q, R = np.asarray(_get(param, "Q"), float), np.asarray(_get(param, "R"), float)
     Te, Th = np.asarray(_get(param, "Te"), float), np.asarray(_get(param, "Th"), float)
     Se, Sh = np.asarray(_get(param, "Se"), float), np.asarray(_get(param, "Sh"), float)
-    rho, sigma = float(so["rho"]), float(so["sigma"])
     sj, cj = np.sin(w * np.arange(N)), np.cos(w * np.arange(N))
     s_sum, c_sum, s2, c2, sc = sj.sum(), cj.sum(), (sj ** 2).sum(), (cj ** 2).sum(), (sj * cj).sum()
     # ---- Hessian (:98-127)
@@ -113,6 +114,19 @@ def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
         C_m = np.vstack([np.kron(np.eye(3), -np.eye(m)[j:j + 1, :]) for j in range(m)])
         C_aux = np.block([[C_n, np.zeros((3 * n, 3 * m))], [np.zeros((3 * m, 3 * n)), C_m]])
         dsoc, n_soc = np.zeros(3 * n_y), n_y
+    LB = np.concatenate([LBu] + [np.concatenate([LBx, LBu])] * (N - 1))
+    UB = np.concatenate([UBu] + [np.concatenate([UBx, UBu])] * (N - 1))
+    return SimpleNamespace(A=A, n=n, m=m, N=N, Q=Q, Te=Te, Se=Se, H=H, G=G, b=b, C_aux=C_aux, dsoc=dsoc, n_soc=n_soc,
+                           use_soc=use_soc, LB=LB, UB=UB, LBy=LBy, UBy=UBy)
+
+
+def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
+    P = _hmpc_problem(controller, opt)
+    A, n, m, N, Q, Te, Se, H, G, b = P.A, P.n, P.m, P.N, P.Q, P.Te, P.Se, P.H, P.G, P.b
+    C_aux, dsoc, n_soc, use_soc, LBy, UBy = P.C_aux, P.dsoc, P.n_soc, P.use_soc, P.LBy, P.UBy
+    nm, dim, n_eq = n + m, H.shape[0], G.shape[0]
+    so = opt.solver
+    rho, sigma = float(so["rho"]), float(so["sigma"])
     C = np.hstack([np.zeros((3 * n_soc, dim - 3 * nm)), C_aux])
     n_s = C.shape[0]
     # ---- KKT matrix and its L D L' (:221-234)
@@ -135,8 +149,7 @@ def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
     v = dict(n=n, m=m, N=N, formulation="HMPC", method=opt.method or "ADMM", submethod="split", terminal=True,
              dim=dim, n_s=n_s, n_eq=n_eq, n_soc=n_soc, use_soc=use_soc, nrow_M=dim + n_s + nc)
     v["A"], v["Q"], v["Te"], v["Se"] = A.copy(), Q.copy(), Te.copy(), Se.copy()
-    v["LB"] = np.concatenate([LBu] + [np.concatenate([LBx, LBu])] * (N - 1))
-    v["UB"] = np.concatenate([UBu] + [np.concatenate([UBx, UBu])] * (N - 1))
+    v["LB"], v["UB"] = P.LB, P.UB
     v["LBy"], v["UBy"] = LBy, UBy
     v["L_val"], v["L_row"], v["L_col"], v["Dinv"] = Lv, Lr, Lc, 1.0 / D
     v["idx_x0"] = inv[:n].astype(np.int32)       # where the first n equality rows (x0 rows) sit in the permuted tail
@@ -155,4 +168,42 @@ def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
     v["tol"] = v["tol_p"]
     v["rho_is_scalar"] = True
     v["H"], v["G"], v["C"], v["d"] = H, G, C, dsoc  # dense forms, for tests (KKT residual of the solution)
+    return v
+
+
+def compute_HMPC_ADMM_ingredients(controller, opt):
+    """HMPC ADMM / SADMM WITHOUT the splitting (the reference's default HMPC solver):
+    ``formulations/+HMPC/compute_HMPC_ADMM_ingredients.m:60-300``, box-constraint case.  Same ``H``, ``G`` and cone rows
+    as the split formulation; here every bounded decision variable gets a slack too, ``C = blkdiag(-I, C_aux)``,
+    ``s`` has ``n_box = dim - 3(n+m)`` box rows followed by the cone rows, and the z-update is the dense
+    ``z = M2 b + M1 q_hat`` with ``Hh = H + rho C'C``, ``W = G Hh^-1 G'``, ``M1 = Hh^-1 G' W^-1 G Hh^-1 - Hh^-1``,
+    ``M2 = (Hh^-1 G' W^-1)(:, 1:n)``  (``:236-254``)."""
+    P = _hmpc_problem(controller, opt)
+    n, m, N, H, G, C_aux = P.n, P.m, P.N, P.H, P.G, P.C_aux
+    nm, dim = n + m, H.shape[0]
+    so = opt.solver
+    n_box = dim - 3 * nm
+    C = np.block([[-np.eye(n_box), np.zeros((n_box, 3 * nm))], [np.zeros((C_aux.shape[0], n_box)), C_aux]])
+    d = np.concatenate([np.zeros(n_box), P.dsoc])
+    rho = float(so["rho"])
+    Hhi = np.linalg.inv(H + rho * (C.T @ C))
+    Wi = np.linalg.inv(G @ Hhi @ G.T)
+    M1 = Hhi @ G.T @ Wi @ G @ Hhi - Hhi
+    M2 = (Hhi @ G.T @ Wi)[:, :n]
+    csr = lambda M: sp_utils.full2CSR(M)[:3]
+    v = dict(n=n, m=m, N=N, formulation="HMPC", method=opt.method or "ADMM", submethod="", terminal=True, dim=dim,
+             n_s=C.shape[0], n_eq=G.shape[0], n_soc=P.n_soc, n_box=n_box, use_soc=P.use_soc)
+    v["A"], v["Q"], v["Te"], v["Se"] = P.A.copy(), P.Q.copy(), P.Te.copy(), P.Se.copy()
+    v["LB"], v["UB"], v["LBy"], v["UBy"] = P.LB, P.UB, P.LBy, P.UBy
+    v["rho"], v["rho_i"] = rho, 1.0 / rho
+    v["alpha"] = float(so.get("alpha", 0.95)) if v["method"] == "SADMM" else 1.0  # :256-258
+    v["k_max"] = int(so["k_max"])
+    v["tol_p"], v["tol_d"] = float(so["tol_p"]), float(so["tol_d"])
+    v["tol"] = v["tol_p"]
+    v["C_val"], v["C_col"], v["C_row"] = csr(C)
+    v["Ct_val"], v["Ct_col"], v["Ct_row"] = csr(C.T)
+    v["d"], v["M1"], v["M2"] = d, M1, M2
+    v["rho_is_scalar"] = True
+    v["sigma"], v["sigma_i"] = 0.0, 0.0
+    v["H"], v["G"], v["C"] = H, G, C  # dense forms, for tests
     return v

@@ -55,6 +55,10 @@ _DEF_SOLVER = {
     # formulations/+ellipMPC/def_options_ellipMPC_ADMM_soc.m
     ("ellipMPC", "ADMM", "soc"): dict(rho=5, sigma=5, tol_p=1e-4, tol_d=1e-4, k_max=1000),
     # formulations/+HMPC/def_options_HMPC_ADMM.m / def_options_HMPC_SADMM.m
+    ("HMPC", "ADMM", ""): dict(rho=1e-2, sigma=1e-2, tol_p=1e-4, tol_d=1e-4, k_max=1000, box_constraints=None,
+                               sparse=False, use_soc=False, alpha=0.95),
+    ("HMPC", "SADMM", ""): dict(rho=1e-2, sigma=1e-2, tol_p=1e-4, tol_d=1e-4, k_max=1000, box_constraints=None,
+                                sparse=False, use_soc=False, alpha=0.95),  # reachable through the C-ABI / benchmarks only
     ("HMPC", "ADMM", "split"): dict(rho=1e-2, sigma=1e-2, tol_p=1e-4, tol_d=1e-4, k_max=1000, box_constraints=None,
                                     sparse=False, use_soc=False, alpha=0.95),
     ("HMPC", "SADMM", "split"): dict(rho=1e-2, sigma=1e-2, tol_p=1e-4, tol_d=1e-4, k_max=1000, box_constraints=None,

@@ -458,6 +458,58 @@ def test_hmpc_vs_reference_template_fixture(variant, golden_dir):
 
 
 # ----------------------------------------------------------------------------------------------
+# HMPC ADMM / SADMM without the splitting (the reference's default HMPC solver; dense M1, M2): GEMM variant -> 1e-10
+# ----------------------------------------------------------------------------------------------
+def _compare_hmpc_nosplit(got, O):
+    u, k, e, sol = got
+    dk = np.abs(np.asarray(k).astype(int) - O[1].astype(int))
+    assert dk.max() <= 1 and (dk > 0).mean() <= 1e-3 + 1.0 / max(len(dk), 1) * (len(dk) < 1000)
+    same = dk == 0
+    assert np.array_equal(np.asarray(e)[same], O[2][same])
+    assert np.abs(u - O[0])[same].max() <= TOL_SPCIES
+    if sol.z is None:
+        return
+    for name, ref in zip(("z", "s", "lam"), O[3:]):
+        scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True)) if name == "lam" else 1.0
+        assert (np.abs(getattr(sol, name) - ref) / scale)[same].max() <= TOL_SPCIES, name
+
+
+@pytest.mark.parametrize("cfg_name,B,overrides", [
+    ("C1_HMPC_nosplit", 40, {}), ("C1_HMPC_SADMM_nosplit", 70, {}), ("C1_HMPC_soc_nosplit", 33, {}),
+    ("C1_HMPC_SADMM_soc_nosplit", 20, {}), ("C5_HMPC_SADMM_nosplit", 65, {}),
+    ("C5_HMPC_SADMM_nosplit", 12, dict(tol_p=1e-5, tol_d=1e-5, k_max=2500)),
+])
+def test_hmpc_nosplit_seeded_batch_vs_oracle(cfg_name, B, overrides):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver(cfg_name, "gemm", **overrides)
+    assert [f for f, _ in s.sol_fields] == ["z", "s", "lambda"]  # header_HMPC_ADMM_C.h:14-22
+    assert dict(s.sol_fields) == {"z": v["dim"], "s": v["n_s"], "lambda": v["n_s"]}
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    if cfg_name.startswith("C1"):
+        st = benchmarks.tester_status(cfg.sys)
+        x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
+    got = s(x0, xr, ur)
+    _compare_hmpc_nosplit(got, oracle.hmpc_dense_batch(v, x0, xr, ur))
+    nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
+    assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
+
+
+def test_hmpc_nosplit_vs_reference_template_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "template_C1_HMPC_nosplit.npz"))
+    cfg, v, s = _fista_solver("C1_HMPC_nosplit")
+    assert s.variant == "gemm"
+    u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
+    assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
+    same = k == g["k"]
+    assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-8
+    # the split and the non-split solver agree on the optimum (their exit tolerances: 1e-7 on the residuals)
+    _, _, s2 = _fista_solver("C1_HMPC")
+    u2, _, e2, sol2 = s2(g["x0"][:1], g["xr"][:1], g["ur"][:1])
+    assert e2[0] == 1 and np.abs(sol2.z[0] - sol.z[0]).max() <= 1e-4
+
+
+# ----------------------------------------------------------------------------------------------
 # Closed-loop batch simulation on the device (examples/cl_in_C/main_cl_in_C.c:98-117)
 # ----------------------------------------------------------------------------------------------
 def _plant_step_ref(AB, x, u):
