@@ -153,7 +153,15 @@ enum spcies_array_id {
      * header flags bit1 = use_soc, reserved = {-, -, tol_d, alpha_SADMM}.  Record: z [dim], s [n_s], lambda [n_s] */
     SPCIES_A_C_VAL = 71, SPCIES_A_C_COL = 72, SPCIES_A_C_ROW = 73,    /* CSR of C  [n_s x dim] (0-based)  */
     SPCIES_A_CT_VAL = 74, SPCIES_A_CT_COL = 75, SPCIES_A_CT_ROW = 76, /* CSR of C' [dim x n_s]            */
-    SPCIES_A_D = 77                          /* [n_s] d (read with use_soc only)                    */
+    SPCIES_A_D = 77,                         /* [n_s] d (read with use_soc only)                    */
+    /* MPCT ADMM on the extended state space (formulation 3, method ADMM, submethod 3 = 'cs'; cons_MPCT_ADMM_cs_C.m:66-112):
+     * LB / UB (10, 11) [2N(n+m)], L_* / Dinv (28-31) with nrow = 2n + (2n+m)(N-1) + n rows, and these; header flags bit0 =
+     * scalar rho (then rho, rho_i come from the header).  Record: z, v, lambda [2N(n+m)]                              */
+    SPCIES_A_TZ = 78, SPCIES_A_SZ = 79,      /* [n][n] = -T/N, [m][m] = -S/N                        */
+    SPCIES_A_AHI_VAL = 80, SPCIES_A_AHI_COL = 81, SPCIES_A_AHI_ROW = 82, /* CSR of -Aeq Hhat^-1  [nrow x dim] */
+    SPCIES_A_HIA_VAL = 83, SPCIES_A_HIA_COL = 84, SPCIES_A_HIA_ROW = 85, /* CSR of -Hhat^-1 Aeq' [dim x nrow] */
+    SPCIES_A_HI_VAL = 86, SPCIES_A_HI_COL = 87, SPCIES_A_HI_ROW = 88,    /* CSR of -Hhat^-1      [dim x dim]  */
+    SPCIES_A_RHO_CS = 89, SPCIES_A_RHO_I_CS = 90                          /* [dim] (vector rho)               */
 };
 
 typedef struct {

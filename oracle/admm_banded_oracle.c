@@ -321,19 +321,36 @@ int oracle_admm_banded_solve(const admm_banded_data *d, const double *x0, const 
 /* Batch driver (instances are independent; used for fixtures and for the timed CPU baseline).
  * x0 is [B][n]; xr/ur are [B][n]/[B][m] when ref_stride != 0, else a single shared reference.
  * Outputs u [B][m], k [B], e_flag [B]; z/v/lam [B][dim] or NULL. */
+int oracle_admm_banded_batch_mt(const admm_banded_data *d, long B, const double *x0, const double *xr, const double *ur,
+                                int ref_stride, double *u, int *k, int *e_flag, double *z, double *v, double *lam,
+                                int threads);
+
 int oracle_admm_banded_batch(const admm_banded_data *d, long B, const double *x0, const double *xr,
                              const double *ur, int ref_stride, double *u, int *k, int *e_flag, double *z,
                              double *v, double *lam) {
+    return oracle_admm_banded_batch_mt(d, B, x0, xr, ur, ref_stride, u, k, e_flag, z, v, lam, 1);
+}
+
+/* the same loop over instances spread over `threads` host threads (OpenMP; instances are independent, every instance
+ * is still solved by the scalar code above): the multi-core CPU baseline of bench.py */
+int oracle_admm_banded_batch_mt(const admm_banded_data *d, long B, const double *x0, const double *xr, const double *ur,
+                                int ref_stride, double *u, int *k, int *e_flag, double *z, double *v, double *lam,
+                                int threads) {
     const size_t dim = (size_t)d->N * (size_t)(d->n + d->m) - (d->terminal ? 0 : (size_t)d->n);
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads > 1 ? threads : 1) if (threads > 1)
     for (long i = 0; i < B; i++) {
         const double *xri = ref_stride ? xr + (size_t)i * d->n : xr;
         const double *uri = ref_stride ? ur + (size_t)i * d->m : ur;
         int rc = oracle_admm_banded_solve(d, x0 + (size_t)i * d->n, xri, uri, u + (size_t)i * d->m, k + i,
                                           e_flag + i, z ? z + (size_t)i * dim : NULL,
                                           v ? v + (size_t)i * dim : NULL, lam ? lam + (size_t)i * dim : NULL);
-        if (rc) return rc;
+        if (rc) {
+#pragma omp atomic write
+            bad = rc;
+        }
     }
-    return 0;
+    return bad;
 }
 
 /* ------------------------------------------------------------------------------------------------

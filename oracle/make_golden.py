@@ -57,7 +57,8 @@ def main():
                                ("C1_HMPC", 6, {}), ("C1_HMPC_SADMM", 6, {}), ("C1_HMPC_soc", 4, {}),
                                ("C1_HMPC_SADMM_soc", 4, {}), ("C5_HMPC_SADMM", 4, {}),
                                ("C1_HMPC_nosplit", 6, {}), ("C1_HMPC_SADMM_nosplit", 6, {}), ("C1_HMPC_soc_nosplit", 4, {}),
-                               ("C1_HMPC_SADMM_soc_nosplit", 4, {}), ("C5_HMPC_SADMM_nosplit", 4, {})):
+                               ("C1_HMPC_SADMM_soc_nosplit", 4, {}), ("C5_HMPC_SADMM_nosplit", 4, {}),
+                               ("C1_MPCT_cs", 8, {}), ("C1_MPCT_cs_vec", 6, {}), ("C2_cs", 6, {}), ("C4_cs", 4, {})):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:  # `python -m oracle.make_golden C1_ellip ...`: only these
             continue
         cfg = benchmarks.config(name)
@@ -106,7 +107,9 @@ def main():
                                 z1=z1t, z2=z2t, z3=z3t, lam=lt, solver_overrides=json.dumps(overrides))
             continue
         ut, kt, et, zt, vt, lt = ref_template.run_admm(so, v, x0, xr, ur)
-        if v["method"] == "FISTA":
+        if v.get("submethod") == "cs":
+            uo, ko, eo, zo, vo, lo = oracle.mpct_cs_batch(v, x0, xr, ur)
+        elif v["method"] == "FISTA":
             uo, ko, eo, zo, lo = oracle.fista_banded_batch(v, x0, xr, ur)
             vt = np.zeros((0,))
         else:

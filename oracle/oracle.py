@@ -13,7 +13,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c", "eadmm_mpct_oracle.c", "admm_soc_oracle.c", "admm_hmpc_oracle.c", "admm_hmpc_dense_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c", "eadmm_mpct_oracle.c", "admm_soc_oracle.c", "admm_hmpc_oracle.c", "admm_hmpc_dense_oracle.c", "admm_mpct_cs_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return so
@@ -37,6 +37,7 @@ def _lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.oracle_admm_banded_batch.restype = C.c_int
+        _LIB.oracle_admm_banded_batch_mt.restype = C.c_int
     return _LIB
 
 
@@ -101,9 +102,10 @@ def admm_tv_batch(v, x0, xr, ur, model, per_instance, want_sol=True, want_factor
     return out
 
 
-def admm_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False):
+def admm_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False, threads=1):
     """Run the C oracle on a batch.  ``v`` is the ingredients dict of
-    ``spcies_amd.formulations.laxMPC.compute_*_ADMM_ingredients``.  Returns ``u, k, e_flag, z, v, lam``."""
+    ``spcies_amd.formulations.laxMPC.compute_*_ADMM_ingredients``.  Returns ``u, k, e_flag, z, v, lam``.
+    ``threads`` > 1 spreads the (independent) instances over host threads - the multi-core CPU baseline."""
     n, m, N = int(v["n"]), int(v["m"]), int(v["N"])
     terminal = bool(v.get("terminal", True))
     qz = quantize_like_reference if quantize else (lambda a: a)
@@ -142,9 +144,10 @@ def admm_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     vv = np.zeros((B, dim)) if want_sol else None
     lam = np.zeros((B, dim)) if want_sol else None
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
-    rc = _lib().oracle_admm_banded_batch(C.byref(d), C.c_long(B), _dp(x0), _dp(xr), _dp(ur), C.c_int(stride),
-                                         _dp(u), ip(k), ip(e), _dp(z) if want_sol else None,
-                                         _dp(vv) if want_sol else None, _dp(lam) if want_sol else None)
+    rc = _lib().oracle_admm_banded_batch_mt(C.byref(d), C.c_long(B), _dp(x0), _dp(xr), _dp(ur), C.c_int(stride),
+                                            _dp(u), ip(k), ip(e), _dp(z) if want_sol else None,
+                                            _dp(vv) if want_sol else None, _dp(lam) if want_sol else None,
+                                            C.c_int(int(threads)))
     if rc != 0:
         raise RuntimeError(f"oracle_admm_banded_batch failed rc={rc}")
     return u, k, e, z, vv, lam
@@ -383,3 +386,55 @@ def hmpc_dense_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     if rc != 0:
         raise RuntimeError(f"oracle_hmpc_dense_batch failed rc={rc}")
     return u, k, e, z, s, lam
+
+
+_D, _I = C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+
+class _MpctCsData(C.Structure):
+    _fields_ = ([(k_, C.c_int) for k_ in ("n", "m", "N", "nrow", "k_max", "scalar_rho")]
+                + [(k_, C.c_double) for k_ in ("tol", "rho", "rho_i")]
+                + [(k_, _D) for k_ in ("rho_v", "rho_i_v", "Tz", "Sz", "LB", "UB")]
+                + [("L_val", _D), ("L_col", _I), ("L_row", _I), ("Dinv", _D), ("AHi_val", _D), ("AHi_col", _I), ("AHi_row", _I),
+                   ("HiA_val", _D), ("HiA_col", _I), ("HiA_row", _I), ("Hi_val", _D), ("Hi_col", _I), ("Hi_row", _I)])
+
+
+def mpct_cs_batch(v, x0, xr, ur, want_sol=True, quantize=False):
+    """C oracle of the MPCT ADMM 'cs' solver.  Returns ``u, k, e_flag, z, v, lam``."""
+    n, m, N = int(v["n"]), int(v["m"]), int(v["N"])
+    qz = quantize_like_reference if quantize else (lambda a: a)
+    scalar = bool(v.get("rho_is_scalar", True))
+    keep, fields = {}, {}
+    ipt = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    fnames = ["Tz", "Sz", "LB", "UB", "L_val", "Dinv", "AHi_val", "HiA_val", "Hi_val"]
+    src = {k_: k_ for k_ in fnames}
+    if not scalar:
+        src.update(rho_v="rho_cs", rho_i_v="rho_i_cs")
+    for k_, s_ in src.items():
+        a = np.ascontiguousarray(qz(np.asarray(v[s_], dtype=float)))
+        if quantize and k_ in ("LB", "UB"):
+            a = np.clip(a, -1e20, 1e20)
+        keep[k_] = a
+        fields[k_] = _dp(a)
+    for k_ in ("L_col", "L_row", "AHi_col", "AHi_row", "HiA_col", "HiA_row", "Hi_col", "Hi_row"):
+        keep[k_] = np.ascontiguousarray(np.asarray(v[k_], dtype=np.int32))
+        fields[k_] = ipt(keep[k_])
+    sc = {k_: (float(qz(v[k_])) if quantize else float(v[k_])) for k_ in ("tol", "rho", "rho_i")}
+    d = _MpctCsData(n=n, m=m, N=N, nrow=int(v["nrow_AHi"]), k_max=int(v["k_max"]), scalar_rho=int(scalar), **sc, **fields)
+    x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
+    B = x0.shape[0]
+    xr = np.ascontiguousarray(np.asarray(xr, dtype=float))
+    ur = np.ascontiguousarray(np.asarray(ur, dtype=float))
+    stride = 1 if xr.ndim == 2 else 0
+    dim = N * 2 * (n + m)
+    u = np.zeros((B, m)); k = np.zeros(B, dtype=np.int32); e = np.zeros(B, dtype=np.int32)
+    mk = lambda: np.zeros((B, dim)) if want_sol else None
+    z, vv, lam = mk(), mk(), mk()
+    o = lambda a: _dp(a) if a is not None else None
+    lib = _lib()
+    lib.oracle_mpct_cs_batch.restype = C.c_int
+    rc = lib.oracle_mpct_cs_batch(C.byref(d), C.c_long(B), _dp(x0), _dp(xr), _dp(ur), C.c_int(stride), _dp(u), ipt(k), ipt(e),
+                                  o(z), o(vv), o(lam))
+    if rc != 0:
+        raise RuntimeError(f"oracle_mpct_cs_batch failed rc={rc}")
+    return u, k, e, z, vv, lam

@@ -95,6 +95,8 @@ def build_admm(v, name):
         return _build_hmpc(v, name, sparse=v.get("_template_sparse", True))
     if form == "HMPC":
         return _build_hmpc_nosplit(v, name)
+    if v.get("submethod") == "cs":
+        return _build_mpct_cs(v, name)
     fdir = os.path.join(REF, "formulations", f"+{form}")
     n, m, N = v["n"], v["m"], v["N"]
     defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
@@ -156,8 +158,11 @@ def run_admm(so, v, x0, xr, ur):
     if v.get("submethod") == "soc":
         raise ValueError("use run_soc for the ellipMPC soc solver (extra input r)")
     dim = N * (n + m) - (0 if v["terminal"] else n)
+    cs = v.get("submethod") == "cs"
+    if cs:
+        dim = int(v["dim"])
     lib = C.CDLL(so)
-    fn = getattr(lib, f"{v['formulation']}_{method}")
+    fn = getattr(lib, f"{v['formulation']}_{method}" + ("_cs" if cs else ""))
     if method == "EADMM":
         return _run_eadmm(lib, fn, v, x0, xr, ur)
     fista = method == "FISTA"
@@ -421,3 +426,42 @@ def run_hmpc_nosplit(so, v, x0, xr, ur):
         for f in out:
             out[f][i] = np.frombuffer(getattr(sol, f))
     return (u, k, e, out["z"], out["s"], out["lam"])
+
+
+def _build_mpct_cs(v, name):
+    """MPCT ADMM on the extended state space ('cs'): cons_MPCT_ADMM_cs_C.m:66-112."""
+    fdir = os.path.join(REF, "formulations", "+MPCT")
+    n, m, N = v["n"], v["m"], v["N"]
+    defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
+            "#define IS_DIAG 1", f"#define nn_ {n}", f"#define mm_ {m}", f"#define nm_ {n + m}", f"#define dnm_ {2 * (n + m)}",
+            f"#define nrow_AHi {v['nrow_AHi']}", f"#define nrow_HiA {v['dim']}", f"#define NN_ {N}",
+            f"#define k_max {int(v['k_max'])}", f"#define tol {_fmt(v['tol'])}"]
+    if v["rho_is_scalar"]:
+        defs.append("#define SCALAR_RHO 1")
+        consts = _decl_scalar("rho", v["rho"]) + _decl_scalar("rho_i", v["rho_i"])
+    else:
+        consts = _decl("rho", v["rho_cs"]) + _decl("rho_i", v["rho_i_cs"])
+    consts += "".join(_decl(k, v[k]) for k in ("Tz", "Sz", "LB", "UB", "L_val"))
+    consts += _decl_int("L_col", v["L_col"]) + _decl_int("L_row", v["L_row"]) + _decl("Dinv", v["Dinv"])
+    for pfx in ("AHi", "HiA", "Hi"):
+        consts += _decl(f"{pfx}_val", v[f"{pfx}_val"]) + _decl_int(f"{pfx}_col", v[f"{pfx}_col"]) + _decl_int(f"{pfx}_row", v[f"{pfx}_row"])
+    with open(os.path.join(REF, "platforms", "+C_code", "generic_solver_struct.c")) as f:
+        code = f.read()
+    with open(os.path.join(fdir, "code_MPCT_ADMM_cs_C.c")) as f:
+        code = code.replace("$INSERT_SOLVER$", f.read())
+    with open(os.path.join(fdir, "header_MPCT_ADMM_cs_C.h")) as f:
+        header = f.read()
+    code = code.replace("$INSERT_CONSTANTS$", consts).replace("$INSERT_VARIABLES$", "")
+    header = header.replace("$INSERT_DEFINES$", "\n".join(defs))
+    code, header = _snippets(code, "c"), _snippets(header, "h")
+    code = _unescape(code.replace("$INSERT_NAME$", name))
+    header = _unescape(header.replace("$INSERT_NAME$", name))
+    os.makedirs(OUT, exist_ok=True)
+    so = os.path.join(OUT, f"lib{name}.so")
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, f"{name}.c"), "w") as f:
+            f.write(code)
+        with open(os.path.join(td, f"{name}.h"), "w") as f:
+            f.write(header)
+        subprocess.check_call(["gcc", "-O3", "-fPIC", "-shared", "-w", "-o", so, os.path.join(td, f"{name}.c"), "-lm"])
+    return so

@@ -90,6 +90,25 @@ def config(name):
             c.param.N, c.B, c.seed = 20, 1048576, 1204
             c.solver_options.update(k_max=200, tol=0.0)
         return c
+    if name in ("C1_MPCT_cs", "C1_MPCT_cs_vec", "C2_cs", "C4_cs"):
+        # tests/test_MPCT_ADMM.m:6-17 (rho: def_options_MPCT_ADMM_cs.m); C2 / C4 shapes with 200 fixed iterations.  At the C4
+        # shape W = Aeq Hhat^-1 Aeq' has a condition number of 1e9: kept for the bit-exact STREAM variant only
+        c = config("C4" if name == "C4_cs" else "C1_MPCT")
+        c.name, c.method, c.submethod = name, "ADMM", "cs"
+        c.solver_options = dict(k_max=5000, tol=1e-7)
+        if name == "C4_cs":
+            c.solver_options = dict(rho=0.05, k_max=200, tol=0.0)
+            c.B = 131072
+        if name == "C2_cs":
+            c.sys = sp_utils.oscillating_masses_sys(6)
+            Q, R, _ = _weights(c.sys, "diag")
+            c.param = SimpleNamespace(Q=Q, R=R, T=10 * Q, S=R, N=15)
+            c.solver_options = dict(rho=0.1, k_max=200, tol=0.0)
+            c.B, c.seed = 65536, 1207
+        if name.endswith("_vec"):
+            dim = 2 * c.param.N * (c.sys.n + c.sys.m)
+            c.solver_options["rho"] = 0.01 * (0.5 + np.random.default_rng(78).random(dim))
+        return c
     if name in ("C1_ellip", "C2_ellip"):  # tests/test_ellipMPC_ADMM.m:6-21; C2: 12-state, N = 15, r = 0.5, 200 fixed iterations
         sys = sp_utils.oscillating_masses_sys(3 if name == "C1_ellip" else 6)
         Q, R, T = _weights(sys, "diag")
@@ -164,6 +183,7 @@ def ingredients(cfg, **solver_overrides):
           ("laxMPC", "FISTA"): laxMPC.compute_laxMPC_FISTA_ingredients,
           ("equMPC", "FISTA"): laxMPC.compute_equMPC_FISTA_ingredients,
           ("MPCT", "EADMM"): MPCT.compute_MPCT_EADMM_ingredients,
+          ("MPCT", "ADMM"): MPCT.compute_MPCT_ADMM_cs_ingredients,
           ("ellipMPC", "ADMM"): (ellipMPC.compute_ellipMPC_ADMM_soc_ingredients if getattr(cfg, "submethod", "") == "soc"
                                  else ellipMPC.compute_ellipMPC_ADMM_ingredients),
           ("HMPC", "ADMM"): hmpc, ("HMPC", "SADMM"): hmpc}

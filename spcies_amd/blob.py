@@ -28,9 +28,12 @@ ARRAY_ID = {"AB": 1, "Alpha": 2, "Beta": 3, "Hi": 4, "Hi_0": 5, "Hi_N": 6, "Q": 
             "scaling_x": 48, "scaling_u": 49, "scaling_i_u": 50, "OpPoint_x": 51, "OpPoint_u": 52,
             "P": 53, "P_half": 54, "Pinv_half": 55, "c": 56, "LBz": 57, "UBz": 58, "LBu0": 59, "UBu0": 60,
             "rho_v": 61, "rho_N": 62, "rho_i_v": 63, "rho_i_0": 64, "rho_i_N": 65, "LBN": 66, "UBN": 67, "M1": 68, "M2": 69, "bh_nat": 70,
-            "C_val": 71, "C_col": 72, "C_row": 73, "Ct_val": 74, "Ct_col": 75, "Ct_row": 76, "d": 77}
+            "C_val": 71, "C_col": 72, "C_row": 73, "Ct_val": 74, "Ct_col": 75, "Ct_row": 76, "d": 77,
+            "Tz": 78, "Sz": 79, "AHi_val": 80, "AHi_col": 81, "AHi_row": 82, "HiA_val": 83, "HiA_col": 84, "HiA_row": 85,
+            "Hi_val": 86, "Hi_col": 87, "Hi_row": 88, "rho_cs": 89, "rho_i_cs": 90}
 INT_ARRAYS = {"L_col", "L_row", "GhHhi_col", "GhHhi_row", "HhiGh_col", "HhiGh_row", "Hhi_col", "Hhi_row", "idx_x0",
-              "C_col", "C_row", "Ct_col", "Ct_row"}
+              "C_col", "C_row", "Ct_col", "Ct_row",
+              "AHi_col", "AHi_row", "HiA_col", "HiA_row", "Hi_col", "Hi_row"}
 SUBMETHOD = {"": 0, "soc": 1, "split": 2, "cs": 3, "semiband": 4}
 _ID_NAME = {v: k for k, v in ARRAY_ID.items()}
 _HDR = "<8sIIIIIIIIIIIIQddd5d"

@@ -17,6 +17,7 @@
 #include "sparse_tile.hpp"
 #include "hmpc_gemm.hpp"
 #include "hmpc_dense.hpp"
+#include "mpct_cs.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -48,10 +49,12 @@ struct Solver {
     std::vector<double> e_rho, e_rho0, e_rhos, e_LB0, e_UB0, e_LBs, e_UBs, e_S, e_H1i, e_W2, e_H3i;  // EADMM-only
     bool is_soc() const { return (formulation == SPCIES_ELLIPMPC && submethod == 1) || is_hmpc(); }  // 6-field (z, s, ...) record
     bool is_hmpc() const { return formulation == SPCIES_HMPC && submethod == 2; }    // split (code_HMPC_ADMM_split_C.c)
+    bool is_cs() const { return formulation == SPCIES_MPCT && method == SPCIES_ADMM && submethod == 3; }  // code_MPCT_ADMM_cs_C.c
     bool is_hdense() const { return formulation == SPCIES_HMPC && submethod == 0; }  // no splitting (code_HMPC_ADMM_C.c)
     int soc_dim() const { return is_hmpc() ? hdev.dim : sdev.dim; }
     int soc_ns() const { return is_hmpc() ? hdev.n_s : sdev.n_s; }
     int lam_dim() const {
+        if (is_cs()) return cdev.dim;
         if (is_hdense()) return hd_host.n_s;
         if (method == SPCIES_FISTA) return host.N * host.n;
         if (method == SPCIES_EADMM) return (host.N + 3) * (host.n + host.m);
@@ -68,6 +71,7 @@ struct Solver {
         const int nm = host.n + host.m;
         if (is_soc()) return (i % 2 == 0) ? soc_dim() : soc_ns();
         if (is_hdense()) return i == 0 ? hd_host.dim : hd_host.n_s;
+        if (is_cs()) return cdev.dim;
         if (method == SPCIES_FISTA) return i == 0 ? host.dim() : lam_dim();
         if (method == SPCIES_EADMM) return i == 1 ? nm : (i == 3 ? lam_dim() : (host.N + 1) * nm);
         return host.dim();
@@ -87,6 +91,7 @@ struct Solver {
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
     std::vector<double> h_M1, h_M2, h_bh_nat;
+    CsDev cdev{};                  // MPCT ADMM on the extended state space (STREAM, TILE)
     hdense::Host hd_host;          // HMPC without the splitting: blob contents, and its GEMM plan
     hdense::Plan hd_plan;
     tile::TileDev tdev{};          // TILE (soc, HMPC): step streams of the sparse operations
@@ -292,6 +297,87 @@ static int parse_hmpc(const uint8_t *blob, size_t bytes, const spcies_blob_heade
     return 0;
 }
 
+// MPCT ADMM on the extended state space (cons_MPCT_ADMM_cs_C.m:66-112)
+static int parse_mpct_cs(const uint8_t *blob, size_t bytes, const spcies_blob_header &h, Solver &s) {
+    s.formulation = (int)h.formulation; s.method = (int)h.method; s.submethod = (int)h.submethod;
+    AdmmHost &a = s.host;
+    a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max; a.terminal = true;
+    a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
+    if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0))
+        return fail(SPCIES_HIP_EINVAL, "bad n/m/N/k_max/rho");
+    const int n = a.n, m = a.m, N = a.N, dnm = 2 * (n + m);
+    CsDev &d = s.cdev;
+    d.n = n; d.m = m; d.N = N; d.dim = N * dnm; d.nrow = 2 * n + (2 * n + m) * (N - 1) + n; d.k_max = a.k_max;
+    d.scalar_rho = (h.flags & 1u) ? 1 : 0;
+    d.tol = h.tol; d.rho = h.rho; d.rho_i = h.rho_i;
+    const int dim = d.dim, nr = d.nrow;
+    struct F { uint32_t id; uint64_t want; int *off; bool optional; };  // want == 0: any length
+    F fs[] = {{SPCIES_A_TZ, (uint64_t)n * n, &d.Tz, false}, {SPCIES_A_SZ, (uint64_t)m * m, &d.Sz, false},
+              {SPCIES_A_LB, (uint64_t)dim, &d.LB, false}, {SPCIES_A_UB, (uint64_t)dim, &d.UB, false},
+              {SPCIES_A_L_VAL, 0, &d.L_val, false}, {SPCIES_A_DINV, (uint64_t)nr, &d.Dinv, false},
+              {SPCIES_A_AHI_VAL, 0, &d.AHi_val, false}, {SPCIES_A_HIA_VAL, 0, &d.HiA_val, false}, {SPCIES_A_HI_VAL, 0, &d.Hi_val, false},
+              {SPCIES_A_RHO_CS, (uint64_t)dim, &d.rho_v, d.scalar_rho != 0}, {SPCIES_A_RHO_I_CS, (uint64_t)dim, &d.rho_i_v, d.scalar_rho != 0}};
+    uint64_t nnz[4] = {0, 0, 0, 0};  // L, AHi, HiA, Hi
+    int vi = 0;
+    for (auto &f : fs) {
+        uint64_t cnt = 0;
+        const double *p = find_farray_any(blob, bytes, h, f.id, &cnt);
+        *f.off = 0;
+        if (f.optional) continue;
+        if (!p || (f.want && cnt != f.want)) return fail(SPCIES_HIP_EINVAL, "blob array id %u missing or mis-sized", f.id);
+        *f.off = (int)s.soc_f64.size();
+        s.soc_f64.insert(s.soc_f64.end(), p, p + cnt);
+        while (s.soc_f64.size() % 8) s.soc_f64.push_back(0.0);
+        if (f.want == 0) nnz[vi++] = cnt;
+    }
+    if (!d.scalar_rho)
+        for (int j = 0; j < dim; j++)
+            if (!(s.soc_f64[d.rho_v + j] > 0)) return fail(SPCIES_HIP_EINVAL, "bad rho");
+    struct G { uint32_t id; uint64_t want; int *off; int maxval; bool is_ptr; };
+    G gs[] = {{SPCIES_A_L_COL, (uint64_t)nr + 1, &d.L_col, (int)nnz[0], true},
+              {SPCIES_A_L_ROW, nnz[0], &d.L_row, nr - 1, false},
+              {SPCIES_A_AHI_COL, nnz[1], &d.AHi_col, dim - 1, false},
+              {SPCIES_A_AHI_ROW, (uint64_t)nr + 1, &d.AHi_row, (int)nnz[1], true},
+              {SPCIES_A_HIA_COL, nnz[2], &d.HiA_col, nr - 1, false},
+              {SPCIES_A_HIA_ROW, (uint64_t)dim + 1, &d.HiA_row, (int)nnz[2], true},
+              {SPCIES_A_HI_COL, nnz[3], &d.Hi_col, dim - 1, false},
+              {SPCIES_A_HI_ROW, (uint64_t)dim + 1, &d.Hi_row, (int)nnz[3], true}};
+    for (auto &g : gs) {
+        uint64_t cnt = 0;
+        const int *p = find_iarray(blob, bytes, h, g.id, &cnt);
+        if (!p || cnt != g.want) return fail(SPCIES_HIP_EINVAL, "blob index array id %u missing or mis-sized", g.id);
+        for (uint64_t i = 0; i < cnt; i++) {
+            if (p[i] < 0 || p[i] > g.maxval) return fail(SPCIES_HIP_EINVAL, "blob index array id %u: value out of range", g.id);
+            if (g.is_ptr && i > 0 && p[i] < p[i - 1]) return fail(SPCIES_HIP_EINVAL, "blob pointer array id %u not monotone", g.id);
+        }
+        if (g.is_ptr && (p[0] != 0 || p[cnt - 1] != g.maxval)) return fail(SPCIES_HIP_EINVAL, "blob pointer array id %u: bad ends", g.id);
+        *g.off = (int)s.soc_i32.size();
+        s.soc_i32.insert(s.soc_i32.end(), p, p + cnt);
+    }
+    {
+        const int *Lc = s.soc_i32.data() + d.L_col, *Lr = s.soc_i32.data() + d.L_row;
+        for (int i = 0; i < nr; i++)
+            for (int j = Lc[i]; j < Lc[i + 1]; j++)
+                if (Lr[j] <= i) return fail(SPCIES_HIP_EINVAL, "L - I is not strictly lower triangular");
+    }
+    {  // TILE variant: step streams (sparse_tile.hpp); LDS rows RH (nr) | QH (dim) | PL (dim)
+        const int *I = s.soc_i32.data();
+        const double *F = s.soc_f64.data();
+        const int lpi = tile::pick_lpi((long)nr + 2L * dim, I + d.L_col, nr);
+        s.tdev = tile::TileDev{};
+        s.tdev.lpi = lpi;
+        if (lpi) {
+            s.tdev.lds_bytes = (size_t)(nr + 2 * dim) * (64 / lpi) * sizeof(double);
+            tile::build_ldl_streams(nr, I + d.L_col, I + d.L_row, F + d.L_val, lpi, s.tile_recs, s.tdev.fwd, s.tdev.bwd);
+            tile::build_spmv_stream(nr, I + d.AHi_row, I + d.AHi_col, F + d.AHi_val, nr, nullptr, nullptr, nullptr, 0, lpi,
+                                    s.tile_recs, s.tdev.rhs);
+            tile::build_spmv_stream(dim, I + d.Hi_row, I + d.Hi_col, F + d.Hi_val, nr, I + d.HiA_row, I + d.HiA_col,
+                                    F + d.HiA_val, 0, lpi, s.tile_recs, s.tdev.prim);
+        }
+    }
+    return 0;
+}
+
 // HMPC ADMM / SADMM without the splitting, box constraints (cons_HMPC_ADMM_C.m:88-131)
 static int parse_hmpc_dense(const uint8_t *blob, size_t bytes, const spcies_blob_header &h, Solver &s) {
     s.formulation = (int)h.formulation; s.method = (int)h.method; s.submethod = (int)h.submethod;
@@ -365,6 +451,11 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         return parse_hmpc(blob, bytes, h, s);
     if (h.formulation == SPCIES_HMPC && (h.method == SPCIES_ADMM || h.method == SPCIES_SADMM) && h.submethod == 0)
         return parse_hmpc_dense(blob, bytes, h, s);
+    if (h.formulation == SPCIES_MPCT && h.method == SPCIES_ADMM) {
+        if (h.submethod != 3) return fail(SPCIES_HIP_ENOSUP, "MPCT ADMM: the 'cs' submethod is built (not 'semiband')");
+        if (h.flags & 8u) return fail(SPCIES_HIP_ENOSUP, "in_engineering is not built for MPCT ADMM cs");
+        return parse_mpct_cs(blob, bytes, h, s);
+    }
     if (!banded && !mpct)
         return fail(SPCIES_HIP_ENOSUP, "formulation %u / method %u not built in this library", h.formulation, h.method);
     const bool vec_rho = (h.method == SPCIES_ADMM && !(h.flags & 1u)), var_b = (h.flags & 16u) != 0;
@@ -492,7 +583,7 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
 static int upload_consts(Solver &s) {
     AdmmHost &a = s.host;
     if (s.is_hdense()) return hdense::plan_build(s.hd_plan, s.hd_host);
-    if (s.is_soc()) {
+    if (s.is_soc() || s.is_cs()) {
         SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_consts, s.soc_f64.size() * sizeof(double)));
         SPCIES_HIP_CHECK(hipMemcpy(s.d_consts, s.soc_f64.data(), s.soc_f64.size() * sizeof(double), hipMemcpyHostToDevice));
         SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_idx, s.soc_i32.size() * sizeof(int)));
@@ -572,6 +663,7 @@ static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
     if (s.tv || s.host.ellip) return SPCIES_VARIANT_STREAM;
     if (s.is_hdense()) return SPCIES_VARIANT_GEMM;
+    if (s.is_cs()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.is_hmpc() && s.hgemm.ok) return SPCIES_VARIANT_GEMM;
     if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
@@ -588,6 +680,7 @@ static size_t stream_scratch_bytes(const Solver &s, long B, bool want_sol) {
     if (s.method == SPCIES_EADMM)
         rows = (size_t)(3 * s.host.N + 5) * (s.host.n + s.host.m) + (size_t)s.host.N * s.host.n;
     if (s.is_soc()) rows = 4 * (size_t)(s.sdev.dim + s.sdev.n_s) + 2 * (size_t)(s.sdev.n_eq + s.sdev.n_s) + (size_t)s.sdev.dim;
+    if (s.is_cs()) rows = 4 * (size_t)s.cdev.dim + (size_t)s.cdev.nrow + 2 * (size_t)(s.cdev.n + s.cdev.m);
     if (s.is_hmpc())
         rows = 2 * (size_t)(s.hdev.dim + s.hdev.n_s) + (size_t)s.hdev.nrow_M + (size_t)(s.hdev.n_eq + s.hdev.n_s) + (size_t)s.hdev.dim;
     return rows * (size_t)Bp * sizeof(double);
@@ -806,6 +899,60 @@ static int launch_soc(Solver &s, const double *x0, const double *xr, const doubl
     return 0;
 }
 
+// MPCT ADMM cs: STREAM (record z, v, lambda = row slices Z, V, LAM) and TILE (V | LAM | Z per tile)
+static int launch_cs_stream(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u,
+                            int *k, int *e, double *const *f, hipStream_t st) {
+    const long Bp = (B + 63) / 64 * 64;
+    const CsDev &d = s.cdev;
+    double *S = s.d_scratch;
+    hipLaunchKernelGGL(cs_stream_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, st, d, s.d_consts, s.d_idx, x0, xr, ur, ref_stride,
+                       B, Bp, S, u, k, e);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    for (int i = 0; i < 3; i++) {
+        if (!f[i]) continue;
+        dim3 tg((unsigned)(Bp / 64), (unsigned)((d.dim + 63) / 64));
+        hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, S + (long)i * d.dim * Bp, Bp, B, d.dim, f[i]);
+    }
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int launch_cs_tile(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u,
+                          int *k, int *e, double *const *f, hipStream_t st) {
+    const int lpi = s.tdev.lpi, T = 64 / lpi;
+    const CsDev &d = s.cdev;
+    const long tiles = ((B + T - 1) / T + tile::WAVES - 1) / tile::WAVES * tile::WAVES;
+    const long rows = 3L * d.dim + d.n + 2 * (d.n + d.m);
+    double *S = s.d_scratch;
+    const size_t shmem = s.tdev.lds_bytes * tile::WAVES;
+    dim3 grid((unsigned)(tiles / tile::WAVES)), block(64 * tile::WAVES);
+#define SPCIES_CS_LAUNCH(LPI)                                                                                              \
+    do {                                                                                                                   \
+        auto kern = tile::cs_tile_kernel<LPI>;                                                                             \
+        if (shmem > 48 * 1024)                                                                                             \
+            SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+        hipLaunchKernelGGL(kern, grid, block, shmem, st, d, s.tdev, s.d_consts, s.d_recs, x0, xr, ur, ref_stride, B, S, k, e); \
+    } while (0)
+    if (lpi == 4) SPCIES_CS_LAUNCH(4);
+    else if (lpi == 8) SPCIES_CS_LAUNCH(8);
+    else if (lpi == 16) SPCIES_CS_LAUNCH(16);
+    else if (lpi == 32) SPCIES_CS_LAUNCH(32);
+    else SPCIES_CS_LAUNCH(64);
+#undef SPCIES_CS_LAUNCH
+    SPCIES_HIP_CHECK(hipGetLastError());
+    auto gather = [&](long row0, int nrows, double *out) {
+        const long total = B * (long)nrows;
+        hipLaunchKernelGGL(tile::tile_rows_to_aos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, rows, T,
+                           (int)row0, nrows, B, out);
+    };
+    gather(2 * d.n, d.m, u);  // u = v[2n .. 2n+m) (:229-231)
+    const long base[3] = {2L * d.dim, 0, d.dim};  // z, v, lambda = Z | V | LAM
+    for (int i = 0; i < 3; i++)
+        if (f[i]) gather(base[i], d.dim, f[i]);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int launch_hmpc(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u,
                        int *k, int *e, double *const *f, hipStream_t st) {
     const long Bp = (B + 63) / 64 * 64;
@@ -831,6 +978,7 @@ static int launch_hmpc(Solver &s, const double *x0, const double *xr, const doub
 static size_t tile_scratch_bytes(const Solver &s, long B) {
     if (!s.tdev.lpi) return 0;
     const long T = 64 / s.tdev.lpi, tiles = ((B + T - 1) / T + tile::WAVES - 1) / tile::WAVES * tile::WAVES;
+    if (s.is_cs()) return (size_t)tiles * (3L * s.cdev.dim + s.cdev.n + 2 * (s.cdev.n + s.cdev.m)) * T * sizeof(double);
     const long np = s.soc_dim() + s.soc_ns();
     const long rows = s.is_hmpc() ? 3 * np + (s.hdev.n_eq + s.hdev.n_s) + s.hdev.dim : 3 * np + (s.sdev.n_eq + s.sdev.n_s) + s.sdev.dim;
     return (size_t)tiles * rows * T * sizeof(double);
@@ -940,6 +1088,19 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
     if (B <= 0) return 0;
     if (s.is_soc() && !s.is_hmpc() && !extra)
         return fail(SPCIES_HIP_EINVAL, "ellipMPC soc solvers take a 4th input r (extra): Spcies:ellipMPC:nrhs:r");
+    if (s.is_cs()) {
+        s.cdev.k_max = s.host.k_max; s.cdev.tol = s.host.tol;  // set_exit overrides
+        if (resolve_variant(s) == SPCIES_VARIANT_TILE) {
+            if (!s.tdev.lpi) return fail(SPCIES_HIP_ENOSUP, "TILE variant not available: the LDL right-hand side does not fit the LDS");
+            int rc = ensure_scratch(s, tile_scratch_bytes(s, B));
+            if (rc) return rc;
+            return launch_cs_tile(s, x0, xr, ur, ref_stride, B, u, k, e, f, st);
+        }
+        if (resolve_variant(s) != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "MPCT ADMM cs: variants STREAM and TILE are built");
+        int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
+        if (rc) return rc;
+        return launch_cs_stream(s, x0, xr, ur, ref_stride, B, u, k, e, f, st);
+    }
     if (s.is_hdense()) {
         if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_GEMM)
             return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variant GEMM is built");
@@ -1181,7 +1342,7 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
     info->formulation = s->formulation;
     info->method = s->method;
     info->submethod = s->submethod;
-    info->n = s->host.n; info->m = s->host.m; info->N = s->host.N; info->dim = s->is_soc() ? s->soc_dim() : (s->is_hdense() ? s->hd_host.dim : s->host.dim());
+    info->n = s->host.n; info->m = s->host.m; info->N = s->host.N; info->dim = s->is_soc() ? s->soc_dim() : (s->is_hdense() ? s->hd_host.dim : (s->is_cs() ? s->cdev.dim : s->host.dim()));
     info->k_max = s->host.k_max; info->tol = s->host.tol; info->rho = s->host.rho;
     info->variant = resolve_variant(*s);
     info->dim_lambda = s->lam_dim();
@@ -1201,6 +1362,12 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     }
     if (variant == SPCIES_VARIANT_GEMM && !(s->is_hmpc() && s->hgemm.ok))
         return fail(SPCIES_HIP_ENOSUP, "GEMM variant: built for HMPC split solvers whose blob carries M1, M2 (%s)", s->hgemm.why.c_str());
+    if (s->is_cs()) {
+        if (variant != SPCIES_VARIANT_AUTO && variant != SPCIES_VARIANT_STREAM && !(variant == SPCIES_VARIANT_TILE && s->tdev.lpi))
+            return fail(SPCIES_HIP_ENOSUP, "MPCT ADMM cs: variants STREAM and TILE (when the right-hand side fits the LDS) are built");
+        s->variant = variant;
+        return 0;
+    }
     if (variant == SPCIES_VARIANT_TILE && !(s->is_soc() && s->tdev.lpi))
         return fail(SPCIES_HIP_ENOSUP, "TILE variant: built for the sparse-KKT solvers (ellipMPC soc, HMPC) whose LDL right-hand side fits the LDS");
     if (variant == SPCIES_VARIANT_MFMA4G && !s->g4plan.ok)

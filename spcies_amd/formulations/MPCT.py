@@ -89,3 +89,76 @@ def compute_MPCT_EADMM_ingredients(controller, opt):
     v["rho_is_scalar"] = True
     v["dim"] = (N + 1) * nm
     return v
+
+
+def compute_MPCT_ADMM_cs_ingredients(controller, opt):
+    """MPCT ADMM on the extended state space ('cs' submethod):
+    ``formulations/+MPCT/compute_MPCT_ADMM_cs_ingredients.m:69-141``.  Stage variable ``(x_j, x_s, u_j, u_s)`` of
+    ``2(n+m)`` entries (the artificial reference is repeated in every stage and tied by equality rows),
+    ``dim = 2N(n+m)``; ``W = Aeq Hhat^-1 Aeq'`` factorised ``L D L'`` from its Cholesky factor (no permutation);
+    ``-Aeq Hhat^-1``, ``-Hhat^-1 Aeq'`` and ``-Hhat^-1`` in CSR."""
+    from .. import sp_utils
+    sys, param = _get(controller, "sys"), _get(controller, "param")
+    A = np.asarray(_get(sys, "A"), dtype=float)
+    B = np.asarray(_get(sys, "B"), dtype=float)
+    n, m = B.shape
+    nm, dnm = n + m, 2 * (n + m)
+    N = int(_get(param, "N"))
+    Q, R = np.asarray(_get(param, "Q"), float), np.asarray(_get(param, "R"), float)
+    T, S = np.asarray(_get(param, "T"), float), np.asarray(_get(param, "S"), float)
+    inf_value = float(opt.inf_value)
+    bnd = lambda name, sign: np.ravel(np.asarray(_get(sys, name, sign * inf_value * np.ones(n if "x" in name else m)), dtype=float))
+    LBx, UBx, LBu, UBu = bnd("LBx", -1), bnd("UBx", 1), bnd("LBu", -1), bnd("UBu", 1)
+    so = opt.solver
+    rho = so["rho"]
+    if np.isscalar(rho) and so.get("force_vector_rho", False):  # (:71-75; the vector has one entry per decision variable)
+        rho = float(rho) * np.ones(N * dnm)
+    rho_is_scalar = bool(np.isscalar(rho) or np.size(rho) == 1)
+    rho = float(np.ravel(rho)[0]) if rho_is_scalar else np.ravel(np.asarray(rho, dtype=float))
+    if not rho_is_scalar and rho.size != N * dnm:
+        raise ValueError("MPCT ADMM cs: a vector rho needs 2 N (n + m) entries")
+    # Hessian (:83-91)
+    Qz = np.block([[Q, -Q], [-Q, Q + T / N]])
+    Rz = np.block([[R, -R], [-R, R + S / N]])
+    Hs = np.block([[Qz, np.zeros((2 * n, 2 * m))], [np.zeros((2 * m, 2 * n)), Rz]])
+    Hhat = np.kron(np.eye(N), Hs) + (rho * np.eye(N * dnm) if rho_is_scalar else np.diag(rho))
+    # equality constraints (:96-110)
+    Z = np.zeros
+    AA = np.block([[A, Z((n, n))], [Z((n, n)), np.eye(n)], [Z((m, 2 * n))]])
+    BB = np.block([[B, Z((n, m))], [Z((n, 2 * m))], [Z((m, m)), np.eye(m)]])
+    II = np.block([[-np.eye(n), Z((n, n + 2 * m))], [Z((n, n)), -np.eye(n), Z((n, 2 * m))], [Z((m, 2 * n + m)), -np.eye(m)]])
+    rs = 2 * n + m
+    Aeq = Z(((N - 1) * rs + n, N * dnm))
+    for j in range(N - 1):
+        Aeq[j * rs:(j + 1) * rs, j * dnm:(j + 1) * dnm] = np.hstack([AA, BB])
+        Aeq[j * rs:(j + 1) * rs, (j + 1) * dnm:(j + 2) * dnm] = II
+    Aeq[(N - 1) * rs:, (N - 1) * dnm:] = np.hstack([A, -np.eye(n), B, Z((n, m))])
+    init = np.block([[np.eye(n), Z((n, n + 2 * m))], [Z((n, n)), A - np.eye(n), Z((n, m)), B]])
+    Aeq = np.vstack([np.hstack([init, Z((2 * n, N * dnm - dnm))]), Aeq])
+    # bounds (:116-122)
+    eps_x, eps_u = float(so["epsilon_x"]), float(so["epsilon_u"])
+    LBs = np.concatenate([LBx, LBx + eps_x, LBu, LBu + eps_u])
+    UBs = np.concatenate([UBx, UBx - eps_x, UBu, UBu - eps_u])
+    # W = Aeq Hhat^-1 Aeq' and its L D L' (:125-134)
+    Hinv = np.linalg.inv(Hhat)
+    W = Aeq @ Hinv @ Aeq.T
+    Wc = np.linalg.cholesky(W).T
+    wd = np.diag(Wc)
+    L = Wc.T / wd[None, :]  # (a division, so that the diagonal is exactly 1 and L - I strictly lower triangular)
+    Lv, Lr, Lc, *_ = sp_utils.full2CSC(L - np.eye(L.shape[0]))
+    csr = lambda M: sp_utils.full2CSR(M)[:3]
+    v = dict(n=n, m=m, N=N, formulation="MPCT", method="ADMM", submethod="cs", terminal=True, dim=N * dnm,
+             nrow_AHi=Aeq.shape[0], rho_is_scalar=rho_is_scalar)
+    v["Tz"], v["Sz"] = -T / N, -S / N
+    v["LB"], v["UB"] = np.tile(LBs, N), np.tile(UBs, N)
+    v["rho"] = rho if rho_is_scalar else float(rho[0])
+    v["rho_i"] = 1.0 / v["rho"]
+    if not rho_is_scalar:
+        v["rho_cs"], v["rho_i_cs"] = rho, 1.0 / rho
+    v["L_val"], v["L_row"], v["L_col"], v["Dinv"] = Lv, Lr, Lc, 1.0 / (wd * wd)
+    v["AHi_val"], v["AHi_col"], v["AHi_row"] = csr(-Aeq @ Hinv)
+    v["HiA_val"], v["HiA_col"], v["HiA_row"] = csr(-Hinv @ Aeq.T)
+    v["Hi_val"], v["Hi_col"], v["Hi_row"] = csr(-Hinv)
+    v["k_max"], v["tol"] = int(so["k_max"]), float(so["tol"])
+    v["Aeq"], v["Hhat"] = Aeq, Hhat  # dense forms, for tests
+    return v

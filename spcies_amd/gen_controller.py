@@ -64,6 +64,12 @@ def cons_HMPC_ADMM_split_HIP(recipe, device=0):
     return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
 
 
+def cons_MPCT_ADMM_cs_HIP(recipe, device=0):
+    """MPCT ADMM on the extended state space (cons_MPCT_ADMM_cs_C.m:40-131)."""
+    v = _eng(_mpct.compute_MPCT_ADMM_cs_ingredients(recipe.controller, recipe.options), recipe)
+    return HipSolver(v, device=device, name=recipe.options.save_name, debug=recipe.options.debug)
+
+
 def cons_HMPC_ADMM_HIP(recipe, device=0):
     """HMPC ADMM without the splitting - the reference's default HMPC solver (cons_HMPC_ADMM_C.m:47-151)."""
     v = _eng(_hmpc.compute_HMPC_ADMM_ingredients(recipe.controller, recipe.options), recipe)
@@ -75,7 +81,7 @@ cons_HMPC_SADMM_split_HIP = cons_HMPC_ADMM_split_HIP  # same ingredients; the me
 _CONSTRUCTORS = {f.__name__: f for f in (cons_laxMPC_ADMM_HIP, cons_equMPC_ADMM_HIP, cons_laxMPC_FISTA_HIP,
                                          cons_equMPC_FISTA_HIP, cons_MPCT_EADMM_HIP, cons_ellipMPC_ADMM_HIP,
                                          cons_ellipMPC_ADMM_soc_HIP,
-                                         cons_HMPC_ADMM_split_HIP, cons_HMPC_ADMM_HIP)}
+                                         cons_HMPC_ADMM_split_HIP, cons_HMPC_ADMM_HIP, cons_MPCT_ADMM_cs_HIP)}
 _CONSTRUCTORS["cons_HMPC_SADMM_split_HIP"] = cons_HMPC_SADMM_split_HIP
 
 

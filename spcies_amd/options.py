@@ -63,6 +63,9 @@ _DEF_SOLVER = {
                                     sparse=False, use_soc=False, alpha=0.95),
     ("HMPC", "SADMM", "split"): dict(rho=1e-2, sigma=1e-2, tol_p=1e-4, tol_d=1e-4, k_max=1000, box_constraints=None,
                                      sparse=False, use_soc=False, alpha=0.95),
+    # formulations/+MPCT/def_options_MPCT_ADMM_cs.m
+    ("MPCT", "ADMM", "cs"): dict(rho=1e-2, epsilon_x=1e-6, epsilon_u=1e-6, tol=1e-4, tol_p=1e-4, tol_d=1e-4, k_max=1000,
+                                 force_vector_rho=False),
     ("MPCT", "EADMM", ""): dict(rho_base=3, rho_mult=20, epsilon_x=1e-6, epsilon_u=1e-6, tol=1e-4, k_max=1000),
 }
 
