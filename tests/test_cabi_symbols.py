@@ -76,3 +76,58 @@ def test_generic_mex_gateway_source_is_valid_c(tmp_path):
         f.write_text(src)
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                                "-I", os.path.join(ROOT, "tests", "mex_stub"), str(f)])
+
+
+_FUZZ_CONFIGS = ["C1", "C1_equ_FISTA", "C1_MPCT", "C1_soc", "C1_HMPC", "C1_HMPC_nosplit", "C1_MPCT_cs", "C1_ellip", "C1_lax_gen"]
+
+
+@pytest.mark.parametrize("cfg_name", _FUZZ_CONFIGS)
+def test_blob_parser_rejects_or_accepts_mutations_without_crashing(cfg_name):
+    """The blob is the drop-in boundary's only untrusted input: `spcies_hip_create` parses it before it touches a device, so the
+    parser can be exercised here.  Every well-formed blob is accepted by the parser (it then fails with ENODEV = -2 on a box
+    without a GPU); truncations, a directory entry pointing outside the blob, counts that disagree with n / m / N and index arrays
+    with out-of-range entries are refused with EINVAL = -1 - and nothing crashes on 200 seeded single-word mutations."""
+    import struct
+
+    import numpy as np
+    lib = _lib.load()
+    n = C.c_int(-1)
+    have_gpu = (lib.spcies_hip_device_count(C.byref(n)) == 0 and n.value > 0)
+    if have_gpu:
+        pytest.skip("parser-only test: on a GPU box create() succeeds and the solver tests cover it")
+    good = blob.pack(benchmarks.ingredients(benchmarks.config(cfg_name)))
+
+    def create(b):
+        h = C.c_void_p()
+        rc = lib.spcies_hip_create(bytes(b), len(b), 0, C.byref(h))
+        assert not h.value
+        return rc
+    assert create(good) == -2                                  # parsed; no device
+    assert create(good[:len(good) // 2]) == -1                 # truncated
+    n_arr = struct.unpack_from("<I", good, 8 + 4 * 10)[0]
+    assert n_arr >= 5
+    # split HMPC: M1 / M2 / bh_nat only enable the GEMM variant; non-split HMPC in diamond mode never reads d
+    optional = {"C1_HMPC": {68, 69, 70}, "C1_HMPC_nosplit": {77}}.get(cfg_name, set())
+    for i in range(n_arr):                                     # an entry that points past the end / holds too many elements
+        aid = struct.unpack_from("<I", good, blob.HEADER_BYTES + i * blob.ENTRY_BYTES)[0]
+        for field_off, val in ((8, len(good) + 64), (16, 1 << 40)):
+            b = bytearray(good)
+            struct.pack_into("<Q", b, blob.HEADER_BYTES + i * blob.ENTRY_BYTES + field_off, val)
+            assert create(b) == (-2 if aid in optional else -1), (i, aid, field_off)
+    b = bytearray(good)                                        # n disagrees with the arrays
+    struct.pack_into("<I", b, 8 + 4 * 6, struct.unpack_from("<I", good, 8 + 4 * 6)[0] + 1)
+    assert create(b) == -1
+    for i in range(n_arr):                                     # an index array with a negative / huge entry
+        aid, dtype, off, count = struct.unpack_from("<IIQQ", good, blob.HEADER_BYTES + i * blob.ENTRY_BYTES)
+        if dtype == 1 and count > 2:
+            for val in (-1, 1 << 30):
+                b = bytearray(good)
+                struct.pack_into("<i", b, off + 4 * (count // 2), val)
+                assert create(b) == -1, (aid, val)
+    rng = np.random.default_rng(5)
+    words = len(good) // 4
+    for _ in range(200):                                       # random single-word mutations: any verdict, no crash
+        b = bytearray(good)
+        w = int(rng.integers(0, min(words, (blob.HEADER_BYTES + n_arr * blob.ENTRY_BYTES) // 4 + 64)))
+        struct.pack_into("<I", b, 4 * w, int(rng.integers(0, 1 << 32)))
+        assert create(b) in (-1, -2, -3, -4)

@@ -50,7 +50,7 @@ def run_ex(cfg, name, B, variant=None):
     if variant:
         s.set_variant(variant)
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
-    extra = (cfg.param.r,) if cfg.formulation == "ellipMPC" else ()
+    extra = (cfg.param.r,) if (cfg.formulation == "ellipMPC" and getattr(cfg, "submethod", "") == "soc") else ()
     s(x0[:256], xr[:256], ur[:256], *extra, want_sol=False)
     s(x0, xr, ur, *extra, want_sol=False)  # first full-size call: scratch allocation, rocBLAS kernel selection for this shape
     u, k, e, sol = s(x0, xr, ur, *extra, want_sol=False)
