@@ -50,26 +50,51 @@ def traffic_from_profile(variant):
     return (2.0 * fetch + write) * 1024.0
 
 
-def cpu_baseline(cfg, v, n_sample, threads):
+def host_threads():
+    """Threads the CPU baseline may use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:  # cgroup v2, then v1
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = max(1, min(n, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(cfg, v, n_sample, threads, seconds=12.0):
     """Oracle (the C port of the reference's loop nests) on the host cores, bounded sample of the same workload:
-    every instance is solved by the scalar code, instances are spread over `threads` OpenMP threads (SURVEY 8d);
-    the one-thread rate is measured on a smaller sample of the same instances and reported next to it."""
+    every instance is solved by the scalar code, instances are spread over `threads` OpenMP threads.
+    The sample is sized from a short probe so that the timed run takes about `seconds`; the one-thread rate is
+    measured on a small sample of the same instances and reported next to it."""
     from oracle import oracle
     from spcies_amd import benchmarks
-    x0, xr, ur = benchmarks.sample_batch(cfg, n_sample, seed=cfg.seed + 1)
+    probe = 64 * threads
+    x0, xr, ur = benchmarks.sample_batch(cfg, max(probe, 1024), seed=cfg.seed + 1)
     oracle.admm_banded_batch(v, x0[:8], xr[:8], ur[:8], want_sol=False)  # warm
-    n1 = max(256, n_sample // (4 * max(threads, 1)))
     t = time.perf_counter()
-    oracle.admm_banded_batch(v, x0[:n1], xr[:n1], ur[:n1], want_sol=False)
+    oracle.admm_banded_batch(v, x0[:1024], xr[:1024], ur[:1024], want_sol=False)
     dt1 = time.perf_counter() - t
+    t = time.perf_counter()
+    oracle.admm_banded_batch(v, x0[:probe], xr[:probe], ur[:probe], want_sol=False, threads=threads)
+    rate = probe / (time.perf_counter() - t)
+    if not n_sample:
+        n_sample = int(min(max(rate * seconds, probe), 1 << 21))
+    x0, xr, ur = benchmarks.sample_batch(cfg, n_sample, seed=cfg.seed + 1)
     t = time.perf_counter()
     oracle.admm_banded_batch(v, x0, xr, ur, want_sol=False, threads=threads)
     dt = time.perf_counter() - t
     return {"value": n_sample / dt, "unit": "solves/s", "cores": threads, "kind": "port",
-            "one_thread_value": n1 / dt1,
+            "one_thread_value": 1024 / dt1, "speedup_over_one_thread": (n_sample / dt) / (1024 / dt1),
             "sample": f"{n_sample} seeded C2 instances, 200 iterations each, oracle/admm_banded_oracle.c "
                       f"(gcc -O3 -ffp-contract=off), {threads} OpenMP threads over instances, {dt:.1f} s "
-                      f"(+ {n1} of them on 1 thread, {dt1:.1f} s)"}
+                      f"(+ 1024 of them on 1 thread, {dt1:.1f} s)"}
 
 
 def main():
@@ -79,7 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--variant", default="auto", choices=["auto", "stream", "mfma", "mfma4"])
-    ap.add_argument("--cpu-sample", type=int, default=0, help="instances of the CPU baseline (0: 6144 per thread, at most 196608)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="instances of the CPU baseline (0: about 12 s of work, sized by a probe)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: all host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -191,8 +216,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if v is None:
                 v = benchmarks.ingredients(cfg)
-            threads = args.cpu_threads or len(os.sched_getaffinity(0))
-            out["cpu_baseline"] = cpu_baseline(cfg, v, args.cpu_sample or min(6144 * threads, 196608), threads)
+            out["cpu_baseline"] = cpu_baseline(cfg, v, args.cpu_sample, args.cpu_threads or host_threads())
             # the same run also re-checks the GPU result against the oracle on the first 64 instances
             from oracle import oracle
             uo, *_ = oracle.admm_banded_batch(v, x0[:64], xr[:64], ur[:64], want_sol=False)

@@ -275,6 +275,18 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
 #else
 #define SPCIES_SEG_BARRIER __builtin_amdgcn_sched_barrier(0)
 #endif
+    // requested issue pattern of a segment: after every MFMA, SPCIES_MFMA4_IL other VALU instructions and one LDS read -
+    // register moves, integer work and the block-stream reads then issue in the shadow of the 16-cycle MFMA before them
+#if defined(SPCIES_MFMA4_IL) && SPCIES_MFMA4_IL > 0
+#define SPCIES_SEG_PATTERN                                                   \
+    _Pragma("unroll") for (int il_ = 0; il_ < 30; il_++) {                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+        __builtin_amdgcn_sched_group_barrier(0x002, SPCIES_MFMA4_IL, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   \
+    }
+#else
+#define SPCIES_SEG_PATTERN
+#endif
 #define MFMA4(acc, a, b) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (acc), 0, 0, 0)
 
     for (long tile = (long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long)gridDim.x * 4) {
@@ -414,6 +426,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
                 mu[l] = acc;
                 qh = qn;
                 qn = qnn;
+                SPCIES_SEG_PATTERN
                 SPCIES_SEG_BARRIER;
             }
             // ============ backward sweep ============
@@ -466,6 +479,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
                 const int t = l + 2;
                 if (LL.stage_exists(t)) zc = stage_z(t, cwc);
                 mu[l] = acc;
+                SPCIES_SEG_PATTERN
                 SPCIES_SEG_BARRIER;
             }
             {

@@ -80,8 +80,22 @@ inline int compile_mfma4(Mfma4Module &out, int N, int KX, int KS, bool terminal)
             return fail(SPCIES_HIP_EHIP, "hiprtcAddNameExpression failed");
         }
     }
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans", "-DSPCIES_RTC_STATIC_LDS=1"};
-    const int crc = rt.compile(prog, 5, opts);
+    std::vector<std::string> extra;  // experiments: SPCIES_MFMA4_RTC_FLAGS holds extra options, blank-separated
+    if (const char *ev = getenv("SPCIES_MFMA4_RTC_FLAGS")) {
+        std::string tok;
+        for (const char *c = ev;; c++) {
+            if (*c == ' ' || *c == '\0') {
+                if (!tok.empty()) extra.push_back(tok);
+                tok.clear();
+                if (!*c) break;
+            } else {
+                tok.push_back(*c);
+            }
+        }
+    }
+    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans", "-DSPCIES_RTC_STATIC_LDS=1"};
+    for (const std::string &e : extra) opts.push_back(e.c_str());
+    const int crc = rt.compile(prog, (int)opts.size(), opts.data());
     if (crc != 0) {
         size_t ls = 0;
         rt.log_size(prog, &ls);

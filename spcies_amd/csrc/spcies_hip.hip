@@ -1299,6 +1299,12 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         if (s->mfma4.needs_rtc && !(ev && ev[0] == '0')) {
             if (ensure_mfma4_rtc(*s) != 0) s->mfma4.why = g_last_error;
         }
+        // kernel experiments: SPCIES_MFMA4_RTC_FLAGS="-DX=1 ..." re-specialises a built-in shape with extra compiler options
+        if (s->mfma4.ok && !s->mfma4_rtc.ok && getenv("SPCIES_MFMA4_RTC_FLAGS")) {
+            const Mfma4Layout &L = s->mfma4.lay;
+            rc = rtc::compile_mfma4(s->mfma4_rtc, L.N, L.KX, L.KS, L.terminal);
+            if (rc) return rc;
+        }
     }
     if (s->method == SPCIES_EADMM) {
         g4::EadmmGHost eh{&s->e_rho, &s->e_rho0, &s->e_rhos, &s->e_LB0, &s->e_UB0, &s->e_LBs, &s->e_UBs, &s->e_S, &s->e_H1i, &s->e_W2, &s->e_H3i};
