@@ -10,6 +10,8 @@
 // State in structure-of-arrays form [row][B_pad]:  T | Z | CI | S | LAM | ZF (record) | QC (the 2n + m non-zero rows of q).
 // Sums run in another order than the reference's loops (M1 C' is formed on the host, the product is blocked):
 // parity with the oracle to 1e-10, iteration counts equal except where a residual sits within rounding of the tolerance.
+// Variant STREAM (dense_stream_kernel below) is the reference-faithful form: one lane per instance, the reference's loops
+// in their order without FMA contraction -> bit-identical; M1 is read through scalar loads, eight rows per pass.
 #pragma once
 #include "hmpc_gemm.hpp"
 
@@ -19,8 +21,8 @@ namespace hdense {
 #pragma clang fp contract(fast)
 
 struct Dev {  // offsets (doubles) into the constants allocation / (ints) into the index allocation, dimensions, scalars
-    int M2xA, M1Q, QQ, Te, Se, LB, UB, LBy, UBy, Cval, dvec;
-    int Crow, Ccol;
+    int M2xA, M1Q, QQ, Te, Se, LB, UB, LBy, UBy, Cval, dvec, M1, M2, A, Ctval;
+    int Crow, Ccol, Ctrow, Ctcol;
     int n, m, N, dim, n_s, n_box, n_soc, k_max, use_soc, symmetric;
     double tol_p, tol_d, rho, rho_i, alpha;
 };
@@ -96,10 +98,18 @@ inline int plan_build(Plan &p, const Host &h) {
     std::vector<double> dv = h.d;
     if (dv.empty()) dv.assign(n_s, 0.0);
     d.dvec = put(dv.data(), dv.size());
+    d.M1 = put(h.M1.data(), h.M1.size());  // STREAM variant: the reference's own arrays
+    d.M2 = put(h.M2.data(), h.M2.size());
+    d.A = put(h.A.data(), h.A.size());
+    d.Ctval = put(h.Ct_val.data(), h.Ct_val.size());
     std::vector<int> idx(h.C_row);
     d.Crow = 0;
     d.Ccol = (int)idx.size();
     idx.insert(idx.end(), h.C_col.begin(), h.C_col.end());
+    d.Ctrow = (int)idx.size();
+    idx.insert(idx.end(), h.Ct_row.begin(), h.Ct_row.end());
+    d.Ctcol = (int)idx.size();
+    idx.insert(idx.end(), h.Ct_col.begin(), h.Ct_col.end());
     d.n = n; d.m = m; d.N = h.N; d.dim = dim; d.n_s = n_s; d.n_box = h.n_box; d.n_soc = h.n_soc; d.k_max = h.k_max;
     d.use_soc = h.use_soc; d.symmetric = h.symmetric;
     d.tol_p = h.tol_p; d.tol_d = h.tol_d; d.rho = h.rho; d.rho_i = h.rho_i; d.alpha = h.alpha;
@@ -302,6 +312,165 @@ inline int launch(Plan &p, const double *x0, const double *xr, const double *ur,
         if (!f[i]) continue;
         dim3 tg((unsigned)(Bp / 64), (unsigned)((src_rows[i] + 63) / 64));
         hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, Sc + src_row[i] * Bp, Bp, B, src_rows[i], f[i]);
+    }
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+#pragma clang fp contract(off)
+
+// ---- variant STREAM: one lane per instance, reference operation order (code_HMPC_ADMM_C.c:82-268), bit-identical.
+// scratch rows: Z (dim) | QH (dim) | S (n_s) | LAM (n_s) | CZ (n_s) | QV (dim) | BV (n)
+inline size_t stream_scratch_bytes(const Dev &d, long B) {
+    const long Bp = (B + 63) / 64 * 64;
+    return (size_t)(3L * d.dim + 3L * d.n_s + d.n) * Bp * sizeof(double);
+}
+__global__ __launch_bounds__(64) void dense_stream_kernel(Dev d, const double *__restrict__ C, const int *__restrict__ I,
+                                                          const double *__restrict__ x0g, const double *__restrict__ xrg,
+                                                          const double *__restrict__ urg, int ref_stride, long B, long Bp,
+                                                          double *__restrict__ Sc, double *__restrict__ u_out,
+                                                          int *__restrict__ k_out, int *__restrict__ e_out) {
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    if (t >= B) return;
+    const int n = d.n, m = d.m, nm = n + m, N = d.N, dim = d.dim, n_s = d.n_s;
+    double *Z = Sc + t, *QH = Z + (long)dim * Bp, *S = QH + (long)dim * Bp, *LAM = S + (long)n_s * Bp, *CZ = LAM + (long)n_s * Bp,
+           *QV = CZ + (long)n_s * Bp, *BV = QV + (long)dim * Bp;
+#define AT(P, i) (P)[(long)(i) * Bp]
+    const double *x0 = x0g + t * n, *xr = ref_stride ? xrg + t * n : xrg, *ur = ref_stride ? urg + t * m : urg;
+    const double *cA = C + d.A, *cQQ = C + d.QQ, *cTe = C + d.Te, *cSe = C + d.Se, *cLB = C + d.LB, *cUB = C + d.UB, *cLBy = C + d.LBy,
+                 *cUBy = C + d.UBy, *cCv = C + d.Cval, *cCtv = C + d.Ctval, *cd = C + d.dvec, *cM1 = C + d.M1, *cM2 = C + d.M2;
+    const int *Crow = I + d.Crow, *Ccol = I + d.Ccol, *Ctrow = I + d.Ctrow, *Ctcol = I + d.Ctcol;
+    // setup (:82-105)
+    for (int j = 0; j < n_s; j++) {
+        AT(S, j) = 0.0;
+        AT(LAM, j) = 0.0;
+    }
+    for (int j = 0; j < dim; j++) AT(QV, j) = 0.0;
+    for (int j = 0; j < n; j++) {
+        double b = 0.0;
+        for (int i = 0; i < n; i++) b -= cA[j * n + i] * x0[i];
+        AT(BV, j) = b;
+    }
+    const int q0 = (N - 1) * nm + m;
+    for (int j = 0; j < n; j++) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < n; i++) {
+            a -= cTe[j * n + i] * xr[i] + cQQ[j * n + i] * x0[i];
+            b -= cQQ[j * n + i] * x0[i];
+        }
+        AT(QV, q0 + j) = a;
+        AT(QV, q0 + 2 * n + j) = b;
+    }
+    for (int j = 0; j < m; j++) {
+        double a = 0.0;
+        for (int i = 0; i < m; i++) a -= cSe[j * m + i] * ur[i];
+        AT(QV, q0 + 3 * n + j) = a;
+    }
+    const double rho = d.rho, rho_i = d.rho_i, ar = d.alpha * d.rho;
+    int k = 0, flag = -1;
+    while (true) {
+        k += 1;
+        // q_hat = q + C'(rho (s - d) + lambda)  (:123-137)
+        for (int i = 0; i < n_s; i++) AT(CZ, i) = d.use_soc ? rho * (AT(S, i) - cd[i]) + AT(LAM, i) : rho * AT(S, i) + AT(LAM, i);
+        for (int i = 0; i < dim; i++) {
+            double a = AT(QV, i);
+            for (int j = Ctrow[i]; j < Ctrow[i + 1]; j++) a += cCtv[j] * AT(CZ, Ctcol[j]);
+            AT(QH, i) = a;
+        }
+        // z = M2 b + M1 q_hat  (:145-157): eight rows per pass over q_hat, every row summed in the reference's order
+        for (int i0 = 0; i0 < dim; i0 += 8) {
+            double acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) acc[r] = 0.0;
+            for (int j = 0; j < n; j++) {
+                const double bj = AT(BV, j);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int i = min(i0 + r, dim - 1);
+                    acc[r] += cM2[(long)i * n + j] * bj;
+                }
+            }
+            for (int j = 0; j < dim; j++) {
+                const double qj = AT(QH, j);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int i = min(i0 + r, dim - 1);
+                    acc[r] += cM1[(long)i * dim + j] * qj;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if (i0 + r < dim) AT(Z, i0 + r) = acc[r];
+        }
+        // C z - d (:161-170), symmetric half step (:174-180), s (:184-204), C z + s, lambda (:207-225), residuals (:229-245)
+        bool res = false;
+        auto cz_row = [&](int i) {
+            double a = d.use_soc ? -cd[i] : 0.0;
+            for (int j = Crow[i]; j < Crow[i + 1]; j++) a += cCv[j] * AT(Z, Ccol[j]);
+            return a;
+        };
+        auto finish_row = [&](int i, double cz, double lam, double so, double s) {
+            cz += s;
+            lam += d.symmetric ? ar * cz : rho * cz;
+            AT(S, i) = s;
+            AT(LAM, i) = lam;
+            res = res || (fabs(cz) > d.tol_p) || (fabs(s - so) > d.tol_d);
+        };
+        for (int i = 0; i < d.n_box; i++) {
+            const double cz = cz_row(i), so = AT(S, i);
+            double lam = AT(LAM, i);
+            if (d.symmetric) lam += ar * (cz + so);
+            double s = -cz - rho_i * lam;
+            s = clamp_ref(s, cLB[i], cUB[i]);
+            finish_row(i, cz, lam, so, s);
+        }
+        for (int j = 0; j < d.n_soc; j++) {
+            double cz[3], so[3], lam[3], s[3];
+            for (int r = 0; r < 3; r++) {
+                const int i = d.n_box + 3 * j + r;
+                cz[r] = cz_row(i);
+                so[r] = AT(S, i);
+                lam[r] = AT(LAM, i);
+                if (d.symmetric) lam[r] += ar * (cz[r] + so[r]);
+                s[r] = -cz[r] - rho_i * lam[r];
+            }
+            if (d.use_soc) {
+                proj_soc3(s[0], s[1], s[2], 1.0, 0.0);
+            } else {
+                proj_soc3(s[0], s[1], s[2], 1.0, cLBy[j]);
+                proj_soc3(s[0], s[1], s[2], -1.0, cUBy[j]);
+            }
+            for (int r = 0; r < 3; r++) finish_row(d.n_box + 3 * j + r, cz[r], lam[r], so[r], s[r]);
+        }
+        if (!res) {
+            flag = 1;
+            break;
+        }
+        if (k >= d.k_max) {
+            flag = -1;
+            break;
+        }
+    }
+    for (int j = 0; j < m; j++) u_out[t * m + j] = AT(Z, j);
+#undef AT
+    k_out[t] = k;
+    e_out[t] = flag;
+}
+
+inline int launch_stream(Plan &p, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *scratch,
+                         double *u, int *k, int *e, double *const *f, hipStream_t st) {
+    if (!p.ok) return fail(SPCIES_HIP_ENOSUP, "HMPC solver unavailable: %s", p.why.c_str());
+    const Dev &d = p.dev;
+    const long Bp = (B + 63) / 64 * 64;
+    hipLaunchKernelGGL(dense_stream_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, st, d, p.d_C, p.d_I, x0, xr, ur, ref_stride, B, Bp,
+                       scratch, u, k, e);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    const long src_row[3] = {0, 2L * d.dim, 2L * d.dim + d.n_s};  // z, s, lambda = Z | S | LAM
+    const int src_rows[3] = {d.dim, d.n_s, d.n_s};
+    for (int i = 0; i < 3; i++) {
+        if (!f[i]) continue;
+        dim3 tg((unsigned)(Bp / 64), (unsigned)((src_rows[i] + 63) / 64));
+        hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, scratch + src_row[i] * Bp, Bp, B, src_rows[i], f[i]);
     }
     SPCIES_HIP_CHECK(hipGetLastError());
     return 0;

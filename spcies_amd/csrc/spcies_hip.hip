@@ -1102,12 +1102,14 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         return launch_cs_stream(s, x0, xr, ur, ref_stride, B, u, k, e, f, st);
     }
     if (s.is_hdense()) {
-        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_GEMM)
-            return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variant GEMM is built");
-        int rc = ensure_scratch(s, hdense::scratch_bytes(s.hd_plan.dev, B));
-        if (rc) return rc;
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_GEMM && s.variant != SPCIES_VARIANT_STREAM)
+            return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variants GEMM and STREAM are built");
         hdense::Dev &hd = s.hd_plan.dev;
         hd.k_max = s.hd_host.k_max; hd.tol_p = s.hd_host.tol_p; hd.tol_d = s.hd_host.tol_d;  // set_exit overrides
+        const bool stream = s.variant == SPCIES_VARIANT_STREAM;
+        int rc = ensure_scratch(s, stream ? hdense::stream_scratch_bytes(hd, B) : hdense::scratch_bytes(hd, B));
+        if (rc) return rc;
+        if (stream) return hdense::launch_stream(s.hd_plan, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f, st);
         return hdense::launch(s.hd_plan, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f, st);
     }
     if (s.is_hmpc() && resolve_variant(s) == SPCIES_VARIANT_GEMM) {
@@ -1361,8 +1363,8 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     Solver *s = reinterpret_cast<Solver *>(h);
     if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_GEMM) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
     if (s->is_hdense()) {
-        if (variant != SPCIES_VARIANT_AUTO && variant != SPCIES_VARIANT_GEMM)
-            return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variant GEMM is built");
+        if (variant != SPCIES_VARIANT_AUTO && variant != SPCIES_VARIANT_GEMM && variant != SPCIES_VARIANT_STREAM)
+            return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variants GEMM and STREAM are built");
         s->variant = variant;
         return 0;
     }
@@ -1405,7 +1407,8 @@ int spcies_hip_reserve(spcies_hip_handle h, long B) {
     Solver *s = reinterpret_cast<Solver *>(h);
     std::lock_guard<std::mutex> lk(s->mu);
     SPCIES_HIP_CHECK(hipSetDevice(s->device));
-    if (s->is_hdense()) return ensure_scratch(*s, hdense::scratch_bytes(s->hd_plan.dev, B));
+    if (s->is_hdense())
+        return ensure_scratch(*s, std::max(hdense::scratch_bytes(s->hd_plan.dev, B), hdense::stream_scratch_bytes(s->hd_plan.dev, B)));
     size_t need = stream_scratch_bytes(*s, B, true);
     if (s->g4plan.ok && s->method == SPCIES_FISTA) need = std::max(need, g4::fista_state_bytes(s->g4plan, s->host, B));
     if (s->g4plan.ok && s->method == SPCIES_ADMM && !s->is_soc()) need = std::max(need, g4::admm_state_bytes(s->g4plan, s->host, B));

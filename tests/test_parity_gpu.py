@@ -460,8 +460,14 @@ def test_hmpc_vs_reference_template_fixture(variant, golden_dir):
 # ----------------------------------------------------------------------------------------------
 # HMPC ADMM / SADMM without the splitting (the reference's default HMPC solver; dense M1, M2): GEMM variant -> 1e-10
 # ----------------------------------------------------------------------------------------------
-def _compare_hmpc_nosplit(got, O):
+def _compare_hmpc_nosplit(got, O, variant="gemm"):
     u, k, e, sol = got
+    if variant == "stream":  # the reference's loops in their order: bit-identical
+        assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+        if sol.z is not None:
+            for name, ref in zip(("z", "s", "lam"), O[3:]):
+                assert np.array_equal(getattr(sol, name), ref), name
+        return
     dk = np.abs(np.asarray(k).astype(int) - O[1].astype(int))
     assert dk.max() <= 1 and (dk > 0).mean() <= 1e-3 + 1.0 / max(len(dk), 1) * (len(dk) < 1000)
     same = dk == 0
@@ -479,10 +485,11 @@ def _compare_hmpc_nosplit(got, O):
     ("C1_HMPC_SADMM_soc_nosplit", 20, {}), ("C5_HMPC_SADMM_nosplit", 65, {}),
     ("C5_HMPC_SADMM_nosplit", 12, dict(tol_p=1e-5, tol_d=1e-5, k_max=2500)),
 ])
-def test_hmpc_nosplit_seeded_batch_vs_oracle(cfg_name, B, overrides):
+@pytest.mark.parametrize("variant", ["gemm", "stream"])
+def test_hmpc_nosplit_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
-    cfg, v, s = _fista_solver(cfg_name, "gemm", **overrides)
+    cfg, v, s = _fista_solver(cfg_name, variant, **overrides)
     assert [f for f, _ in s.sol_fields] == ["z", "s", "lambda"]  # header_HMPC_ADMM_C.h:14-22
     assert dict(s.sol_fields) == {"z": v["dim"], "s": v["n_s"], "lambda": v["n_s"]}
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
@@ -490,7 +497,7 @@ def test_hmpc_nosplit_seeded_batch_vs_oracle(cfg_name, B, overrides):
         st = benchmarks.tester_status(cfg.sys)
         x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
     got = s(x0, xr, ur)
-    _compare_hmpc_nosplit(got, oracle.hmpc_dense_batch(v, x0, xr, ur))
+    _compare_hmpc_nosplit(got, oracle.hmpc_dense_batch(v, x0, xr, ur), variant)
     nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
     assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
 
