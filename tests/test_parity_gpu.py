@@ -583,6 +583,37 @@ def test_mpct_cs_vs_reference_template_fixture(variant, golden_dir):
 
 
 # ----------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 at their per-GPU sizes: size-independent properties on the default (AUTO) variants
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg_name,B,fn,extra", [
+    ("C4", 131072, "eadmm_mpct_batch", False),          # MPCT-EADMM shard of 1 048 576 / 8 (MFMA4G)
+    ("C5_soc", 65536, "admm_soc_batch", True),          # ellipMPC-ADMM-soc shard of 524 288 / 8 (TILE)
+    ("C5_HMPC_SADMM", 65536, "admm_hmpc_batch", False), # HMPC-SADMM split shard (GEMM = the reference's NON_SPARSE path)
+    ("C5_HMPC_SADMM_nosplit", 65536, "hmpc_dense_batch", False),
+])
+def test_configs_4_and_5_full_size_properties(cfg_name, B, fn, extra):
+    """200 fixed iterations on every instance, inputs inside their box, determinism (two runs agree bit for bit), shard
+    invariance (the two halves solved separately give the full batch's answer), and a random subset against the oracle."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver(cfg_name)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    ex = (cfg.param.r + 0.3 * np.random.default_rng(4).random(B),) if extra else ()
+    u, k, e, _ = s(x0, xr, ur, *ex, want_sol=False)
+    assert (k == 200).all() and (e == -1).all() and np.isfinite(u).all()
+    u2, k2, *_ = s(x0, xr, ur, *ex, want_sol=False)
+    assert np.array_equal(u2, u) and np.array_equal(k2, k)
+    h = B // 2
+    ua, *_ = s(x0[:h], xr[:h], ur[:h], *(a[:h] for a in ex), want_sol=False)
+    ub, *_ = s(x0[h:], xr[h:], ur[h:], *(a[h:] for a in ex), want_sol=False)
+    assert np.array_equal(np.vstack([ua, ub]), u)
+    idx = np.sort(np.random.default_rng(9).choice(B, 24, replace=False))
+    kw = dict(sparse=False) if fn == "admm_hmpc_batch" else {}
+    O = getattr(oracle, fn)(v, x0[idx], xr[idx], ur[idx], *(a[idx] for a in ex), want_sol=False, **kw)
+    assert np.abs(u[idx] - O[0]).max() <= TOL_SPCIES
+
+
+# ----------------------------------------------------------------------------------------------
 # Closed-loop batch simulation on the device (SURVEY section 8f rank 4; examples/cl_in_C/main_cl_in_C.c:98-117)
 # ----------------------------------------------------------------------------------------------
 def _plant_step_ref(AB, x, u):
