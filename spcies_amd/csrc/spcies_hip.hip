@@ -26,6 +26,7 @@ thread_local std::string g_last_error;
 
 struct Solver {
     int device = 0;
+    bool device_bound = false;  // hipSetDevice(device) succeeded: device resources may exist
     int formulation = 0, method = 0, submethod = 0;
     int variant = SPCIES_VARIANT_AUTO;
     AdmmHost host;
@@ -1257,10 +1258,31 @@ int spcies_hip_device_count(int *count) {
     return 0;
 }
 
+// releases everything a (possibly half-built) solver owns: the deleter of create()'s guard and the body of destroy()
+static void free_solver(Solver *s) {
+    if (!s) return;
+    if (s->device_bound) hipSetDevice(s->device);
+    if (s->d_consts) hipFree(s->d_consts);
+    if (s->d_scratch) hipFree(s->d_scratch);
+    if (s->d_io) hipFree(s->d_io);
+    if (s->d_idx) hipFree(s->d_idx);
+    if (s->d_recs) hipFree(s->d_recs);
+    hgemm::plan_free(s->hgemm);
+    hdense::plan_free(s->hd_plan);
+    if (s->d_eng) hipFree(s->d_eng);
+    if (s->d_eng_in) hipFree(s->d_eng_in);
+    mfma_plan_free(s->mfma);
+    mfma4_plan_free(s->mfma4);
+    rtc::module_free(s->mfma4_rtc);
+    g4::plan_free(s->g4plan);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
 int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_handle *out) {
     if (!out) return fail(SPCIES_HIP_EINVAL, "out is NULL");
     *out = nullptr;
-    std::unique_ptr<Solver> s(new Solver);
+    std::unique_ptr<Solver, void (*)(Solver *)> s(new Solver, free_solver);  // an error return below frees what was built so far
     int rc = parse_blob(blob, bytes, *s);
     if (rc) return rc;
     int ndev = 0;
@@ -1269,6 +1291,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     if (device < 0 || device >= ndev) return fail(SPCIES_HIP_EINVAL, "device %d out of range (0..%d)", device, ndev - 1);
     s->device = device;
     SPCIES_HIP_CHECK(hipSetDevice(device));
+    s->device_bound = true;
     SPCIES_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     rc = upload_consts(*s);
     if (rc) return rc;
@@ -1324,23 +1347,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
 
 int spcies_hip_destroy(spcies_hip_handle h) {
     if (!h) return 0;
-    Solver *s = reinterpret_cast<Solver *>(h);
-    hipSetDevice(s->device);
-    if (s->d_consts) hipFree(s->d_consts);
-    if (s->d_scratch) hipFree(s->d_scratch);
-    if (s->d_io) hipFree(s->d_io);
-    if (s->d_idx) hipFree(s->d_idx);
-    if (s->d_recs) hipFree(s->d_recs);
-    hgemm::plan_free(s->hgemm);
-    hdense::plan_free(s->hd_plan);
-    if (s->d_eng) hipFree(s->d_eng);
-    if (s->d_eng_in) hipFree(s->d_eng_in);
-    mfma_plan_free(s->mfma);
-    mfma4_plan_free(s->mfma4);
-    rtc::module_free(s->mfma4_rtc);
-    g4::plan_free(s->g4plan);
-    if (s->stream) hipStreamDestroy(s->stream);
-    delete s;
+    free_solver(reinterpret_cast<Solver *>(h));
     return 0;
 }
 
