@@ -1,0 +1,620 @@
+// Variant BSP ("block-sparse program") of the ellipMPC ADMM soc solver (code_ellipMPC_ADMM_soc_C.c:84-296): the sparse
+// KKT machinery on the FP64 matrix pipe.  The controller's sparse matrices - the L D L' factor of W, -Gh Hh^-1,
+// -Hh^-1 Gh', -Hh^-1 - are block-sparse with dense 4x4 blocks (banded KKT structure), so one ADMM iteration is a FIXED
+// sequence of v_mfma_f64_4x4x4 block products on 16 instances per wavefront (the MFMA4 lane layout, admm_mfma4.hpp:
+// a register holds rows 4s+g of slab s for instance c = lane % 16, g = lane / 16; D layout == B layout).  Spcies is a
+// code generator - its C platform prints one solver per controller - and so is this variant: the host emits the program
+// as straight-line HIP (every register index and table offset a literal), hiprtc compiles it at create time, the blocks
+// sit in LDS in issue order, the solver state (z, s, lambda, mu, the right-hand side) lives in registers for the whole
+// solve.  C5 soc: 1 012 MFMAs per iteration for 16 instances, against TILE's ~900 dependent LDS steps for 2.
+//
+// Internal row layout: z in slabs 0 .. ZS-1 (dim rows, zero padded), s in the next SS slabs (so no slab mixes z and s
+// rows); the rows of the right-hand side in their natural order.  Triangular solves by blocks with the diagonal blocks
+// inverted on the host:  x_I = Linv_II rhs_I - sum_{J<I} (Linv_II L_IJ) x_J ;  y_I = (Uinv_II Dinv_I) x_I - sum_{J>I}
+// (Uinv_II U_IJ) y_J  (U = L').  Sums run in another order than the reference's loops: parity 1e-10, not bit-exact.
+#pragma once
+#include <map>
+
+#include "mfma4_rtc.hpp"
+#include "soc_stream.hpp"
+
+namespace spcies {
+namespace bsp {
+
+struct Args {  // mirrored in the generated source
+    int n, m, N, dim, n_s, n_eq, k_max, ref_stride, r_stride, pad;
+    double tol_p, tol_d, rho, rho_i, sigma, sigma_i;
+    long B;
+};
+
+struct Plan {
+    bool ok = false;
+    std::string why = "not built";
+    std::string src;             // generated kernel source
+    std::vector<double> table;   // blocks in issue order, then LB / UB rows (internal layout)
+    int n_blocks = 0, ZS = 0, SS = 0, NR = 0, n_mfma = 0;
+    double *d_table = nullptr, *d_consts = nullptr;  // d_consts: A | Q | R | T | PhiP (dense, for the per-instance setup)
+    hipModule_t module = nullptr;
+    hipFunction_t fn[2] = {nullptr, nullptr};
+    Args args{};
+    int num_cu = 256;
+};
+inline void plan_free(Plan &p) {
+    if (p.module) hipModuleUnload(p.module);
+    if (p.d_table) hipFree(p.d_table);
+    if (p.d_consts) hipFree(p.d_consts);
+    p.module = nullptr;
+    p.d_table = p.d_consts = nullptr;
+    p.ok = false;
+}
+
+typedef std::vector<double> Dense;  // row-major
+
+struct BlockList {  // non-zero 4x4 blocks of a matrix, row-wise and column-wise
+    int R = 0, C = 0;
+    std::vector<std::vector<int>> by_row, by_col;
+};
+inline BlockList blocks_of(const Dense &M, int rows, int cols) {
+    BlockList b;
+    b.R = rows / 4;
+    b.C = cols / 4;
+    b.by_row.resize(b.R);
+    b.by_col.resize(b.C);
+    for (int I = 0; I < b.R; I++)
+        for (int J = 0; J < b.C; J++) {
+            bool nz = false;
+            for (int i = 0; i < 4 && !nz; i++)
+                for (int k = 0; k < 4; k++)
+                    if (M[(size_t)(4 * I + i) * cols + 4 * J + k] != 0.0) { nz = true; break; }
+            if (nz) {
+                b.by_row[I].push_back(J);
+                b.by_col[J].push_back(I);
+            }
+        }
+    return b;
+}
+
+// Builds the program (source + table) of one soc controller.  Host only: no device call.
+inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I) {
+    const int n = c.n, m = c.m, nm = n + m, N = c.N, dim = c.dim, n_s = c.n_s, n_eq = c.n_eq;
+    const int ZS = (dim + 3) / 4, SS = (n_s + 3) / 4, NP = ZS + SS, nr = n_eq + n_s, NR = (nr + 3) / 4;
+    const int PR_ = 4 * NP, RR = 4 * NR;
+    auto ip = [&](int j) { return j < dim ? j : 4 * ZS + (j - dim); };  // internal row of primal row j
+    p.ok = false;
+    p.ZS = ZS; p.SS = SS; p.NR = NR;
+    // ---- dense forms in the internal layout
+    Dense G((size_t)RR * PR_, 0.0), HG((size_t)PR_ * RR, 0.0), H((size_t)PR_ * PR_, 0.0), L((size_t)RR * RR, 0.0), Dinv(RR, 1.0);
+    {
+        const double *Gv = F + c.GhHhi_val, *HGv = F + c.HhiGh_val, *Hv = F + c.Hhi_val, *Lv = F + c.L_val, *Dv = F + c.Dinv;
+        const int *Gc = I + c.GhHhi_col, *Gr = I + c.GhHhi_row, *HGc = I + c.HhiGh_col, *HGr = I + c.HhiGh_row, *Hc = I + c.Hhi_col,
+                  *Hr = I + c.Hhi_row, *Lc = I + c.L_col, *Lr = I + c.L_row;
+        for (int i = 0; i < nr; i++)
+            for (int j = Gr[i]; j < Gr[i + 1]; j++) G[(size_t)i * PR_ + ip(Gc[j])] = Gv[j];
+        for (int i = 0; i < dim + n_s; i++) {
+            for (int j = HGr[i]; j < HGr[i + 1]; j++) HG[(size_t)ip(i) * RR + HGc[j]] = HGv[j];
+            for (int j = Hr[i]; j < Hr[i + 1]; j++) H[(size_t)ip(i) * PR_ + ip(Hc[j])] = Hv[j];
+        }
+        for (int i = 0; i < RR; i++) L[(size_t)i * RR + i] = 1.0;
+        for (int j = 0; j < nr; j++) {
+            for (int q = Lc[j]; q < Lc[j + 1]; q++) L[(size_t)Lr[q] * RR + j] = Lv[q];
+            Dinv[j] = Dv[j];
+        }
+    }
+    const BlockList bG = blocks_of(G, RR, PR_), bHG = blocks_of(HG, PR_, RR), bH = blocks_of(H, PR_, PR_), bL = blocks_of(L, RR, RR);
+    // ---- table + program text
+    // scheduling fences every SEG_EVERY block rows / columns: without them the compiler hoists the LDS reads of whole phases
+    int SEG_EVERY = 4, PF = 16;
+    if (const char *ev = getenv("SPCIES_BSP_PF")) PF = std::min(64, std::max(2, atoi(ev)));
+    if (const char *ev = getenv("SPCIES_BSP_SEG")) SEG_EVERY = std::max(1, atoi(ev));
+    std::vector<double> &tab = p.table;
+    tab.clear();
+    std::string body;
+    char line[512];
+    int n_mfma = 0;
+    auto emit_block = [&](const double *blk /* [i][k] row-major 4x4 */) {
+        const int t = (int)(tab.size() / 16);
+        for (int k = 0; k < 4; k++)
+            for (int i = 0; i < 4; i++) tab.push_back(blk[i * 4 + k]);  // element (i, k) at k*4 + i  (A operand: i = lane%4, k = lane/16)
+        return t;
+    };
+    auto block_of = [&](const Dense &M, int cols, int Ib, int Jb, double *out) {
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) out[i * 4 + k] = M[(size_t)(4 * Ib + i) * cols + 4 * Jb + k];
+    };
+    auto mul44 = [&](const double *a, const double *b, double *o, double sign) {
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) {
+                double s = 0.0;
+                for (int q = 0; q < 4; q++) s += a[i * 4 + q] * b[q * 4 + k];
+                o[i * 4 + k] = sign * s;
+            }
+    };
+    auto inv_unit_lower = [&](const double *a, double *o) {  // a = unit lower 4x4; forward substitution on the identity
+        for (int col = 0; col < 4; col++)
+            for (int i = 0; i < 4; i++) {
+                double s = (i == col) ? 1.0 : 0.0;
+                for (int q = 0; q < i; q++) s -= a[i * 4 + q] * o[q * 4 + col];
+                o[i * 4 + col] = s;
+            }
+    };
+    auto MF = [&](const char *acc, int t, const char *x) {
+        // the A operand comes from a ring of PF named registers refilled PF blocks ahead of their use (the LDS round trip is
+        // ~8 MFMAs long and the compiler does not hoist these reads by itself); @t@ is resolved once the block count is known
+        snprintf(line, sizeof(line), "            MF(%s, a%d, %s); @%d@\n", acc, t % PF, x, t);
+        body += line;
+        n_mfma++;
+    };
+    char a1[64], a2[64];
+    // q_hat of slab J from the current state (z slabs: q + lambda - sigma z; s slabs: mu - rho s)
+    auto qhat_expr = [&](int J, char *out, size_t cap) {
+        if (J < ZS) snprintf(out, cap, "QHZ(%d)", J);
+        else snprintf(out, cap, "(mu[%d] - rho * sc[%d])", J - ZS, J - ZS);
+    };
+    // ---- A. rhs = -bh, B. rhs += G q_hat  (column-oriented: q_hat of a slab is formed once, used, and dropped)
+    body += "            // rhs = (-Gh Hh^-1) q_hat - bh\n";
+    std::vector<int> bh_slabs;  // slabs of the right-hand side that hold a row of bh: -A x0, r, -PhiP xr (:97-131)
+    for (int Ib = 0; Ib < NR; Ib++) {
+        bool any = false;
+        for (int r = 4 * Ib; r < 4 * Ib + 4; r++) any |= (r < n) || (r == n_eq - 1) || (r > n_eq && r <= n_eq + n);
+        if (any) {
+            snprintf(line, sizeof(line), "            rh[%d] = -bh[%d];\n", Ib, (int)bh_slabs.size());
+            bh_slabs.push_back(Ib);
+        } else {
+            snprintf(line, sizeof(line), "            rh[%d] = 0.0;\n", Ib);
+        }
+        body += line;
+    }
+    for (int J = 0; J < NP; J++) {
+        if (bG.by_col[J].empty()) continue;
+        char e[128];
+        qhat_expr(J, e, sizeof(e));
+        snprintf(line, sizeof(line), "            { const double qh = %s;\n", e);
+        body += line;
+        for (int Ib : bG.by_col[J]) {
+            double blk[16];
+            block_of(G, PR_, Ib, J, blk);
+            snprintf(a1, sizeof(a1), "rh[%d]", Ib);
+            MF(a1, emit_block(blk), "qh");
+        }
+        body += "            }\n";
+        if (J % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
+    }
+    body += "            SEG;\n            // W mu = rhs: forward substitution by blocks\n";
+    std::vector<std::vector<double>> Linv(NR, std::vector<double>(16));
+    for (int Ib = 0; Ib < NR; Ib++) {
+        double d[16];
+        block_of(L, RR, Ib, Ib, d);
+        inv_unit_lower(d, Linv[Ib].data());
+        snprintf(line, sizeof(line), "            { double acc = 0.0;\n");
+        body += line;
+        snprintf(a2, sizeof(a2), "rh[%d]", Ib);
+        MF("acc", emit_block(Linv[Ib].data()), a2);
+        for (int J : bL.by_row[Ib]) {
+            if (J >= Ib) continue;
+            double b[16], o[16];
+            block_of(L, RR, Ib, J, b);
+            mul44(Linv[Ib].data(), b, o, -1.0);
+            snprintf(a2, sizeof(a2), "rh[%d]", J);
+            MF("acc", emit_block(o), a2);
+        }
+        snprintf(line, sizeof(line), "              rh[%d] = acc; }\n", Ib);
+        body += line;
+        if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
+    }
+    body += "            SEG;\n            // D^-1 and the backward substitution by blocks (U = L')\n";
+    for (int Ib = NR - 1; Ib >= 0; Ib--) {
+        // Uinv_II = (Linv_II)';  Bk_II = Uinv_II diag(Dinv_I);  Bk_IJ = -Uinv_II U_IJ,  U_IJ = (L_JI)'
+        double ui[16], d[16];
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) ui[i * 4 + k] = Linv[Ib][k * 4 + i];
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) d[i * 4 + k] = ui[i * 4 + k] * Dinv[4 * Ib + k];
+        body += "            { double acc = 0.0;\n";
+        snprintf(a2, sizeof(a2), "rh[%d]", Ib);
+        MF("acc", emit_block(d), a2);
+        for (int J : bL.by_col[Ib]) {  // blocks (J, Ib) of L with J > Ib  <=>  blocks (Ib, J) of U
+            if (J <= Ib) continue;
+            double lj[16], u[16], o[16];
+            block_of(L, RR, J, Ib, lj);
+            for (int i = 0; i < 4; i++)
+                for (int k = 0; k < 4; k++) u[i * 4 + k] = lj[k * 4 + i];
+            mul44(ui, u, o, -1.0);
+            snprintf(a2, sizeof(a2), "rh[%d]", J);
+            MF("acc", emit_block(o), a2);
+        }
+        snprintf(line, sizeof(line), "              rh[%d] = acc; }\n", Ib);
+        body += line;
+        if (Ib % SEG_EVERY == 0) body += "            SEG;\n";
+    }
+    // ---- E. primal_hat = H q_hat + HG mu, row by row, each row consumed by the z / s update straight away.  A q_hat that a
+    // LATER row needs from an EARLIER slab (off-diagonal blocks of -Hh^-1: the dense terminal weight) is saved before that
+    // slab's state is overwritten.
+    std::vector<int> last_use(NP, -1);
+    for (int Ib = 0; Ib < NP; Ib++)
+        for (int J : bH.by_row[Ib]) last_use[J] = std::max(last_use[J], Ib);
+    std::map<int, int> saved;  // slab -> index into sv[]
+    for (int J = 0; J < NP; J++)
+        if (last_use[J] > J) { const int idx = (int)saved.size(); saved[J] = idx; }
+    body += "            // primal_hat = (-Hh^-1) q_hat + (-Hh^-1 Gh') mu; z: box, lambda; s: cone, mu; residuals\n";
+    auto prim_row = [&](int Ib, const char *acc) {
+        for (int J : bH.by_row[Ib]) {
+            double blk[16];
+            block_of(H, PR_, Ib, J, blk);
+            char e[128];
+            if (J < Ib && J < ZS) snprintf(e, sizeof(e), "sv[%d]", saved.at(J));  // (the s slabs are all updated at the end)
+            else qhat_expr(J, e, sizeof(e));
+            snprintf(line, sizeof(line), "            { const double qh = %s;\n  ", e);
+            body += line;
+            MF(acc, emit_block(blk), "qh");
+            body += "            }\n";
+        }
+        for (int J : bHG.by_row[Ib]) {
+            double blk[16];
+            block_of(HG, RR, Ib, J, blk);
+            snprintf(a2, sizeof(a2), "rh[%d]", J);
+            MF(acc, emit_block(blk), a2);
+        }
+    };
+    for (int Ib = 0; Ib < ZS; Ib++) {
+        body += "            { double ph = 0.0;\n";
+        prim_row(Ib, "ph");
+        if (saved.count(Ib)) {
+            char e[128];
+            qhat_expr(Ib, e, sizeof(e));
+            snprintf(line, sizeof(line), "              sv[%d] = %s;\n", saved[Ib], e);
+            body += line;
+        }
+        snprintf(line, sizeof(line), "              ZUPD(%d, ph); }\n", Ib);
+        body += line;
+        if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
+    }
+    if (SS > 8) { p.why = "more than 32 cone rows"; return 0; }
+    body += "            { double sh[SS_];\n";
+    for (int k = 0; k < SS; k++) {
+        snprintf(line, sizeof(line), "              sh[%d] = 0.0;\n", k);
+        body += line;
+        snprintf(a1, sizeof(a1), "sh[%d]", k);
+        prim_row(ZS + k, a1);
+    }
+    body += "              SUPD(sh); }\n";
+    p.n_blocks = (int)(tab.size() / 16);
+    p.n_mfma = n_mfma;
+    {  // resolve the refill markers.  The stream is padded to a multiple of PF positions (the holes past the last block consume
+       // nothing), so that position t always sits in ring slot t % PF, also across the wrap into the next iteration: after
+       // block t is consumed its slot takes position t + PF; the slots of the holes are refilled at the end of the iteration
+        const int nb = p.n_blocks, n_pad = (nb + PF - 1) / PF * PF;
+        std::string out;
+        out.reserve(body.size() + (size_t)nb * 40);
+        auto refill = [&](int t) {
+            const int nx = (t + PF) % n_pad;
+            if (nx >= nb) return;
+            snprintf(line, sizeof(line), "a%d = BLK(blk%d, %d);", t % PF, nx / 512, nx % 512);
+            out += line;
+        };
+        for (size_t i = 0; i < body.size();) {
+            if (body[i] == '@') {
+                const size_t j = body.find('@', i + 1);
+                refill(atoi(body.substr(i + 1, j - i - 1).c_str()));
+                i = j + 1;
+            } else {
+                out.push_back(body[i++]);
+            }
+        }
+        out += "            ";
+        for (int t = nb; t < n_pad; t++) refill(t);
+        out += "\n";
+        body.swap(out);
+    }
+    // ---- LB / UB rows of the z slabs (rows past dim - n - 1 are free; pads are pinned to 0 by 0 <= z <= 0)
+    const int rc_lb = (int)tab.size();
+    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < dim - n - 1 ? F[c.LB + r] : (r < dim ? -1e300 : 0.0));
+    const int rc_ub = (int)tab.size();
+    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < dim - n - 1 ? F[c.UB + r] : (r < dim ? 1e300 : 0.0));
+    for (double x : tab)
+        if (!std::isfinite(x)) { p.why = "non-finite block"; return 0; }
+    const size_t lds_bytes = tab.size() * sizeof(double);
+    if (lds_bytes > 160 * 1024 - 1024 || p.n_blocks > 1536) { p.why = "block table exceeds the LDS"; return 0; }
+    if (p.n_blocks <= PF) { p.why = "fewer blocks than the prefetch ring"; return 0; }
+    if (NR + ZS + 2 * SS > 190) { p.why = "state does not fit the register file"; return 0; }
+    // ---- q: slabs with the same row pattern share one register
+    std::map<std::vector<int>, int> sig_index;
+    std::vector<int> qi(ZS), qrow;
+    auto row_type = [&](int r) {  // 0: zero; 1 + j: (R ur)_j; 1000 + j: (Q xr)_j; 2000 + j: (T xr)_j
+        if (r >= dim) return 0;
+        if (r < m) return 1 + r;
+        if (r < m + (N - 1) * nm) { const int e = (r - m) % nm; return e < n ? 1000 + e : 1 + (e - n); }
+        if (r < m + (N - 1) * nm + n) return 2000 + (r - m - (N - 1) * nm);
+        return 0;
+    };
+    for (int J = 0; J < ZS; J++) {
+        std::vector<int> sig = {row_type(4 * J), row_type(4 * J + 1), row_type(4 * J + 2), row_type(4 * J + 3)};
+        auto it = sig_index.find(sig);
+        if (it == sig_index.end()) {
+            it = sig_index.emplace(sig, (int)qrow.size()).first;
+            qrow.push_back(4 * J);
+        }
+        qi[J] = it->second;
+    }
+    // ---- source
+    std::string s;
+    auto def = [&](const char *name, long v) { snprintf(line, sizeof(line), "#define %s %ld\n", name, v); s += line; };
+    def("ZS_", ZS); def("SS_", SS); def("NP_", NP); def("NR_", NR); def("NQ_", (long)qrow.size()); def("NSV_", (long)std::max<size_t>(saved.size(), 1));
+    def("TAB_DOUBLES_", (long)tab.size()); def("RC_LB_", rc_lb); def("RC_UB_", rc_ub);
+    s += "#define RING_INIT";
+    for (int i = 0; i < PF; i++) { snprintf(line, sizeof(line), " double a%d = BLK(blk%d, %d);", i, (i % p.n_blocks) / 512, (i % p.n_blocks) % 512); s += line; }
+    s += "\n";
+    {
+        const int nb = p.n_blocks;
+        def("NB0_", std::max(1, std::min(nb, 512))); def("NB1_", std::max(1, std::min(nb - 512, 512))); def("NB2_", std::max(1, nb - 1024));
+    }
+    for (int J = 0; J < ZS; J++) { snprintf(line, sizeof(line), "#define QI_%d %d\n", J, qi[J]); s += line; }
+    def("NBH_", (long)bh_slabs.size());
+    s += "static __device__ const int BHSLAB_[NBH_] = {";
+    for (size_t i = 0; i < bh_slabs.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", bh_slabs[i]); s += line; }
+    s += "};\n";
+    s += "static __device__ const int QROW_[NQ_] = {";
+    for (size_t i = 0; i < qrow.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", qrow[i]); s += line; }
+    s += "};\n";
+    s += R"SRC(
+struct Args {
+    int n, m, N, dim, n_s, n_eq, k_max, ref_stride, r_stride, pad;
+    double tol_p, tol_d, rho, rho_i, sigma, sigma_i;
+    long B;
+};
+template <bool WANT_SOL>
+__device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__restrict__ table_g, const double *__restrict__ cst,
+                                             const double *__restrict__ x0g, const double *__restrict__ xrg,
+                                             const double *__restrict__ urg, const double *__restrict__ rg,
+                                             double *__restrict__ u_out, int *__restrict__ k_out, int *__restrict__ e_out,
+                                             double *__restrict__ f0, double *__restrict__ f1, double *__restrict__ f2,
+                                             double *__restrict__ f3, double *__restrict__ f4, double *__restrict__ f5) {
+    __shared__ __attribute__((aligned(16))) double ldsr[2 * 4 * ZS_];
+    __shared__ __attribute__((aligned(16))) double blk0[NB0_ * 16];
+    __shared__ __attribute__((aligned(16))) double blk1[NB1_ * 16];
+    __shared__ __attribute__((aligned(16))) double blk2[NB2_ * 16];
+    for (int i = threadIdx.x; i < NB0_ * 16; i += 256) blk0[i] = table_g[i];
+    for (int i = threadIdx.x; i < NB1_ * 16; i += 256) blk1[i] = table_g[512 * 16 + i];
+    for (int i = threadIdx.x; i < NB2_ * 16; i += 256) blk2[i] = table_g[1024 * 16 + i];
+    for (int i = threadIdx.x; i < 2 * 4 * ZS_; i += 256) ldsr[i] = table_g[RC_LB_ + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int n = p.n, m = p.m, nm = n + m, N = p.N, dim = p.dim, n_s = p.n_s, n_eq = p.n_eq;
+    const double rho = p.rho, rho_i = p.rho_i, sigma = p.sigma, sigma_i = p.sigma_i, tol_p = p.tol_p, tol_d = p.tol_d;
+    const double *cA = cst, *cQ = cA + n * n, *cR = cQ + n * n, *cT = cR + m * m, *cPhiP = cT + n * n;
+    int ao = g * 4 + (lane & 3);
+    const long n_tiles = (p.B + 15) / 16;
+#define BLK(arr, t) arr[(t) * 16 + ao]
+#define MF(acc, a, x) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((a), (x), (acc), 0, 0, 0)
+#define SEG __builtin_amdgcn_sched_barrier(0)
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long)gridDim.x * 4) {
+        const long inst = tile * 16 + c;
+        const bool valid = inst < p.B;
+        const long ii = valid ? inst : 0;
+        const double *x0 = x0g + ii * n;
+        const double *xr = p.ref_stride ? xrg + ii * n : xrg;
+        const double *ur = p.ref_stride ? urg + ii * m : urg;
+        const double r_ellip = rg[p.r_stride ? ii : 0];
+        // per-instance constants: bh (rows of the right-hand side), q (one register per distinct slab pattern)
+        double bh[NBH_];
+#pragma unroll
+        for (int I = 0; I < NBH_; I++) {
+            const int row = 4 * BHSLAB_[I] + g;
+            double v = 0.0;
+            if (row < n) {
+                for (int i = 0; i < n; i++) v -= cA[row * n + i] * x0[i];
+            } else if (row == n_eq - 1) {
+                v = r_ellip;
+            } else if (row > n_eq && row <= n_eq + n) {
+                const int jj = row - n_eq - 1;
+                for (int i = 0; i < n; i++) v -= cPhiP[jj * n + i] * xr[i];
+            }
+            bh[I] = v;
+        }
+        double qv[NQ_];
+#pragma unroll
+        for (int u = 0; u < NQ_; u++) {
+            const int j = QROW_[u] + g;
+            double v = 0.0;
+            if (j < m) {
+                for (int i = 0; i < m; i++) v += cR[j * m + i] * ur[i];
+            } else if (j < m + (N - 1) * nm) {
+                const int e = (j - m) % nm;
+                if (e < n) {
+                    for (int i = 0; i < n; i++) v += cQ[e * n + i] * xr[i];
+                } else {
+                    for (int i = 0; i < m; i++) v += cR[(e - n) * m + i] * ur[i];
+                }
+            } else if (j < m + (N - 1) * nm + n) {
+                const int e = j - m - (N - 1) * nm;
+                for (int i = 0; i < n; i++) v += cT[e * n + i] * xr[i];
+            }
+            qv[u] = v;
+        }
+        // state: w = z + lambda / sigma per z slab (z = clamp(w), lambda = sigma (w - z): the update w+ = z_hat + (w - clamp(w))
+        // is the reference's z / lambda step, admm_mfma4.hpp); the cone slabs keep s and mu
+        double w[ZS_], sc[SS_], mu[SS_], rh[NR_], sv[NSV_];
+#pragma unroll
+        for (int I = 0; I < ZS_; I++) w[I] = 0.0;
+#pragma unroll
+        for (int I = 0; I < SS_; I++) { sc[I] = 0.0; mu[I] = 0.0; }
+        int go = g;  // (laundered once per iteration like ao: keeps LICM from hoisting every bound read out of the loop)
+#define LBR(I) ldsr[4 * (I) + go]
+#define UBR(I) ldsr[4 * ZS_ + 4 * (I) + go]
+#define QHZ(J) (qv[QI_##J] + sigma * (w[J] - 2.0 * fmin(fmax(w[J], LBR(J)), UBR(J))))
+        bool active = valid, res = false;
+        int kk = 0;
+        RING_INIT
+        // z rows of slab I: box, lambda, residuals (:209-217, 246-248, 256-267)
+#define ZUPD(I, zh)                                                                              \
+    do {                                                                                         \
+        const double lb_ = LBR(I), ub_ = UBR(I);                                                 \
+        const double wo_ = w[I], zo_ = fmin(fmax(wo_, lb_), ub_);                                \
+        const double wn_ = (zh) + (wo_ - zo_), z_ = fmin(fmax(wn_, lb_), ub_);                   \
+        w[I] = wn_;                                                                              \
+        res |= (fabs(zo_ - z_) > tol_d) | (fabs(z_ - (zh)) > tol_p);                             \
+        if (WANT_SOL && active && 4 * (I) + g < dim) f2[inst * dim + 4 * (I) + g] = (zh);        \
+    } while (0)
+        // the cone rows: s = proj_SOC(s_hat + mu / rho), mu, residuals (:220-242, 251-253)
+#define SUPD(sh)                                                                                 \
+    do {                                                                                         \
+        double v_[SS_], nrm_ = 0.0;                                                              \
+        _Pragma("unroll") for (int k_ = 0; k_ < SS_; k_++) {                                     \
+            v_[k_] = (sh)[k_] + rho_i * mu[k_];                                                  \
+            nrm_ += (k_ == 0 && g == 0) ? 0.0 : v_[k_] * v_[k_];                                 \
+        }                                                                                        \
+        nrm_ += __shfl_xor(nrm_, 16);                                                            \
+        nrm_ += __shfl_xor(nrm_, 32);                                                            \
+        const double s_norm_ = sqrt(nrm_), s0_ = __shfl(v_[0], c);                               \
+        _Pragma("unroll") for (int k_ = 0; k_ < SS_; k_++) {                                     \
+            double v = v_[k_];                                                                   \
+            if (s_norm_ <= s0_) {                                                                \
+            } else if (s_norm_ <= -s0_) {                                                        \
+                v = 0.0;                                                                         \
+            } else {                                                                             \
+                const double step_ = (s0_ + s_norm_) / (2 * s_norm_);                            \
+                v = (k_ == 0 && g == 0) ? step_ * s_norm_ : step_ * v;                           \
+            }                                                                                    \
+            const double so_ = sc[k_], mu_ = mu[k_];                                             \
+            sc[k_] = v;                                                                          \
+            mu[k_] = mu_ + rho * ((sh)[k_] - v);                                                 \
+            res |= (fabs(so_ - v) > tol_d) | (fabs(v - (sh)[k_]) > tol_p);                       \
+            if (WANT_SOL && active && 4 * k_ + g < n_s) f3[inst * n_s + 4 * k_ + g] = (sh)[k_];  \
+        }                                                                                        \
+    } while (0)
+        while (true) {
+            kk += 1;
+            res = false;
+            asm volatile("" : "+v"(ao), "+v"(go));
+)SRC";
+    s += body;
+    s += R"SRC(
+            SEG;
+            // exit test per instance (:269-286)
+            unsigned long long bal = __ballot(res);
+            bal |= bal >> 32;
+            bal |= bal >> 16;
+            const bool res_inst = (bal >> c) & 1ull;
+            const bool done_now = active && (!res_inst || kk >= p.k_max);
+            if (__any(done_now)) {
+                if (done_now) {
+                    if (g == 0) {
+                        k_out[inst] = kk;
+                        e_out[inst] = res_inst ? -1 : 1;
+                    }
+                    if (g < m) u_out[inst * m + g] = fmin(fmax(w[0], LBR(0)), UBR(0));  // u = z[0 .. m)  (m <= 4: inside slab 0)
+                    if (WANT_SOL) {
+#pragma unroll
+                        for (int I = 0; I < ZS_; I++)
+                            if (4 * I + g < dim) {
+                                const double z_ = fmin(fmax(w[I], LBR(I)), UBR(I));
+                                f0[inst * dim + 4 * I + g] = z_;
+                                f4[inst * dim + 4 * I + g] = sigma * (w[I] - z_);
+                            }
+#pragma unroll
+                        for (int k = 0; k < SS_; k++)
+                            if (4 * k + g < n_s) {
+                                f1[inst * n_s + 4 * k + g] = sc[k];
+                                f5[inst * n_s + 4 * k + g] = mu[k];
+                            }
+                    }
+                    active = false;
+                }
+            }
+            if (!__any(active)) break;
+        }
+    }
+}
+extern "C" __global__ __launch_bounds__(256, 1) void soc_bsp_kernel(Args p, const double *table_g, const double *cst, const double *x0g,
+                                                                   const double *xrg, const double *urg, const double *rg, double *u_out,
+                                                                   int *k_out, int *e_out) {
+    soc_bsp_body<false>(p, table_g, cst, x0g, xrg, urg, rg, u_out, k_out, e_out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+extern "C" __global__ __launch_bounds__(256, 1) void soc_bsp_kernel_sol(Args p, const double *table_g, const double *cst, const double *x0g,
+                                                                       const double *xrg, const double *urg, const double *rg, double *u_out,
+                                                                       int *k_out, int *e_out, double *f0, double *f1, double *f2, double *f3,
+                                                                       double *f4, double *f5) {
+    soc_bsp_body<true>(p, table_g, cst, x0g, xrg, urg, rg, u_out, k_out, e_out, f0, f1, f2, f3, f4, f5);
+}
+)SRC";
+    p.src = s;
+    p.args = Args{n, m, N, dim, n_s, n_eq, c.k_max, 0, 0, 0, c.tol_p, c.tol_d, c.rho, c.rho_i, c.sigma, c.sigma_i, 0};
+    if (m > 4) { p.why = "m > 4 (u rows outside slab 0)"; return 0; }
+    if (const char *path = getenv("SPCIES_BSP_DUMP")) {  // kernel experiments: keep the generated program
+        if (FILE *f = fopen(path, "w")) {
+            fputs(s.c_str(), f);
+            fclose(f);
+        }
+    }
+    p.why = "not compiled yet";
+    return 0;
+}
+
+// device part: upload the table and the dense setup constants, compile the program (hiprtc)
+inline int finish_soc(Plan &p, const SocDev &c, const double *F) {
+    if (p.src.empty()) return 0;
+    static rtc::Hiprtc rt;
+    int rc = rt.open();
+    if (rc) return rc;
+    void *prog = nullptr;
+    if (rt.create(&prog, p.src.c_str(), "spcies_soc_bsp.hip", 0, nullptr, nullptr) != 0) return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans"};
+    if (rt.compile(prog, 4, opts) != 0) {
+        size_t ls = 0;
+        rt.log_size(prog, &ls);
+        std::string lg(ls + 1, '\0');
+        if (ls) rt.log(prog, &lg[0]);
+        rt.destroy(&prog);
+        return fail(SPCIES_HIP_EHIP, "BSP program: hiprtcCompileProgram failed: %.600s", lg.c_str());
+    }
+    size_t cs = 0;
+    rt.code_size(prog, &cs);
+    std::vector<char> code(cs);
+    rt.code(prog, code.data());
+    rt.destroy(&prog);
+    SPCIES_HIP_CHECK(hipModuleLoadData(&p.module, code.data()));
+    SPCIES_HIP_CHECK(hipModuleGetFunction(&p.fn[0], p.module, "soc_bsp_kernel"));
+    SPCIES_HIP_CHECK(hipModuleGetFunction(&p.fn[1], p.module, "soc_bsp_kernel_sol"));
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_table, p.table.size() * sizeof(double)));
+    SPCIES_HIP_CHECK(hipMemcpy(p.d_table, p.table.data(), p.table.size() * sizeof(double), hipMemcpyHostToDevice));
+    const int n = c.n, m = c.m;
+    std::vector<double> cst;
+    cst.insert(cst.end(), F + c.A, F + c.A + n * n);
+    cst.insert(cst.end(), F + c.Q, F + c.Q + n * n);
+    cst.insert(cst.end(), F + c.R, F + c.R + m * m);
+    cst.insert(cst.end(), F + c.T, F + c.T + n * n);
+    cst.insert(cst.end(), F + c.PhiP, F + c.PhiP + n * n);
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_consts, cst.size() * sizeof(double)));
+    SPCIES_HIP_CHECK(hipMemcpy(p.d_consts, cst.data(), cst.size() * sizeof(double), hipMemcpyHostToDevice));
+    hipDeviceProp_t prop;
+    int dev = 0;
+    SPCIES_HIP_CHECK(hipGetDevice(&dev));
+    SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    p.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    p.ok = true;
+    p.why.clear();
+    return 0;
+}
+
+// fields = z, s, z_hat, s_hat, lambda, mu (all or none)
+inline int launch_soc(Plan &p, const SocDev &c, const double *x0, const double *xr, const double *ur, int ref_stride, const double *r,
+                      int r_stride, long B, double *u, int *k, int *e, double *const *f, hipStream_t st) {
+    if (!p.ok) return fail(SPCIES_HIP_ENOSUP, "BSP variant not available: %s", p.why.c_str());
+    bool any = false, all = true;
+    for (int i = 0; i < 6; i++) { any |= f[i] != nullptr; all &= f[i] != nullptr; }
+    if (any && !all) return fail(SPCIES_HIP_EINVAL, "BSP variant: pass all six record fields or none");
+    Args a = p.args;
+    a.k_max = c.k_max; a.tol_p = c.tol_p; a.tol_d = c.tol_d;  // set_exit overrides
+    a.ref_stride = ref_stride; a.r_stride = r_stride; a.B = B;
+    const long n_tiles = (B + 15) / 16;
+    long wgs = (n_tiles + 3) / 4;
+    if (wgs > p.num_cu) wgs = p.num_cu;
+    const double *table = p.d_table, *cst = p.d_consts;
+    double *f0 = f[0], *f1 = f[1], *f2 = f[2], *f3 = f[3], *f4 = f[4], *f5 = f[5];
+    void *params[] = {&a, &table, &cst, &x0, &xr, &ur, &r, &u, &k, &e, &f0, &f1, &f2, &f3, &f4, &f5};
+    SPCIES_HIP_CHECK(hipModuleLaunchKernel(p.fn[any ? 1 : 0], (unsigned)wgs, 1, 1, 256, 1, 1, 0, st, params, nullptr));
+    return 0;
+}
+
+}  // namespace bsp
+}  // namespace spcies

@@ -18,6 +18,7 @@
 #include "hmpc_gemm.hpp"
 #include "hmpc_dense.hpp"
 #include "mpct_cs.hpp"
+#include "soc_bsp.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -92,6 +93,7 @@ struct Solver {
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
     std::vector<double> h_M1, h_M2, h_bh_nat;
+    bsp::Plan bsp;                 // BSP (ellipMPC soc): block-sparse MFMA program, generated per controller
     CsDev cdev{};                  // MPCT ADMM on the extended state space (STREAM, TILE)
     hdense::Host hd_host;          // HMPC without the splitting: blob contents, and its GEMM plan
     hdense::Plan hd_plan;
@@ -220,7 +222,7 @@ static int parse_soc(const uint8_t *blob, size_t bytes, const spcies_blob_header
                                     F + d.HhiGh_val, 0, lpi, s.tile_recs, s.tdev.prim);
         }
     }
-    return 0;
+    return bsp::build_soc(s.bsp, d, s.soc_f64.data(), s.soc_i32.data());  // BSP variant: generate the program (host only)
 }
 
 // HMPC ADMM / SADMM split, sparse KKT path, box constraints (cons_HMPC_ADMM_split_C.m:88-181)
@@ -1120,6 +1122,8 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         s.hgemm.dev.k_max = s.hdev.k_max; s.hgemm.dev.tol_p = s.hdev.tol_p; s.hgemm.dev.tol_d = s.hdev.tol_d;  // set_exit overrides
         return hgemm::launch(s.hgemm, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f, st);
     }
+    if (s.is_soc() && !s.is_hmpc() && s.variant == SPCIES_VARIANT_BSP)
+        return bsp::launch_soc(s.bsp, s.sdev, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, f, st);
     if (s.is_soc() && resolve_variant(s) == SPCIES_VARIANT_TILE) {
         if (!s.tdev.lpi) return fail(SPCIES_HIP_ENOSUP, "TILE variant not available: the LDL right-hand side does not fit the LDS");
         int rc = ensure_scratch(s, tile_scratch_bytes(s, B));
@@ -1269,6 +1273,7 @@ static void free_solver(Solver *s) {
     if (s->d_recs) hipFree(s->d_recs);
     hgemm::plan_free(s->hgemm);
     hdense::plan_free(s->hd_plan);
+    bsp::plan_free(s->bsp);
     if (s->d_eng) hipFree(s->d_eng);
     if (s->d_eng_in) hipFree(s->d_eng_in);
     mfma_plan_free(s->mfma);
@@ -1368,7 +1373,18 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
 int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_GEMM) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_BSP) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant == SPCIES_VARIANT_BSP) {
+        if (!(s->is_soc() && !s->is_hmpc())) return fail(SPCIES_HIP_ENOSUP, "BSP variant: built for the ellipMPC soc solver");
+        if (!s->bsp.ok) {  // compile the controller's program now (hiprtc; the kernel is ~1 000 MFMAs of straight-line code)
+            if (s->bsp.src.empty()) return fail(SPCIES_HIP_ENOSUP, "BSP variant not available: %s", s->bsp.why.c_str());
+            SPCIES_HIP_CHECK(hipSetDevice(s->device));
+            int rc = bsp::finish_soc(s->bsp, s->sdev, s->soc_f64.data());
+            if (rc) return rc;
+        }
+        s->variant = variant;
+        return 0;
+    }
     if (s->is_hdense()) {
         if (variant != SPCIES_VARIANT_AUTO && variant != SPCIES_VARIANT_GEMM && variant != SPCIES_VARIANT_STREAM)
             return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variants GEMM and STREAM are built");

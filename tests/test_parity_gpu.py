@@ -360,6 +360,7 @@ def test_mpct_vs_reference_template_fixture(variant, golden_dir):
 # ----------------------------------------------------------------------------------------------
 _SOC_FIELDS = ("z", "s", "z_hat", "s_hat", "lam", "mu")
 SPARSE_VARIANTS = ["stream", "tile"]  # TILE: LDS-resident LDL solve, sums in another order -> 1e-10
+SOC_VARIANTS = SPARSE_VARIANTS + ["bsp"]  # BSP: the sparse solve as a per-controller program of 4x4 MFMA blocks -> 1e-10
 
 
 def _compare_sparse(variant, got, O):
@@ -381,7 +382,7 @@ def _compare_sparse(variant, got, O):
         assert (np.abs(getattr(sol, name) - ref) / scale)[same].max() <= TOL_SPCIES, name
 
 
-@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+@pytest.mark.parametrize("variant", SOC_VARIANTS)
 def test_soc_reference_test_instance(variant, golden_dir):
     from oracle import oracle
     from spcies_amd import benchmarks
@@ -402,7 +403,7 @@ def test_soc_reference_test_instance(variant, golden_dir):
 
 @pytest.mark.parametrize("cfg_name,B,overrides", [("C1_soc", 70, {}), ("C5_soc", 130, {}),
                                                   ("C5_soc", 40, dict(tol_p=1e-6, tol_d=1e-6, k_max=3000))])
-@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+@pytest.mark.parametrize("variant", SOC_VARIANTS)
 def test_soc_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
@@ -414,7 +415,7 @@ def test_soc_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     _compare_sparse(variant, shared, oracle.admm_soc_batch(v, x0[:20], xr[:20], ur[:20], 0.4, want_sol=False))
 
 
-@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+@pytest.mark.parametrize("variant", SOC_VARIANTS)
 def test_soc_vs_reference_template_fixture(variant, golden_dir):
     g = np.load(os.path.join(golden_dir, "template_C5_soc.npz"))
     cfg, v, s = _fista_solver("C5_soc", variant)
