@@ -30,9 +30,18 @@ struct Hiprtc {
     int (*destroy)(void **) = nullptr;
     int open() {
         if (lib) return 0;
+        // First choice: the ROCm installation's hiprtc in a link namespace of its own.  A process that has loaded another ROCm
+        // user-space before us (PyTorch wheels bundle libhiprtc / libamd_comgr) would otherwise hand us THAT compiler by soname,
+        // whatever path we ask for - and the generated kernels are tuned against the installed one (an older comgr spills
+        // the BSP program's state to scratch memory: 77-99 ms instead of 11 at C5 soc).
+        {
+            const char *root = getenv("ROCM_PATH");
+            const std::string path = std::string(root && *root ? root : "/opt/rocm") + "/lib/libhiprtc.so";
+            if (!(getenv("SPCIES_HIPRTC_SHARED_NAMESPACE"))) lib = dlmopen(LM_ID_NEWLM, path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        }
         for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!lib) return fail(SPCIES_HIP_ENOSUP, "run-time specialisation: cannot load libhiprtc.so (%s)", dlerror());
 #define SPCIES_SYM(field, sym) field = (decltype(field))dlsym(lib, sym)
@@ -52,6 +61,11 @@ struct Hiprtc {
     }
 };
 
+inline Hiprtc &hiprtc() {  // one binding (and one link namespace) per process
+    static Hiprtc rt;
+    return rt;
+}
+
 struct Mfma4Module {
     hipModule_t module = nullptr;
     hipFunction_t fn[2] = {nullptr, nullptr};  // WANT_SOL = false, true
@@ -65,7 +79,7 @@ inline void module_free(Mfma4Module &m) {
 
 // compile admm_mfma4_kernel<N, KX, KS, TERMINAL, false / true> for gfx950
 inline int compile_mfma4(Mfma4Module &out, int N, int KX, int KS, bool terminal) {
-    static Hiprtc rt;
+    Hiprtc &rt = hiprtc();
     int rc = rt.open();
     if (rc) return rc;
     void *prog = nullptr;

@@ -75,7 +75,7 @@ inline BlockList blocks_of(const Dense &M, int rows, int cols) {
 }
 
 // Builds the program (source + table) of one soc controller.  Host only: no device call.
-inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I) {
+inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, int pf_request = 0) {
     const int n = c.n, m = c.m, nm = n + m, N = c.N, dim = c.dim, n_s = c.n_s, n_eq = c.n_eq;
     const int ZS = (dim + 3) / 4, SS = (n_s + 3) / 4, NP = ZS + SS, nr = n_eq + n_s, NR = (nr + 3) / 4;
     const int PR_ = 4 * NP, RR = 4 * NR;
@@ -105,6 +105,8 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I) {
     // scheduling fences every SEG_EVERY block rows / columns: without them the compiler hoists the LDS reads of whole phases
     int SEG_EVERY = 4, PF = 16;
     if (const char *ev = getenv("SPCIES_BSP_PF")) PF = std::min(64, std::max(2, atoi(ev)));
+    if (pf_request > 0) PF = pf_request;
+    p.src.clear();
     if (const char *ev = getenv("SPCIES_BSP_SEG")) SEG_EVERY = std::max(1, atoi(ev));
     std::vector<double> &tab = p.table;
     tab.clear();
@@ -550,10 +552,11 @@ extern "C" __global__ __launch_bounds__(256, 1) void soc_bsp_kernel_sol(Args p, 
     return 0;
 }
 
-// device part: upload the table and the dense setup constants, compile the program (hiprtc)
-inline int finish_soc(Plan &p, const SocDev &c, const double *F) {
-    if (p.src.empty()) return 0;
-    static rtc::Hiprtc rt;
+// compiles p.src (hiprtc) and loads the module; *scratch = bytes of scratch memory per lane of the no-record kernel
+inline int compile_program(Plan &p, int *scratch) {
+    if (p.module) hipModuleUnload(p.module);
+    p.module = nullptr;
+    rtc::Hiprtc &rt = rtc::hiprtc();
     int rc = rt.open();
     if (rc) return rc;
     void *prog = nullptr;
@@ -575,6 +578,34 @@ inline int finish_soc(Plan &p, const SocDev &c, const double *F) {
     SPCIES_HIP_CHECK(hipModuleLoadData(&p.module, code.data()));
     SPCIES_HIP_CHECK(hipModuleGetFunction(&p.fn[0], p.module, "soc_bsp_kernel"));
     SPCIES_HIP_CHECK(hipModuleGetFunction(&p.fn[1], p.module, "soc_bsp_kernel_sol"));
+    int local = 0;
+    if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, p.fn[0]) != hipSuccess) local = 0;
+    *scratch = local;
+    return 0;
+}
+
+// device part: compile the program - with a shallower prefetch ring if the register allocator had to spill (scratch memory
+// in the iteration loop costs more than the ring buys) - and upload the table and the dense setup constants
+inline int finish_soc(Plan &p, const SocDev &c, const double *F, const int *I) {
+    if (p.src.empty() || p.ok) return 0;
+    if (p.d_table) hipFree(p.d_table);
+    if (p.d_consts) hipFree(p.d_consts);
+    p.d_table = p.d_consts = nullptr;
+    int scratch = 0;
+    int rc = compile_program(p, &scratch);
+    if (rc) return rc;
+    if (!getenv("SPCIES_BSP_PF"))
+        for (int pf : {12, 8, 4}) {
+            if (scratch == 0) break;
+            rc = build_soc(p, c, F, I, pf);
+            if (rc) return rc;
+            if (p.src.empty()) return fail(SPCIES_HIP_ENOSUP, "BSP program: %s", p.why.c_str());
+            rc = compile_program(p, &scratch);
+            if (rc) return rc;
+        }
+    if (getenv("SPCIES_BSP_VERBOSE"))
+        fprintf(stderr, "[spcies bsp] %d blocks, %d MFMAs per iteration, table %zu B, scratch %d B per lane\n", p.n_blocks, p.n_mfma,
+                p.table.size() * sizeof(double), scratch);
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_table, p.table.size() * sizeof(double)));
     SPCIES_HIP_CHECK(hipMemcpy(p.d_table, p.table.data(), p.table.size() * sizeof(double), hipMemcpyHostToDevice));
     const int n = c.n, m = c.m;

@@ -668,6 +668,7 @@ static int resolve_variant(const Solver &s) {
     if (s.is_hdense()) return SPCIES_VARIANT_GEMM;
     if (s.is_cs()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.is_hmpc() && s.hgemm.ok) return SPCIES_VARIANT_GEMM;
+    if (s.is_soc() && !s.is_hmpc() && s.bsp.ok) return SPCIES_VARIANT_BSP;
     if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
@@ -1122,7 +1123,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         s.hgemm.dev.k_max = s.hdev.k_max; s.hgemm.dev.tol_p = s.hdev.tol_p; s.hgemm.dev.tol_d = s.hdev.tol_d;  // set_exit overrides
         return hgemm::launch(s.hgemm, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f, st);
     }
-    if (s.is_soc() && !s.is_hmpc() && s.variant == SPCIES_VARIANT_BSP)
+    if (s.is_soc() && !s.is_hmpc() && resolve_variant(s) == SPCIES_VARIANT_BSP)
         return bsp::launch_soc(s.bsp, s.sdev, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, f, st);
     if (s.is_soc() && resolve_variant(s) == SPCIES_VARIANT_TILE) {
         if (!s.tdev.lpi) return fail(SPCIES_HIP_ENOSUP, "TILE variant not available: the LDL right-hand side does not fit the LDS");
@@ -1307,6 +1308,12 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
                                hd.dim - 3 * (hd.n + hd.m), F + hd.UB, F + hd.LBy, F + hd.UBy);
         if (rc) return rc;
     }
+    // ellipMPC soc: compile the controller's block program now (hiprtc, a few seconds; SPCIES_HIP_BSP=0 turns it off).  A
+    // failure is not an error: AUTO then runs TILE, and the reason is reported if BSP is asked for.
+    if (s->is_soc() && !s->is_hmpc() && !s->bsp.src.empty()) {
+        const char *ev = getenv("SPCIES_HIP_BSP");
+        if (!(ev && ev[0] == '0') && bsp::finish_soc(s->bsp, s->sdev, s->soc_f64.data(), s->soc_i32.data()) != 0) s->bsp.why = g_last_error;
+    }
     if (s->eng) {
         if (s->tv) return fail(SPCIES_HIP_ENOSUP, "in_engineering with time_varying is not built");
         SPCIES_HIP_CHECK(hipMalloc((void **)&s->d_eng, s->eng_v.size() * sizeof(double)));
@@ -1376,10 +1383,10 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_BSP) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
     if (variant == SPCIES_VARIANT_BSP) {
         if (!(s->is_soc() && !s->is_hmpc())) return fail(SPCIES_HIP_ENOSUP, "BSP variant: built for the ellipMPC soc solver");
-        if (!s->bsp.ok) {  // compile the controller's program now (hiprtc; the kernel is ~1 000 MFMAs of straight-line code)
+        if (!s->bsp.ok) {  // not compiled at create time (SPCIES_HIP_BSP=0, or it failed): try now and report
             if (s->bsp.src.empty()) return fail(SPCIES_HIP_ENOSUP, "BSP variant not available: %s", s->bsp.why.c_str());
             SPCIES_HIP_CHECK(hipSetDevice(s->device));
-            int rc = bsp::finish_soc(s->bsp, s->sdev, s->soc_f64.data());
+            int rc = bsp::finish_soc(s->bsp, s->sdev, s->soc_f64.data(), s->soc_i32.data());
             if (rc) return rc;
         }
         s->variant = variant;
