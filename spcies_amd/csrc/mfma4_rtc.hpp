@@ -7,6 +7,9 @@
 // the environment turns it off; libhiprtc.so is bound with dlopen on first use.
 #pragma once
 #include <dlfcn.h>
+#include <limits.h>
+#include <link.h>
+#include <unistd.h>
 
 #include "admm_mfma4.hpp"
 
@@ -28,16 +31,37 @@ struct Hiprtc {
     int (*log_size)(void *, size_t *) = nullptr;
     int (*log)(void *, char *) = nullptr;
     int (*destroy)(void **) = nullptr;
+    char ***ns_environ = nullptr;  // &__environ of the private namespace's libc (dlmopen case)
+    void sync_env() const {
+        if (ns_environ) *ns_environ = environ;
+    }
     int open() {
         if (lib) return 0;
-        // First choice: the ROCm installation's hiprtc in a link namespace of its own.  A process that has loaded another ROCm
-        // user-space before us (PyTorch wheels bundle libhiprtc / libamd_comgr) would otherwise hand us THAT compiler by soname,
-        // whatever path we ask for - and the generated kernels are tuned against the installed one (an older comgr spills
-        // the BSP program's state to scratch memory: 77-99 ms instead of 11 at C5 soc).
+        // A process that has loaded another ROCm user-space before us (PyTorch wheels bundle libhiprtc / libamd_comgr) hands us
+        // THAT compiler by soname, whatever path we ask for - and the generated kernels are tuned against the installed one
+        // (an older comgr spills the BSP program's state to scratch memory: 77-99 ms instead of 11 at C5 soc).  Only in such
+        // a process the installation's hiprtc is opened in a link namespace of its own (dlmopen).  The namespace has its own
+        // libc, whose view of the environment goes stale when the host program calls setenv: sync_env() before every call.
         {
             const char *root = getenv("ROCM_PATH");
-            const std::string path = std::string(root && *root ? root : "/opt/rocm") + "/lib/libhiprtc.so";
-            if (!(getenv("SPCIES_HIPRTC_SHARED_NAMESPACE"))) lib = dlmopen(LM_ID_NEWLM, path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            const std::string dir = std::string(root && *root ? root : "/opt/rocm") + "/lib/";
+            char real[PATH_MAX];
+            const std::string rdir = realpath(dir.c_str(), real) ? std::string(real) + "/" : dir;
+            struct Probe { const std::string *a, *b; bool foreign; } probe{&dir, &rdir, false};
+            dl_iterate_phdr(
+                [](struct dl_phdr_info *info, size_t, void *data) {
+                    Probe *pr = static_cast<Probe *>(data);
+                    const char *nm = info->dlpi_name ? info->dlpi_name : "";
+                    if ((strstr(nm, "libamd_comgr") || strstr(nm, "libhiprtc")) && strncmp(nm, pr->a->c_str(), pr->a->size()) != 0 &&
+                        strncmp(nm, pr->b->c_str(), pr->b->size()) != 0)
+                        pr->foreign = true;
+                    return 0;
+                },
+                &probe);
+            if (probe.foreign && !getenv("SPCIES_HIPRTC_SHARED_NAMESPACE")) {
+                lib = dlmopen(LM_ID_NEWLM, (dir + "libhiprtc.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+                if (lib) ns_environ = (char ***)dlsym(lib, "__environ");
+            }
         }
         for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
             if (lib) break;
@@ -82,6 +106,7 @@ inline int compile_mfma4(Mfma4Module &out, int N, int KX, int KS, bool terminal)
     Hiprtc &rt = hiprtc();
     int rc = rt.open();
     if (rc) return rc;
+    rt.sync_env();
     void *prog = nullptr;
     if (rt.create(&prog, kMfma4Source, "spcies_mfma4_rtc.hip", 0, nullptr, nullptr) != 0)
         return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");

@@ -341,7 +341,7 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     std::string s;
     auto def = [&](const char *name, long v) { snprintf(line, sizeof(line), "#define %s %ld\n", name, v); s += line; };
     def("ZS_", ZS); def("SS_", SS); def("NP_", NP); def("NR_", NR); def("NQ_", (long)qrow.size()); def("NSV_", (long)std::max<size_t>(saved.size(), 1));
-    def("TAB_DOUBLES_", (long)tab.size()); def("RC_LB_", rc_lb); def("RC_UB_", rc_ub);
+    def("TAB_DOUBLES_", (long)tab.size()); def("RC_LB_", rc_lb); def("RC_UB_", rc_ub); def("DIM_", dim); def("NSC_", n_s);
     s += "#define RING_INIT";
     for (int i = 0; i < PF; i++) { snprintf(line, sizeof(line), " double a%d = BLK(blk%d, %d);", i, (i % p.n_blocks) / 512, (i % p.n_blocks) % 512); s += line; }
     s += "\n";
@@ -382,6 +382,7 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int n = p.n, m = p.m, nm = n + m, N = p.N, dim = p.dim, n_s = p.n_s, n_eq = p.n_eq;
+    double *dump = const_cast<double *>(table_g) + TAB_DOUBLES_;  // (4 NP + 8 doubles behind the table: bsp::finish_soc)
     const double rho = p.rho, rho_i = p.rho_i, sigma = p.sigma, sigma_i = p.sigma_i, tol_p = p.tol_p, tol_d = p.tol_d;
     const double *cA = cst, *cQ = cA + n * n, *cR = cQ + n * n, *cT = cR + m * m, *cPhiP = cT + n * n;
     int ao = g * 4 + (lane & 3);
@@ -455,7 +456,7 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
         const double wn_ = (zh) + (wo_ - zo_), z_ = fmin(fmax(wn_, lb_), ub_);                   \
         w[I] = wn_;                                                                              \
         res |= (fabs(zo_ - z_) > tol_d) | (fabs(z_ - (zh)) > tol_p);                             \
-        if (WANT_SOL && active && 4 * (I) + g < dim) f2[inst * dim + 4 * (I) + g] = (zh);        \
+        if (WANT_SOL) *((4 * (I) + 3 < DIM_ || 4 * (I) + g < DIM_) ? zhp + 4 * (I) : dump) = (zh); \
     } while (0)
         // the cone rows: s = proj_SOC(s_hat + mu / rho), mu, residuals (:220-242, 251-253)
 #define SUPD(sh)                                                                                 \
@@ -481,13 +482,16 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
             sc[k_] = v;                                                                          \
             mu[k_] = mu_ + rho * ((sh)[k_] - v);                                                 \
             res |= (fabs(so_ - v) > tol_d) | (fabs(v - (sh)[k_]) > tol_p);                       \
-            if (WANT_SOL && active && 4 * k_ + g < n_s) f3[inst * n_s + 4 * k_ + g] = (sh)[k_];  \
+            if (WANT_SOL) *((4 * k_ + 3 < NSC_ || 4 * k_ + g < NSC_) ? shp + 4 * k_ : dump) = (sh)[k_]; \
         }                                                                                        \
     } while (0)
         while (true) {
             kk += 1;
             res = false;
             asm volatile("" : "+v"(ao), "+v"(go));
+            // record of z_hat / s_hat: every iteration overwrites the instance's row; finished instances write to a dump row
+            double *zhp = (WANT_SOL && active) ? f2 + inst * dim + g : dump;
+            double *shp = (WANT_SOL && active) ? f3 + inst * n_s + g : dump;
 )SRC";
     s += body;
     s += R"SRC(
@@ -506,19 +510,22 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
                     }
                     if (g < m) u_out[inst * m + g] = fmin(fmax(w[0], LBR(0)), UBR(0));  // u = z[0 .. m)  (m <= 4: inside slab 0)
                     if (WANT_SOL) {
+                        double *zp = f0 + inst * dim + g, *lp = f4 + inst * dim + g, *sp = f1 + inst * n_s + g, *mp = f5 + inst * n_s + g;
 #pragma unroll
                         for (int I = 0; I < ZS_; I++)
-                            if (4 * I + g < dim) {
-                                const double z_ = fmin(fmax(w[I], LBR(I)), UBR(I));
-                                f0[inst * dim + 4 * I + g] = z_;
-                                f4[inst * dim + 4 * I + g] = sigma * (w[I] - z_);
-                            }
+                        {
+                            const bool in_ = 4 * I + 3 < DIM_ || 4 * I + g < DIM_;
+                            const double z_ = fmin(fmax(w[I], LBR(I)), UBR(I));
+                            *(in_ ? zp + 4 * I : dump) = z_;
+                            *(in_ ? lp + 4 * I : dump) = sigma * (w[I] - z_);
+                        }
 #pragma unroll
                         for (int k = 0; k < SS_; k++)
-                            if (4 * k + g < n_s) {
-                                f1[inst * n_s + 4 * k + g] = sc[k];
-                                f5[inst * n_s + 4 * k + g] = mu[k];
-                            }
+                        {
+                            const bool in_ = 4 * k + 3 < NSC_ || 4 * k + g < NSC_;
+                            *(in_ ? sp + 4 * k : dump) = sc[k];
+                            *(in_ ? mp + 4 * k : dump) = mu[k];
+                        }
                     }
                     active = false;
                 }
@@ -559,6 +566,7 @@ inline int compile_program(Plan &p, int *scratch) {
     rtc::Hiprtc &rt = rtc::hiprtc();
     int rc = rt.open();
     if (rc) return rc;
+    rt.sync_env();
     void *prog = nullptr;
     if (rt.create(&prog, p.src.c_str(), "spcies_soc_bsp.hip", 0, nullptr, nullptr) != 0) return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans"};
@@ -606,7 +614,7 @@ inline int finish_soc(Plan &p, const SocDev &c, const double *F, const int *I) {
     if (getenv("SPCIES_BSP_VERBOSE"))
         fprintf(stderr, "[spcies bsp] %d blocks, %d MFMAs per iteration, table %zu B, scratch %d B per lane\n", p.n_blocks, p.n_mfma,
                 p.table.size() * sizeof(double), scratch);
-    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_table, p.table.size() * sizeof(double)));
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_table, (p.table.size() + 4 * (size_t)(p.ZS + p.SS) + 8) * sizeof(double)));
     SPCIES_HIP_CHECK(hipMemcpy(p.d_table, p.table.data(), p.table.size() * sizeof(double), hipMemcpyHostToDevice));
     const int n = c.n, m = c.m;
     std::vector<double> cst;
