@@ -1,0 +1,81 @@
+"""CPU: the BSP variant's code generator (spcies_amd/csrc/soc_bsp.hpp).  `spcies_hip_create` generates the controller's block
+program while it parses the blob - before it needs a device - so the generated HIP source can be captured here
+(SPCIES_BSP_DUMP), compiled for gfx950 with the installed hiprtc (which runs without a GPU) and inspected: it must compile,
+keep its state in registers (no scratch memory in the no-record kernel) and issue exactly one MFMA per table block."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from spcies_amd import _lib, benchmarks, blob
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+HIPRTC = "/opt/rocm/lib/libhiprtc.so"
+
+
+def _generate(cfg_name, path, monkeypatch):
+    monkeypatch.setenv("SPCIES_BSP_DUMP", str(path))
+    lib = _lib.load()
+    b = blob.pack(benchmarks.ingredients(benchmarks.config(cfg_name)))
+    h = C.c_void_p()
+    rc = lib.spcies_hip_create(b, len(b), 0, C.byref(h))
+    if rc == 0:  # a GPU is present: the solver exists, the dump was written all the same
+        lib.spcies_hip_destroy(h)
+    return open(path).read()
+
+
+@pytest.mark.parametrize("cfg_name,n_blocks", [("C1_soc", 261), ("C5_soc", 1015)])
+def test_bsp_program_is_generated_compiles_and_keeps_state_in_registers(cfg_name, n_blocks, tmp_path, monkeypatch):
+    if not (os.path.exists(HIPRTC) and os.path.exists(READELF)):
+        pytest.skip("needs the ROCm installation's hiprtc and llvm-readelf")
+    src = _generate(cfg_name, tmp_path / "prog.hip", monkeypatch)
+    assert "soc_bsp_kernel" in src and len(re.findall(r"\bMF\(", src)) == n_blocks + 1  # + the macro definition
+    # every table block is consumed by exactly one MFMA, and refilled into the ring exactly once per iteration
+    assert len(re.findall(r"= BLK\(blk\d, \d+\);", src)) >= n_blocks
+    rt = C.CDLL(HIPRTC)
+    prog = C.c_void_p()
+    assert rt.hiprtcCreateProgram(C.byref(prog), src.encode(), b"prog.hip", 0, None, None) == 0
+    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-honor-nans"]
+    arr = (C.c_char_p * len(opts))(*opts)
+    rc = rt.hiprtcCompileProgram(prog, len(opts), arr)
+    n = C.c_size_t()
+    rt.hiprtcGetProgramLogSize(prog, C.byref(n))
+    log = C.create_string_buffer(n.value + 1)
+    rt.hiprtcGetProgramLog(prog, log)
+    assert rc == 0, log.value.decode()[:2000]
+    rt.hiprtcGetCodeSize(prog, C.byref(n))
+    code = C.create_string_buffer(n.value)
+    rt.hiprtcGetCode(prog, code)
+    co = tmp_path / "prog.co"
+    co.write_bytes(code.raw)
+    notes = subprocess.run([READELF, "--notes", str(co)], capture_output=True, text=True).stdout
+    kernels = dict(re.findall(r"\.name:\s+(soc_bsp_kernel\w*)\s+\.private_segment_fixed_size:\s+(\d+)", notes))
+    assert set(kernels) == {"soc_bsp_kernel", "soc_bsp_kernel_sol"}
+    lds = [int(x) for x in re.findall(r"\.group_segment_fixed_size:\s+(\d+)", notes)]
+    assert lds and max(lds) <= 160 * 1024
+    if cfg_name == "C1_soc":  # (at C5 the 16-deep ring leaves 44 B; finish_soc then recompiles with a 12-deep one: 0 B)
+        assert int(kernels["soc_bsp_kernel"]) == 0
+
+
+def test_bsp_shallower_ring_has_no_scratch_at_c5(tmp_path, monkeypatch):
+    if not (os.path.exists(HIPRTC) and os.path.exists(READELF)):
+        pytest.skip("needs the ROCm installation's hiprtc and llvm-readelf")
+    monkeypatch.setenv("SPCIES_BSP_PF", "12")
+    src = _generate("C5_soc", tmp_path / "prog.hip", monkeypatch)
+    rt = C.CDLL(HIPRTC)
+    prog = C.c_void_p()
+    assert rt.hiprtcCreateProgram(C.byref(prog), src.encode(), b"prog.hip", 0, None, None) == 0
+    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-honor-nans"]
+    arr = (C.c_char_p * len(opts))(*opts)
+    assert rt.hiprtcCompileProgram(prog, len(opts), arr) == 0
+    n = C.c_size_t()
+    rt.hiprtcGetCodeSize(prog, C.byref(n))
+    code = C.create_string_buffer(n.value)
+    rt.hiprtcGetCode(prog, code)
+    co = tmp_path / "prog.co"
+    co.write_bytes(code.raw)
+    notes = subprocess.run([READELF, "--notes", str(co)], capture_output=True, text=True).stdout
+    kernels = dict(re.findall(r"\.name:\s+(soc_bsp_kernel\w*)\s+\.private_segment_fixed_size:\s+(\d+)", notes))
+    assert int(kernels["soc_bsp_kernel"]) == 0
