@@ -14,6 +14,39 @@ from spcies_amd import _lib, benchmarks, blob
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 HIPRTC = "/opt/rocm/lib/libhiprtc.so"
 
+_COMPILE = r"""
+import ctypes as C, sys
+rt = C.CDLL(sys.argv[1])
+src = open(sys.argv[2], "rb").read()
+prog = C.c_void_p()
+assert rt.hiprtcCreateProgram(C.byref(prog), src, b"prog.hip", 0, None, None) == 0
+opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-honor-nans"]
+arr = (C.c_char_p * len(opts))(*opts)
+rc = rt.hiprtcCompileProgram(prog, len(opts), arr)
+n = C.c_size_t()
+rt.hiprtcGetProgramLogSize(prog, C.byref(n))
+log = C.create_string_buffer(n.value + 1)
+rt.hiprtcGetProgramLog(prog, log)
+if rc != 0:
+    sys.exit(log.value.decode()[:2000])
+rt.hiprtcGetCodeSize(prog, C.byref(n))
+code = C.create_string_buffer(n.value)
+rt.hiprtcGetCode(prog, code)
+open(sys.argv[3], "wb").write(code.raw)
+"""
+
+
+def _compile(src_path, co_path):
+    """hiprtc in a process of its own: this one may have loaded another ROCm user-space (PyTorch bundles an older comgr, which
+    the loader would then hand to the installed hiprtc as well - mfma4_rtc.hpp opens a private link namespace for that case)."""
+    import sys
+    r = subprocess.run([sys.executable, "-c", _COMPILE, HIPRTC, str(src_path), str(co_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    notes = subprocess.run([READELF, "--notes", str(co_path)], capture_output=True, text=True).stdout
+    kernels = dict(re.findall(r"\.name:\s+(soc_bsp_kernel\w*)\s+\.private_segment_fixed_size:\s+(\d+)", notes))
+    lds = [int(x) for x in re.findall(r"\.group_segment_fixed_size:\s+(\d+)", notes)]
+    return kernels, lds
+
 
 def _generate(cfg_name, path, monkeypatch):
     monkeypatch.setenv("SPCIES_BSP_DUMP", str(path))
@@ -34,26 +67,8 @@ def test_bsp_program_is_generated_compiles_and_keeps_state_in_registers(cfg_name
     assert "soc_bsp_kernel" in src and len(re.findall(r"\bMF\(", src)) == n_blocks + 1  # + the macro definition
     # every table block is consumed by exactly one MFMA, and refilled into the ring exactly once per iteration
     assert len(re.findall(r"= BLK\(blk\d, \d+\);", src)) >= n_blocks
-    rt = C.CDLL(HIPRTC)
-    prog = C.c_void_p()
-    assert rt.hiprtcCreateProgram(C.byref(prog), src.encode(), b"prog.hip", 0, None, None) == 0
-    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-honor-nans"]
-    arr = (C.c_char_p * len(opts))(*opts)
-    rc = rt.hiprtcCompileProgram(prog, len(opts), arr)
-    n = C.c_size_t()
-    rt.hiprtcGetProgramLogSize(prog, C.byref(n))
-    log = C.create_string_buffer(n.value + 1)
-    rt.hiprtcGetProgramLog(prog, log)
-    assert rc == 0, log.value.decode()[:2000]
-    rt.hiprtcGetCodeSize(prog, C.byref(n))
-    code = C.create_string_buffer(n.value)
-    rt.hiprtcGetCode(prog, code)
-    co = tmp_path / "prog.co"
-    co.write_bytes(code.raw)
-    notes = subprocess.run([READELF, "--notes", str(co)], capture_output=True, text=True).stdout
-    kernels = dict(re.findall(r"\.name:\s+(soc_bsp_kernel\w*)\s+\.private_segment_fixed_size:\s+(\d+)", notes))
+    kernels, lds = _compile(tmp_path / "prog.hip", tmp_path / "prog.co")
     assert set(kernels) == {"soc_bsp_kernel", "soc_bsp_kernel_sol"}
-    lds = [int(x) for x in re.findall(r"\.group_segment_fixed_size:\s+(\d+)", notes)]
     assert lds and max(lds) <= 160 * 1024
     if cfg_name == "C1_soc":  # (at C5 the 16-deep ring leaves 44 B; finish_soc then recompiles with a 12-deep one: 0 B)
         assert int(kernels["soc_bsp_kernel"]) == 0
@@ -64,18 +79,5 @@ def test_bsp_shallower_ring_has_no_scratch_at_c5(tmp_path, monkeypatch):
         pytest.skip("needs the ROCm installation's hiprtc and llvm-readelf")
     monkeypatch.setenv("SPCIES_BSP_PF", "12")
     src = _generate("C5_soc", tmp_path / "prog.hip", monkeypatch)
-    rt = C.CDLL(HIPRTC)
-    prog = C.c_void_p()
-    assert rt.hiprtcCreateProgram(C.byref(prog), src.encode(), b"prog.hip", 0, None, None) == 0
-    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-honor-nans"]
-    arr = (C.c_char_p * len(opts))(*opts)
-    assert rt.hiprtcCompileProgram(prog, len(opts), arr) == 0
-    n = C.c_size_t()
-    rt.hiprtcGetCodeSize(prog, C.byref(n))
-    code = C.create_string_buffer(n.value)
-    rt.hiprtcGetCode(prog, code)
-    co = tmp_path / "prog.co"
-    co.write_bytes(code.raw)
-    notes = subprocess.run([READELF, "--notes", str(co)], capture_output=True, text=True).stdout
-    kernels = dict(re.findall(r"\.name:\s+(soc_bsp_kernel\w*)\s+\.private_segment_fixed_size:\s+(\d+)", notes))
+    kernels, _ = _compile(tmp_path / "prog.hip", tmp_path / "prog.co")
     assert int(kernels["soc_bsp_kernel"]) == 0
