@@ -24,6 +24,7 @@ struct Dev {  // offsets (doubles) into the constants allocation / (ints) into t
     int M2xA, M1Q, QQ, Te, Se, LB, UB, LBy, UBy, Cval, dvec, M1, M2, A, Ctval;
     int Crow, Ccol, Ctrow, Ctcol;
     int n, m, N, dim, n_s, n_box, n_soc, k_max, use_soc, symmetric;
+    int ks, ds;  // rows of T and of Z in the scratch = n_s and dim rounded up to a multiple of 32: the GEMM has no edge tiles
     double tol_p, tol_d, rho, rho_i, alpha;
 };
 constexpr int CHUNK = 24;  // rows of s per thread of the post kernel (a multiple of 3)
@@ -85,6 +86,13 @@ inline int plan_build(Plan &p, const Host &h) {
     for (double x : G1)
         if (!std::isfinite(x)) { p.why = "non-finite M1"; return 0; }
     Dev d{};
+    int pad_to = 32;
+    if (const char *ev = getenv("SPCIES_GEMM_PAD")) pad_to = std::max(1, atoi(ev));
+    d.ks = (n_s + pad_to - 1) / pad_to * pad_to;
+    d.ds = (dim + pad_to - 1) / pad_to * pad_to;
+    std::vector<double> G1p((size_t)d.ds * d.ks, 0.0);
+    for (int i = 0; i < dim; i++)
+        for (int j = 0; j < n_s; j++) G1p[(size_t)i * d.ks + j] = G1[(size_t)i * n_s + j];
     d.M2xA = put(M2xA.data(), M2xA.size());
     d.M1Q = put(M1Q.data(), M1Q.size());
     d.QQ = put(h.QQ.data(), h.QQ.size());
@@ -113,8 +121,8 @@ inline int plan_build(Plan &p, const Host &h) {
     d.n = n; d.m = m; d.N = h.N; d.dim = dim; d.n_s = n_s; d.n_box = h.n_box; d.n_soc = h.n_soc; d.k_max = h.k_max;
     d.use_soc = h.use_soc; d.symmetric = h.symmetric;
     d.tol_p = h.tol_p; d.tol_d = h.tol_d; d.rho = h.rho; d.rho_i = h.rho_i; d.alpha = h.alpha;
-    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_G1, G1.size() * sizeof(double)));
-    SPCIES_HIP_CHECK(hipMemcpy(p.d_G1, G1.data(), G1.size() * sizeof(double), hipMemcpyHostToDevice));
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_G1, G1p.size() * sizeof(double)));
+    SPCIES_HIP_CHECK(hipMemcpy(p.d_G1, G1p.data(), G1p.size() * sizeof(double), hipMemcpyHostToDevice));
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_C, flat.size() * sizeof(double)));
     SPCIES_HIP_CHECK(hipMemcpy(p.d_C, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_I, idx.size() * sizeof(int)));
@@ -131,7 +139,7 @@ struct Rows {
 };
 __host__ __device__ inline Rows rows_of(const Dev &d) {
     Rows r;
-    r.T = 0; r.Z = r.T + d.n_s; r.CI = r.Z + d.dim; r.S = r.CI + d.dim; r.LAM = r.S + d.n_s; r.ZF = r.LAM + d.n_s;
+    r.T = 0; r.Z = r.T + d.ks; r.CI = r.Z + d.ds; r.S = r.CI + d.dim; r.LAM = r.S + d.n_s; r.ZF = r.LAM + d.n_s;
     r.QC = r.ZF + d.dim; r.total = r.QC + 2 * d.n + d.m;
     return r;
 }
@@ -181,6 +189,7 @@ __global__ __launch_bounds__(64) void setup_kernel(Dev d, const double *__restri
         AT(R.LAM, i) = 0.0;
         AT(R.T, i) = d.use_soc ? -d.rho * cd[i] : 0.0;
     }
+    for (int i = d.n_s; i < d.ks; i++) AT(R.T, i) = 0.0;  // pad rows of the GEMM operand stay zero
 #undef AT
 }
 
@@ -289,8 +298,8 @@ inline int launch(Plan &p, const double *x0, const double *xr, const double *ur,
     const bool can_stop_early = d.tol_p > 0 || d.tol_d > 0;
     for (int it = 1; it <= d.k_max; it++) {
         // Z [Bp x dim] = T [Bp x n_s] * G1'  (column-major operands: T ld = Bp; the row-major G1 [dim][n_s] IS G1' column-major)
-        if (p.blas.dgemm(p.blas.handle, hgemm::ROCBLAS_OP_N, hgemm::ROCBLAS_OP_N, (int)Bp, d.dim, d.n_s, &one, Sc + R.T * Bp, (int)Bp,
-                         p.d_G1, d.n_s, &zero, Sc + R.Z * Bp, (int)Bp) != 0)
+        if (p.blas.dgemm(p.blas.handle, hgemm::ROCBLAS_OP_N, hgemm::ROCBLAS_OP_N, (int)Bp, d.ds, d.ks, &one, Sc + R.T * Bp, (int)Bp,
+                         p.d_G1, d.ks, &zero, Sc + R.Z * Bp, (int)Bp) != 0)
             return fail(SPCIES_HIP_EHIP, "rocblas_dgemm failed");
         hipLaunchKernelGGL(post_kernel, pgrid, dim3(256), 0, st, d, p.d_C, p.d_I, Bp, Sc, RES, ACT, box_chunks);
         hipLaunchKernelGGL(finish_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, st, d, it, Bp, Sc, RES, ACT, k, e, NACT);

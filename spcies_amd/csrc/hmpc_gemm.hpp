@@ -52,7 +52,7 @@ constexpr int ROCBLAS_OP_N = 111;  // rocblas_operation_none
 
 struct Dev {  // offsets (doubles) into the GEMM constants allocation, dimensions, scalars
     int M2xA, c_const, A, QQ, Te, Se, LB, UB, LBy, UBy;
-    int n, m, N, dim, n_s, np, n_soc, k_max, use_soc, symmetric;
+    int n, m, N, dim, n_s, np, npad, n_soc, k_max, use_soc, symmetric;  // npad: rows per state vector = np rounded up (GEMM n, k)
     double tol_p, tol_d, rho, rho_i, sigma, sigma_i, alpha;
 };
 constexpr int CHUNK = 24;  // rows per thread of the post kernel (a multiple of 3: cone triples never straddle chunks)
@@ -105,13 +105,21 @@ inline int plan_build(Plan &p, const HmpcDev &h, const std::vector<double> &M1, 
     d.UB = put(UB, (size_t)n_lb);
     d.LBy = put(LBy, (size_t)nm);
     d.UBy = put(UBy, (size_t)nm);
+    int pad_to = 32;
+    if (const char *ev = getenv("SPCIES_GEMM_PAD")) pad_to = std::max(1, atoi(ev));
+    d.npad = (np + pad_to - 1) / pad_to * pad_to;
     d.n = n; d.m = m; d.N = h.N; d.dim = h.dim; d.n_s = h.n_s; d.np = np; d.n_soc = h.n_soc; d.k_max = h.k_max;
     d.use_soc = h.use_soc; d.symmetric = h.symmetric;
     d.tol_p = h.tol_p; d.tol_d = h.tol_d; d.rho = h.rho; d.rho_i = h.rho_i; d.sigma = h.sigma; d.sigma_i = h.sigma_i; d.alpha = h.alpha;
     for (double x : M1)
         if (!std::isfinite(x)) { p.why = "non-finite M1"; return 0; }
-    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_M1, M1.size() * sizeof(double)));
-    SPCIES_HIP_CHECK(hipMemcpy(p.d_M1, M1.data(), M1.size() * sizeof(double), hipMemcpyHostToDevice));
+    {  // M1 zero-padded to [npad][npad]: the product then has no edge tiles (n = k = 288 instead of 282 at C5)
+        std::vector<double> M1p((size_t)d.npad * d.npad, 0.0);
+        for (int i = 0; i < np; i++)
+            for (int j = 0; j < np; j++) M1p[(size_t)i * d.npad + j] = M1[(size_t)i * np + j];
+        SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_M1, M1p.size() * sizeof(double)));
+        SPCIES_HIP_CHECK(hipMemcpy(p.d_M1, M1p.data(), M1p.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_C, flat.size() * sizeof(double)));
     SPCIES_HIP_CHECK(hipMemcpy(p.d_C, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
     p.dev = d;
@@ -123,7 +131,7 @@ inline int plan_build(Plan &p, const HmpcDev &h, const std::vector<double> &M1, 
 // scratch rows: PR | DU | QH | PH | CI | ZH (np each) | QC (2n + m);  ints: RES [Bp], ACT [Bp]
 inline size_t scratch_bytes(const Dev &d, long B) {
     const long Bp = (B + 63) / 64 * 64;
-    return (size_t)(6 * d.np + 2 * d.n + d.m) * Bp * sizeof(double) + 2 * (size_t)Bp * sizeof(int) + 64;
+    return (size_t)(6 * d.npad + 2 * d.n + d.m) * Bp * sizeof(double) + 2 * (size_t)Bp * sizeof(int) + 64;
 }
 
 // row j of q (only 2n + m rows of q are non-zero, :110-129): index into QC, or -1
@@ -142,8 +150,8 @@ __global__ __launch_bounds__(64) void setup_kernel(Dev d, const double *__restri
                                                    int *__restrict__ ACT) {
     const long t = (long)blockIdx.x * 64 + threadIdx.x;
     if (t >= Bp) return;
-    const int n = d.n, m = d.m, np = d.np;
-    double *PR = S + t, *DU = PR + (long)np * Bp, *QH = DU + (long)np * Bp, *CI = QH + 2L * np * Bp, *QC = CI + 2L * np * Bp;
+    const int n = d.n, m = d.m, np = d.np, ns = d.npad;
+    double *PR = S + t, *DU = PR + (long)ns * Bp, *QH = DU + (long)ns * Bp, *CI = QH + 2L * ns * Bp, *QC = CI + 2L * ns * Bp;
 #define AT(P, i) (P)[(long)(i) * Bp]
     RES[t] = 0;
     ACT[t] = (t < B) ? 1 : 0;
@@ -173,6 +181,7 @@ __global__ __launch_bounds__(64) void setup_kernel(Dev d, const double *__restri
         const int qr = (j < d.dim) ? qc_row(d, j) : -1;
         AT(QH, j) = (qr >= 0) ? -AT(QC, qr) : 0.0;
     }
+    for (int j = np; j < ns; j++) AT(QH, j) = 0.0;  // pad rows of the GEMM operand stay zero
 #undef AT
 }
 
@@ -183,8 +192,8 @@ __global__ __launch_bounds__(256) void post_kernel(Dev d, const double *__restri
     if (t >= Bp || !ACT[t]) return;
     const int np = d.np, dim = d.dim, nm = d.n + d.m;
     const int r0 = blockIdx.y * CHUNK, r1 = min(r0 + CHUNK, np);
-    double *PR = S + t, *DU = PR + (long)np * Bp, *QH = DU + (long)np * Bp, *PH = QH + (long)np * Bp, *CI = PH + (long)np * Bp,
-           *QC = CI + 2L * np * Bp;
+    const long ns = d.npad;
+    double *PR = S + t, *DU = PR + ns * Bp, *QH = DU + ns * Bp, *PH = QH + ns * Bp, *CI = PH + ns * Bp, *QC = CI + 2L * ns * Bp;
 #define AT(P, i) (P)[(long)(i) * Bp]
     const double *cLB = C + d.LB, *cUB = C + d.UB, *cLBy = C + d.LBy, *cUBy = C + d.UBy;
     const double rho = d.rho, rho_i = d.rho_i, sigma = d.sigma, sigma_i = d.sigma_i;
@@ -251,8 +260,9 @@ __global__ __launch_bounds__(64) void finish_kernel(Dev d, int k, long Bp, doubl
     RES[t] = 0;
     if (r && k < d.k_max) return;
     const int np = d.np;
-    const double *PH = S + t + 3L * np * Bp, *CI = PH + (long)np * Bp;
-    double *ZH = S + t + 5L * np * Bp;
+    const long ns = d.npad;
+    const double *PH = S + t + 3L * ns * Bp, *CI = PH + ns * Bp;
+    double *ZH = S + t + 5L * ns * Bp;
     for (int j = 0; j < np; j++) ZH[(long)j * Bp] = PH[(long)j * Bp] + CI[(long)j * Bp];
     k_out[t] = k;
     e_out[t] = r ? -1 : 1;
@@ -268,10 +278,10 @@ inline int launch(Plan &p, const double *x0, const double *xr, const double *ur,
     if (rc) return rc;
     const Dev &d = p.dev;
     const long Bp = (B + 63) / 64 * 64;
-    const int np = d.np;
+    const int np = d.np, ns = d.npad;
     double *S = scratch;
-    int *RES = reinterpret_cast<int *>(S + (size_t)(6 * np + 2 * d.n + d.m) * Bp), *ACT = RES + Bp, *NACT = ACT + Bp;
-    double *QH = S + 2L * np * Bp, *PH = S + 3L * np * Bp;
+    int *RES = reinterpret_cast<int *>(S + (size_t)(6 * ns + 2 * d.n + d.m) * Bp), *ACT = RES + Bp, *NACT = ACT + Bp;
+    double *QH = S + 2L * ns * Bp, *PH = S + 3L * ns * Bp;
     const int nact0 = (int)B;
     SPCIES_HIP_CHECK(hipMemcpyAsync(NACT, &nact0, sizeof(int), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(setup_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, st, d, p.d_C, x0, xr, ur, ref_stride, B, Bp, S, RES, ACT);
@@ -282,7 +292,7 @@ inline int launch(Plan &p, const double *x0, const double *xr, const double *ur,
     const bool can_stop_early = d.tol_p > 0 || d.tol_d > 0;
     for (int it = 1; it <= d.k_max; it++) {
         // PH [Bp x np] = -QH [Bp x np] * M1'  (column-major operands: QH ld = Bp; the row-major M1 IS M1' column-major)
-        if (p.blas.dgemm(p.blas.handle, ROCBLAS_OP_N, ROCBLAS_OP_N, (int)Bp, np, np, &alpha, QH, (int)Bp, p.d_M1, np, &beta, PH,
+        if (p.blas.dgemm(p.blas.handle, ROCBLAS_OP_N, ROCBLAS_OP_N, (int)Bp, ns, ns, &alpha, QH, (int)Bp, p.d_M1, ns, &beta, PH,
                          (int)Bp) != 0)
             return fail(SPCIES_HIP_EHIP, "rocblas_dgemm failed");
         hipLaunchKernelGGL(post_kernel, pgrid, dim3(256), 0, st, d, p.d_C, Bp, S, RES, ACT);
@@ -300,7 +310,7 @@ inline int launch(Plan &p, const double *x0, const double *xr, const double *ur,
         dim3 tg((unsigned)(Bp / 64), (unsigned)((d.m + 63) / 64));
         hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, S, Bp, B, d.m, u);
     }
-    const double *base[3] = {S, S + 5L * np * Bp, S + (long)np * Bp};
+    const double *base[3] = {S, S + 5L * ns * Bp, S + (long)ns * Bp};
     for (int i = 0; i < 6; i++) {
         if (!f[i]) continue;
         const int rows = (i % 2 == 0) ? d.dim : d.n_s;
