@@ -97,6 +97,53 @@ def cpu_baseline(cfg, v, n_sample, threads, seconds=12.0):
                       f"(+ 1024 of them on 1 thread, {dt1:.1f} s)"}
 
 
+def cpu_reference_baseline(cfg, threads, seconds=10.0):
+    """The reference's C template for this configuration - `code_laxMPC_ADMM_C.c` instantiated with the C2 constants and
+    compiled by `__graft_entry__.build()` where /root/reference exists (oracle/_ref/libbench_C2_lax.so, gcc -O3 like the
+    toolbox's mex build) - called once per instance, instances spread over `threads` host threads.  None if the object is
+    not there."""
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "libbench_C2_lax.so")
+    if not os.path.exists(so):
+        return None
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from spcies_amd import benchmarks
+    n, m, dim = cfg.sys.n, cfg.sys.m, cfg.param.N * (cfg.sys.n + cfg.sys.m)
+    fn = C.CDLL(so).laxMPC_ADMM
+    fn.restype = None
+
+    class Sol(C.Structure):
+        _fields_ = [("z", C.c_double * dim), ("v", C.c_double * dim), ("lam", C.c_double * dim), ("t", C.c_double * 4)]
+
+    def work(args):
+        x0, xr, ur = args
+        sol, u, k, e = Sol(), (C.c_double * m)(), C.c_int(0), C.c_int(0)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        for i in range(x0.shape[0]):
+            fn(dp(x0[i]), dp(xr[i]), dp(ur[i]), u, C.byref(k), C.byref(e), C.byref(sol))
+        return k.value
+
+    def run(count, nthreads):
+        x0, xr, ur = benchmarks.sample_batch(cfg, count, seed=cfg.seed + 1)
+        parts = [(x0[i::nthreads].copy(), xr[i::nthreads].copy(), ur[i::nthreads].copy()) for i in range(nthreads)]
+        t = time.perf_counter()
+        with ThreadPoolExecutor(nthreads) as ex:
+            ks = list(ex.map(work, parts))
+        assert all(k == cfg.solver_options["k_max"] for k in ks)
+        return count / (time.perf_counter() - t)
+    rate1 = run(512, 1)
+    rate = run(64 * threads, threads)
+    n_sample = int(min(max(rate * seconds, 64 * threads), 1 << 20))
+    t = time.perf_counter()
+    value = run(n_sample, threads)
+    dt = time.perf_counter() - t
+    return {"value": value, "unit": "solves/s", "cores": threads, "kind": "template", "one_thread_value": rate1,
+            "sample": f"{n_sample} seeded C2 instances, 200 iterations each, the reference's generated laxMPC_ADMM solver "
+                      f"(formulations/+laxMPC/code_laxMPC_ADMM_C.c instantiated for C2, gcc -O3), one call per instance from "
+                      f"{threads} host threads, {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,7 +263,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if v is None:
                 v = benchmarks.ingredients(cfg)
-            out["cpu_baseline"] = cpu_baseline(cfg, v, args.cpu_sample, args.cpu_threads or host_threads())
+            threads = args.cpu_threads or host_threads()
+            port = cpu_baseline(cfg, v, args.cpu_sample, threads)
+            # The baseline is the port.  The reference's C template instantiated for C2 is timed next to it when its object is
+            # there; it is NOT a reference build (MATLAB, which prints the constants of a generated solver, is absent: the
+            # constants block is ours), so it rides along as information and does not change `kind`.
+            tmpl = cpu_reference_baseline(cfg, threads)
+            if tmpl is not None:
+                port["reference_template"] = {"value": tmpl["value"], "one_thread_value": tmpl["one_thread_value"],
+                                              "cores": tmpl["cores"], "note": tmpl["sample"] + "; constants printed by this "
+                                              "repository's generator under the reference's dec_var.m rules, not by MATLAB"}
+            out["cpu_baseline"] = port
             # the same run also re-checks the GPU result against the oracle on the first 64 instances
             from oracle import oracle
             uo, *_ = oracle.admm_banded_batch(v, x0[:64], xr[:64], ur[:64], want_sol=False)
