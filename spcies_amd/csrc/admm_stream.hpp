@@ -101,10 +101,16 @@ __host__ __device__ inline TvLayout tv_layout(int n, int m, int N) {
 // (code_laxMPC_ADMM_C.c:659-684): m head entries, N-1 rows of n+m, n tail entries.
 // time-varying instantiation: every constant is a per-lane global load; a compiler barrier per row keeps hipcc
 // from hoisting a whole sweep's loads to the top (510 spilled registers without it)
-#define SPCIES_TV_ROW_BARRIER()                          \
-    do {                                                 \
-        if constexpr (TV) asm volatile("" ::: "memory"); \
+#ifndef SPCIES_TV_BARRIER_EVERY
+#define SPCIES_TV_BARRIER_EVERY 1
+#endif
+#define SPCIES_TV_ROW_BARRIER_AT(j)                                                            \
+    do {                                                                                       \
+        if constexpr (TV) {                                                                    \
+            if ((j) % SPCIES_TV_BARRIER_EVERY == 0) asm volatile("" ::: "memory");             \
+        }                                                                                      \
     } while (0)
+#define SPCIES_TV_ROW_BARRIER() SPCIES_TV_ROW_BARRIER_AT(j)
 
 template <int n, int m, bool TERMINAL, bool EXACT, bool TV = false, bool ELLIP = false, bool GEN = false>
 __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double *__restrict__ C,
@@ -261,8 +267,20 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                             for (int i = 0; i < n; i++) acc = madd<EXACT>(acc, cHi_N[j * n + i], qc[i]);
                         }
                     }
+                    if constexpr (TV) {  // all loads of the row first (the compiler otherwise waits for every pair: 2 loads in flight)
+                        double ab_[nm], hi_[nm];
 #pragma unroll
-                    for (int i = 0; i < nm; i++) acc = acc - cAB[j * nm + i] * cHi[(l - 1) * nm + i] * qp[i];
+                        for (int i = 0; i < nm; i++) {
+                            ab_[i] = cAB[j * nm + i];
+                            hi_[i] = cHi[(l - 1) * nm + i];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < nm; i++) acc = acc - ab_[i] * hi_[i] * qp[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < nm; i++) acc = acc - cAB[j * nm + i] * cHi[(l - 1) * nm + i] * qp[i];
+                    }
                     if (last) {
                         if constexpr (!TERMINAL) acc = acc - xr[j];
                     }
@@ -276,13 +294,31 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
             for (int j = 0; j < n; j++) {
                 SPCIES_TV_ROW_BARRIER();
                 double acc = y[j];
-                if (l > 0) {
+                if constexpr (TV) {
+                    double al_[n], bl_[n];
+                    if (l > 0) {
 #pragma unroll
-                    for (int i = 0; i < n; i++) acc = msub<EXACT>(acc, Al[i * n + j], yp[i]);
+                        for (int i = 0; i < n; i++) al_[i] = Al[i * n + j];
+                    }
+#pragma unroll
+                    for (int i = 0; i <= j; i++) bl_[i] = Bl[i * n + j];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (l > 0) {
+#pragma unroll
+                        for (int i = 0; i < n; i++) acc = msub<EXACT>(acc, al_[i], yp[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < j; i++) acc = msub<EXACT>(acc, bl_[i], y[i]);
+                    y[j] = bl_[j] * acc;
+                } else {
+                    if (l > 0) {
+#pragma unroll
+                        for (int i = 0; i < n; i++) acc = msub<EXACT>(acc, Al[i * n + j], yp[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < j; i++) acc = msub<EXACT>(acc, Bl[i * n + j], y[i]);
+                    y[j] = Bl[j * n + j] * acc;
                 }
-#pragma unroll
-                for (int i = 0; i < j; i++) acc = msub<EXACT>(acc, Bl[i * n + j], y[i]);
-                y[j] = Bl[j * n + j] * acc;
             }
 #pragma unroll
             for (int j = 0; j < n; j++) {
@@ -306,13 +342,31 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
             for (int j = n - 1; j >= 0; j--) {
                 SPCIES_TV_ROW_BARRIER();
                 double acc = mu[j];
-                if (l < N - 1) {
+                if constexpr (TV) {
+                    double al_[n], bl_[n];
+                    if (l < N - 1) {
 #pragma unroll
-                    for (int i = n - 1; i >= 0; i--) acc = msub<EXACT>(acc, Al[j * n + i], mun[i]);
+                        for (int i = 0; i < n; i++) al_[i] = Al[j * n + i];
+                    }
+#pragma unroll
+                    for (int i = j; i < n; i++) bl_[i] = Bl[j * n + i];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (l < N - 1) {
+#pragma unroll
+                        for (int i = n - 1; i >= 0; i--) acc = msub<EXACT>(acc, al_[i], mun[i]);
+                    }
+#pragma unroll
+                    for (int i = n - 1; i > j; i--) acc = msub<EXACT>(acc, bl_[i], mu[i]);
+                    mu[j] = bl_[j] * acc;
+                } else {
+                    if (l < N - 1) {
+#pragma unroll
+                        for (int i = n - 1; i >= 0; i--) acc = msub<EXACT>(acc, Al[j * n + i], mun[i]);
+                    }
+#pragma unroll
+                    for (int i = n - 1; i > j; i--) acc = msub<EXACT>(acc, Bl[j * n + i], mu[i]);
+                    mu[j] = Bl[j * n + j] * acc;
                 }
-#pragma unroll
-                for (int i = n - 1; i > j; i--) acc = msub<EXACT>(acc, Bl[j * n + i], mu[i]);
-                mu[j] = Bl[j * n + j] * acc;
             }
             if (l == N - 1) {
                 if constexpr (TERMINAL) {
@@ -399,8 +453,17 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                     double vold = first ? 0.0 : Vt[e * Bp];
                     double zz = q[j] + lam - RM(l, j) * vold;
                     if (j < n) zz = zz - mu[j];
+                    if constexpr (TV) {
+                        double ab_[n];
 #pragma unroll
-                    for (int i = 0; i < n; i++) zz = madd<EXACT>(zz, cAB[i * nm + j], mun[i]);
+                        for (int i = 0; i < n; i++) ab_[i] = cAB[i * nm + j];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < n; i++) zz = madd<EXACT>(zz, ab_[i], mun[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < n; i++) zz = madd<EXACT>(zz, cAB[i * nm + j], mun[i]);
+                    }
                     zz = -cHi[l * nm + j] * zz;
                     double vn = (ELLIP || GEN) ? clamp_ref(zz + RIM(l, j) * lam, cLBz[l * nm + j], cUBz[l * nm + j])
                                                : clamp_ref(zz + rho_i * lam, cLB[j], cUB[j]);
