@@ -228,13 +228,24 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
             double qc[nm];
             const bool last = (l == N - 1);
             if (!last) {
+                // (the block's lambda / v rows are gathered before they are used: hipcc otherwise waits for every pair of loads)
+                double lamv[nm], vvv[nm];
 #pragma unroll
                 for (int j = 0; j < nm; j++) {
-                    long e = off_mid + (long)l * nm + j;
-                    double lam = first ? 0.0 : Lt[e * Bp];
-                    double vv = first ? 0.0 : Vt[e * Bp];
-                    qc[j] = q[j] + lam - RM(l, j) * vv;
+                    lamv[j] = 0.0;
+                    vvv[j] = 0.0;
                 }
+                if (!first) {
+#pragma unroll
+                    for (int j = 0; j < nm; j++) {
+                        long e = off_mid + (long)l * nm + j;
+                        lamv[j] = Lt[e * Bp];
+                        vvv[j] = Vt[e * Bp];
+                    }
+                }
+                if constexpr (!TV) __builtin_amdgcn_sched_barrier(0);  // (time-varying: the registers go to the coefficient rows)
+#pragma unroll
+                for (int j = 0; j < nm; j++) qc[j] = q[j] + lamv[j] - RM(l, j) * vvv[j];
             } else if constexpr (TERMINAL) {
                 double lamN[n], vN[n], qN[n];
 #pragma unroll
@@ -445,12 +456,27 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                 }
             } else {
                 // reference block l: z[l] = -Hi[l] (q_hat - [mu_l; 0] + AB' mu_{l+1})  (:464-474)
+                double lamb[nm], vob[nm];  // lambda / v of the block, gathered before the rows are processed
+#pragma unroll
+                for (int j = 0; j < nm; j++) {
+                    lamb[j] = 0.0;
+                    vob[j] = 0.0;
+                }
+                if (!first) {
+#pragma unroll
+                    for (int j = 0; j < nm; j++) {
+                        long e = off_mid + (long)l * nm + j;
+                        lamb[j] = Lt[e * Bp];
+                        vob[j] = Vt[e * Bp];
+                    }
+                }
+                if constexpr (!TV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < nm; j++) {
                     SPCIES_TV_ROW_BARRIER();
                     long e = off_mid + (long)l * nm + j;
-                    double lam = first ? 0.0 : Lt[e * Bp];
-                    double vold = first ? 0.0 : Vt[e * Bp];
+                    double lam = lamb[j];
+                    double vold = vob[j];
                     double zz = q[j] + lam - RM(l, j) * vold;
                     if (j < n) zz = zz - mu[j];
                     if constexpr (TV) {
