@@ -97,14 +97,10 @@ __global__ __launch_bounds__(64) void hmpc_stream_kernel(HmpcDev c, const double
         // KKT solve through L D L' (:193-209)
         for (int i = 0; i < nrow; i++) {
             const double xi = AT(RH, i);
-            for (int j = Lc[i]; j < Lc[i + 1]; j++) AT(RH, Lr[j]) -= Lv[j] * xi;
+            csc_scatter(Lv, Lr, Lc[i], Lc[i + 1], xi, RH, Bp);
         }
         for (int j = 0; j < nrow; j++) AT(RH, j) *= Dinv[j];
-        for (int i = nrow - 1; i >= 0; i--) {
-            double acc = AT(RH, i);
-            for (int j = Lc[i]; j < Lc[i + 1]; j++) acc -= Lv[j] * AT(RH, Lr[j]);
-            AT(RH, i) = acc;
-        }
+        for (int i = nrow - 1; i >= 0; i--) AT(RH, i) = csr_dot<true>(AT(RH, i), Lv, Lr, Lc[i], Lc[i + 1], RH, Bp);
         bool res = false;
         // z (:215-238, 288-312, 318-333): half dual step (symmetric), box, dual step, residuals
         for (int j = 0; j < dim; j++) {

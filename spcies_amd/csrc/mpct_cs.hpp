@@ -66,28 +66,21 @@ __global__ __launch_bounds__(64) void cs_stream_kernel(CsDev c, const double *__
         for (int j = 0; j < dim; j++) AT(QH, j) = AT(QV, j % dnm) + AT(LAM, j) - (sr ? rho : cRho[j]) * AT(V, j);
         // rhs = (-Aeq Hhat^-1) q_hat - b  (:113-121)
         for (int i = 0; i < nrow; i++) {
-            double acc = 0.0;
-            for (int j = Ar[i]; j < Ar[i + 1]; j++) acc += Av[j] * AT(QH, Ac[j]);
-            AT(MU, i) = acc;
+            AT(MU, i) = csr_dot<false>(0.0, Av, Ac, Ar[i], Ar[i + 1], QH, Bp);
         }
         for (int j = 0; j < n; j++) AT(MU, j) -= x0[j];
         // W mu = rhs through L D L' (:126-146)
         for (int i = 0; i < nrow; i++) {
             const double xi = AT(MU, i);
-            for (int j = Lc[i]; j < Lc[i + 1]; j++) AT(MU, Lr[j]) -= Lv[j] * xi;
+            csc_scatter(Lv, Lr, Lc[i], Lc[i + 1], xi, MU, Bp);
         }
         for (int j = 0; j < nrow; j++) AT(MU, j) *= Dinv[j];
-        for (int i = nrow - 1; i >= 0; i--) {
-            double acc = AT(MU, i);
-            for (int j = Lc[i]; j < Lc[i + 1]; j++) acc -= Lv[j] * AT(MU, Lr[j]);
-            AT(MU, i) = acc;
-        }
+        for (int i = nrow - 1; i >= 0; i--) AT(MU, i) = csr_dot<true>(AT(MU, i), Lv, Lr, Lc[i], Lc[i + 1], MU, Bp);
         // z = (-Hhat^-1) q_hat + (-Hhat^-1 Aeq') mu (:152-164), v (:168-177), lambda (:181-188), residuals (:192-207)
         bool res = false;
         for (int i = 0; i < dim; i++) {
-            double z = 0.0;
-            for (int j = Hr[i]; j < Hr[i + 1]; j++) z += Hv[j] * AT(QH, Hc[j]);
-            for (int j = HAr[i]; j < HAr[i + 1]; j++) z += HAv[j] * AT(MU, HAc[j]);
+            double z = csr_dot<false>(0.0, Hv, Hc, Hr[i], Hr[i + 1], QH, Bp);
+            z = csr_dot<false>(z, HAv, HAc, HAr[i], HAr[i + 1], MU, Bp);
             const double lam = AT(LAM, i), v1 = AT(V, i);
             double v = z + (sr ? rho_i : cRhoi[i]) * lam;
             v = clamp_ref(v, cLB[i], cUB[i]);

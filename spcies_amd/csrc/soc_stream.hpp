@@ -22,6 +22,37 @@ struct SocDev {
 
 #pragma clang fp contract(off)
 
+// Sparse row / column kernels of the STREAM variants: the reference's sums in its order, but the operands of eight terms are
+// loaded before the first is used - hipcc otherwise waits for every load of such a chain (one load in flight per wavefront).
+// acc (+/-)= sum_j val[j] * X[idx[j]],  j = r0 .. r1 - 1
+template <bool SUB>
+__device__ __forceinline__ double csr_dot(double acc, const double *__restrict__ val, const int *__restrict__ idx, int r0, int r1,
+                                          const double *X, long Bp) {
+    int j = r0;
+    for (; j + 8 <= r1; j += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = X[(long)idx[j + u] * Bp];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc = SUB ? acc - val[j + u] * x[u] : acc + val[j + u] * x[u];
+    }
+    for (; j < r1; j++) acc = SUB ? acc - val[j] * X[(long)idx[j] * Bp] : acc + val[j] * X[(long)idx[j] * Bp];
+    return acc;
+}
+// X[idx[j]] -= val[j] * xi,  j = r0 .. r1 - 1  (the targets of one column of L are distinct rows)
+__device__ __forceinline__ void csc_scatter(const double *__restrict__ val, const int *__restrict__ idx, int r0, int r1, double xi,
+                                            double *X, long Bp) {
+    int j = r0;
+    for (; j + 8 <= r1; j += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = X[(long)idx[j + u] * Bp];
+#pragma unroll
+        for (int u = 0; u < 8; u++) X[(long)idx[j + u] * Bp] = x[u] - val[j + u] * xi;
+    }
+    for (; j < r1; j++) X[(long)idx[j] * Bp] -= val[j] * xi;
+}
+
 // scratch rows: PR (dim+n_s) | PH (dim+n_s) | DU (dim+n_s) | QH (dim+n_s) | RH (n_eq+n_s) | BH (n_eq+n_s) | QV (dim)
 __global__ __launch_bounds__(64) void soc_stream_kernel(SocDev c, const double *__restrict__ C, const int *__restrict__ I,
                                                         const double *__restrict__ x0g, const double *__restrict__ xrg,
@@ -96,26 +127,20 @@ __global__ __launch_bounds__(64) void soc_stream_kernel(SocDev c, const double *
         for (int j = 0; j < n_s; j++) AT(QH, dim + j) = AT(DU, dim + j) - rho * AT(PR, dim + j);
         // rhs = (-Gh Hh^-1) q_hat - bh  (:152-160)
         for (int i = 0; i < nr; i++) {
-            double acc = 0.0;
-            for (int j = Gr[i]; j < Gr[i + 1]; j++) acc += Gv[j] * AT(QH, Gc[j]);
+            const double acc = csr_dot<false>(0.0, Gv, Gc, Gr[i], Gr[i + 1], QH, Bp);
             AT(RH, i) = acc - AT(BH, i);
         }
         // W mu = rhs through L D L' (:166-188)
         for (int i = 0; i < nr; i++) {
             const double xi = AT(RH, i);
-            for (int j = Lc[i]; j < Lc[i + 1]; j++) AT(RH, Lr[j]) -= Lv[j] * xi;
+            csc_scatter(Lv, Lr, Lc[i], Lc[i + 1], xi, RH, Bp);
         }
         for (int j = 0; j < nr; j++) AT(RH, j) *= Dinv[j];
-        for (int i = nr - 1; i >= 0; i--) {
-            double acc = AT(RH, i);
-            for (int j = Lc[i]; j < Lc[i + 1]; j++) acc -= Lv[j] * AT(RH, Lr[j]);
-            AT(RH, i) = acc;
-        }
+        for (int i = nr - 1; i >= 0; i--) AT(RH, i) = csr_dot<true>(AT(RH, i), Lv, Lr, Lc[i], Lc[i + 1], RH, Bp);
         // primal_hat = (-Hh^-1) q_hat + (-Hh^-1 Gh') mu  (:193-205)
         for (int i = 0; i < np; i++) {
-            double acc = 0.0;
-            for (int j = Hr[i]; j < Hr[i + 1]; j++) acc += Hv[j] * AT(QH, Hc[j]);
-            for (int j = HGr[i]; j < HGr[i + 1]; j++) acc += HGv[j] * AT(RH, HGc[j]);
+            double acc = csr_dot<false>(0.0, Hv, Hc, Hr[i], Hr[i + 1], QH, Bp);
+            acc = csr_dot<false>(acc, HGv, HGc, HGr[i], HGr[i + 1], RH, Bp);
             AT(PH, i) = acc;
         }
         // z: box on the first dim-n-1 entries (:209-217), lambda (:246-248), residuals (:256-267)
