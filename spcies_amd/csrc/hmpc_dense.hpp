@@ -399,7 +399,21 @@ __global__ __launch_bounds__(64) void dense_stream_kernel(Dev d, const double *_
                     acc[r] += cM2[(long)i * n + j] * bj;
                 }
             }
-            for (int j = 0; j < dim; j++) {
+            int j = 0;
+            for (; j + 8 <= dim; j += 8) {  // eight entries of q_hat loaded before the first is used (one load in flight otherwise)
+                double qv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) qv[u] = AT(QH, j + u);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const int i = min(i0 + r, dim - 1);
+                        acc[r] += cM1[(long)i * dim + j + u] * qv[u];
+                    }
+                }
+            }
+            for (; j < dim; j++) {
                 const double qj = AT(QH, j);
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
