@@ -748,6 +748,31 @@ def test_mfma4g_admm_arbitrary_shapes(n, m, N, formulation):
     s.close()
 
 
+@pytest.mark.parametrize("n,m,N", [(6, 2, 7), (5, 3, 6), (8, 1, 10), (10, 4, 5), (7, 2, 13)])
+def test_bsp_arbitrary_shapes(n, m, N):
+    """BSP prints a program per controller: shapes whose z / s / right-hand-side sizes leave 1, 2 or 3 rows in the last slab, a
+    dense terminal weight (off-diagonal blocks of -Hh^-1: the saved q_hat path of the generator) and a genuine ellipsoid."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=300 + n)
+    rng = np.random.default_rng(7 * n + m)
+    M = rng.standard_normal((n, n))
+    cfg.formulation, cfg.method, cfg.submethod = "ellipMPC", "ADMM", "soc"
+    cfg.param.P, cfg.param.c, cfg.param.r = np.eye(n) + 0.05 * (M @ M.T), 0.05 * rng.standard_normal(n), 0.6
+    cfg.solver_options = dict(rho=8.0, sigma=5.0, tol_p=1e-6, tol_d=1e-6, k_max=400)
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    s.set_variant("bsp")
+    B = 50
+    x0 = 0.3 * rng.standard_normal((B, n))
+    xr = 0.1 * rng.standard_normal((B, n))
+    ur = 0.05 * rng.standard_normal((B, m))
+    r = 0.6 + 0.2 * rng.random(B)
+    _compare_sparse("bsp", s(x0, xr, ur, r), oracle.admm_soc_batch(v, x0, xr, ur, r))
+    s.close()
+
+
 @pytest.mark.parametrize("n,m,N,formulation", [(10, 3, 9, "laxMPC"), (16, 4, 6, "equMPC"), (9, 2, 31, "laxMPC")])
 def test_mfma4g_fista_arbitrary_shapes(n, m, N, formulation):
     from oracle import oracle
