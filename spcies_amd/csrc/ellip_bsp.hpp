@@ -1,0 +1,613 @@
+// Variant BSP of the ellipMPC ADMM solver (formulations/+ellipMPC/code_ellipMPC_ADMM_C.c:20-523): the generator of
+// soc_bsp.hpp applied to a banded solver.  The z-update of the lax-type iteration is the equality-constrained QP
+//     z = -H^-1 (q_hat + G' mu),   W mu = -(G H^-1 q_hat + b),   W = G H^-1 G',
+// with H^-1 = blkdiag(Hi_0, Hi_1 .. Hi_{N-1}, Hi_N) (diagonal but for the dense terminal block inv(T + rho P)) and G the
+// dynamics [B -I; A B -I; ...] - which the reference solves through its banded Cholesky factors Alpha / Beta
+// (:355-486).  Here W is factorised L D L' on the host and the iteration becomes the same kind of program as the soc
+// solver's: rhs = (-G H^-1) q_hat - b column by column, block forward / backward substitution, z = (-H^-1) q_hat +
+// (-H^-1 G') mu row by row with the box update of each slab in w-form (w = v + lambda / rho), and the terminal block in
+// the reference's P-coordinates (:146-156, 318-386): q_hat_N = qT + P_half lambda_N - rho P v_N,
+// v_N = ellipsoid projection of z_N + (1/rho) Pinv_half lambda_N, lambda_N += P_half rho (z_N - v_N) - four dense block
+// products of the terminal slabs and one cross-lane norm.  Same result as the banded path up to rounding (1e-10 bar).
+#pragma once
+#include "soc_bsp.hpp"
+
+namespace spcies {
+namespace bsp {
+
+struct EArgs {  // mirrored in the generated source
+    int n, m, N, dim, k_max, ref_stride;
+    double tol, rho, rho_i, r2, r;
+    long B;
+};
+
+// dense L D L' of a symmetric positive definite matrix (no pivoting)
+inline bool dense_ldl(const Dense &W, int n, Dense &L, std::vector<double> &Dinv) {
+    L.assign((size_t)n * n, 0.0);
+    Dinv.assign(n, 0.0);
+    std::vector<double> D(n, 0.0);
+    for (int j = 0; j < n; j++) {
+        double d = W[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k] * D[k];
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        D[j] = d;
+        Dinv[j] = 1.0 / d;
+        L[(size_t)j * n + j] = 1.0;
+        for (int i = j + 1; i < n; i++) {
+            double s = W[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k] * D[k];
+            L[(size_t)i * n + j] = s / d;
+        }
+    }
+    return true;
+}
+
+inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
+    const int n = a.n, m = a.m, nm = n + m, N = a.N, dim = N * nm, dz = m + (N - 1) * nm, nr = N * n;
+    const int ZS = (dz + 3) / 4, TS = (n + 3) / 4, NP = ZS + TS, NR = (nr + 3) / 4, PR_ = 4 * NP, RR = 4 * NR;
+    p.ok = false;
+    p.src.clear();
+    p.ZS = ZS; p.SS = TS; p.NR = NR;
+    if (!a.ellip || !a.terminal) { p.why = "not an ellipMPC ADMM solver"; return 0; }
+    if (m > 4) { p.why = "m > 4 (u rows outside slab 0)"; return 0; }
+    if (NR + ZS + 4 * TS > 190) { p.why = "state does not fit the register file"; return 0; }
+    auto ip = [&](int j) { return j < dz ? j : 4 * ZS + (j - dz); };
+    // ---- H^-1, G (natural order), W = G H^-1 G'
+    Dense Hinv((size_t)dim * dim, 0.0), G((size_t)nr * dim, 0.0);
+    for (int j = 0; j < m; j++) Hinv[(size_t)j * dim + j] = a.Hi_0[j];
+    for (int l = 0; l < N - 1; l++)
+        for (int j = 0; j < nm; j++) {
+            const int r = m + l * nm + j;
+            Hinv[(size_t)r * dim + r] = a.Hi[(size_t)l * nm + j];
+        }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Hinv[(size_t)(dz + i) * dim + dz + j] = a.Hi_N[(size_t)i * n + j];
+    for (int i = 0; i < n; i++) {  // block 0: B u0 - x1 = -A x0
+        for (int j = 0; j < m; j++) G[(size_t)i * dim + j] = a.AB[(size_t)i * nm + n + j];
+        G[(size_t)i * dim + m + i] = -1.0;
+    }
+    for (int l = 1; l < N; l++)  // block l: A x_l + B u_l - x_{l+1} = 0
+        for (int i = 0; i < n; i++) {
+            const int row = l * n + i, c0 = m + (l - 1) * nm;
+            for (int j = 0; j < nm; j++) G[(size_t)row * dim + c0 + j] = a.AB[(size_t)i * nm + j];
+            G[(size_t)row * dim + (l < N - 1 ? m + l * nm + i : dz + i)] = -1.0;
+        }
+    Dense GH((size_t)nr * dim, 0.0), W((size_t)nr * nr, 0.0);
+    for (int i = 0; i < nr; i++)
+        for (int k = 0; k < dim; k++) {
+            const double g = G[(size_t)i * dim + k];
+            if (g == 0.0) continue;
+            for (int j = 0; j < dim; j++) {
+                const double h = Hinv[(size_t)k * dim + j];
+                if (h != 0.0) GH[(size_t)i * dim + j] += g * h;
+            }
+        }
+    for (int i = 0; i < nr; i++)
+        for (int j = 0; j < nr; j++) {
+            double s = 0.0;
+            for (int k = 0; k < dim; k++) s += GH[(size_t)i * dim + k] * G[(size_t)j * dim + k];
+            W[(size_t)i * nr + j] = s;
+        }
+    Dense Ln;
+    std::vector<double> Dn;
+    if (!dense_ldl(W, nr, Ln, Dn)) { p.why = "W = G H^-1 G' is not positive definite"; return 0; }
+    // ---- internal layout
+    Dense Gm((size_t)RR * PR_, 0.0), HG((size_t)PR_ * RR, 0.0), H((size_t)PR_ * PR_, 0.0), L((size_t)RR * RR, 0.0), Dinv(RR, 1.0);
+    for (int i = 0; i < nr; i++)
+        for (int j = 0; j < dim; j++) {
+            Gm[(size_t)i * PR_ + ip(j)] = -GH[(size_t)i * dim + j];
+            HG[(size_t)ip(j) * RR + i] = -GH[(size_t)i * dim + j];  // -H^-1 G' = (-G H^-1)'  (H symmetric)
+        }
+    for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++) H[(size_t)ip(i) * PR_ + ip(j)] = -Hinv[(size_t)i * dim + j];
+    for (int i = 0; i < RR; i++) L[(size_t)i * RR + i] = 1.0;
+    for (int i = 0; i < nr; i++) {
+        for (int j = 0; j < i; j++) L[(size_t)i * RR + j] = Ln[(size_t)i * nr + j];
+        Dinv[i] = Dn[i];
+    }
+    const BlockList bG = blocks_of(Gm, RR, PR_), bHG = blocks_of(HG, PR_, RR), bH = blocks_of(H, PR_, PR_), bL = blocks_of(L, RR, RR);
+    int SEG_EVERY = 4, PF = 12;
+    if (const char *ev = getenv("SPCIES_BSP_SEG")) SEG_EVERY = std::max(1, atoi(ev));
+    if (const char *ev = getenv("SPCIES_BSP_PF")) PF = std::min(64, std::max(2, atoi(ev)));
+    if (pf_request > 0) PF = pf_request;
+    std::vector<double> &tab = p.table;
+    tab.clear();
+    std::string body;
+    char line[512], a1[64], a2[64];
+    int n_mfma = 0;
+    auto emit_block = [&](const double *blk) {
+        const int t = (int)(tab.size() / 16);
+        for (int k = 0; k < 4; k++)
+            for (int i = 0; i < 4; i++) tab.push_back(blk[i * 4 + k]);
+        return t;
+    };
+    auto block_of = [&](const Dense &M, int cols, int Ib, int Jb, double *out) {
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) out[i * 4 + k] = M[(size_t)(4 * Ib + i) * cols + 4 * Jb + k];
+    };
+    auto mul44 = [&](const double *x, const double *y, double *o, double sign) {
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) {
+                double s = 0.0;
+                for (int q = 0; q < 4; q++) s += x[i * 4 + q] * y[q * 4 + k];
+                o[i * 4 + k] = sign * s;
+            }
+    };
+    auto inv_unit_lower = [&](const double *x, double *o) {
+        for (int col = 0; col < 4; col++)
+            for (int i = 0; i < 4; i++) {
+                double s = (i == col) ? 1.0 : 0.0;
+                for (int q = 0; q < i; q++) s -= x[i * 4 + q] * o[q * 4 + col];
+                o[i * 4 + col] = s;
+            }
+    };
+    auto MF = [&](const char *acc, int t, const char *x) {
+        snprintf(line, sizeof(line), "            MF(%s, a%d, %s); @%d@\n", acc, t % PF, x, t);
+        body += line;
+        n_mfma++;
+    };
+    // a dense n x n matrix (scaled) applied to TS slabs: out[k] += sum_j M[k][j] in[j]
+    auto dense_tail = [&](const std::vector<double> &M, double scale, const char *out, const char *in) {
+        Dense Mp((size_t)4 * TS * 4 * TS, 0.0);
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) Mp[(size_t)i * 4 * TS + j] = scale * M[(size_t)i * n + j];
+        for (int k = 0; k < TS; k++)
+            for (int j = 0; j < TS; j++) {
+                double blk[16];
+                block_of(Mp, 4 * TS, k, j, blk);
+                bool nz = false;
+                for (double x : blk) nz |= x != 0.0;
+                if (!nz) continue;
+                snprintf(a1, sizeof(a1), "%s[%d]", out, k);
+                snprintf(a2, sizeof(a2), "%s[%d]", in, j);
+                MF(a1, emit_block(blk), a2);
+            }
+    };
+    auto qhat_expr = [&](int J, char *out, size_t cap) {
+        if (J < ZS) snprintf(out, cap, "QHZ(%d)", J);
+        else snprintf(out, cap, "qt[%d]", J - ZS);
+    };
+    // ---- terminal q_hat in P-coordinates (:146-156)
+    body += "            // q_hat_N = qT + P_half lambda_N - rho P v_N\n            double qt[TS_];\n";
+    for (int k = 0; k < TS; k++) {
+        snprintf(line, sizeof(line), "            qt[%d] = qTv[%d];\n", k, k);
+        body += line;
+    }
+    dense_tail(a.P_half, 1.0, "qt", "lamN");
+    dense_tail(a.P, -a.rho, "qt", "vN");
+    body += "            SEG;\n            // rhs = (-G H^-1) q_hat - b\n";
+    const int bh_slabs = (n + 3) / 4;  // b = -A x0 in the first n rows
+    for (int Ib = 0; Ib < NR; Ib++) {
+        if (Ib < bh_slabs) snprintf(line, sizeof(line), "            rh[%d] = -bh[%d];\n", Ib, Ib);
+        else snprintf(line, sizeof(line), "            rh[%d] = 0.0;\n", Ib);
+        body += line;
+    }
+    for (int J = 0; J < NP; J++) {
+        if (bG.by_col[J].empty()) continue;
+        char e[64];
+        qhat_expr(J, e, sizeof(e));
+        snprintf(line, sizeof(line), "            { const double qh = %s;\n", e);
+        body += line;
+        for (int Ib : bG.by_col[J]) {
+            double blk[16];
+            block_of(Gm, PR_, Ib, J, blk);
+            snprintf(a1, sizeof(a1), "rh[%d]", Ib);
+            MF(a1, emit_block(blk), "qh");
+        }
+        body += "            }\n";
+        if (J % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
+    }
+    // (the bound rows are read again in the update phase: laundering their index keeps the compiler from holding all of them
+    // in registers across the solve)
+    body += "            SEG;\n            LAUNDER;\n            // W mu = rhs: forward substitution by blocks\n";
+    std::vector<std::vector<double>> Linv(NR, std::vector<double>(16));
+    for (int Ib = 0; Ib < NR; Ib++) {
+        double d[16];
+        block_of(L, RR, Ib, Ib, d);
+        inv_unit_lower(d, Linv[Ib].data());
+        body += "            { double acc = 0.0;\n";
+        snprintf(a2, sizeof(a2), "rh[%d]", Ib);
+        MF("acc", emit_block(Linv[Ib].data()), a2);
+        for (int J : bL.by_row[Ib]) {
+            if (J >= Ib) continue;
+            double b[16], o[16];
+            block_of(L, RR, Ib, J, b);
+            mul44(Linv[Ib].data(), b, o, -1.0);
+            snprintf(a2, sizeof(a2), "rh[%d]", J);
+            MF("acc", emit_block(o), a2);
+        }
+        snprintf(line, sizeof(line), "              rh[%d] = acc; }\n", Ib);
+        body += line;
+        if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
+    }
+    body += "            SEG;\n            // D^-1 and the backward substitution by blocks (U = L')\n";
+    for (int Ib = NR - 1; Ib >= 0; Ib--) {
+        double ui[16], d[16];
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) ui[i * 4 + k] = Linv[Ib][k * 4 + i];
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) d[i * 4 + k] = ui[i * 4 + k] * Dinv[4 * Ib + k];
+        body += "            { double acc = 0.0;\n";
+        snprintf(a2, sizeof(a2), "rh[%d]", Ib);
+        MF("acc", emit_block(d), a2);
+        for (int J : bL.by_col[Ib]) {
+            if (J <= Ib) continue;
+            double lj[16], u[16], o[16];
+            block_of(L, RR, J, Ib, lj);
+            for (int i = 0; i < 4; i++)
+                for (int k = 0; k < 4; k++) u[i * 4 + k] = lj[k * 4 + i];
+            mul44(ui, u, o, -1.0);
+            snprintf(a2, sizeof(a2), "rh[%d]", J);
+            MF("acc", emit_block(o), a2);
+        }
+        snprintf(line, sizeof(line), "              rh[%d] = acc; }\n", Ib);
+        body += line;
+        if (Ib % SEG_EVERY == 0) body += "            SEG;\n";
+    }
+    // ---- z = (-H^-1) q_hat + (-H^-1 G') mu.  -H^-1 is diagonal on the z slabs (a block never reaches another slab) and dense
+    // only inside the terminal slabs, whose q_hat sits in qt[] for the whole iteration: no q_hat has to be saved.
+    for (int Ib = 0; Ib < ZS; Ib++)
+        for (int J : bH.by_row[Ib])
+            if (J != Ib) { p.why = "H^-1 couples two z slabs"; return 0; }
+    body += "            LAUNDER;\n            // z = (-H^-1) q_hat + (-H^-1 G') mu; box update of the z slabs\n";
+    auto prim_row = [&](int Ib, const char *acc) {
+        for (int J : bH.by_row[Ib]) {
+            double blk[16];
+            block_of(H, PR_, Ib, J, blk);
+            char e[64];
+            qhat_expr(J, e, sizeof(e));
+            snprintf(line, sizeof(line), "            { const double qh = %s;\n  ", e);
+            body += line;
+            MF(acc, emit_block(blk), "qh");
+            body += "            }\n";
+        }
+        for (int J : bHG.by_row[Ib]) {
+            double blk[16];
+            block_of(HG, RR, Ib, J, blk);
+            snprintf(a2, sizeof(a2), "rh[%d]", J);
+            MF(acc, emit_block(blk), a2);
+        }
+    };
+    for (int Ib = 0; Ib < ZS; Ib++) {
+        body += "            { double ph = 0.0;\n";
+        prim_row(Ib, "ph");
+        snprintf(line, sizeof(line), "              ZUPD(%d, ph); }\n", Ib);
+        body += line;
+        if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
+    }
+    // ---- terminal block (:318-386)
+    body += "            SEG;\n            { double zN[TS_], vn[TS_], dd[TS_], pv[TS_], tt[TS_];\n";
+    for (int k = 0; k < TS; k++) {
+        snprintf(line, sizeof(line), "              zN[%d] = 0.0;\n", k);
+        body += line;
+        snprintf(a1, sizeof(a1), "zN[%d]", k);
+        prim_row(ZS + k, a1);
+    }
+    body += "              _Pragma(\"unroll\") for (int k_ = 0; k_ < TS_; k_++) vn[k_] = zN[k_];\n";
+    dense_tail(a.Pinv_half, a.rho_i, "vn", "lamN");
+    body += "              _Pragma(\"unroll\") for (int k_ = 0; k_ < TS_; k_++) { dd[k_] = vn[k_] - CE(k_); pv[k_] = 0.0; }\n";
+    dense_tail(a.P, 1.0, "pv", "dd");
+    body += "              EUPD_A;\n";
+    dense_tail(a.P_half, 1.0, "lamN", "tt");
+    body += "              EUPD_B; }\n";
+    p.n_blocks = (int)(tab.size() / 16);
+    p.n_mfma = n_mfma;
+    {
+        const int nb = p.n_blocks, n_pad = (nb + PF - 1) / PF * PF;
+        std::string out;
+        out.reserve(body.size() + (size_t)nb * 40);
+        auto refill = [&](int t) {
+            const int nx = (t + PF) % n_pad;
+            if (nx >= nb) return;
+            snprintf(line, sizeof(line), "a%d = BLK(blk%d, %d);", t % PF, nx / 512, nx % 512);
+            out += line;
+        };
+        for (size_t i = 0; i < body.size();) {
+            if (body[i] == '@') {
+                const size_t j = body.find('@', i + 1);
+                refill(atoi(body.substr(i + 1, j - i - 1).c_str()));
+                i = j + 1;
+            } else {
+                out.push_back(body[i++]);
+            }
+        }
+        out += "            ";
+        for (int t = nb; t < n_pad; t++) refill(t);
+        out += "\n";
+        body.swap(out);
+    }
+    // ---- row tables behind the blocks: LB, UB of the z slabs (pads pinned to 0), c of the terminal slabs
+    const int rc_lb = (int)tab.size();
+    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < m ? a.LBu0[r] : (r < dz ? a.LBz[r - m] : 0.0));
+    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < m ? a.UBu0[r] : (r < dz ? a.UBz[r - m] : 0.0));
+    for (int r = 0; r < 4 * TS; r++) tab.push_back(r < n ? a.c_ell[r] : 0.0);
+    for (double &x : tab) {
+        if (x > 1e300) x = 1e300;  // (+-inf bounds)
+        if (x < -1e300) x = -1e300;
+        if (!std::isfinite(x)) { p.why = "non-finite block"; return 0; }
+    }
+    if (tab.size() * sizeof(double) > 160 * 1024 - 1024 || p.n_blocks > 1536) { p.why = "block table exceeds the LDS"; return 0; }
+    if (p.n_blocks <= PF) { p.why = "fewer blocks than the prefetch ring"; return 0; }
+    // ---- q: slabs with the same row pattern share one register
+    std::map<std::vector<int>, int> sig_index;
+    std::vector<int> qi(ZS), qrow;
+    auto row_type = [&](int r) {
+        if (r >= dz) return 0;
+        if (r < m) return 1 + r;
+        const int e = (r - m) % nm;
+        return e < n ? 1000 + e : 1 + (e - n);
+    };
+    for (int J = 0; J < ZS; J++) {
+        std::vector<int> sig = {row_type(4 * J), row_type(4 * J + 1), row_type(4 * J + 2), row_type(4 * J + 3)};
+        auto it = sig_index.find(sig);
+        if (it == sig_index.end()) {
+            it = sig_index.emplace(sig, (int)qrow.size()).first;
+            qrow.push_back(4 * J);
+        }
+        qi[J] = it->second;
+    }
+    std::string s;
+    auto def = [&](const char *name, long v) { snprintf(line, sizeof(line), "#define %s %ld\n", name, v); s += line; };
+    def("ZS_", ZS); def("TS_", TS); def("NR_", NR); def("NQ_", (long)qrow.size()); def("NBH_", bh_slabs);
+    def("TAB_DOUBLES_", (long)tab.size()); def("RC_", rc_lb); def("DIM_", dim); def("DZ_", dz); def("NN_", n);
+    s += "#define RING_INIT";
+    for (int i = 0; i < PF; i++) { snprintf(line, sizeof(line), " double a%d = BLK(blk%d, %d);", i, (i % p.n_blocks) / 512, (i % p.n_blocks) % 512); s += line; }
+    s += "\n";
+    {
+        const int nb = p.n_blocks;
+        def("NB0_", std::max(1, std::min(nb, 512))); def("NB1_", std::max(1, std::min(nb - 512, 512))); def("NB2_", std::max(1, nb - 1024));
+    }
+    for (int J = 0; J < ZS; J++) { snprintf(line, sizeof(line), "#define QI_%d %d\n", J, qi[J]); s += line; }
+    s += "static __device__ const int QROW_[NQ_] = {";
+    for (size_t i = 0; i < qrow.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", qrow[i]); s += line; }
+    s += "};\n";
+    s += R"SRC(
+struct EArgs {
+    int n, m, N, dim, k_max, ref_stride;
+    double tol, rho, rho_i, r2, r;
+    long B;
+};
+template <bool WANT_SOL>
+__device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__restrict__ table_g, const double *__restrict__ cst,
+                                               const double *__restrict__ x0g, const double *__restrict__ xrg,
+                                               const double *__restrict__ urg, double *__restrict__ u_out, int *__restrict__ k_out,
+                                               int *__restrict__ e_out, double *__restrict__ f0, double *__restrict__ f1,
+                                               double *__restrict__ f2) {
+    __shared__ __attribute__((aligned(16))) double ldsr[2 * 4 * ZS_ + 4 * TS_];
+    __shared__ __attribute__((aligned(16))) double blk0[NB0_ * 16];
+    __shared__ __attribute__((aligned(16))) double blk1[NB1_ * 16];
+    __shared__ __attribute__((aligned(16))) double blk2[NB2_ * 16];
+    for (int i = threadIdx.x; i < NB0_ * 16; i += 256) blk0[i] = table_g[i];
+    for (int i = threadIdx.x; i < NB1_ * 16; i += 256) blk1[i] = table_g[512 * 16 + i];
+    for (int i = threadIdx.x; i < NB2_ * 16; i += 256) blk2[i] = table_g[1024 * 16 + i];
+    for (int i = threadIdx.x; i < 2 * 4 * ZS_ + 4 * TS_; i += 256) ldsr[i] = table_g[RC_ + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int n = p.n, m = p.m, nm = n + m, dim = p.dim;
+    double *dump = const_cast<double *>(table_g) + TAB_DOUBLES_;
+    const double rho = p.rho, tol = p.tol;
+    const double *cA = cst, *cQ = cA + n * n, *cR = cQ + n * n, *cT = cR + m * m;  // A, diag(Q), diag(R) (negated weights), T
+    int ao = g * 4 + (lane & 3);
+    const long n_tiles = (p.B + 15) / 16;
+#define BLK(arr, t) arr[(t) * 16 + ao]
+#define MF(acc, a, x) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((a), (x), (acc), 0, 0, 0)
+#define SEG __builtin_amdgcn_sched_barrier(0)
+#define LAUNDER asm volatile("" : "+v"(go))
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long)gridDim.x * 4) {
+        const long inst = tile * 16 + c;
+        const bool valid = inst < p.B;
+        const long ii = valid ? inst : 0;
+        const double *x0 = x0g + ii * n;
+        const double *xr = p.ref_stride ? xrg + ii * n : xrg;
+        const double *ur = p.ref_stride ? urg + ii * m : urg;
+        double bh[NBH_];
+#pragma unroll
+        for (int I = 0; I < NBH_; I++) {
+            const int row = 4 * I + g;
+            double v = 0.0;
+            if (row < n)
+                for (int i = 0; i < n; i++) v -= cA[row * n + i] * x0[i];
+            bh[I] = v;
+        }
+        double qv[NQ_], qTv[TS_];
+#pragma unroll
+        for (int u = 0; u < NQ_; u++) {
+            const int j = QROW_[u] + g;
+            double v = 0.0;
+            if (j < m) {
+                for (int i = 0; i < m; i++) v += cR[j * m + i] * ur[i];
+            } else if (j < DZ_) {
+                const int e = (j - m) % nm;
+                if (e < n) {
+                    for (int i = 0; i < n; i++) v += cQ[e * n + i] * xr[i];
+                } else {
+                    for (int i = 0; i < m; i++) v += cR[(e - n) * m + i] * ur[i];
+                }
+            }
+            qv[u] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < TS_; k++) {
+            const int e = 4 * k + g;
+            double v = 0.0;
+            if (e < n)
+                for (int i = 0; i < n; i++) v += cT[e * n + i] * xr[i];
+            qTv[k] = v;
+        }
+        // state: w = v + lambda / rho per z slab (v = clamp(w), lambda = rho (w - v)); the terminal slabs keep v_N, lambda_N
+        double w[ZS_], vN[TS_], lamN[TS_], rh[NR_];
+#pragma unroll
+        for (int I = 0; I < ZS_; I++) w[I] = 0.0;
+#pragma unroll
+        for (int I = 0; I < TS_; I++) { vN[I] = 0.0; lamN[I] = 0.0; }
+        int go = g;
+#define LBR(I) ldsr[4 * (I) + go]
+#define UBR(I) ldsr[4 * ZS_ + 4 * (I) + go]
+#define CE(k) ldsr[8 * ZS_ + 4 * (k) + go]
+#define QHZ(J) (qv[QI_##J] + rho * (w[J] - 2.0 * fmin(fmax(w[J], LBR(J)), UBR(J))))
+        bool active = valid, res = false;
+        int kk = 0;
+        RING_INIT
+        // z slab I: v = clamp(z + lambda / rho), lambda += rho (z - v), residuals (:490-568)
+#define ZUPD(I, zh)                                                                              \
+    do {                                                                                         \
+        const double lb_ = LBR(I), ub_ = UBR(I);                                                 \
+        const double wo_ = w[I], vo_ = fmin(fmax(wo_, lb_), ub_);                                \
+        const double wn_ = (zh) + (wo_ - vo_), v_ = fmin(fmax(wn_, lb_), ub_);                   \
+        w[I] = wn_;                                                                              \
+        res |= (fabs(vo_ - v_) > tol) | (fabs((zh) - v_) > tol);                                 \
+        if (WANT_SOL) *((4 * (I) + 3 < DZ_ || 4 * (I) + g < DZ_) ? zp + 4 * (I) : dump) = (zh); \
+    } while (0)
+        // terminal block: the P-projection onto the ellipsoid (:318-352) ...
+#define EUPD_A                                                                                   \
+    do {                                                                                         \
+        double vpv_ = 0.0;                                                                       \
+        _Pragma("unroll") for (int k_ = 0; k_ < TS_; k_++) vpv_ += dd[k_] * pv[k_];              \
+        vpv_ += __shfl_xor(vpv_, 16);                                                            \
+        vpv_ += __shfl_xor(vpv_, 32);                                                            \
+        if (vpv_ > p.r2) {                                                                       \
+            const double sc_ = p.r / sqrt(vpv_);                                                 \
+            _Pragma("unroll") for (int k_ = 0; k_ < TS_; k_++) vn[k_] = sc_ * dd[k_] + CE(k_);   \
+        }                                                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < TS_; k_++) tt[k_] = rho * (zN[k_] - vn[k_]);     \
+    } while (0)
+        // ... and, after lambda_N += P_half tt, the residuals and the new v_N (:374-386)
+#define EUPD_B                                                                                   \
+    do {                                                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < TS_; k_++) {                                     \
+            res |= (fabs(vN[k_] - vn[k_]) > tol) | (fabs(zN[k_] - vn[k_]) > tol);                \
+            vN[k_] = vn[k_];                                                                     \
+            if (WANT_SOL) *((4 * k_ + 3 < NN_ || 4 * k_ + g < NN_) ? zp + DZ_ + 4 * k_ : dump) = zN[k_]; \
+        }                                                                                        \
+    } while (0)
+        while (true) {
+            kk += 1;
+            res = false;
+            asm volatile("" : "+v"(ao), "+v"(go));
+            double *zp = (WANT_SOL && active) ? f0 + inst * dim + g : dump;
+)SRC";
+    s += body;
+    s += R"SRC(
+            SEG;
+            unsigned long long bal = __ballot(res);
+            bal |= bal >> 32;
+            bal |= bal >> 16;
+            const bool res_inst = (bal >> c) & 1ull;
+            const bool done_now = active && (!res_inst || kk >= p.k_max);
+            if (__any(done_now)) {
+                if (done_now) {
+                    if (g == 0) {
+                        k_out[inst] = kk;
+                        e_out[inst] = res_inst ? -1 : 1;
+                    }
+                    if (g < m) u_out[inst * m + g] = fmin(fmax(w[0], LBR(0)), UBR(0));  // u = v_0
+                    if (WANT_SOL) {
+                        double *vp = f1 + inst * dim + g, *lp = f2 + inst * dim + g;
+#pragma unroll
+                        for (int I = 0; I < ZS_; I++) {
+                            const bool in_ = 4 * I + 3 < DZ_ || 4 * I + g < DZ_;
+                            const double v_ = fmin(fmax(w[I], LBR(I)), UBR(I));
+                            *(in_ ? vp + 4 * I : dump) = v_;
+                            *(in_ ? lp + 4 * I : dump) = rho * (w[I] - v_);
+                        }
+#pragma unroll
+                        for (int k = 0; k < TS_; k++) {
+                            const bool in_ = 4 * k + 3 < NN_ || 4 * k + g < NN_;
+                            *(in_ ? vp + DZ_ + 4 * k : dump) = vN[k];
+                            *(in_ ? lp + DZ_ + 4 * k : dump) = lamN[k];
+                        }
+                    }
+                    active = false;
+                }
+            }
+            if (!__any(active)) break;
+        }
+    }
+}
+extern "C" __global__ __launch_bounds__(256, 1) void ellip_bsp_kernel(EArgs p, const double *table_g, const double *cst, const double *x0g,
+                                                                     const double *xrg, const double *urg, double *u_out, int *k_out,
+                                                                     int *e_out) {
+    ellip_bsp_body<false>(p, table_g, cst, x0g, xrg, urg, u_out, k_out, e_out, nullptr, nullptr, nullptr);
+}
+extern "C" __global__ __launch_bounds__(256, 1) void ellip_bsp_kernel_sol(EArgs p, const double *table_g, const double *cst,
+                                                                         const double *x0g, const double *xrg, const double *urg,
+                                                                         double *u_out, int *k_out, int *e_out, double *f0, double *f1,
+                                                                         double *f2) {
+    ellip_bsp_body<true>(p, table_g, cst, x0g, xrg, urg, u_out, k_out, e_out, f0, f1, f2);
+}
+)SRC";
+    p.src = s;
+    if (const char *path = getenv("SPCIES_BSP_DUMP")) {
+        if (FILE *f = fopen(path, "w")) {
+            fputs(s.c_str(), f);
+            fclose(f);
+        }
+    }
+    p.why = "not compiled yet";
+    return 0;
+}
+
+inline int finish_ellip(Plan &p, const AdmmHost &a) {
+    if (p.src.empty() || p.ok) return 0;
+    if (p.d_table) hipFree(p.d_table);
+    if (p.d_consts) hipFree(p.d_consts);
+    p.d_table = p.d_consts = nullptr;
+    int scratch = 0;
+    int rc = compile_program(p, &scratch, "ellip_bsp_kernel", "ellip_bsp_kernel_sol");
+    if (rc) return rc;
+    if (!getenv("SPCIES_BSP_PF"))
+        for (int pf : {8, 4}) {
+            if (scratch == 0) break;
+            rc = build_ellip(p, a, pf);
+            if (rc) return rc;
+            if (p.src.empty()) return fail(SPCIES_HIP_ENOSUP, "BSP program: %s", p.why.c_str());
+            rc = compile_program(p, &scratch, "ellip_bsp_kernel", "ellip_bsp_kernel_sol");
+            if (rc) return rc;
+        }
+    if (getenv("SPCIES_BSP_VERBOSE"))
+        fprintf(stderr, "[spcies bsp] ellipMPC ADMM: %d blocks, %d MFMAs per iteration, table %zu B, scratch %d B per lane\n", p.n_blocks,
+                p.n_mfma, p.table.size() * sizeof(double), scratch);
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_table, (p.table.size() + 4 * (size_t)(p.ZS + p.SS) + 8) * sizeof(double)));
+    SPCIES_HIP_CHECK(hipMemcpy(p.d_table, p.table.data(), p.table.size() * sizeof(double), hipMemcpyHostToDevice));
+    const int n = a.n, m = a.m, nm = n + m;
+    std::vector<double> cst((size_t)n * n * 2 + (size_t)m * m + (size_t)n * n, 0.0);
+    double *cA = cst.data(), *cQ = cA + n * n, *cR = cQ + n * n, *cT = cR + m * m;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) {
+            cA[i * n + j] = a.AB[(size_t)i * nm + j];
+            cT[i * n + j] = a.T[(size_t)i * n + j];
+        }
+        cQ[i * n + i] = a.Q[i];
+    }
+    for (int j = 0; j < m; j++) cR[j * m + j] = a.R[j];
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_consts, cst.size() * sizeof(double)));
+    SPCIES_HIP_CHECK(hipMemcpy(p.d_consts, cst.data(), cst.size() * sizeof(double), hipMemcpyHostToDevice));
+    hipDeviceProp_t prop;
+    int dev = 0;
+    SPCIES_HIP_CHECK(hipGetDevice(&dev));
+    SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    p.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    p.ok = true;
+    p.why.clear();
+    return 0;
+}
+
+// z, v, lambda: all or none
+inline int launch_ellip(Plan &p, const AdmmHost &a, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u,
+                        int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
+    if (!p.ok) return fail(SPCIES_HIP_ENOSUP, "BSP variant not available: %s", p.why.c_str());
+    const bool any = z || v || lam;
+    if (any && !(z && v && lam)) return fail(SPCIES_HIP_EINVAL, "BSP variant: pass all of z, v, lambda or none");
+    EArgs ar{a.n, a.m, a.N, a.N * (a.n + a.m), a.k_max, ref_stride, a.tol, a.rho, a.rho_i, a.r_ell * a.r_ell, a.r_ell, B};
+    const long n_tiles = (B + 15) / 16;
+    long wgs = (n_tiles + 3) / 4;
+    if (wgs > p.num_cu) wgs = p.num_cu;
+    const double *table = p.d_table, *cst = p.d_consts;
+    void *params[] = {&ar, &table, &cst, &x0, &xr, &ur, &u, &k, &e, &z, &v, &lam};
+    SPCIES_HIP_CHECK(hipModuleLaunchKernel(p.fn[any ? 1 : 0], (unsigned)wgs, 1, 1, 256, 1, 1, 0, st, params, nullptr));
+    return 0;
+}
+
+}  // namespace bsp
+}  // namespace spcies

@@ -560,7 +560,7 @@ extern "C" __global__ __launch_bounds__(256, 1) void soc_bsp_kernel_sol(Args p, 
 }
 
 // compiles p.src (hiprtc) and loads the module; *scratch = bytes of scratch memory per lane of the no-record kernel
-inline int compile_program(Plan &p, int *scratch) {
+inline int compile_program(Plan &p, int *scratch, const char *name0 = "soc_bsp_kernel", const char *name1 = "soc_bsp_kernel_sol") {
     if (p.module) hipModuleUnload(p.module);
     p.module = nullptr;
     rtc::Hiprtc &rt = rtc::hiprtc();
@@ -584,8 +584,8 @@ inline int compile_program(Plan &p, int *scratch) {
     rt.code(prog, code.data());
     rt.destroy(&prog);
     SPCIES_HIP_CHECK(hipModuleLoadData(&p.module, code.data()));
-    SPCIES_HIP_CHECK(hipModuleGetFunction(&p.fn[0], p.module, "soc_bsp_kernel"));
-    SPCIES_HIP_CHECK(hipModuleGetFunction(&p.fn[1], p.module, "soc_bsp_kernel_sol"));
+    SPCIES_HIP_CHECK(hipModuleGetFunction(&p.fn[0], p.module, name0));
+    SPCIES_HIP_CHECK(hipModuleGetFunction(&p.fn[1], p.module, name1));
     int local = 0;
     if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, p.fn[0]) != hipSuccess) local = 0;
     *scratch = local;

@@ -19,6 +19,7 @@
 #include "hmpc_dense.hpp"
 #include "mpct_cs.hpp"
 #include "soc_bsp.hpp"
+#include "ellip_bsp.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -580,6 +581,7 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         for (double r : a.rho_0) if (!(r > 0)) return fail(SPCIES_HIP_EINVAL, "bad rho");
         for (double r : a.rho_v) if (!(r > 0)) return fail(SPCIES_HIP_EINVAL, "bad rho");
     }
+    if (a.ellip) return bsp::build_ellip(s.bsp, a);  // BSP variant: generate the controller's block program (host only)
     return 0;
 }
 
@@ -664,7 +666,8 @@ static int ensure_mfma4_rtc(Solver &s) {
 
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
-    if (s.tv || s.host.ellip) return SPCIES_VARIANT_STREAM;
+    if (s.host.ellip) return s.bsp.ok ? SPCIES_VARIANT_BSP : SPCIES_VARIANT_STREAM;
+    if (s.tv) return SPCIES_VARIANT_STREAM;
     if (s.is_hdense()) return SPCIES_VARIANT_GEMM;
     if (s.is_cs()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.is_hmpc() && s.hgemm.ok) return SPCIES_VARIANT_GEMM;
@@ -1187,9 +1190,11 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (s.host.n == 12 && s.host.m == 2) return launch_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
     }
+    if (s.host.ellip && resolve_variant(s) == SPCIES_VARIANT_BSP)
+        return bsp::launch_ellip(s.bsp, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
     if (s.host.ellip) {
         if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
-            return fail(SPCIES_HIP_ENOSUP, "ellipMPC ADMM: only the STREAM variant is built");
+            return fail(SPCIES_HIP_ENOSUP, "ellipMPC ADMM: variants BSP and STREAM are built");
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, z || v || lam));
         if (rc) return rc;
         if (s.host.n == 6 && s.host.m == 2) return launch_stream_nm<6, 2, true>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
@@ -1314,6 +1319,10 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         const char *ev = getenv("SPCIES_HIP_BSP");
         if (!(ev && ev[0] == '0') && bsp::finish_soc(s->bsp, s->sdev, s->soc_f64.data(), s->soc_i32.data()) != 0) s->bsp.why = g_last_error;
     }
+    if (s->host.ellip && !s->bsp.src.empty()) {  // ellipMPC ADMM: the same kind of program (ellip_bsp.hpp)
+        const char *ev = getenv("SPCIES_HIP_BSP");
+        if (!(ev && ev[0] == '0') && bsp::finish_ellip(s->bsp, s->host) != 0) s->bsp.why = g_last_error;
+    }
     if (s->eng) {
         if (s->tv) return fail(SPCIES_HIP_ENOSUP, "in_engineering with time_varying is not built");
         SPCIES_HIP_CHECK(hipMalloc((void **)&s->d_eng, s->eng_v.size() * sizeof(double)));
@@ -1382,11 +1391,12 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     Solver *s = reinterpret_cast<Solver *>(h);
     if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_BSP) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
     if (variant == SPCIES_VARIANT_BSP) {
-        if (!(s->is_soc() && !s->is_hmpc())) return fail(SPCIES_HIP_ENOSUP, "BSP variant: built for the ellipMPC soc solver");
+        const bool soc = s->is_soc() && !s->is_hmpc();
+        if (!soc && !s->host.ellip) return fail(SPCIES_HIP_ENOSUP, "BSP variant: built for the ellipMPC solvers (ADMM and ADMM soc)");
         if (!s->bsp.ok) {  // not compiled at create time (SPCIES_HIP_BSP=0, or it failed): try now and report
             if (s->bsp.src.empty()) return fail(SPCIES_HIP_ENOSUP, "BSP variant not available: %s", s->bsp.why.c_str());
             SPCIES_HIP_CHECK(hipSetDevice(s->device));
-            int rc = bsp::finish_soc(s->bsp, s->sdev, s->soc_f64.data(), s->soc_i32.data());
+            int rc = soc ? bsp::finish_soc(s->bsp, s->sdev, s->soc_f64.data(), s->soc_i32.data()) : bsp::finish_ellip(s->bsp, s->host);
             if (rc) return rc;
         }
         s->variant = variant;

@@ -681,13 +681,14 @@ def test_ellip_admm_reference_test_instance(golden_dir):
 
 @pytest.mark.parametrize("cfg_name,B,overrides", [("C1_ellip", 70, {}), ("C2_ellip", 130, {}),
                                                   ("C2_ellip", 40, dict(tol=1e-6, k_max=3000))])
-def test_ellip_admm_seeded_batch_vs_oracle(cfg_name, B, overrides):
+@pytest.mark.parametrize("variant", ["stream", "bsp"])  # BSP: the iteration as a per-controller program of 4x4 MFMA blocks -> 1e-10
+def test_ellip_admm_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
-    cfg, v, s = _solver(cfg_name, "stream", **overrides)
+    cfg, v, s = _solver(cfg_name, variant, **overrides)
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
     got = s(x0, xr, ur)
-    _compare("stream", got, oracle.admm_banded_batch(v, x0, xr, ur), v)
+    _compare(variant, got, oracle.admm_banded_batch(v, x0, xr, ur), v)
     if cfg_name == "C2_ellip":  # v_N lies in the ellipsoid; before convergence some instances sit on its boundary
         n = cfg.sys.n
         d = got[3].v[:, -n:] - cfg.param.c
