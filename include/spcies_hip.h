@@ -200,7 +200,7 @@ typedef struct spcies_hip_solver_s *spcies_hip_handle;
 #define SPCIES_VARIANT_MFMA4G 4 /* v_mfma_f64_4x4x4 with a rolled stage loop: any N, state streamed through HBM   */
 #define SPCIES_VARIANT_TILE 5   /* sparse-KKT solvers: 4-64 lanes per instance, LDL right-hand side in LDS          */
 #define SPCIES_VARIANT_GEMM 6   /* HMPC (split NON_SPARSE path; no-split solver): one dgemm per iteration for the batch */
-#define SPCIES_VARIANT_BSP 7    /* ellipMPC soc: the sparse KKT solve as a per-controller program of 4x4 MFMA blocks     */
+#define SPCIES_VARIANT_BSP 7    /* ellipMPC ADMM / soc: the KKT iteration as a per-controller program of 4x4 MFMA blocks */
 
 typedef struct {
     int formulation, method, submethod;

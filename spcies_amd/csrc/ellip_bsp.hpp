@@ -106,7 +106,7 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         Dinv[i] = Dn[i];
     }
     const BlockList bG = blocks_of(Gm, RR, PR_), bHG = blocks_of(HG, PR_, RR), bH = blocks_of(H, PR_, PR_), bL = blocks_of(L, RR, RR);
-    int SEG_EVERY = 4, PF = 12;
+    int SEG_EVERY = 4, PF = 8;  // (a 12-deep ring leaves 116 B of scratch at the C2 shape)
     if (const char *ev = getenv("SPCIES_BSP_SEG")) SEG_EVERY = std::max(1, atoi(ev));
     if (const char *ev = getenv("SPCIES_BSP_PF")) PF = std::min(64, std::max(2, atoi(ev)));
     if (pf_request > 0) PF = pf_request;
@@ -250,12 +250,15 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         for (int J : bH.by_row[Ib])
             if (J != Ib) { p.why = "H^-1 couples two z slabs"; return 0; }
     body += "            LAUNDER;\n            // z = (-H^-1) q_hat + (-H^-1 G') mu; box update of the z slabs\n";
+    // (in the update phase q_hat of a z slab is recomputed from a laundered copy of w: the compiler would otherwise keep the
+    // value it formed for the right-hand side alive across both solves - one register pair per slab)
     auto prim_row = [&](int Ib, const char *acc) {
         for (int J : bH.by_row[Ib]) {
             double blk[16];
             block_of(H, PR_, Ib, J, blk);
             char e[64];
-            qhat_expr(J, e, sizeof(e));
+            if (J < ZS) snprintf(e, sizeof(e), "QHZP(%d)", J);
+            else qhat_expr(J, e, sizeof(e));
             snprintf(line, sizeof(line), "            { const double qh = %s;\n  ", e);
             body += line;
             MF(acc, emit_block(blk), "qh");
@@ -271,7 +274,9 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     for (int Ib = 0; Ib < ZS; Ib++) {
         body += "            { double ph = 0.0;\n";
         prim_row(Ib, "ph");
-        snprintf(line, sizeof(line), "              ZUPD(%d, ph); }\n", Ib);
+        // (the index of the bound rows is laundered right before the update: the compiler otherwise issues the bound reads of
+        // all slabs at the top of the phase and holds 2 x ZS values in registers - 1 KB of scratch at the C2 shape)
+        snprintf(line, sizeof(line), "              LAUNDER; ZUPD(%d, ph); }\n", Ib);
         body += line;
         if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
     }
@@ -358,6 +363,28 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         def("NB0_", std::max(1, std::min(nb, 512))); def("NB1_", std::max(1, std::min(nb - 512, 512))); def("NB2_", std::max(1, nb - 1024));
     }
     for (int J = 0; J < ZS; J++) { snprintf(line, sizeof(line), "#define QI_%d %d\n", J, qi[J]); s += line; }
+    // bound rows: slabs with the same (LB, UB) pattern share a register pair (6-8 patterns with stage-invariant bounds); with
+    // more than 24 patterns the rows are read from LDS at every use
+    {
+        const int lb0 = rc_lb, ub0 = rc_lb + 4 * ZS;
+        std::map<std::vector<double>, int> pat;
+        std::vector<int> bi(ZS), brow;
+        for (int J = 0; J < ZS; J++) {
+            std::vector<double> key;
+            for (int r = 0; r < 4; r++) { key.push_back(tab[lb0 + 4 * J + r]); key.push_back(tab[ub0 + 4 * J + r]); }
+            auto it = pat.find(key);
+            if (it == pat.end()) { it = pat.emplace(key, (int)brow.size()).first; brow.push_back(J); }
+            bi[J] = it->second;
+        }
+        bool in_regs = true && brow.size() <= 24;  // (measured: registers win for the ellipMPC ADMM program, LDS reads for soc)
+        if (const char *ev = getenv("SPCIES_BSP_BND_REGS")) in_regs = atoi(ev) != 0 && brow.size() <= 24;
+        def("BND_IN_REGS_", in_regs ? 1 : 0);
+        def("NBND_", (long)brow.size());
+        for (int J = 0; J < ZS; J++) { snprintf(line, sizeof(line), "#define BI_%d %d\n", J, bi[J]); s += line; }
+        s += "static __device__ const int BROW_[NBND_] = {";
+        for (size_t i = 0; i < brow.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", brow[i]); s += line; }
+        s += "};\n";
+    }
     s += "static __device__ const int QROW_[NQ_] = {";
     for (size_t i = 0; i < qrow.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", qrow[i]); s += line; }
     s += "};\n";
@@ -442,10 +469,21 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
 #pragma unroll
         for (int I = 0; I < TS_; I++) { vN[I] = 0.0; lamN[I] = 0.0; }
         int go = g;
-#define LBR(I) ldsr[4 * (I) + go]
-#define UBR(I) ldsr[4 * ZS_ + 4 * (I) + go]
+#define LBL(I) ldsr[4 * (I) + go]
+#define UBL(I) ldsr[4 * ZS_ + 4 * (I) + go]
+#if BND_IN_REGS_
+        double lbv[NBND_], ubv[NBND_];
+#pragma unroll
+        for (int u = 0; u < NBND_; u++) { lbv[u] = ldsr[4 * BROW_[u] + g]; ubv[u] = ldsr[4 * ZS_ + 4 * BROW_[u] + g]; }
+#define LBR(I) lbv[BI_##I]
+#define UBR(I) ubv[BI_##I]
+#else
+#define LBR(I) LBL(I)
+#define UBR(I) UBL(I)
+#endif
 #define CE(k) ldsr[8 * ZS_ + 4 * (k) + go]
 #define QHZ(J) (qv[QI_##J] + rho * (w[J] - 2.0 * fmin(fmax(w[J], LBR(J)), UBR(J))))
+#define QHZP(J) ({ double wl_ = w[J]; asm volatile("" : "+v"(wl_)); qv[QI_##J] + rho * (wl_ - 2.0 * fmin(fmax(wl_, LBR(J)), UBR(J))); })
         bool active = valid, res = false;
         int kk = 0;
         RING_INIT
@@ -501,13 +539,13 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
                         k_out[inst] = kk;
                         e_out[inst] = res_inst ? -1 : 1;
                     }
-                    if (g < m) u_out[inst * m + g] = fmin(fmax(w[0], LBR(0)), UBR(0));  // u = v_0
+                    if (g < m) u_out[inst * m + g] = fmin(fmax(w[0], LBL(0)), UBL(0));  // u = v_0
                     if (WANT_SOL) {
                         double *vp = f1 + inst * dim + g, *lp = f2 + inst * dim + g;
 #pragma unroll
                         for (int I = 0; I < ZS_; I++) {
                             const bool in_ = 4 * I + 3 < DZ_ || 4 * I + g < DZ_;
-                            const double v_ = fmin(fmax(w[I], LBR(I)), UBR(I));
+                            const double v_ = fmin(fmax(w[I], LBL(I)), UBL(I));
                             *(in_ ? vp + 4 * I : dump) = v_;
                             *(in_ ? lp + 4 * I : dump) = rho * (w[I] - v_);
                         }
@@ -557,7 +595,7 @@ inline int finish_ellip(Plan &p, const AdmmHost &a) {
     int rc = compile_program(p, &scratch, "ellip_bsp_kernel", "ellip_bsp_kernel_sol");
     if (rc) return rc;
     if (!getenv("SPCIES_BSP_PF"))
-        for (int pf : {8, 4}) {
+        for (int pf : {4}) {
             if (scratch == 0) break;
             rc = build_ellip(p, a, pf);
             if (rc) return rc;
