@@ -774,6 +774,35 @@ def test_bsp_arbitrary_shapes(n, m, N):
     s.close()
 
 
+@pytest.mark.parametrize("n,m,N", [(6, 2, 7), (5, 3, 6), (8, 1, 10), (10, 4, 5), (7, 2, 13)])
+def test_bsp_ellip_admm_arbitrary_shapes(n, m, N):
+    """ellipMPC ADMM through its block program on shapes no STREAM kernel is instantiated for: partial last slabs of the box and
+    of the terminal block, a dense terminal weight, a non-spherical ellipsoid that is active for part of the batch."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=400 + n)
+    rng = np.random.default_rng(11 * n + m)
+    M = rng.standard_normal((n, n))
+    cfg.formulation, cfg.method, cfg.submethod = "ellipMPC", "ADMM", ""
+    cfg.param.P, cfg.param.c, cfg.param.r = np.eye(n) + 0.05 * (M @ M.T), 0.05 * rng.standard_normal(n), 0.25
+    cfg.solver_options = dict(rho=8.0, tol=1e-6, k_max=400)
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    assert s.variant == "bsp"
+    B = 50
+    x0 = 0.4 * rng.standard_normal((B, n))
+    xr = 0.15 * rng.standard_normal((B, n))
+    ur = 0.05 * rng.standard_normal((B, m))
+    got = s(x0, xr, ur)
+    O = oracle.admm_banded_batch(v, x0, xr, ur)
+    _compare("bsp", got, O, v)
+    d = O[4][:, -n:] - cfg.param.c
+    q = np.einsum("bi,ij,bj->b", d, cfg.param.P, d)
+    assert (q >= cfg.param.r ** 2 * (1 - 1e-6)).any()  # the projection is exercised
+    s.close()
+
+
 @pytest.mark.parametrize("n,m,N,formulation", [(10, 3, 9, "laxMPC"), (16, 4, 6, "equMPC"), (9, 2, 31, "laxMPC")])
 def test_mfma4g_fista_arbitrary_shapes(n, m, N, formulation):
     from oracle import oracle
