@@ -48,7 +48,23 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     p.ok = false;
     p.src.clear();
     p.ZS = ZS; p.SS = TS; p.NR = NR;
-    if (!a.ellip || !a.terminal) { p.why = "not an ellipMPC ADMM solver"; return 0; }
+    // lax mode: the same program for the laxMPC ADMM solver (scalar or vector rho, constant or stage-wise bounds): the terminal
+    // block is a box like the others, its dense weight inv(T + rho I) stays inside the terminal slabs
+    const bool lax = !a.ellip;
+    if (!a.terminal) { p.why = "no terminal block (equMPC): not built"; return 0; }
+    std::vector<double> rho_row(dim, a.rho), lb_row(dim, 0.0), ub_row(dim, 0.0);
+    for (int r = 0; r < dim; r++) {
+        const int e = (r < m) ? -1 : (r < dz ? (r - m) % nm : -2);
+        if (a.ellip || a.gen) {
+            lb_row[r] = r < m ? a.LBu0[r] : (r < dz ? a.LBz[r - m] : (lax ? a.LBN[r - dz] : 0.0));
+            ub_row[r] = r < m ? a.UBu0[r] : (r < dz ? a.UBz[r - m] : (lax ? a.UBN[r - dz] : 0.0));
+            if (a.gen) rho_row[r] = r < m ? a.rho_0[r] : (r < dz ? a.rho_v[r - m] : a.rho_N[r - dz]);
+        } else {
+            const int j = (e == -1) ? n + r : (e == -2 ? r - dz : e);
+            lb_row[r] = a.LB[j];
+            ub_row[r] = a.UB[j];
+        }
+    }
     if (m > 4) { p.why = "m > 4 (u rows outside slab 0)"; return 0; }
     if (NR + ZS + 4 * TS > 190) { p.why = "state does not fit the register file"; return 0; }
     auto ip = [&](int j) { return j < dz ? j : 4 * ZS + (j - dz); };
@@ -168,13 +184,16 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         else snprintf(out, cap, "qt[%d]", J - ZS);
     };
     // ---- terminal q_hat in P-coordinates (:146-156)
-    body += "            // q_hat_N = qT + P_half lambda_N - rho P v_N\n            double qt[TS_];\n";
+    body += "            // q_hat_N = qT + P_half lambda_N - rho P v_N  (lax: qT + lambda_N - rho v_N)\n            double qt[TS_];\n";
     for (int k = 0; k < TS; k++) {
-        snprintf(line, sizeof(line), "            qt[%d] = qTv[%d];\n", k, k);
+        if (lax) snprintf(line, sizeof(line), "            qt[%d] = qTv[%d] + RHOT(%d) * (wN[%d] - 2.0 * fmin(fmax(wN[%d], LBT(%d)), UBT(%d)));\n", k, k, k, k, k, k, k);
+        else snprintf(line, sizeof(line), "            qt[%d] = qTv[%d];\n", k, k);
         body += line;
     }
-    dense_tail(a.P_half, 1.0, "qt", "lamN");
-    dense_tail(a.P, -a.rho, "qt", "vN");
+    if (!lax) {
+        dense_tail(a.P_half, 1.0, "qt", "lamN");
+        dense_tail(a.P, -a.rho, "qt", "vN");
+    }
     body += "            SEG;\n            // rhs = (-G H^-1) q_hat - b\n";
     const int bh_slabs = (n + 3) / 4;  // b = -A x0 in the first n rows
     for (int Ib = 0; Ib < NR; Ib++) {
@@ -288,13 +307,18 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         snprintf(a1, sizeof(a1), "zN[%d]", k);
         prim_row(ZS + k, a1);
     }
-    body += "              _Pragma(\"unroll\") for (int k_ = 0; k_ < TS_; k_++) vn[k_] = zN[k_];\n";
-    dense_tail(a.Pinv_half, a.rho_i, "vn", "lamN");
-    body += "              _Pragma(\"unroll\") for (int k_ = 0; k_ < TS_; k_++) { dd[k_] = vn[k_] - CE(k_); pv[k_] = 0.0; }\n";
-    dense_tail(a.P, 1.0, "pv", "dd");
-    body += "              EUPD_A;\n";
-    dense_tail(a.P_half, 1.0, "lamN", "tt");
-    body += "              EUPD_B; }\n";
+    if (lax) {
+        body += "              _Pragma(\"unroll\") for (int k_ = 0; k_ < TS_; k_++) ZUPDT(k_, zN[k_]);\n";
+        body += "              (void)vn; (void)dd; (void)pv; (void)tt; }\n";
+    } else {
+        body += "              _Pragma(\"unroll\") for (int k_ = 0; k_ < TS_; k_++) vn[k_] = zN[k_];\n";
+        dense_tail(a.Pinv_half, a.rho_i, "vn", "lamN");
+        body += "              _Pragma(\"unroll\") for (int k_ = 0; k_ < TS_; k_++) { dd[k_] = vn[k_] - CE(k_); pv[k_] = 0.0; }\n";
+        dense_tail(a.P, 1.0, "pv", "dd");
+        body += "              EUPD_A;\n";
+        dense_tail(a.P_half, 1.0, "lamN", "tt");
+        body += "              EUPD_B; }\n";
+    }
     p.n_blocks = (int)(tab.size() / 16);
     p.n_mfma = n_mfma;
     {
@@ -323,9 +347,12 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     }
     // ---- row tables behind the blocks: LB, UB of the z slabs (pads pinned to 0), c of the terminal slabs
     const int rc_lb = (int)tab.size();
-    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < m ? a.LBu0[r] : (r < dz ? a.LBz[r - m] : 0.0));
-    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < m ? a.UBu0[r] : (r < dz ? a.UBz[r - m] : 0.0));
-    for (int r = 0; r < 4 * TS; r++) tab.push_back(r < n ? a.c_ell[r] : 0.0);
+    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < dz ? lb_row[r] : 0.0);
+    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < dz ? ub_row[r] : 0.0);
+    for (int r = 0; r < 4 * TS; r++) tab.push_back(r < n ? (lax ? lb_row[dz + r] : a.c_ell[r]) : 0.0);
+    for (int r = 0; r < 4 * TS; r++) tab.push_back(r < n ? ub_row[dz + r] : 0.0);
+    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < dz ? rho_row[r] : 1.0);
+    for (int r = 0; r < 4 * TS; r++) tab.push_back(r < n ? rho_row[dz + r] : 1.0);
     for (double &x : tab) {
         if (x > 1e300) x = 1e300;  // (+-inf bounds)
         if (x < -1e300) x = -1e300;
@@ -353,6 +380,8 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     }
     std::string s;
     auto def = [&](const char *name, long v) { snprintf(line, sizeof(line), "#define %s %ld\n", name, v); s += line; };
+    def("LAX_", lax ? 1 : 0);
+    def("RHO_SCALAR_", a.gen ? 0 : 1);
     def("ZS_", ZS); def("TS_", TS); def("NR_", NR); def("NQ_", (long)qrow.size()); def("NBH_", bh_slabs);
     def("TAB_DOUBLES_", (long)tab.size()); def("RC_", rc_lb); def("DIM_", dim); def("DZ_", dz); def("NN_", n);
     s += "#define RING_INIT";
@@ -371,7 +400,11 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         std::vector<int> bi(ZS), brow;
         for (int J = 0; J < ZS; J++) {
             std::vector<double> key;
-            for (int r = 0; r < 4; r++) { key.push_back(tab[lb0 + 4 * J + r]); key.push_back(tab[ub0 + 4 * J + r]); }
+            for (int r = 0; r < 4; r++) {
+                key.push_back(tab[lb0 + 4 * J + r]);
+                key.push_back(tab[ub0 + 4 * J + r]);
+                key.push_back(tab[lb0 + 8 * ZS + 8 * TS + 4 * J + r]);  // rho of the row
+            }
             auto it = pat.find(key);
             if (it == pat.end()) { it = pat.emplace(key, (int)brow.size()).first; brow.push_back(J); }
             bi[J] = it->second;
@@ -400,14 +433,14 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
                                                const double *__restrict__ urg, double *__restrict__ u_out, int *__restrict__ k_out,
                                                int *__restrict__ e_out, double *__restrict__ f0, double *__restrict__ f1,
                                                double *__restrict__ f2) {
-    __shared__ __attribute__((aligned(16))) double ldsr[2 * 4 * ZS_ + 4 * TS_];
+    __shared__ __attribute__((aligned(16))) double ldsr[3 * 4 * ZS_ + 3 * 4 * TS_];
     __shared__ __attribute__((aligned(16))) double blk0[NB0_ * 16];
     __shared__ __attribute__((aligned(16))) double blk1[NB1_ * 16];
     __shared__ __attribute__((aligned(16))) double blk2[NB2_ * 16];
     for (int i = threadIdx.x; i < NB0_ * 16; i += 256) blk0[i] = table_g[i];
     for (int i = threadIdx.x; i < NB1_ * 16; i += 256) blk1[i] = table_g[512 * 16 + i];
     for (int i = threadIdx.x; i < NB2_ * 16; i += 256) blk2[i] = table_g[1024 * 16 + i];
-    for (int i = threadIdx.x; i < 2 * 4 * ZS_ + 4 * TS_; i += 256) ldsr[i] = table_g[RC_ + i];
+    for (int i = threadIdx.x; i < 3 * 4 * ZS_ + 3 * 4 * TS_; i += 256) ldsr[i] = table_g[RC_ + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -463,27 +496,51 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
             qTv[k] = v;
         }
         // state: w = v + lambda / rho per z slab (v = clamp(w), lambda = rho (w - v)); the terminal slabs keep v_N, lambda_N
-        double w[ZS_], vN[TS_], lamN[TS_], rh[NR_];
+        double w[ZS_], vN[TS_], lamN[TS_], wN[TS_], rh[NR_];  // (lax: wN; ellip: vN, lamN - the unused ones fold away)
 #pragma unroll
         for (int I = 0; I < ZS_; I++) w[I] = 0.0;
 #pragma unroll
-        for (int I = 0; I < TS_; I++) { vN[I] = 0.0; lamN[I] = 0.0; }
+        for (int I = 0; I < TS_; I++) { vN[I] = 0.0; lamN[I] = 0.0; wN[I] = 0.0; }
         int go = g;
 #define LBL(I) ldsr[4 * (I) + go]
 #define UBL(I) ldsr[4 * ZS_ + 4 * (I) + go]
+#if RHO_SCALAR_
+#define RHOL(I) rho
+#else
+#define RHOL(I) ldsr[8 * ZS_ + 8 * TS_ + 4 * (I) + go]
+#endif
 #if BND_IN_REGS_
         double lbv[NBND_], ubv[NBND_];
 #pragma unroll
-        for (int u = 0; u < NBND_; u++) { lbv[u] = ldsr[4 * BROW_[u] + g]; ubv[u] = ldsr[4 * ZS_ + 4 * BROW_[u] + g]; }
+        for (int u = 0; u < NBND_; u++) {
+            lbv[u] = ldsr[4 * BROW_[u] + g];
+            ubv[u] = ldsr[4 * ZS_ + 4 * BROW_[u] + g];
+        }
 #define LBR(I) lbv[BI_##I]
 #define UBR(I) ubv[BI_##I]
+#if RHO_SCALAR_
+#define RHOR(I) rho
+#else
+        double rhov[NBND_];
+#pragma unroll
+        for (int u = 0; u < NBND_; u++) rhov[u] = ldsr[8 * ZS_ + 8 * TS_ + 4 * BROW_[u] + g];
+#define RHOR(I) rhov[BI_##I]
+#endif
 #else
 #define LBR(I) LBL(I)
 #define UBR(I) UBL(I)
+#define RHOR(I) RHOL(I)
 #endif
 #define CE(k) ldsr[8 * ZS_ + 4 * (k) + go]
-#define QHZ(J) (qv[QI_##J] + rho * (w[J] - 2.0 * fmin(fmax(w[J], LBR(J)), UBR(J))))
-#define QHZP(J) ({ double wl_ = w[J]; asm volatile("" : "+v"(wl_)); qv[QI_##J] + rho * (wl_ - 2.0 * fmin(fmax(wl_, LBR(J)), UBR(J))); })
+#define LBT(k) ldsr[8 * ZS_ + 4 * (k) + go]
+#define UBT(k) ldsr[8 * ZS_ + 4 * TS_ + 4 * (k) + go]
+#if RHO_SCALAR_
+#define RHOT(k) rho
+#else
+#define RHOT(k) ldsr[12 * ZS_ + 8 * TS_ + 4 * (k) + go]
+#endif
+#define QHZ(J) (qv[QI_##J] + RHOR(J) * (w[J] - 2.0 * fmin(fmax(w[J], LBR(J)), UBR(J))))
+#define QHZP(J) ({ double wl_ = w[J]; asm volatile("" : "+v"(wl_)); qv[QI_##J] + RHOR(J) * (wl_ - 2.0 * fmin(fmax(wl_, LBR(J)), UBR(J))); })
         bool active = valid, res = false;
         int kk = 0;
         RING_INIT
@@ -496,6 +553,16 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
         w[I] = wn_;                                                                              \
         res |= (fabs(vo_ - v_) > tol) | (fabs((zh) - v_) > tol);                                 \
         if (WANT_SOL) *((4 * (I) + 3 < DZ_ || 4 * (I) + g < DZ_) ? zp + 4 * (I) : dump) = (zh); \
+    } while (0)
+        // lax: the terminal slabs are boxes like the others
+#define ZUPDT(k, zh)                                                                             \
+    do {                                                                                         \
+        const double lb_ = LBT(k), ub_ = UBT(k);                                                 \
+        const double wo_ = wN[k], vo_ = fmin(fmax(wo_, lb_), ub_);                               \
+        const double wn_ = (zh) + (wo_ - vo_), v_ = fmin(fmax(wn_, lb_), ub_);                   \
+        wN[k] = wn_;                                                                             \
+        res |= (fabs(vo_ - v_) > tol) | (fabs((zh) - v_) > tol);                                 \
+        if (WANT_SOL) *((4 * (k) + 3 < NN_ || 4 * (k) + g < NN_) ? zp + DZ_ + 4 * (k) : dump) = (zh); \
     } while (0)
         // terminal block: the P-projection onto the ellipsoid (:318-352) ...
 #define EUPD_A                                                                                   \
@@ -547,13 +614,19 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
                             const bool in_ = 4 * I + 3 < DZ_ || 4 * I + g < DZ_;
                             const double v_ = fmin(fmax(w[I], LBL(I)), UBL(I));
                             *(in_ ? vp + 4 * I : dump) = v_;
-                            *(in_ ? lp + 4 * I : dump) = rho * (w[I] - v_);
+                            *(in_ ? lp + 4 * I : dump) = RHOL(I) * (w[I] - v_);
                         }
 #pragma unroll
                         for (int k = 0; k < TS_; k++) {
                             const bool in_ = 4 * k + 3 < NN_ || 4 * k + g < NN_;
+#if LAX_
+                            const double vt_ = fmin(fmax(wN[k], LBT(k)), UBT(k));
+                            *(in_ ? vp + DZ_ + 4 * k : dump) = vt_;
+                            *(in_ ? lp + DZ_ + 4 * k : dump) = RHOT(k) * (wN[k] - vt_);
+#else
                             *(in_ ? vp + DZ_ + 4 * k : dump) = vN[k];
                             *(in_ ? lp + DZ_ + 4 * k : dump) = lamN[k];
+#endif
                         }
                     }
                     active = false;

@@ -1190,7 +1190,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (s.host.n == 12 && s.host.m == 2) return launch_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
     }
-    if (s.host.ellip && resolve_variant(s) == SPCIES_VARIANT_BSP)
+    if ((s.host.ellip && resolve_variant(s) == SPCIES_VARIANT_BSP) || (s.variant == SPCIES_VARIANT_BSP && s.bsp.ok && !s.is_soc()))
         return bsp::launch_ellip(s.bsp, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
     if (s.host.ellip) {
         if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
@@ -1392,7 +1392,13 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_BSP) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
     if (variant == SPCIES_VARIANT_BSP) {
         const bool soc = s->is_soc() && !s->is_hmpc();
-        if (!soc && !s->host.ellip) return fail(SPCIES_HIP_ENOSUP, "BSP variant: built for the ellipMPC solvers (ADMM and ADMM soc)");
+        const bool lax = s->formulation == SPCIES_LAXMPC && s->method == SPCIES_ADMM && !s->tv && !s->eng;
+        if (!soc && !s->host.ellip && !lax)
+            return fail(SPCIES_HIP_ENOSUP, "BSP variant: built for the ellipMPC solvers (ADMM and ADMM soc) and, on request, laxMPC ADMM");
+        if (lax && !s->bsp.ok && s->bsp.src.empty()) {  // laxMPC ADMM: the program is only generated when it is asked for
+            int rc = bsp::build_ellip(s->bsp, s->host);
+            if (rc) return rc;
+        }
         if (!s->bsp.ok) {  // not compiled at create time (SPCIES_HIP_BSP=0, or it failed): try now and report
             if (s->bsp.src.empty()) return fail(SPCIES_HIP_ENOSUP, "BSP variant not available: %s", s->bsp.why.c_str());
             SPCIES_HIP_CHECK(hipSetDevice(s->device));

@@ -774,6 +774,21 @@ def test_bsp_arbitrary_shapes(n, m, N):
     s.close()
 
 
+@pytest.mark.parametrize("cfg_name,B,overrides", [("C1_lax", 70, {}), ("C2_lax", 130, {}), ("C2_lax", 40, dict(tol=1e-6, k_max=3000)),
+                                                  ("C1_lax_gen", 60, {}), ("C2_lax_gen", 64, {})])
+def test_bsp_lax_admm_on_request(cfg_name, B, overrides):
+    """The banded block program also runs laxMPC ADMM (scalar or vector rho, constant or stage-wise bounds) when the variant is
+    asked for (AUTO keeps MFMA4 / MFMA4G there)."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _solver(cfg_name, "bsp", **overrides)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    got = s(x0, xr, ur)
+    _compare("bsp", got, oracle.admm_banded_batch(v, x0, xr, ur), v)
+    nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
+    assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
+
+
 @pytest.mark.parametrize("n,m,N", [(6, 2, 7), (5, 3, 6), (8, 1, 10), (10, 4, 5), (7, 2, 13)])
 def test_bsp_ellip_admm_arbitrary_shapes(n, m, N):
     """ellipMPC ADMM through its block program on shapes no STREAM kernel is instantiated for: partial last slabs of the box and
