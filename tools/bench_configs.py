@@ -68,7 +68,7 @@ def run_ex(cfg, name, B, variant=None):
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    jobs = [("C2", 65536, "mfma4"), ("C2", 65536, "mfma4g"), ("C2", 65536, "mfma"), ("C2", 65536, "stream"), ("C2_equ", 65536, "mfma4"),
+    jobs = [("C2", 65536, "mfma4"), ("C2", 65536, "mfma4g"), ("C2", 65536, "mfma"), ("C2", 65536, "stream"), ("C2_equ", 65536, "mfma4"), ("C2", 65536, "bsp"), ("C2_lax_gen", 65536, "bsp"), ("C2_lax_gen", 65536, "mfma4g"),
             ("C3", 262144, "mfma4g"), ("C3", 262144, "stream"), ("C2_lax_FISTA", 65536, "mfma4g"),
             ("C4", 131072, "mfma4g"), ("C4", 131072, "stream"), ("C5_soc", 65536, "bsp"), ("C5_soc", 65536, "tile"), ("C5_soc", 65536, "stream"),
             ("C5_HMPC_SADMM", 65536, "gemm"), ("C5_HMPC_SADMM_nosplit", 65536, "gemm"), ("C5_HMPC_SADMM_nosplit", 65536, "stream"), ("C2_cs", 65536, "tile"), ("C2_cs", 16384, "stream"), ("C2_ellip", 65536, "bsp"), ("C2_ellip", 65536, "stream"), ("C5_HMPC_SADMM", 65536, "tile"), ("C5_HMPC_SADMM", 16384, "stream")]
