@@ -2,21 +2,24 @@
 """bench.py - headline metric of BASELINE.json: MPC solves/sec (whole node), laxMPC-ADMM,
 12-state oscillating masses, N=15, 200 iterations (config C2), B = 65 536 instances per GPU.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # any N: for N > 1 it starts its own N rank processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          # or under a launcher (RANK / WORLD_SIZE in the env)
 
 One "step" = one pass of the hot path over one batch of B synthetic instances that are already
 resident in HBM (x0, xr, ur in; u, k, e_flag out).  The batch shards trivially: every rank solves its
 own B instances (weak scaling), the only collective is a one-time RCCL broadcast of the problem blob.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  At N = 1 the line also carries the other BASELINE.json configurations
+(`configs`: C3, C4, C5 soc, C5 HMPC at their per-GPU shard), the host-buffer (PCIe-inclusive) rate and the
+CPU baseline.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,26 +31,42 @@ IO_BYTES_PER_SOLVE = 232              # compulsory HBM bytes per solve (per-inst
 PEAK_FP64_MFMA_TFLOPS = 78.6          # MI355X dense FP64 matrix peak = 256 CU x 128 flop/clk x 2.4 GHz (spec)
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
 
+# The other BASELINE.json configurations, at the per-GPU shard of SURVEY.md section 8d (C4, C5: 1/8 of the 8-GPU batch).
+# flop = algorithmic flop per solve (SURVEY 8d / section 2.4 formulas; HMPC: the reference's default dense M1 product,
+# 2 (dim + n_s)^2 per iteration, code_HMPC_ADMM_split_C.c:174-190), io = compulsory HBM bytes per solve.
+EXTRA_CONFIGS = {
+    "C3": dict(name="C3", B=262144, flop=47.5e3 * 100, io=232,
+               what="configs[2]: equMPC-FISTA, 12-state, N=30, 100 iterations, batch=262144"),
+    "C4": dict(name="C4", B=131072, flop=101e3 * 200, io=360,
+               what="configs[3]: MPCT-EADMM, 20-state, N=20, 200 iterations, 1/8 shard (131072) of batch=1048576"),
+    "C5_soc": dict(name="C5_soc", B=65536, flop=23.4e3 * 200, io=240,
+                   what="configs[4]a: ellipMPC-ADMM-soc, 12-state, N=15, 200 iterations, 1/8 shard (65536) of batch=524288"),
+    "C5_hmpc": dict(name="C5_HMPC_SADMM", B=65536, flop=2.0 * 282 * 282 * 200, io=232,
+                    what="configs[4]b: HMPC-SADMM split, 12-state, N=15, 200 iterations, 1/8 shard (65536) of batch=524288"),
+}
+
 
 def traffic_from_profile(variant):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_<variant>_pmc_summary.txt: separate FETCH_SIZE / WRITE_SIZE runs of this same command),
-    corrected as MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE x 2 on gfx950, values in KB."""
-    path = os.path.join(ROOT, "profiles", f"r01_{variant}_pmc_summary.txt")
-    if not os.path.exists(path):
-        return None
-    fetch = write = None
-    for line in open(path):
-        if f"admm_{variant}_kernel" not in line:
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (newest round first;
+    profiles/rNN_<variant>_pmc_summary.txt: separate FETCH_SIZE / WRITE_SIZE runs of this same command), corrected as
+    MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE x 2 on gfx950, values in KB.  Returns (bytes, file) -
+    a constant read from the repository, NOT a measurement of the run that prints it (`traffic_source` says so)."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{variant}_pmc_summary.txt")
+        if not os.path.exists(path):
             continue
-        val = float(line.split("mean=")[1].split()[0])
-        if line.startswith("FETCH_SIZE"):
-            fetch = val
-        elif line.startswith("WRITE_SIZE"):
-            write = val
-    if fetch is None or write is None:
-        return None
-    return (2.0 * fetch + write) * 1024.0
+        fetch = write = None
+        for line in open(path):
+            if f"admm_{variant}_kernel" not in line:
+                continue
+            val = float(line.split("mean=")[1].split()[0])
+            if line.startswith("FETCH_SIZE"):
+                fetch = val
+            elif line.startswith("WRITE_SIZE"):
+                write = val
+        if fetch is not None and write is not None:
+            return (2.0 * fetch + write) * 1024.0, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def host_threads():
@@ -107,7 +126,6 @@ def cpu_reference_baseline(cfg, threads, seconds=10.0):
         return None
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
-    import numpy as np
     from spcies_amd import benchmarks
     n, m, dim = cfg.sys.n, cfg.sys.m, cfg.param.N * (cfg.sys.n + cfg.sys.m)
     fn = C.CDLL(so).laxMPC_ADMM
@@ -144,7 +162,301 @@ def cpu_reference_baseline(cfg, threads, seconds=10.0):
                       f"{threads} host threads, {dt:.1f} s"}
 
 
-def main():
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a launcher's environment starts its own N rank processes
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Parent of a self-launched multi-GPU run.  It makes NO GPU call (a process that initialised the GPU must not be
+    replaced or forked on this pool): it starts N fresh children of this script with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, relays rank 0's stdout (the JSON line) and returns the worst exit code."""
+    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the other BASELINE.json configurations (N = 1 only), each with its own roofline and an in-region oracle check
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_check(cfg, v, x0, xr, ur, u_gpu, k_gpu, count=32):
+    """GPU result of the timed region against the oracle on the first `count` instances."""
+    import numpy as np
+    from oracle import oracle
+    a = (x0[:count], xr[:count], ur[:count])
+    if cfg.formulation == "HMPC":
+        o = oracle.admm_hmpc_batch(v, *a, want_sol=False) if getattr(cfg, "submethod", "") == "split" \
+            else oracle.hmpc_dense_batch(v, *a, want_sol=False)
+    elif cfg.formulation == "ellipMPC" and getattr(cfg, "submethod", "") == "soc":
+        o = oracle.admm_soc_batch(v, *a, cfg.param.r, want_sol=False)
+    elif cfg.method == "FISTA":
+        o = oracle.fista_banded_batch(v, *a, want_sol=False)
+    elif cfg.method == "EADMM":
+        o = oracle.eadmm_mpct_batch(v, *a, want_sol=False)
+    else:
+        o = oracle.admm_banded_batch(v, *a, want_sol=False)
+    return {"instances": count, "max_abs_du": float(np.abs(u_gpu[:count] - o[0]).max()),
+            "k_equal": bool(np.array_equal(k_gpu[:count], o[1]))}
+
+
+def bench_config(spec, dev, steps, warmup):
+    import torch
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = benchmarks.config(spec["name"])
+    B = spec["B"]
+    v = benchmarks.ingredients(cfg)
+    solver = HipSolver(v, device=dev.index)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tx0, txr, tur = t(x0), t(xr), t(ur)
+    tu = torch.empty((B, cfg.sys.m), dtype=torch.float64, device=dev)
+    tk = torch.empty(B, dtype=torch.int32, device=dev)
+    te = torch.empty(B, dtype=torch.int32, device=dev)
+    extra = None
+    if cfg.formulation == "ellipMPC" and getattr(cfg, "submethod", "") == "soc":
+        extra = torch.full((1,), float(cfg.param.r), dtype=torch.float64, device=dev)
+    solver.reserve(B)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        solver.solve_device_ex(tx0, txr, tur, tu, tk, te, extra=extra, extra_stride=0, stream=stream)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    ms = ev0.elapsed_time(ev1) / steps
+    tf = spec["flop"] * B / (ms * 1e-3) / 1e12
+    gbs = spec["io"] * B / (ms * 1e-3) / 1e9
+    variant = solver.variant
+    out = {"workload": spec["what"], "batch": B, "variant": variant, "steps": steps, "kernel_ms": ms,
+           "solves_per_s": B / (ms * 1e-3),
+           "roofline": {"bound": "hbm" if variant in ("mfma4g", "stream", "tile") else "mfma",
+                        "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_MFMA_TFLOPS,
+                        "flop_per_solve": spec["flop"], "algorithmic_io_gbs": gbs, "hbm_frac_algorithmic": gbs / PEAK_HBM_GBS},
+           "oracle_check": _oracle_check(cfg, v, x0, xr, ur, tu[:32].cpu().numpy(), tk[:32].cpu().numpy())}
+    solver.close()
+    return out
+
+
+def pcie_inclusive(solver, cfg, B, reps=5):
+    """Host-buffer entry point (what a mex binds): pageable numpy buffers in and out through spcies_hip_solve_batch;
+    wall time per call including H2D / D2H.  Never the bench `value`."""
+    from spcies_amd import benchmarks
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    solver(x0, xr, ur, want_sol=False)
+    best, tim = None, None
+    for _ in range(reps):
+        t = time.perf_counter()
+        u, k, e, sol = solver(x0, xr, ur, want_sol=False)
+        dt = time.perf_counter() - t
+        if best is None or dt < best:
+            best, tim = dt, sol
+    return {"solves_per_s": B / best, "ms_per_call": best * 1e3, "batch": B,
+            "h2d_ms": tim.update_time, "solve_ms": tim.solve_time, "d2h_ms": tim.polish_time,
+            "note": "spcies_hip_solve_batch from pageable host buffers, best of %d calls, u/k/e_flag out" % reps}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_rank(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from spcies_amd import benchmarks, blob as blobmod, distributed as spdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dry = args.dry_run
+    if dry:  # CPU rehearsal of the launch / rendezvous / timing plumbing (tests/test_bench_contract.py): no solver, no GPU
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: local GPU {local_rank} does not exist ({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize(dev)
+
+    cfg = benchmarks.config("C2")
+    # rank 0 factorises the controller once; the blob travels by one RCCL broadcast (xGMI)
+    v = benchmarks.ingredients(cfg) if rank == 0 else None
+    blob = blobmod.pack(v) if rank == 0 else None
+    blob = spdist.broadcast_blob(blob, None if dry else dev)
+    ranks_seen = 1
+    if world > 1:  # every rank adds one on its device: the sum is the number of ranks RCCL actually connected
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+
+    B = args.batch
+    x0, xr, ur = spdist.shard_inputs(cfg, B, rank)  # weak scaling: every rank draws its own B instances, seeded by (seed, rank)
+    solver, variant = None, "dry-run"
+    if not dry:
+        from spcies_amd.solver import HipSolver
+        solver = HipSolver(blob, device=local_rank)
+        solver.set_variant(args.variant)
+        variant = solver.variant
+        tx0, txr, tur = (torch.from_numpy(a).to(dev) for a in (x0, xr, ur))
+        tu = torch.empty((B, cfg.sys.m), dtype=torch.float64, device=dev)
+        tk = torch.empty(B, dtype=torch.int32, device=dev)
+        te = torch.empty(B, dtype=torch.int32, device=dev)
+        solver.reserve(B)
+        stream = torch.cuda.current_stream(dev).cuda_stream  # the stream the kernel is launched on
+
+    def step():
+        if not dry:
+            solver.solve_device(tx0, txr, tur, tu, tk, te, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    # Untimed queue priming: the HIP runtime grows its per-queue signal / kernarg pools the first time more
+    # launches are in flight than ever before, and that one-off growth (tens of ms, tools/wall_jitter.py) would
+    # otherwise land inside the timed region, which queues all K launches back to back.
+    sync()
+    for _ in range(args.steps):
+        step()
+
+    def fence():
+        sync()
+        if world > 1:
+            dist.barrier()
+            sync()
+
+    if not dry:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+    fence()
+    t0 = time.perf_counter()
+    if not dry:
+        ev0.record()
+    for _ in range(args.steps):
+        step()
+    if not dry:
+        ev1.record()
+    fence()
+    dt_local = time.perf_counter() - t0
+    kernel_ms = 0.0 if dry else ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream, over the timed region
+    per_rank_ms = [dt_local / args.steps * 1e3]
+    dt = dt_local
+    if world > 1:
+        tdt = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(tdt) for _ in range(world)]
+        dist.all_gather(gathered, tdt)
+        per_rank_ms = [float(g.item()) / args.steps * 1e3 for g in gathered]
+        dt = max(float(g.item()) for g in gathered)  # MAX over ranks
+
+    # sanity on what was computed inside the timed region
+    k_ok = None if dry else (bool((tk == 200).all().item()) and bool((te == -1).all().item()))
+    u_host = None if dry else tu[:64].cpu().numpy()
+
+    if rank == 0:
+        out = {
+            "metric": "MPC solves/sec (whole node), laxMPC-ADMM 12-state N=15, 200 iters",
+            "value": None if dry else world * B * args.steps / dt,
+            "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: laxMPC-ADMM, 12-state osc-masses (n=12, m=2), N=15, rho=15, tol=0, "
+                                   "k_max=200, batch=65536 random x0 / per-instance (xr, ur) per GPU",
+                       "batch_per_gpu": B, "variant": variant, "all_k_200_eflag_-1": k_ok,
+                       "launch": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else ("self" if world > 1 else "single")},
+            "rccl_ranks_seen": ranks_seen, "per_rank_ms_per_step": per_rank_ms,
+        }
+        if dry:
+            out["dry_run"] = True
+        secs = kernel_ms * 1e-3
+        if dry:
+            pass
+        elif variant in ("mfma", "mfma4"):
+            ach = FLOP_PER_SOLVE * B / secs / 1e12
+            traffic, src = traffic_from_profile(variant)
+            io_gbs = IO_BYTES_PER_SOLVE * B / secs / 1e9
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": src,
+                               "kernel_ms": kernel_ms, "flop_per_solve": FLOP_PER_SOLVE,
+                               "hbm_frac": (traffic / secs / 1e9 / PEAK_HBM_GBS) if traffic else io_gbs / PEAK_HBM_GBS,
+                               "hbm_frac_algorithmic": io_gbs / PEAK_HBM_GBS}
+        else:
+            # STREAM variant: state is streamed through HBM by design; algorithmic bytes are only the I/O
+            ach = IO_BYTES_PER_SOLVE * B / secs / 1e9
+            traffic, src = traffic_from_profile("stream")
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": ach / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": src, "kernel_ms": kernel_ms,
+                               "algorithmic_bytes_per_solve": IO_BYTES_PER_SOLVE}
+        if world == 1 and not dry:
+            if v is None:
+                v = benchmarks.ingredients(cfg)
+            # the same run re-checks the GPU result of the timed region against the oracle on the first 64 instances
+            from oracle import oracle
+            uo, *_ = oracle.admm_banded_batch(v, x0[:64], xr[:64], ur[:64], want_sol=False)
+            out["config"]["max_abs_du_vs_oracle_first64"] = float(np.abs(u_host - uo).max())
+            if not args.no_pcie:
+                out["pcie_inclusive"] = pcie_inclusive(solver, cfg, B)
+            if not args.no_configs:
+                out["configs"] = {}
+                for key, spec in EXTRA_CONFIGS.items():
+                    if args.configs and key not in args.configs.split(","):
+                        continue
+                    t = time.perf_counter()
+                    try:
+                        out["configs"][key] = bench_config(spec, dev, args.config_steps, 1)
+                    except Exception as ex:  # a failing side configuration must not lose the headline line
+                        out["configs"][key] = {"error": f"{type(ex).__name__}: {ex}"}
+                    out["configs"][key]["wall_s"] = time.perf_counter() - t
+            if not args.no_cpu_baseline:
+                threads = args.cpu_threads or host_threads()
+                port = cpu_baseline(cfg, v, args.cpu_sample, threads)
+                # The baseline is the port.  The reference's C template instantiated for C2 is timed next to it when its object
+                # is there; it is NOT a reference build (MATLAB, which prints the constants of a generated solver, is absent:
+                # the constants block is ours), so it rides along as information and does not change `kind`.
+                tmpl = cpu_reference_baseline(cfg, threads)
+                if tmpl is not None:
+                    port["reference_template"] = {"value": tmpl["value"], "one_thread_value": tmpl["one_thread_value"],
+                                                  "cores": tmpl["cores"], "note": tmpl["sample"] + "; constants printed by this "
+                                                  "repository's generator under the reference's dec_var.m rules, not by MATLAB"}
+                out["cpu_baseline"] = port
+        print(json.dumps(out), flush=True)
+    if solver is not None:
+        solver.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -154,134 +466,20 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances of the CPU baseline (0: about 12 s of work, sized by a probe)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: all host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
-    from spcies_amd import benchmarks, blob as blobmod, distributed as spdist
-    from spcies_amd.solver import HipSolver
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
-    cfg = benchmarks.config("C2")
-    # rank 0 factorises the controller once; the blob travels by one RCCL broadcast (xGMI)
-    v = benchmarks.ingredients(cfg) if rank == 0 else None
-    blob = blobmod.pack(v) if rank == 0 else None
-    blob = spdist.broadcast_blob(blob, dev)
-    solver = HipSolver(blob, device=local_rank)
-    solver.set_variant(args.variant)
-    variant = solver.variant
-
-    B = args.batch
-    # weak scaling: rank r owns global instances [r*B, (r+1)*B) of the seeded stream
-    x0, xr, ur = spdist.shard_inputs(cfg, B, rank)
-    tx0 = torch.from_numpy(x0).to(dev)
-    txr = torch.from_numpy(xr).to(dev)
-    tur = torch.from_numpy(ur).to(dev)
-    tu = torch.empty((B, cfg.sys.m), dtype=torch.float64, device=dev)
-    tk = torch.empty(B, dtype=torch.int32, device=dev)
-    te = torch.empty(B, dtype=torch.int32, device=dev)
-    solver.reserve(B)
-    stream = torch.cuda.current_stream(dev).cuda_stream  # the stream the kernel is launched on
-
-    def step():
-        solver.solve_device(tx0, txr, tur, tu, tk, te, stream=stream)
-
-    for _ in range(args.warmup):
-        step()
-    # Untimed queue priming: the HIP runtime grows its per-queue signal / kernarg pools the first time more
-    # launches are in flight than ever before, and that one-off growth (tens of ms, tools/wall_jitter.py) would
-    # otherwise land inside the timed region, which queues all K launches back to back.
-    torch.cuda.synchronize(dev)
-    for _ in range(args.steps):
-        step()
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    fence()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    fence()
-    dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream, over the timed region
-    tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-    dt = float(tdt.item())
-
-    # sanity on what was computed inside the timed region
-    k_ok = bool((tk == 200).all().item()) and bool((te == -1).all().item())
-    u_host = tu[:64].cpu().numpy()
-
-    if rank == 0:
-        out = {
-            "metric": "MPC solves/sec (whole node), laxMPC-ADMM 12-state N=15, 200 iters",
-            "value": world * B * args.steps / dt,
-            "unit": "solves/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: laxMPC-ADMM, 12-state osc-masses (n=12, m=2), N=15, rho=15, tol=0, "
-                                   "k_max=200, batch=65536 random x0 / per-instance (xr, ur) per GPU",
-                       "batch_per_gpu": B, "variant": variant, "all_k_200_eflag_-1": k_ok},
-        }
-        secs = kernel_ms * 1e-3
-        if variant in ("mfma", "mfma4"):
-            ach = FLOP_PER_SOLVE * B / secs / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic_from_profile(variant),
-                               "kernel_ms": kernel_ms, "flop_per_solve": FLOP_PER_SOLVE}
-        else:
-            # STREAM variant: state is streamed through HBM by design; algorithmic bytes are only the I/O
-            ach = IO_BYTES_PER_SOLVE * B / secs / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": ach / PEAK_HBM_GBS, "traffic": traffic_from_profile("stream"), "kernel_ms": kernel_ms,
-                               "algorithmic_bytes_per_solve": IO_BYTES_PER_SOLVE}
-        if world == 1 and not args.no_cpu_baseline:
-            if v is None:
-                v = benchmarks.ingredients(cfg)
-            threads = args.cpu_threads or host_threads()
-            port = cpu_baseline(cfg, v, args.cpu_sample, threads)
-            # The baseline is the port.  The reference's C template instantiated for C2 is timed next to it when its object is
-            # there; it is NOT a reference build (MATLAB, which prints the constants of a generated solver, is absent: the
-            # constants block is ours), so it rides along as information and does not change `kind`.
-            tmpl = cpu_reference_baseline(cfg, threads)
-            if tmpl is not None:
-                port["reference_template"] = {"value": tmpl["value"], "one_thread_value": tmpl["one_thread_value"],
-                                              "cores": tmpl["cores"], "note": tmpl["sample"] + "; constants printed by this "
-                                              "repository's generator under the reference's dec_var.m rules, not by MATLAB"}
-            out["cpu_baseline"] = port
-            # the same run also re-checks the GPU result against the oracle on the first 64 instances
-            from oracle import oracle
-            uo, *_ = oracle.admm_banded_batch(v, x0[:64], xr[:64], ur[:64], want_sol=False)
-            out["config"]["max_abs_du_vs_oracle_first64"] = float(np.abs(u_host - uo).max())
-        print(json.dumps(out), flush=True)
-    solver.close()
-    if world > 1:
-        dist.destroy_process_group()
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations (N = 1 runs them by default)")
+    ap.add_argument("--configs", default="", help="comma-separated subset of " + ",".join(EXTRA_CONFIGS))
+    ap.add_argument("--config-steps", type=int, default=3)
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank plumbing: no solver, no GPU")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # must be set before any rank touches the GPU (ROCr reads it at initialisation): the children inherit it
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        raise SystemExit(launch_ranks(args, argv))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before `import torch` / any HIP call of this process
+    run_rank(args)
 
 
 if __name__ == "__main__":

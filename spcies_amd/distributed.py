@@ -18,8 +18,8 @@ def shard_range(total, world, rank):
 
 
 def shard_inputs(cfg, B_per_rank, rank):
-    """Weak-scaling inputs: rank r's B instances are rows [r*B, (r+1)*B) of ONE seeded global stream, so
-    the union over ranks is independent of the world size (checked by the gloo test)."""
+    """Weak-scaling inputs: rank r draws its own B instances from a generator seeded with ``(cfg.seed, r)``, so a
+    rank's shard does not depend on the world size and two ranks never share a stream (checked by the gloo test)."""
     from . import benchmarks
     rng = np.random.default_rng([cfg.seed, rank])
     sys = cfg.sys

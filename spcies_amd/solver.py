@@ -211,6 +211,21 @@ class HipSolver:
         _lib.check(self._lib.spcies_hip_solve_batch_device(self._h, ptr(x0), ptr(xr), ptr(ur), C.c_int(per), C.c_long(B), ptr(u), ptr(k),
                                                           ptr(e_flag), ptr(z), ptr(v), ptr(lam), C.c_void_p(stream)))
 
+    def solve_device_ex(self, x0, xr, ur, u, k, e_flag, extra=None, extra_stride=0, fields=None, stream=0):
+        """Device-resident call through ``spcies_hip_solve_batch_device_ex``: any solver, its own record
+        (``fields``: one tensor or ``None`` per entry of ``sol_fields``) and its extra input (``extra``)."""
+        ptr = lambda a: None if a is None else C.c_void_p(a if isinstance(a, int) else a.data_ptr())
+        nf = len(self.sol_fields)
+        fp = None
+        if fields is not None:
+            if len(fields) != nf:
+                raise SpciesArgError(f"Spcies:{self.formulation}:sol:fields", f"this solver's record has {nf} fields")
+            fp = (C.c_void_p * nf)(*[ptr(f) for f in fields])
+        per = 1 if xr.dim() == 2 else 0
+        _lib.check(self._lib.spcies_hip_solve_batch_device_ex(self._h, ptr(x0), ptr(xr), ptr(ur), C.c_int(per), ptr(extra),
+                                                             C.c_int(int(extra_stride)), C.c_long(x0.shape[0]), ptr(u), ptr(k),
+                                                             ptr(e_flag), fp, nf, C.c_void_p(stream)))
+
     def time_device(self, x0, xr, ur, u, k, e_flag, stream=0, reps=1):
         """Mean ms per launch over ``reps`` back-to-back solves, hipEvents on ``stream``."""
         ptr = lambda a: C.c_void_p(a.data_ptr())
