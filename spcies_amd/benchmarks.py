@@ -153,6 +153,22 @@ def config(name):
     raise KeyError(name)
 
 
+def hmpc_rotate_to_reference_phase(z, n, m, N, w):
+    """The reference tests' HMPC ``z_opt`` (``tests/test_HMPC_ADMM_s.m:25``, ``test_HMPC_SADMM_s.m:25``,
+    ``test_HMPC_ADMM.m:24``) counts the harmonic phase from the END of the horizon - it satisfies
+    ``x_N = xe + xc`` - whereas the snapshot's code imposes ``x_N = xe + xs sin(wN) + xc cos(wN)``
+    (``compute_HMPC_ADMM_split_ingredients.m:139``).  Same trajectory, harmonic coefficients rotated by ``wN``:
+    ``xs' = xs cos(wN) - xc sin(wN)``, ``xc' = xs sin(wN) + xc cos(wN)`` (and the same for ``us, uc``)."""
+    z = np.array(z, dtype=float)
+    c, s = np.cos(w * N), np.sin(w * N)
+    o = (N - 1) * (n + m) + m
+    for a, b, wd in ((o + n, o + 2 * n, n), (o + 3 * n + m, o + 3 * n + 2 * m, m)):
+        hs, hc = z[..., a:a + wd].copy(), z[..., b:b + wd].copy()
+        z[..., a:a + wd] = hs * c - hc * s
+        z[..., b:b + wd] = hs * s + hc * c
+    return z
+
+
 def sample_batch(cfg, B=None, seed=None, around_xr=None):
     """Seeded instances: ``x0 ~ U(-0.1, 0.1)^n``, ``ur = 0.5 + 0.1 U(-1, 1)^m``, ``xr`` the steady state of ``ur``.
 

@@ -41,7 +41,13 @@ def _ldl_nopivot(M):
 
 def _hmpc_problem(controller, opt):
     """H, G, the cone rows C_aux / dsoc and the bounds of the HMPC problem (box-constraint case) - common to the split and
-    the non-split solver (``compute_HMPC_ADMM_split_ingredients.m:60-218`` = ``compute_HMPC_ADMM_ingredients.m:60-230``)."""
+    the non-split solver (``compute_HMPC_ADMM_split_ingredients.m:60-218`` = ``compute_HMPC_ADMM_ingredients.m:60-230``).
+
+    Solver option ``stage0_cost`` (default true = the snapshot as coded).  False drops the stage-0 STATE term
+    ``|x0 - xe - xc|_Q^2`` from the objective: ``H22`` then sums ``j = 1 .. N-1`` (``:114-116`` sum ``j = 0 .. N-1``:
+    ``N*Q``, ``sum cos``, ``sum cos^2``) and the solver's ``q`` gets no ``-Q x0`` rows (``QQ`` is shipped as zeros;
+    ``code_HMPC_ADMM_split_C.c:115-124``).  That is the formulation the reference tests' ``z_opt`` was computed for
+    (``tests/test_HMPC_ADMM_s.m:25``, ``test_HMPC_ADMM.m:24``) - it is what pins the HMPC oracles."""
     sys, param = _get(controller, "sys"), _get(controller, "param")
     A = np.asarray(_get(sys, "A"), dtype=float)
     B = np.asarray(_get(sys, "B"), dtype=float)
@@ -61,7 +67,11 @@ def _hmpc_problem(controller, opt):
     Te, Th = np.asarray(_get(param, "Te"), float), np.asarray(_get(param, "Th"), float)
     Se, Sh = np.asarray(_get(param, "Se"), float), np.asarray(_get(param, "Sh"), float)
     sj, cj = np.sin(w * np.arange(N)), np.cos(w * np.arange(N))
-    s_sum, c_sum, s2, c2, sc = sj.sum(), cj.sum(), (sj ** 2).sum(), (cj ** 2).sum(), (sj * cj).sum()
+    stage0 = bool(so.get("stage0_cost", True))
+    j0 = 0 if stage0 else 1  # first stage whose state enters the objective
+    NQ = N - j0
+    s_sum, c_sum, s2, c2, sc = sj[j0:].sum(), cj[j0:].sum(), (sj[j0:] ** 2).sum(), (cj[j0:] ** 2).sum(), (sj[j0:] * cj[j0:]).sum()
+    sR, cR, s2R, c2R, scR = sj.sum(), cj.sum(), (sj ** 2).sum(), (cj ** 2).sum(), (sj * cj).sum()  # inputs: every stage
     # ---- Hessian (:98-127)
     d1 = (N - 1) * nm + m
     H11 = np.zeros((d1, d1))
@@ -76,8 +86,8 @@ def _hmpc_problem(controller, opt):
     H13 = np.zeros((d1, 3 * m))
     for j in range(N):
         H13[j * nm:j * nm + m, :] = np.kron(np.array([[1.0, sj[j], cj[j]]]), -R)
-    H22 = np.block([[Te + N * Q, s_sum * Q, c_sum * Q], [s_sum * Q, Th + s2 * Q, sc * Q], [c_sum * Q, sc * Q, Th + c2 * Q]])
-    H33 = np.block([[Se + N * R, s_sum * R, c_sum * R], [s_sum * R, Sh + s2 * R, sc * R], [c_sum * R, sc * R, Sh + c2 * R]])
+    H22 = np.block([[Te + NQ * Q, s_sum * Q, c_sum * Q], [s_sum * Q, Th + s2 * Q, sc * Q], [c_sum * Q, sc * Q, Th + c2 * Q]])
+    H33 = np.block([[Se + N * R, sR * R, cR * R], [sR * R, Sh + s2R * R, scR * R], [cR * R, scR * R, Sh + c2R * R]])
     H = np.block([[H11, H12, H13], [H12.T, H22, np.zeros((3 * n, 3 * m))], [H13.T, np.zeros((3 * m, 3 * n)), H33]])
     dim = H.shape[0]
     # ---- equality constraints (:131-142): N-2 interior -I blocks, harmonic closure of the last dynamics row,
@@ -116,6 +126,8 @@ def _hmpc_problem(controller, opt):
         dsoc, n_soc = np.zeros(3 * n_y), n_y
     LB = np.concatenate([LBu] + [np.concatenate([LBx, LBu])] * (N - 1))
     UB = np.concatenate([UBu] + [np.concatenate([UBx, UBu])] * (N - 1))
+    if not stage0:
+        Q = np.zeros_like(Q)  # QQ of the generated solver: only multiplies x0 (code_HMPC_ADMM_split_C.c:115-124)
     return SimpleNamespace(A=A, n=n, m=m, N=N, Q=Q, Te=Te, Se=Se, H=H, G=G, b=b, C_aux=C_aux, dsoc=dsoc, n_soc=n_soc,
                            use_soc=use_soc, LB=LB, UB=UB, LBy=LBy, UBy=UBy)
 

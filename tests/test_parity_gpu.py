@@ -458,6 +458,36 @@ def test_hmpc_vs_reference_template_fixture(variant, golden_dir):
     assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-8
 
 
+@pytest.mark.parametrize("cfg_name,test_name,variant", [
+    ("C1_HMPC", "test_HMPC_ADMM_s", "stream"), ("C1_HMPC", "test_HMPC_ADMM_s", "tile"), ("C1_HMPC", "test_HMPC_ADMM_s", "gemm"),
+    ("C1_HMPC_SADMM", "test_HMPC_SADMM_s", "stream"), ("C1_HMPC_SADMM", "test_HMPC_SADMM_s", "tile"),
+    ("C1_HMPC_SADMM", "test_HMPC_SADMM_s", "gemm"), ("C1_HMPC_SADMM_soc", "test_HMPC_SADMM_s", "gemm"),
+    ("C1_HMPC_nosplit", "test_HMPC_ADMM", "gemm"), ("C1_HMPC_nosplit", "test_HMPC_ADMM", "stream"),
+    ("C1_HMPC_SADMM_nosplit", "test_HMPC_ADMM", "gemm")])
+def test_hmpc_reference_optimum_on_gpu(cfg_name, test_name, variant, golden_dir):
+    """The reference tests' HMPC z_opt (tests/test_HMPC_ADMM_s.m:25, test_HMPC_SADMM_s.m:25, test_HMPC_ADMM.m:24) on every HIP
+    variant: tester instance, the formulation the golden was computed for (ingredients switch stage0_cost = False, see
+    tests/test_oracle_golden.py::test_hmpc_oracles_reproduce_reference_optimum), harmonic phase rotated by wN: <= tol_opt."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
+        z_opt = np.array(json.load(f)[test_name])
+    cfg, v, s = _fista_solver(cfg_name, variant, stage0_cost=False)
+    st = benchmarks.tester_status(cfg.sys)
+    u, k, e, sol = s(st.x, st.xr, st.ur)
+    assert e == 1
+    z = benchmarks.hmpc_rotate_to_reference_phase(sol.z, cfg.sys.n, cfg.sys.m, cfg.param.N, cfg.param.w)
+    err = np.abs(z - z_opt).max()
+    print(f"{cfg_name} [{variant}]: k = {k}, |z - z_opt| = {err:.2e}")
+    assert err <= TOL_OPT and np.allclose(u, [0.8, 0.8], atol=1e-5)
+    # and against the oracle on the same data
+    nosplit = "nosplit" in cfg_name
+    O = oracle.hmpc_dense_batch(v, st.x[None], st.xr, st.ur) if nosplit else oracle.admm_hmpc_batch(v, st.x[None], st.xr, st.ur, sparse=(variant != "gemm"))
+    assert abs(int(k) - int(O[1][0])) <= (0 if variant == "stream" else 1)
+    if k == O[1][0]:
+        assert np.abs(sol.z - O[3][0]).max() <= (0.0 if variant == "stream" else TOL_SPCIES)
+
+
 # ----------------------------------------------------------------------------------------------
 # HMPC ADMM / SADMM without the splitting (the reference's default HMPC solver; dense M1, M2): GEMM variant -> 1e-10
 # ----------------------------------------------------------------------------------------------
