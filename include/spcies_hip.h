@@ -38,6 +38,11 @@
  *  - x0 is [B][n]; xr is [B][n] and ur is [B][m] when ref_stride != 0, else one shared reference
  *    ([n], [m]) for the whole batch.
  *  - no CPU fallback exists: without a usable HIP device the calls fail with SPCIES_HIP_ENODEV.
+ *  - ONE handle = ONE solve in flight: a handle owns a single set of device scratch, so calls on the same handle are
+ *    serialised (internal mutex) and must not be queued on two streams at once; use one handle per stream (handles are
+ *    independent and may live on different devices of one process).  A record field left NULL on a variant whose kernel
+ *    writes the whole record (MFMA, MFMA4, BSP) lands in handle-owned scratch that is allocated on first use: make
+ *    one such call before capturing into a hipGraph.
  */
 #ifndef SPCIES_HIP_H
 #define SPCIES_HIP_H

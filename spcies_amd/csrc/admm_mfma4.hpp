@@ -562,12 +562,9 @@ static int launch_mfma4_shape(Mfma4Plan &pl, const AdmmHost &a, const MfmaArgs &
 #define SPCIES_LAUNCH(TERM, SOL)                                                                                     \
     do {                                                                                                             \
         auto kern = admm_mfma4_kernel<N, KX, KS, TERM, SOL>;                                                         \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+        /* per device, so set before every launch (a handle may live on any GPU of the process) */                   \
+        SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                                  160 * 1024));                                                      \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
         hipLaunchKernelGGL(kern, grid, block, shmem, st, args, pl.d_table, x0, xr, ur, u, k, e, z, v, lam,           \
                            pl.d_table + pl.table_bytes / sizeof(double));                                            \
     } while (0)

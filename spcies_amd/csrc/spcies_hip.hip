@@ -107,6 +107,9 @@ struct Solver {
     // staging buffers of the host entry point
     double *d_io = nullptr;
     size_t io_bytes = 0;
+    // record fields the caller did not ask for, for the variants whose kernels write the whole record or nothing
+    double *d_part = nullptr;
+    size_t part_bytes = 0;
     hipStream_t stream = nullptr;  // owned; used by the host entry point
     std::mutex mu;
 };
@@ -1091,9 +1094,32 @@ static int solve_device(Solver &s, const double *x0, const double *xr, const dou
 }
 
 static int solve_device_scaled(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
-                               double *u, int *k, int *e, double *const *f, const double *extra, int extra_stride,
+                               double *u, int *k, int *e, double *const *f_in, const double *extra, int extra_stride,
                                hipStream_t st) {
     if (B <= 0) return 0;
+    // "a NULL entry skips that output" (include/spcies_hip.h) holds for every variant: the register-resident kernels (MFMA,
+    // MFMA4, BSP) write the whole record or nothing, so the fields the caller left out land in handle-owned scratch.
+    double *f[6] = {f_in[0], f_in[1], f_in[2], f_in[3], f_in[4], f_in[5]};
+    {
+        const int nf = s.n_fields();
+        bool any = false, all = true;
+        for (int i = 0; i < nf; i++) { any |= f[i] != nullptr; all &= f[i] != nullptr; }
+        const int var = resolve_variant(s);
+        if (any && !all && (var == SPCIES_VARIANT_MFMA || var == SPCIES_VARIANT_MFMA4 || var == SPCIES_VARIANT_BSP)) {
+            size_t need = 0;
+            for (int i = 0; i < nf; i++)
+                if (!f[i]) need += (size_t)B * s.field_dim(i) * sizeof(double);
+            if (need > s.part_bytes) {
+                if (s.d_part) SPCIES_HIP_CHECK(hipFree(s.d_part));
+                s.d_part = nullptr; s.part_bytes = 0;
+                SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_part, need));
+                s.part_bytes = need;
+            }
+            double *p = s.d_part;
+            for (int i = 0; i < nf; i++)
+                if (!f[i]) { f[i] = p; p += (size_t)B * s.field_dim(i); }
+        }
+    }
     if (s.is_soc() && !s.is_hmpc() && !extra)
         return fail(SPCIES_HIP_EINVAL, "ellipMPC soc solvers take a 4th input r (extra): Spcies:ellipMPC:nrhs:r");
     if (s.is_cs()) {
@@ -1276,6 +1302,7 @@ static void free_solver(Solver *s) {
     if (s->d_consts) hipFree(s->d_consts);
     if (s->d_scratch) hipFree(s->d_scratch);
     if (s->d_io) hipFree(s->d_io);
+    if (s->d_part) hipFree(s->d_part);
     if (s->d_idx) hipFree(s->d_idx);
     if (s->d_recs) hipFree(s->d_recs);
     hgemm::plan_free(s->hgemm);

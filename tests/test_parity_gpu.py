@@ -974,3 +974,28 @@ def test_mfma4_run_time_specialisation(n, m, N, formulation):
     nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
     assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
     s.close()
+
+
+@pytest.mark.parametrize("cfg_name,variant", [("C2", "mfma4"), ("C2", "mfma"), ("C1", "mfma4"), ("C2", "mfma4g"), ("C2", "stream"),
+                                              ("C2_ellip", "bsp"), ("C2_lax_gen", "bsp")])
+def test_partial_record_through_the_c_abi(cfg_name, variant):
+    """include/spcies_hip.h: "z, v, lambda may be NULL" - each one independently, on every variant (the register-resident
+    kernels write the whole record or nothing: the fields left out go to handle-owned scratch)."""
+    import ctypes as C
+    from spcies_amd import _lib, benchmarks
+    cfg, v, s = _solver(cfg_name, variant)
+    x0, xr, ur = benchmarks.sample_batch(cfg, 50)
+    u, k, e, sol = s(x0, xr, ur)
+    B, dim = x0.shape[0], s.dim
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    for pick in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1)):
+        bufs = [np.full((B, dim), np.nan) if p else None for p in pick]
+        u2, k2, e2 = np.zeros((B, s.m)), np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        _lib.check(s._lib.spcies_hip_solve_batch(s._h, dp(x0), dp(xr), dp(ur), 1, C.c_long(B), dp(u2), ip(k2), ip(e2),
+                                                 *[dp(b) if b is not None else None for b in bufs], None))
+        assert np.array_equal(u2, u) and np.array_equal(k2, k) and np.array_equal(e2, e)
+        for b, ref in zip(bufs, (sol.z, sol.v, sol.lam)):
+            if b is not None:
+                assert np.array_equal(b, ref)
+    s.close()
