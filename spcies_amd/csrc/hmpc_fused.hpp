@@ -1,0 +1,42 @@
+// Variant FUSED of the HMPC solvers: the dense contraction of an iteration (the reference's NON_SPARSE path,
+// code_HMPC_ADMM_split_C.c:174-190; the non-split solver's z-update, code_HMPC_ADMM_C.c:123-157) AND everything
+// between two contractions (box / proj_SOC3 projections, dual steps, residual flags, exit test) in ONE hand-written
+// kernel on v_mfma_f64_4x4x4: four instances per wavefront, sixteen rows per register, all state and all accumulators
+// in registers, the controller's matrix streamed L2 -> LDS by LDS-DMA (hmpc_fused_kernel.inc).  No library GEMM, no
+// state in HBM.  Host side: the table in the kernel's issue order, build-time instantiations for the benchmark
+// shapes, hiprtc specialisation for any other controller (Spcies prints one solver per controller; so does this).
+#pragma once
+#include "common.hpp"
+
+namespace spcies {
+namespace hfused {
+
+struct SplitHost {  // what parse_hmpc collected (HMPC ADMM / SADMM split, blob arrays of cons_HMPC_ADMM_split_C.m:121-150)
+    int n, m, N, dim, n_s, n_eq, n_soc, use_soc, symmetric, k_max;
+    double tol_p, tol_d, rho, rho_i, sigma, sigma_i, alpha;
+    const double *M1, *M2, *bh_nat;                            // [np][np], [np][n_eq + n_s], [n_eq + n_s]
+    const double *A, *QQ, *Te, *Se, *LB, *UB, *LBy, *UBy;     // dense small matrices and bounds
+};
+
+struct Plan {
+    bool ok = false;
+    std::string why = "not built";
+    int n = 0, m = 0, N = 0, use_soc = 0, symmetric = 0;
+    int NR = 0, NK = 0, NCH = 0, CHB = 0;
+    double *d_ME = nullptr, *d_C = nullptr;
+    int oQQ = 0, oTe = 0, oSe = 0, oLB = 0, oUB = 0, oD1 = 0, oD2 = 0;
+    int num_cu = 256;
+    void *module = nullptr;        // hipModule_t of a run-time specialised kernel (shapes not instantiated at build time)
+    void *fn[2] = {nullptr, nullptr};  // WANT_SOL = false, true
+    int builtin = -1;              // index into the build-time instantiations, or -1
+};
+
+int plan_build_split(Plan &p, const SplitHost &h);
+void plan_free(Plan &p);
+// u, k, e, fields (z, s, z_hat, s_hat, lambda, mu; NULL entries are skipped) are device pointers; k_max / tolerances as given
+int launch_split(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rho_i, double sigma, double sigma_i, double alpha,
+                 const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u, int *k, int *e,
+                 double *const *f, hipStream_t st);
+
+}  // namespace hfused
+}  // namespace spcies

@@ -20,6 +20,7 @@
 #include "mpct_cs.hpp"
 #include "soc_bsp.hpp"
 #include "ellip_bsp.hpp"
+#include "hmpc_fused.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -93,6 +94,7 @@ struct Solver {
     rtc::Mfma4Module mfma4_rtc;  // run-time compiled MFMA4 kernel when the shape was not instantiated at build time
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
+    hfused::Plan hfused;           // FUSED (HMPC split NON_SPARSE path: product + projections in one MFMA kernel)
     std::vector<double> h_M1, h_M2, h_bh_nat;
     bsp::Plan bsp;                 // BSP (ellipMPC soc): block-sparse MFMA program, generated per controller
     CsDev cdev{};                  // MPCT ADMM on the extended state space (STREAM, TILE)
@@ -673,6 +675,7 @@ static int resolve_variant(const Solver &s) {
     if (s.tv) return SPCIES_VARIANT_STREAM;
     if (s.is_hdense()) return SPCIES_VARIANT_GEMM;
     if (s.is_cs()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
+    if (s.is_hmpc() && s.hfused.ok) return SPCIES_VARIANT_FUSED;
     if (s.is_hmpc() && s.hgemm.ok) return SPCIES_VARIANT_GEMM;
     if (s.is_soc() && !s.is_hmpc() && s.bsp.ok) return SPCIES_VARIANT_BSP;
     if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
@@ -1146,6 +1149,11 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (stream) return hdense::launch_stream(s.hd_plan, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f, st);
         return hdense::launch(s.hd_plan, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f, st);
     }
+    if (s.is_hmpc() && resolve_variant(s) == SPCIES_VARIANT_FUSED) {
+        const HmpcDev &hd = s.hdev;  // k_max / tolerances: set_exit overrides land here
+        return hfused::launch_split(s.hfused, hd.k_max, hd.tol_p, hd.tol_d, hd.rho, hd.rho_i, hd.sigma, hd.sigma_i, hd.alpha, x0, xr, ur,
+                                    ref_stride, B, u, k, e, f, st);
+    }
     if (s.is_hmpc() && resolve_variant(s) == SPCIES_VARIANT_GEMM) {
         if (!s.hgemm.ok) return fail(SPCIES_HIP_ENOSUP, "GEMM variant not available: %s", s.hgemm.why.c_str());
         int rc = ensure_scratch(s, hgemm::scratch_bytes(s.hgemm.dev, B));
@@ -1306,6 +1314,7 @@ static void free_solver(Solver *s) {
     if (s->d_idx) hipFree(s->d_idx);
     if (s->d_recs) hipFree(s->d_recs);
     hgemm::plan_free(s->hgemm);
+    hfused::plan_free(s->hfused);
     hdense::plan_free(s->hd_plan);
     bsp::plan_free(s->bsp);
     if (s->d_eng) hipFree(s->d_eng);
@@ -1339,6 +1348,14 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         const double *F = s->soc_f64.data();
         rc = hgemm::plan_build(s->hgemm, hd, s->h_M1, s->h_M2, s->h_bh_nat, F + hd.A, F + hd.QQ, F + hd.Te, F + hd.Se, F + hd.LB,
                                hd.dim - 3 * (hd.n + hd.m), F + hd.UB, F + hd.LBy, F + hd.UBy);
+        if (rc) return rc;
+        const int nb = hd.dim - 3 * (hd.n + hd.m);
+        (void)nb;
+        hfused::SplitHost fh{hd.n, hd.m, hd.N, hd.dim, hd.n_s, hd.n_eq, hd.n_soc, hd.use_soc, hd.symmetric, hd.k_max,
+                             hd.tol_p, hd.tol_d, hd.rho, hd.rho_i, hd.sigma, hd.sigma_i, hd.alpha,
+                             s->h_M1.data(), s->h_M2.data(), s->h_bh_nat.data(),
+                             F + hd.A, F + hd.QQ, F + hd.Te, F + hd.Se, F + hd.LB, F + hd.UB, F + hd.LBy, F + hd.UBy};
+        rc = hfused::plan_build_split(s->hfused, fh);
         if (rc) return rc;
     }
     // ellipMPC soc: compile the controller's block program now (hiprtc, a few seconds; SPCIES_HIP_BSP=0 turns it off).  A
@@ -1427,7 +1444,13 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
 int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_BSP) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_FUSED) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant == SPCIES_VARIANT_FUSED) {
+        if (!(s->is_hmpc() && s->hfused.ok))
+            return fail(SPCIES_HIP_ENOSUP, "FUSED variant: built for the HMPC solvers whose blob carries the dense M1, M2 (%s)", s->hfused.why.c_str());
+        s->variant = variant;
+        return 0;
+    }
     if (variant == SPCIES_VARIANT_BSP) {
         const bool soc = s->is_soc() && !s->is_hmpc();
         const bool lax = s->formulation == SPCIES_LAXMPC && s->method == SPCIES_ADMM && !s->tv && !s->eng;

@@ -432,7 +432,7 @@ def test_soc_vs_reference_template_fixture(variant, golden_dir):
     ("C5_HMPC_SADMM", 65, {}),                                  # BASELINE config 5 shape, 200 fixed iterations
     ("C5_HMPC_SADMM", 12, dict(tol_p=1e-5, tol_d=1e-5, k_max=2500)),
 ])
-@pytest.mark.parametrize("variant", SPARSE_VARIANTS + ["gemm"])  # GEMM: the reference's NON_SPARSE path (dense M1, M2)
+@pytest.mark.parametrize("variant", SPARSE_VARIANTS + ["gemm", "fused"])  # GEMM, FUSED: the reference's NON_SPARSE path (dense M1, M2)
 def test_hmpc_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
@@ -443,7 +443,7 @@ def test_hmpc_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
         st = benchmarks.tester_status(cfg.sys)
         x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
     got = s(x0, xr, ur)
-    _compare_sparse(variant, got, oracle.admm_hmpc_batch(v, x0, xr, ur, sparse=(variant != "gemm")))
+    _compare_sparse(variant, got, oracle.admm_hmpc_batch(v, x0, xr, ur, sparse=(variant not in ("gemm", "fused"))))
     nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
     assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
 
@@ -460,6 +460,7 @@ def test_hmpc_vs_reference_template_fixture(variant, golden_dir):
 
 @pytest.mark.parametrize("cfg_name,test_name,variant", [
     ("C1_HMPC", "test_HMPC_ADMM_s", "stream"), ("C1_HMPC", "test_HMPC_ADMM_s", "tile"), ("C1_HMPC", "test_HMPC_ADMM_s", "gemm"),
+    ("C1_HMPC", "test_HMPC_ADMM_s", "fused"), ("C1_HMPC_SADMM", "test_HMPC_SADMM_s", "fused"), ("C1_HMPC_SADMM_soc", "test_HMPC_SADMM_s", "fused"),
     ("C1_HMPC_SADMM", "test_HMPC_SADMM_s", "stream"), ("C1_HMPC_SADMM", "test_HMPC_SADMM_s", "tile"),
     ("C1_HMPC_SADMM", "test_HMPC_SADMM_s", "gemm"), ("C1_HMPC_SADMM_soc", "test_HMPC_SADMM_s", "gemm"),
     ("C1_HMPC_nosplit", "test_HMPC_ADMM", "gemm"), ("C1_HMPC_nosplit", "test_HMPC_ADMM", "stream"),
@@ -482,7 +483,7 @@ def test_hmpc_reference_optimum_on_gpu(cfg_name, test_name, variant, golden_dir)
     assert err <= TOL_OPT and np.allclose(u, [0.8, 0.8], atol=1e-5)
     # and against the oracle on the same data
     nosplit = "nosplit" in cfg_name
-    O = oracle.hmpc_dense_batch(v, st.x[None], st.xr, st.ur) if nosplit else oracle.admm_hmpc_batch(v, st.x[None], st.xr, st.ur, sparse=(variant != "gemm"))
+    O = oracle.hmpc_dense_batch(v, st.x[None], st.xr, st.ur) if nosplit else oracle.admm_hmpc_batch(v, st.x[None], st.xr, st.ur, sparse=(variant not in ("gemm", "fused")))
     assert abs(int(k) - int(O[1][0])) <= (0 if variant == "stream" else 1)
     if k == O[1][0]:
         assert np.abs(sol.z - O[3][0]).max() <= (0.0 if variant == "stream" else TOL_SPCIES)
