@@ -13,24 +13,26 @@ static const char *const kFusedSource =
 #include "hmpc_fused_src.inc"
     ;
 
-// ---- shapes instantiated at build time: (n, m, N, SYM, USE_SOC).  Everything else is compiled by hiprtc at create time.
-#define SPCIES_HFUSED_SPLIT_SHAPES(X) X(12, 2, 15, true, false)
+// ---- shapes instantiated at build time: (n, m, N, SYM, USE_SOC, MODE).  Everything else is compiled by hiprtc at create time.
+#define SPCIES_HFUSED_SHAPES(X) X(12, 2, 15, true, false, 0) X(12, 2, 15, true, false, 1)
 
 namespace {
 
 struct Dims {  // mirrors Shape<> of the kernel file for run-time values
-    int nm, dim, n_soc, n_s, n_box, NZ, NC, NR, NX, NK, JC, NCH, CHB, o0;
-    Dims(int n, int m, int N, bool use_soc) {
+    int nm, dim, n_soc, n_s, n_box, NA, NC, NR, NXS, NUS, NE, NK, JC, NCH, CHB, o0;
+    Dims(int n, int m, int N, bool use_soc, int mode) {
         nm = n + m;
         dim = (N - 1) * nm + m + 3 * nm;
         n_soc = use_soc ? 2 * nm : nm;
-        n_s = 3 * n_soc;
         n_box = dim - 3 * nm;
-        NZ = (dim + 15) / 16;
+        n_s = mode == 0 ? 3 * n_soc : n_box + 3 * n_soc;
+        NA = ((mode == 0 ? dim : n_box) + 15) / 16;
         NC = (n_soc + 3) / 4;
-        NR = NZ + NC;
-        NX = (n + 3) / 4;
-        NK = 4 * NR + NX + 1;
+        NR = NA + NC;
+        NXS = (n + 3) / 4;
+        NUS = (m + 3) / 4;
+        NE = mode == 0 ? NXS : 2 * NXS + NUS;
+        NK = 4 * NR + NE + 1;
         JC = (40960 / (NR * 512)) > 0 ? (40960 / (NR * 512)) : 1;
         NCH = (NK + JC - 1) / JC;
         CHB = ((JC * NR * 512 + 1023) / 1024) * 1024;
@@ -38,26 +40,94 @@ struct Dims {  // mirrors Shape<> of the kernel file for run-time values
     }
 };
 
-int builtin_index(int n, int m, int N, bool sym, bool use_soc) {
+int builtin_index(int n, int m, int N, bool sym, bool use_soc, int mode) {
     int idx = 0;
-#define X(nn, mm, NN, SS, UU)                                                     \
-    if (n == nn && m == mm && N == NN && sym == SS && use_soc == UU) return idx; \
+#define X(nn, mm, NN, SS, UU, MM)                                                               \
+    if (n == nn && m == mm && N == NN && sym == SS && use_soc == UU && mode == MM) return idx; \
     idx++;
-    SPCIES_HFUSED_SPLIT_SHAPES(X)
+    SPCIES_HFUSED_SHAPES(X)
 #undef X
     return -1;
 }
 
-template <int n, int m, int N, bool SYM, bool USE_SOC>
+template <int n, int m, int N, bool SYM, bool USE_SOC, int MODE>
 int launch_builtin(const Args &a, const double *ME, const double *C, const double *x0, const double *xr, const double *ur, double *u,
                    int *k, int *e, double *const *f, bool want_sol, unsigned grid, hipStream_t st) {
     if (want_sol)
-        hipLaunchKernelGGL((hmpc_split_fused_kernel<n, m, N, SYM, USE_SOC, true>), dim3(grid), dim3(512), 0, st, a, ME, C, x0, xr, ur, u, k, e,
+        hipLaunchKernelGGL((hmpc_fused_kernel<n, m, N, SYM, USE_SOC, MODE, true>), dim3(grid), dim3(512), 0, st, a, ME, C, x0, xr, ur, u, k, e,
                            f[0], f[1], f[2], f[3], f[4], f[5]);
     else
-        hipLaunchKernelGGL((hmpc_split_fused_kernel<n, m, N, SYM, USE_SOC, false>), dim3(grid), dim3(512), 0, st, a, ME, C, x0, xr, ur, u, k, e,
+        hipLaunchKernelGGL((hmpc_fused_kernel<n, m, N, SYM, USE_SOC, MODE, false>), dim3(grid), dim3(512), 0, st, a, ME, C, x0, xr, ur, u, k, e,
                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Common tail of the two plan builders: Mx = the extended matrix [16 NR][4 NCH JC] in internal row / column order
+int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int symmetric, int mode, const std::vector<double> &Mx,
+                std::vector<double> &flat) {
+    const int ncol = 4 * D.NCH * D.JC;
+    for (double x : Mx)
+        if (!std::isfinite(x)) { p.why = "non-finite M1 / M2"; return 0; }
+    // the table in issue order: chunk | k-slab in chunk | row register | lane (k = l >> 4, b = (l >> 2) & 3, i = l & 3)
+    std::vector<double> tab((size_t)D.NCH * (D.CHB / 8), 0.0);
+    for (int c = 0; c < D.NCH; c++)
+        for (int jj = 0; jj < D.JC; jj++) {
+            const int J = c * D.JC + jj;
+            for (int R = 0; R < D.NR; R++)
+                for (int l = 0; l < 64; l++) {
+                    const int k = l >> 4, b = (l >> 2) & 3, i = l & 3;
+                    tab[(size_t)c * (D.CHB / 8) + (size_t)(jj * D.NR + R) * 64 + l] = Mx[(size_t)(16 * R + 4 * b + i) * ncol + 4 * J + k];
+                }
+        }
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_ME, tab.size() * sizeof(double)));
+    SPCIES_HIP_CHECK(hipMemcpy(p.d_ME, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_C, flat.size() * sizeof(double)));
+    SPCIES_HIP_CHECK(hipMemcpy(p.d_C, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
+    p.n = n; p.m = m; p.N = N; p.use_soc = use_soc; p.symmetric = symmetric; p.mode = mode;
+    p.NR = D.NR; p.NK = D.NK; p.NCH = D.NCH; p.CHB = D.CHB;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    SPCIES_HIP_CHECK(hipGetDevice(&dev));
+    SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    p.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    p.builtin = builtin_index(n, m, N, symmetric != 0, use_soc != 0, mode);
+    const char *force = getenv("SPCIES_HFUSED_RTC");  // kernel experiments: re-specialise a built-in shape (with SPCIES_HFUSED_FLAGS)
+    if (force && force[0] == '1') p.builtin = -1;
+    if (p.builtin < 0) {  // not among the build-time shapes: specialise now (SPCIES_HIP_RTC=0 turns it off)
+        const char *ev = getenv("SPCIES_HIP_RTC");
+        if (ev && ev[0] == '0') { p.why = "shape not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
+        std::vector<std::string> names, extra;
+        for (int s = 0; s < 2; s++) {
+            char nm[160];
+            snprintf(nm, sizeof(nm), "spcies::hfused::hmpc_fused_kernel<%d, %d, %d, %s, %s, %d, %s>", n, m, N, symmetric ? "true" : "false",
+                     use_soc ? "true" : "false", mode, s ? "true" : "false");
+            names.push_back(nm);
+        }
+        if (const char *fl = getenv("SPCIES_HFUSED_FLAGS")) {
+            std::string tok;
+            for (const char *c = fl;; c++) {
+                if (*c == ' ' || *c == '\0') {
+                    if (!tok.empty()) extra.push_back(tok);
+                    tok.clear();
+                    if (!*c) break;
+                } else {
+                    tok.push_back(*c);
+                }
+            }
+        }
+        hipModule_t mod = nullptr;
+        hipFunction_t fns[2] = {nullptr, nullptr};
+        if (rtc::compile_module(kFusedSource, "spcies_hmpc_fused.hip", names, extra, &mod, fns) != 0) {
+            p.why = g_last_error;
+            return 0;  // not an error: AUTO falls back, the reason is reported when FUSED is asked for
+        }
+        p.module = mod;
+        p.fn[0] = fns[0];
+        p.fn[1] = fns[1];
+    }
+    p.ok = true;
+    p.why.clear();
     return 0;
 }
 
@@ -72,9 +142,16 @@ void plan_free(Plan &p) {
     p.ok = false;
 }
 
+static int put(std::vector<double> &flat, const std::vector<double> &v) {
+    const int off = (int)flat.size();
+    flat.insert(flat.end(), v.begin(), v.end());
+    while (flat.size() % 8) flat.push_back(0.0);
+    return off;
+}
+
 int plan_build_split(Plan &p, const SplitHost &h) {
     const int n = h.n, m = h.m, N = h.N;
-    const Dims D(n, m, N, h.use_soc != 0);
+    const Dims D(n, m, N, h.use_soc != 0, 0);
     if (D.dim != h.dim || D.n_s != h.n_s || D.n_soc != h.n_soc) { p.why = "unexpected HMPC dimensions"; return 0; }
     if (D.NR > 24) { p.why = "FUSED: more than 24 row registers (dim + padded cones > 384 rows)"; return 0; }
     const int np = h.dim + h.n_s, nc = h.n_eq + h.n_s;
@@ -83,9 +160,9 @@ int plan_build_split(Plan &p, const SplitHost &h) {
     std::vector<int> orig(NP, -1);
     for (int r = 0; r < h.dim; r++) orig[r] = r;
     for (int t = 0; t < D.n_soc; t++)
-        for (int i = 0; i < 3; i++) orig[16 * D.NZ + 4 * t + i] = h.dim + 3 * t + i;
+        for (int i = 0; i < 3; i++) orig[16 * D.NA + 4 * t + i] = h.dim + 3 * t + i;
     // extended matrix: hat = -M1 q_hat + M2 bh,  M2 bh = c_const + (-M2[:, :n] A) x0  (:97-104, :174-190)
-    const int NKP = D.NCH * D.JC, ncol = 4 * NKP;
+    const int ncol = 4 * D.NCH * D.JC;
     std::vector<double> Mx((size_t)NP * ncol, 0.0);
     for (int ri = 0; ri < NP; ri++) {
         const int ro = orig[ri];
@@ -100,30 +177,11 @@ int plan_build_split(Plan &p, const SplitHost &h) {
         }
         double cc = 0.0;
         for (int j = n; j < nc; j++) cc += h.M2[(size_t)ro * nc + j] * h.bh_nat[j];
-        row[NP + 4 * D.NX] = cc;
+        row[NP + 4 * D.NE] = cc;
     }
-    for (double x : Mx)
-        if (!std::isfinite(x)) { p.why = "non-finite M1 / M2"; return 0; }
-    // the table in issue order: chunk | k-slab in chunk | row register | lane (k = l >> 4, b = (l >> 2) & 3, i = l & 3)
-    std::vector<double> tab((size_t)D.NCH * (D.CHB / 8), 0.0);
-    for (int c = 0; c < D.NCH; c++)
-        for (int jj = 0; jj < D.JC; jj++) {
-            const int J = c * D.JC + jj;
-            for (int R = 0; R < D.NR; R++)
-                for (int l = 0; l < 64; l++) {
-                    const int k = l >> 4, b = (l >> 2) & 3, i = l & 3;
-                    tab[(size_t)c * (D.CHB / 8) + (size_t)(jj * D.NR + R) * 64 + l] = Mx[(size_t)(16 * R + 4 * b + i) * ncol + 4 * J + k];
-                }
-        }
     // constants: QQ, Te, Se, bounds per internal z row, cone shifts per internal cone row
     std::vector<double> flat;
-    auto put = [&](const std::vector<double> &v) {
-        const int off = (int)flat.size();
-        flat.insert(flat.end(), v.begin(), v.end());
-        while (flat.size() % 8) flat.push_back(0.0);
-        return off;
-    };
-    std::vector<double> lbv(16 * D.NZ, 0.0), ubv(16 * D.NZ, 0.0), d1(16 * D.NC, 0.0), d2(16 * D.NC, 0.0);
+    std::vector<double> lbv(16 * D.NA, 0.0), ubv(16 * D.NA, 0.0), d1(16 * D.NC, 0.0), d2(16 * D.NC, 0.0);
     for (int r = 0; r < h.dim; r++) {
         lbv[r] = r < D.n_box ? h.LB[r] : -1e300;
         ubv[r] = r < D.n_box ? h.UB[r] : 1e300;
@@ -131,73 +189,158 @@ int plan_build_split(Plan &p, const SplitHost &h) {
     if (!h.use_soc)
         for (int t = 0; t < D.n_soc; t++)
             for (int i = 0; i < 4; i++) { d1[4 * t + i] = h.LBy[t]; d2[4 * t + i] = h.UBy[t]; }
-    p.oQQ = put(std::vector<double>(h.QQ, h.QQ + n * n));
-    p.oTe = put(std::vector<double>(h.Te, h.Te + n * n));
-    p.oSe = put(std::vector<double>(h.Se, h.Se + m * m));
-    p.oLB = put(lbv);
-    p.oUB = put(ubv);
-    p.oD1 = put(d1);
-    p.oD2 = put(d2);
-    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_ME, tab.size() * sizeof(double)));
-    SPCIES_HIP_CHECK(hipMemcpy(p.d_ME, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_C, flat.size() * sizeof(double)));
-    SPCIES_HIP_CHECK(hipMemcpy(p.d_C, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
-    p.n = n; p.m = m; p.N = N; p.use_soc = h.use_soc; p.symmetric = h.symmetric;
-    p.NR = D.NR; p.NK = D.NK; p.NCH = D.NCH; p.CHB = D.CHB;
-    hipDeviceProp_t prop;
-    int dev = 0;
-    SPCIES_HIP_CHECK(hipGetDevice(&dev));
-    SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    p.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    p.builtin = builtin_index(n, m, N, h.symmetric != 0, h.use_soc != 0);
-    if (p.builtin < 0) {  // not among the build-time shapes: specialise now (SPCIES_HIP_RTC=0 turns it off)
-        const char *ev = getenv("SPCIES_HIP_RTC");
-        if (ev && ev[0] == '0') { p.why = "shape not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
-        std::vector<std::string> names;
-        for (int s = 0; s < 2; s++) {
-            char nm[160];
-            snprintf(nm, sizeof(nm), "spcies::hfused::hmpc_split_fused_kernel<%d, %d, %d, %s, %s, %s>", n, m, N, h.symmetric ? "true" : "false",
-                     h.use_soc ? "true" : "false", s ? "true" : "false");
-            names.push_back(nm);
-        }
-        hipModule_t mod = nullptr;
-        hipFunction_t fns[2] = {nullptr, nullptr};
-        if (rtc::compile_module(kFusedSource, "spcies_hmpc_fused.hip", names, {}, &mod, fns) != 0) {
-            p.why = g_last_error;
-            return 0;  // not an error: AUTO falls back, the reason is reported when FUSED is asked for
-        }
-        p.module = mod;
-        p.fn[0] = fns[0];
-        p.fn[1] = fns[1];
-    }
-    p.ok = true;
-    p.why.clear();
-    return 0;
+    p.oQQ = put(flat, std::vector<double>(h.QQ, h.QQ + n * n));
+    p.oTe = put(flat, std::vector<double>(h.Te, h.Te + n * n));
+    p.oSe = put(flat, std::vector<double>(h.Se, h.Se + m * m));
+    p.oLB = put(flat, lbv);
+    p.oUB = put(flat, ubv);
+    p.oD1 = put(flat, d1);
+    p.oD2 = put(flat, d2);
+    p.oZcol = p.oZcoef = p.oZd = 0;
+    return finish_plan(p, D, n, m, N, h.use_soc, h.symmetric, 0, Mx, flat);
 }
 
-int launch_split(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rho_i, double sigma, double sigma_i, double alpha,
-                 const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u, int *k, int *e,
-                 double *const *f, hipStream_t st) {
+int plan_build_nosplit(Plan &p, const NosplitHost &h) {
+    const int n = h.n, m = h.m, N = h.N;
+    const Dims D(n, m, N, h.use_soc != 0, 1);
+    if (D.dim != h.dim || D.n_s != h.n_s || D.n_soc != h.n_soc || D.n_box != h.n_box) { p.why = "unexpected HMPC dimensions"; return 0; }
+    if (D.NR > 24) { p.why = "FUSED: more than 24 row registers"; return 0; }
+    const int dim = h.dim, n_s = h.n_s, NP = 16 * D.NR;
+    // dense C [n_s][dim] from its CSR form
+    std::vector<double> Cd((size_t)n_s * dim, 0.0);
+    for (int i = 0; i < n_s; i++)
+        for (int q = h.C_row[i]; q < h.C_row[i + 1]; q++) Cd[(size_t)i * dim + h.C_col[q]] += h.C_val[q];
+    // G1 = M1 C'  [dim][n_s];  CG = C G1  [n_s][n_s]  (code_HMPC_ADMM_C.c:123-157, 161-171 folded)
+    std::vector<double> G1((size_t)dim * n_s, 0.0), CG((size_t)n_s * n_s, 0.0);
+    for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++) {
+            const double mij = h.M1[(size_t)i * dim + j];
+            if (mij == 0.0) continue;
+            for (int r = 0; r < n_s; r++) {
+                const double c = Cd[(size_t)r * dim + j];
+                if (c != 0.0) G1[(size_t)i * n_s + r] += mij * c;
+            }
+        }
+    for (int i = 0; i < n_s; i++)
+        for (int j = 0; j < dim; j++) {
+            const double c = Cd[(size_t)i * dim + j];
+            if (c == 0.0) continue;
+            for (int r = 0; r < n_s; r++) CG[(size_t)i * n_s + r] += c * G1[(size_t)j * n_s + r];
+        }
+    // CIz = M2 b + M1 q = Lx0 x0 + Lxr xr + Lur ur   (b = -A x0, q rows xe / xc / ue: :83-105)
+    const int o0 = D.o0, xe = o0, xc = o0 + 2 * n, ue = o0 + 3 * n;
+    const int nin = 2 * n + m;
+    std::vector<double> L((size_t)dim * nin, 0.0);  // columns: x0 (n), xr (n), ur (m)
+    for (int i = 0; i < dim; i++) {
+        for (int c = 0; c < n; c++) {
+            double acc = 0.0;
+            for (int j = 0; j < n; j++) {
+                acc -= h.M2[(size_t)i * n + j] * h.A[j * n + c];
+                acc -= (h.M1[(size_t)i * dim + xe + j] + h.M1[(size_t)i * dim + xc + j]) * h.QQ[j * n + c];
+            }
+            L[(size_t)i * nin + c] = acc;
+            double accr = 0.0;
+            for (int j = 0; j < n; j++) accr -= h.M1[(size_t)i * dim + xe + j] * h.Te[j * n + c];
+            L[(size_t)i * nin + n + c] = accr;
+        }
+        for (int c = 0; c < m; c++) {
+            double acc = 0.0;
+            for (int j = 0; j < m; j++) acc -= h.M1[(size_t)i * dim + ue + j] * h.Se[j * m + c];
+            L[(size_t)i * nin + 2 * n + c] = acc;
+        }
+    }
+    std::vector<double> dv(h.d, h.d + (h.d ? n_s : 0));
+    if (dv.empty()) dv.assign(n_s, 0.0);
+    // internal row -> row of s, or -1
+    std::vector<int> orig(NP, -1);
+    for (int r = 0; r < D.n_box; r++) orig[r] = r;
+    for (int t = 0; t < D.n_soc; t++)
+        for (int i = 0; i < 3; i++) orig[16 * D.NA + 4 * t + i] = D.n_box + 3 * t + i;
+    const int ncol = 4 * D.NCH * D.JC;
+    std::vector<double> Mx((size_t)NP * ncol, 0.0);
+    const int cx0 = NP, cxr = NP + 4 * D.NXS, cur = NP + 8 * D.NXS, cone = NP + 4 * D.NE;
+    for (int ri = 0; ri < NP; ri++) {
+        const int ro = orig[ri];
+        if (ro < 0) continue;
+        double *row = &Mx[(size_t)ri * ncol];
+        double cst = -dv[ro];
+        for (int ci = 0; ci < NP; ci++)
+            if (orig[ci] >= 0) {
+                row[ci] = CG[(size_t)ro * n_s + orig[ci]];
+                cst -= h.rho * CG[(size_t)ro * n_s + orig[ci]] * dv[orig[ci]];  // operand is rho s + lambda: -rho d goes to the constant
+            }
+        for (int j = 0; j < dim; j++) {
+            const double c = Cd[(size_t)ro * dim + j];
+            if (c == 0.0) continue;
+            for (int q = 0; q < n; q++) {
+                row[cx0 + q] += c * L[(size_t)j * nin + q];
+                row[cxr + q] += c * L[(size_t)j * nin + n + q];
+            }
+            for (int q = 0; q < m; q++) row[cur + q] += c * L[(size_t)j * nin + 2 * n + q];
+        }
+        row[cone] = cst;
+    }
+    // z of the last product from C z - d: one slack row per decision variable whose row of C holds that entry alone
+    std::vector<double> zcol(NP, -1.0), zcoef(NP, 0.0), zd(NP, 0.0);
+    std::vector<int> inv(n_s, -1);
+    for (int ri = 0; ri < NP; ri++)
+        if (orig[ri] >= 0) inv[orig[ri]] = ri;
+    for (int c = 0; c < dim; c++) {
+        int found = -1;
+        for (int i = 0; i < n_s && found < 0; i++) {
+            if (Cd[(size_t)i * dim + c] == 0.0 || zcol[inv[i]] >= 0) continue;
+            int nnz = 0;
+            for (int j = 0; j < dim; j++) nnz += Cd[(size_t)i * dim + j] != 0.0;
+            if (nnz == 1) found = i;
+        }
+        if (found < 0) { p.why = "FUSED: a decision variable has no slack row of its own (coupled constraints)"; return 0; }
+        zcol[inv[found]] = c;
+        zcoef[inv[found]] = 1.0 / Cd[(size_t)found * dim + c];
+        zd[inv[found]] = dv[found];
+    }
+    std::vector<double> flat;
+    std::vector<double> lbv(16 * D.NA, 0.0), ubv(16 * D.NA, 0.0), d1(16 * D.NC, 0.0), d2(16 * D.NC, 0.0);
+    for (int r = 0; r < D.n_box; r++) { lbv[r] = h.LB[r]; ubv[r] = h.UB[r]; }
+    if (!h.use_soc)
+        for (int t = 0; t < D.n_soc; t++)
+            for (int i = 0; i < 4; i++) { d1[4 * t + i] = h.LBy[t]; d2[4 * t + i] = h.UBy[t]; }
+    p.oQQ = p.oTe = p.oSe = 0;
+    p.oLB = put(flat, lbv);
+    p.oUB = put(flat, ubv);
+    p.oD1 = put(flat, d1);
+    p.oD2 = put(flat, d2);
+    p.oZcol = put(flat, zcol);
+    p.oZcoef = put(flat, zcoef);
+    p.oZd = put(flat, zd);
+    return finish_plan(p, D, n, m, N, h.use_soc, h.symmetric, 1, Mx, flat);
+}
+
+int launch(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rho_i, double sigma, double sigma_i, double alpha,
+           const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u, int *k, int *e,
+           double *const *f, hipStream_t st) {
     if (!p.ok) return fail(SPCIES_HIP_ENOSUP, "FUSED variant unavailable: %s", p.why.c_str());
     Args a{};
     a.B = B; a.ref_stride = ref_stride; a.k_max = k_max; a.tol_p = tol_p; a.tol_d = tol_d; a.rho = rho; a.rho_i = rho_i;
     a.sigma = sigma; a.sigma_i = sigma_i; a.alpha = alpha;
     a.oQQ = p.oQQ; a.oTe = p.oTe; a.oSe = p.oSe; a.oLB = p.oLB; a.oUB = p.oUB; a.oD1 = p.oD1; a.oD2 = p.oD2;
+    a.oZcol = p.oZcol; a.oZcoef = p.oZcoef; a.oZd = p.oZd;
+    const int nf = p.mode == 0 ? 6 : 3;
+    double *ff[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool want_sol = false;
-    for (int i = 0; i < 6; i++) want_sol |= f[i] != nullptr;
+    for (int i = 0; i < nf; i++) { ff[i] = f[i]; want_sol |= f[i] != nullptr; }
     const long groups = (B + 31) / 32;
     const unsigned grid = (unsigned)std::min<long>(groups, p.num_cu);
     const double *ME = p.d_ME, *C = p.d_C;
     if (p.builtin >= 0) {
         int idx = 0;
-#define X(nn, mm, NN, SS, UU)                                                                                            \
-    if (p.builtin == idx) return launch_builtin<nn, mm, NN, SS, UU>(a, ME, C, x0, xr, ur, u, k, e, f, want_sol, grid, st); \
+#define X(nn, mm, NN, SS, UU, MM)                                                                                              \
+    if (p.builtin == idx) return launch_builtin<nn, mm, NN, SS, UU, MM>(a, ME, C, x0, xr, ur, u, k, e, ff, want_sol, grid, st); \
     idx++;
-        SPCIES_HFUSED_SPLIT_SHAPES(X)
+        SPCIES_HFUSED_SHAPES(X)
 #undef X
         return fail(SPCIES_HIP_ENOSUP, "FUSED: bad build-time shape index");
     }
-    double *f0 = f[0], *f1 = f[1], *f2 = f[2], *f3 = f[3], *f4 = f[4], *f5 = f[5];
+    double *f0 = ff[0], *f1 = ff[1], *f2 = ff[2], *f3 = ff[3], *f4 = ff[4], *f5 = ff[5];
     void *params[] = {&a, &ME, &C, &x0, &xr, &ur, &u, &k, &e, &f0, &f1, &f2, &f3, &f4, &f5};
     SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 1 : 0], grid, 1, 1, 512, 1, 1, 0, st, params, nullptr));
     return 0;

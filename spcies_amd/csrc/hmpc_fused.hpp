@@ -18,13 +18,22 @@ struct SplitHost {  // what parse_hmpc collected (HMPC ADMM / SADMM split, blob 
     const double *A, *QQ, *Te, *Se, *LB, *UB, *LBy, *UBy;     // dense small matrices and bounds
 };
 
+struct NosplitHost {  // what parse_hmpc_dense collected (HMPC ADMM / SADMM without the splitting, cons_HMPC_ADMM_C.m:88-131)
+    int n, m, N, dim, n_s, n_box, n_soc, use_soc, symmetric, k_max;
+    double tol_p, tol_d, rho, rho_i, alpha;
+    const double *M1, *M2;                                     // [dim][dim], [dim][n]
+    const double *A, *QQ, *Te, *Se, *LB, *UB, *LBy, *UBy, *d;  // d: [n_s] or NULL (diamond mode)
+    const double *C_val;                                       // CSR of C [n_s x dim]
+    const int *C_row, *C_col;
+};
+
 struct Plan {
     bool ok = false;
     std::string why = "not built";
-    int n = 0, m = 0, N = 0, use_soc = 0, symmetric = 0;
+    int n = 0, m = 0, N = 0, use_soc = 0, symmetric = 0, mode = 0;  // mode 0: split, 1: no splitting
     int NR = 0, NK = 0, NCH = 0, CHB = 0;
     double *d_ME = nullptr, *d_C = nullptr;
-    int oQQ = 0, oTe = 0, oSe = 0, oLB = 0, oUB = 0, oD1 = 0, oD2 = 0;
+    int oQQ = 0, oTe = 0, oSe = 0, oLB = 0, oUB = 0, oD1 = 0, oD2 = 0, oZcol = 0, oZcoef = 0, oZd = 0;
     int num_cu = 256;
     void *module = nullptr;        // hipModule_t of a run-time specialised kernel (shapes not instantiated at build time)
     void *fn[2] = {nullptr, nullptr};  // WANT_SOL = false, true
@@ -32,9 +41,11 @@ struct Plan {
 };
 
 int plan_build_split(Plan &p, const SplitHost &h);
+int plan_build_nosplit(Plan &p, const NosplitHost &h);
 void plan_free(Plan &p);
-// u, k, e, fields (z, s, z_hat, s_hat, lambda, mu; NULL entries are skipped) are device pointers; k_max / tolerances as given
-int launch_split(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rho_i, double sigma, double sigma_i, double alpha,
+// u, k, e, fields (split: z, s, z_hat, s_hat, lambda, mu; no splitting: z, s, lambda; NULL entries are skipped) are device
+// pointers; k_max / tolerances as given (sigma is not used without the splitting)
+int launch(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rho_i, double sigma, double sigma_i, double alpha,
                  const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u, int *k, int *e,
                  double *const *f, hipStream_t st);
 

@@ -673,7 +673,7 @@ static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
     if (s.host.ellip) return s.bsp.ok ? SPCIES_VARIANT_BSP : SPCIES_VARIANT_STREAM;
     if (s.tv) return SPCIES_VARIANT_STREAM;
-    if (s.is_hdense()) return SPCIES_VARIANT_GEMM;
+    if (s.is_hdense()) return s.hfused.ok ? SPCIES_VARIANT_FUSED : SPCIES_VARIANT_GEMM;
     if (s.is_cs()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.is_hmpc() && s.hfused.ok) return SPCIES_VARIANT_FUSED;
     if (s.is_hmpc() && s.hgemm.ok) return SPCIES_VARIANT_GEMM;
@@ -1139,8 +1139,13 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         return launch_cs_stream(s, x0, xr, ur, ref_stride, B, u, k, e, f, st);
     }
     if (s.is_hdense()) {
+        if (resolve_variant(s) == SPCIES_VARIANT_FUSED) {
+            const hdense::Host &hh = s.hd_host;  // k_max / tolerances: set_exit overrides land here
+            return hfused::launch(s.hfused, hh.k_max, hh.tol_p, hh.tol_d, hh.rho, hh.rho_i, 0.0, 0.0, hh.alpha, x0, xr, ur, ref_stride, B, u, k,
+                                  e, f, st);
+        }
         if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_GEMM && s.variant != SPCIES_VARIANT_STREAM)
-            return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variants GEMM and STREAM are built");
+            return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variants FUSED, GEMM and STREAM are built");
         hdense::Dev &hd = s.hd_plan.dev;
         hd.k_max = s.hd_host.k_max; hd.tol_p = s.hd_host.tol_p; hd.tol_d = s.hd_host.tol_d;  // set_exit overrides
         const bool stream = s.variant == SPCIES_VARIANT_STREAM;
@@ -1151,7 +1156,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
     }
     if (s.is_hmpc() && resolve_variant(s) == SPCIES_VARIANT_FUSED) {
         const HmpcDev &hd = s.hdev;  // k_max / tolerances: set_exit overrides land here
-        return hfused::launch_split(s.hfused, hd.k_max, hd.tol_p, hd.tol_d, hd.rho, hd.rho_i, hd.sigma, hd.sigma_i, hd.alpha, x0, xr, ur,
+        return hfused::launch(s.hfused, hd.k_max, hd.tol_p, hd.tol_d, hd.rho, hd.rho_i, hd.sigma, hd.sigma_i, hd.alpha, x0, xr, ur,
                                     ref_stride, B, u, k, e, f, st);
     }
     if (s.is_hmpc() && resolve_variant(s) == SPCIES_VARIANT_GEMM) {
@@ -1343,6 +1348,15 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     SPCIES_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     rc = upload_consts(*s);
     if (rc) return rc;
+    if (s->is_hdense()) {
+        const hdense::Host &hh = s->hd_host;
+        hfused::NosplitHost fh{hh.n, hh.m, hh.N, hh.dim, hh.n_s, hh.n_box, hh.n_soc, hh.use_soc, hh.symmetric, hh.k_max,
+                               hh.tol_p, hh.tol_d, hh.rho, hh.rho_i, hh.alpha, hh.M1.data(), hh.M2.data(),
+                               hh.A.data(), hh.QQ.data(), hh.Te.data(), hh.Se.data(), hh.LB.data(), hh.UB.data(), hh.LBy.data(), hh.UBy.data(),
+                               hh.d.empty() ? nullptr : hh.d.data(), hh.C_val.data(), hh.C_row.data(), hh.C_col.data()};
+        rc = hfused::plan_build_nosplit(s->hfused, fh);
+        if (rc) return rc;
+    }
     if (s->is_hmpc() && !s->h_M1.empty()) {
         const HmpcDev &hd = s->hdev;
         const double *F = s->soc_f64.data();
@@ -1446,7 +1460,7 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     Solver *s = reinterpret_cast<Solver *>(h);
     if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_FUSED) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
     if (variant == SPCIES_VARIANT_FUSED) {
-        if (!(s->is_hmpc() && s->hfused.ok))
+        if (!((s->is_hmpc() || s->is_hdense()) && s->hfused.ok))
             return fail(SPCIES_HIP_ENOSUP, "FUSED variant: built for the HMPC solvers whose blob carries the dense M1, M2 (%s)", s->hfused.why.c_str());
         s->variant = variant;
         return 0;

@@ -464,7 +464,8 @@ def test_hmpc_vs_reference_template_fixture(variant, golden_dir):
     ("C1_HMPC_SADMM", "test_HMPC_SADMM_s", "stream"), ("C1_HMPC_SADMM", "test_HMPC_SADMM_s", "tile"),
     ("C1_HMPC_SADMM", "test_HMPC_SADMM_s", "gemm"), ("C1_HMPC_SADMM_soc", "test_HMPC_SADMM_s", "gemm"),
     ("C1_HMPC_nosplit", "test_HMPC_ADMM", "gemm"), ("C1_HMPC_nosplit", "test_HMPC_ADMM", "stream"),
-    ("C1_HMPC_SADMM_nosplit", "test_HMPC_ADMM", "gemm")])
+    ("C1_HMPC_SADMM_nosplit", "test_HMPC_ADMM", "gemm"), ("C1_HMPC_nosplit", "test_HMPC_ADMM", "fused"),
+    ("C1_HMPC_SADMM_soc_nosplit", "test_HMPC_ADMM", "fused")])
 def test_hmpc_reference_optimum_on_gpu(cfg_name, test_name, variant, golden_dir):
     """The reference tests' HMPC z_opt (tests/test_HMPC_ADMM_s.m:25, test_HMPC_SADMM_s.m:25, test_HMPC_ADMM.m:24) on every HIP
     variant: tester instance, the formulation the golden was computed for (ingredients switch stage0_cost = False, see
@@ -517,7 +518,7 @@ def _compare_hmpc_nosplit(got, O, variant="gemm"):
     ("C1_HMPC_SADMM_soc_nosplit", 20, {}), ("C5_HMPC_SADMM_nosplit", 65, {}),
     ("C5_HMPC_SADMM_nosplit", 12, dict(tol_p=1e-5, tol_d=1e-5, k_max=2500)),
 ])
-@pytest.mark.parametrize("variant", ["gemm", "stream"])
+@pytest.mark.parametrize("variant", ["gemm", "stream", "fused"])
 def test_hmpc_nosplit_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
@@ -537,7 +538,7 @@ def test_hmpc_nosplit_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
 def test_hmpc_nosplit_vs_reference_template_fixture(golden_dir):
     g = np.load(os.path.join(golden_dir, "template_C1_HMPC_nosplit.npz"))
     cfg, v, s = _fista_solver("C1_HMPC_nosplit")
-    assert s.variant == "gemm"
+    assert s.variant == "fused"
     u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
     assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
     same = k == g["k"]
