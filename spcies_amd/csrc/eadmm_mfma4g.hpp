@@ -8,9 +8,10 @@
 //                  mu_l = Bi_l' y_l - Bi_l' Alpha_{l-1}' mu_{l-1};   mu_l = Bi_l mu_l - Bi_l Alpha_l mu_{l+1}
 //                  z3_l = -H3i_l o ( q3_l - [mu_{l-1}; 0] + AB' mu_l )
 //   duals (:371-405) lambda_{l+1} += rho_l (z2 + z3_l - z1_l), lambda_0 += rho_0 (z1_0[x] - x0), lambda_{N+2} += rho_s (z2 - z1_N)
-// Three sweeps per iteration (A: P1 + q2, B: forward substitution, C: backward substitution, z3, duals).
-// State in HBM per 16 instances: z1, z3 ((N+1) KS slab vectors each), lambda ((N+3) KS), mu (N KX), KS =
-// ceil((n+m)/4), KX = ceil(n/4); traffic per iteration and stage: (10 KS + 2 KX) x 512 B.
+// Two sweeps per iteration (B: z1, q3, forward substitution; C: backward substitution, z1, z3, duals and - fused - P1 + q2 of
+// the next iteration); a stand-alone P1 sweep (A) runs once before iteration 1.
+// State in HBM per 16 instances: z3 ((N+1) KS slab vectors), lambda ((N+3) KS), mu (N KX), KS = ceil((n+m)/4),
+// KX = ceil(n/4) (z1 only when the record asks for it); traffic per iteration and stage: (6 KS + 2 KX) x 512 B.
 #pragma once
 #include "mfma4g.hpp"
 
@@ -119,7 +120,12 @@ inline int eadmm_plan_build_shape(Plan &p, const AdmmHost &a, const EadmmGHost &
 }
 
 // -------------------------------------------------------------------------------------------------
-template <int KX, int KS, int WG_PER_CU>
+// Two sweeps per iteration.  P1 is elementwise, so z1 is never stored: sweep B and sweep C rebuild z1^k_l from
+// (z3^{k-1}_l, lambda^{k-1}_{l+1}, z2^{k-1}) where they need it, and sweep C - which has z3^k_l, lambda^k_{l+1} and z2^k in
+// registers - evaluates P1 of iteration k + 1 on the spot to accumulate q2^{k+1}.  The stand-alone P1 sweep ("A") runs
+// once, before iteration 1.  Traffic per iteration and stage: (6 KS + 2 KX) x 512 B (was 10 KS + 2 KX).
+// WANT_Z1: the record's z1 is requested, sweep C then also writes z1^k.
+template <int KX, int KS, int WG_PER_CU, bool WANT_Z1>
 __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const double *__restrict__ tab,
                                                                  const double *__restrict__ x0g,
                                                                  const double *__restrict__ xrg,
@@ -152,13 +158,16 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
         const long tile = group * 4 + wave;
         const long inst = tile * 16 + c;
         const bool valid = inst < p.B;
-        const SlabBuf Z1(Z1g + tile * (long)(N + 1) * KS * 64, (long)(N + 1) * KS), Z3(Z3g + tile * (long)(N + 1) * KS * 64, (long)(N + 1) * KS);
+        const SlabBuf Z1(Z1g + (WANT_Z1 ? tile * (long)(N + 1) * KS * 64 : 0), WANT_Z1 ? (long)(N + 1) * KS : 0);
+        const SlabBuf Z3(Z3g + tile * (long)(N + 1) * KS * 64, (long)(N + 1) * KS);
         const SlabBuf LAM(LAMg + tile * (long)(N + 3) * KS * 64, (long)(N + 3) * KS), MU(MUg + tile * (long)N * KX * 64, (long)N * KX);
         const int voff = lane * 8;
 #define SPCIES_V(P, blk, s) (P).ld((blk) * KS + (s), voff)
 #define SPCIES_VST(P, blk, s, x) (P).st((blk) * KS + (s), voff, (x))
         // ---- per-instance setup: x0 and c2 = [T xr; S ur] (:128-137)
-        double z2[KS];
+        double z2[KS];  // z2 of this iteration; the previous one (the one P1 of this iteration saw) is parked in LDS
+        double *z2park = lds + LY::LDS_D + wave * (KS * 64) + lane;
+#define Z2O(s) z2park[(s) * 64]
         const SlabBuf C2(C2g + tile * (long)KS * 64, KS);  // c2 = [T xr; S ur], parked in HBM (read once per iteration)
         auto load_x0 = [&](int s) -> double {
             const int row = 4 * s + g;
@@ -192,103 +201,90 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
         __syncthreads();
         int slot = 0, sq = 0;  // sq: index of the chunk in the current slot
         int ao_l = ao;  // laundered once per stage: keeps LICM from hoisting the stage-invariant LDS block reads
-        auto next_chunk = [&]() {  // prefetch chunk sq + 1 (cyclic); to be followed by commit_chunk() at the end of the stage
+        auto next_chunk = [&]() __attribute__((always_inline)) {  // prefetch the chunk after sq (the sweep-A chunks 0..N are visited once: 3N wraps to N + 1)
             asm volatile("" : "+v"(ao_l));
-            const int nx = (sq + 1 == n_seq) ? 0 : sq + 1;
+            const int nx = (sq + 1 == n_seq) ? N + 1 : sq + 1;
             stg.issue(seq + (long)nx * LY::CHD);
         };
-        auto commit_chunk = [&]() {
+        auto commit_chunk = [&]() __attribute__((always_inline)) {
             stg.commit(ring + (slot ^ 1) * LY::CHD);
             __syncthreads();
             slot ^= 1;
-            sq = (sq + 1 == n_seq) ? 0 : sq + 1;
+            sq = (sq + 1 == n_seq) ? N + 1 : sq + 1;
+        };
+        // P1 of one row (:97-117): stage 0 carries `add` = rho_0 x0 - lambda_0, stage N the x_s = x_N, u_s = u_N rows
+        auto p1 = [&](const double *K, int s, double z3v, double l1, double add, double zz) -> double {
+            const double v = (SPCIES_K(K, LY::K_RHO, s) * (z3v + zz) + l1 + add) * SPCIES_K(K, LY::K_H1I, s);
+            return fmin(fmax(v, SPCIES_K(K, LY::K_LB, s)), SPCIES_K(K, LY::K_UB, s));
+        };
+        auto p1_mid = [&](const double *K, int s, double z3v, double l1, double zz) -> double {
+            const double v = (SPCIES_K(K, LY::K_RHO, s) * (z3v + zz) + l1) * SPCIES_K(K, LY::K_H1I, s);
+            return fmin(fmax(v, SPCIES_K(K, LY::K_LB, s)), SPCIES_K(K, LY::K_UB, s));
+        };
+        auto p1_N = [&](const double *K, int s, double z3v, double l1, double l2, double zz) -> double {
+            const double r = SPCIES_K(K, LY::K_RHO, s), rs = SPCIES_K(inv_rc, LY::C_RHOS, s);
+            const double v = (r * z3v + (r + rs) * zz + l1 + l2) * SPCIES_K(K, LY::K_H1I, s);
+            return fmin(fmax(v, SPCIES_K(K, LY::K_LB, s)), SPCIES_K(K, LY::K_UB, s));
         };
 
         bool active = valid;
         int kk = 0;
+        double q2[KS];
+        // ======================= sweep A, once: q2 of iteration 1 (z3 = lambda = z2 = 0: zero-filled by the launcher) ===========
+        {  // stage N
+            next_chunk();
+            const double *K = ring + slot * LY::CHD + LY::NT_PAD * 16;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const double z3v = SPCIES_V(Z3, N, s);
+                const double l1 = SPCIES_V(LAM, N + 1, s), l2 = SPCIES_V(LAM, N + 2, s);
+                const double r = SPCIES_K(K, LY::K_RHO, s), rs = SPCIES_K(inv_rc, LY::C_RHOS, s);
+                const double v = p1_N(K, s, z3v, l1, l2, z2[s]);
+                q2[s] = r * z3v - (r + rs) * v + l1 + l2 + C2.ld(s, voff);
+            }
+            commit_chunk();
+        }
+        for (int l = 0; l < N; l++) {
+            next_chunk();
+            const double *K = ring + slot * LY::CHD + LY::NT_PAD * 16;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const double z3v = SPCIES_V(Z3, l, s), l1 = SPCIES_V(LAM, l + 1, s);
+                double v;
+                if (l == 0) {
+                    v = p1(K, s, z3v, l1, SPCIES_K(inv_rc, LY::C_RHO0, s) * load_x0(s) - SPCIES_V(LAM, 0, s), z2[s]);
+                } else {
+                    v = p1_mid(K, s, z3v, l1, z2[s]);
+                }
+                q2[s] += SPCIES_K(K, LY::K_RHO, s) * (z3v - v) + l1;
+            }
+            commit_chunk();
+        }
         while (true) {
             kk += 1;
-            // (iteration 1 reads z3 = lambda = 0: the launcher zero-fills those arrays)
-            double q2[KS];
             bool res = false;
-            // ======================= sweep A: P1 and the q2 accumulation =======================
-            {  // stage N
-                next_chunk();
-                const double *K = ring + slot * LY::CHD + LY::NT_PAD * 16;
-                double z1w[KS];
+            {  // z2 = W2 q2 (:145-151) and its part of the exit test (:408-415)
+                double z2n[KS];
+#pragma unroll
+                for (int s = 0; s < KS; s++) z2n[s] = 0.0;
+                int tix = LY::T_W2;
+                double2 cur;
+                prod<KS, KS, DENSE>(z2n, q2, lds, ao_l, tix, cur);
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
-                    const double z3v = SPCIES_V(Z3, N, s);
-                    const double l1 = SPCIES_V(LAM, N + 1, s), l2 = SPCIES_V(LAM, N + 2, s);
-                    const double r = SPCIES_K(K, LY::K_RHO, s), rs = SPCIES_K(inv_rc, LY::C_RHOS, s);
-                    double v = (r * z3v + (r + rs) * z2[s] + l1 + l2) * SPCIES_K(K, LY::K_H1I, s);
-                    v = fmin(fmax(v, SPCIES_K(K, LY::K_LB, s)), SPCIES_K(K, LY::K_UB, s));
-                    z1w[s] = v;
-                    q2[s] = r * z3v - (r + rs) * v + l1 + l2 + C2.ld(s, voff);
-                }
-                if (active) {
-#pragma unroll
-                    for (int s = 0; s < KS; s++) SPCIES_VST(Z1, N, s, z1w[s]);
-                }
-                commit_chunk();
-            }
-            {
-                double z3n[KS], l1n[KS];  // stage l + 1, in flight
-#pragma unroll
-                for (int s = 0; s < KS; s++) {
-                    z3n[s] = SPCIES_V(Z3, 0, s);
-                    l1n[s] = SPCIES_V(LAM, 1, s);
-                }
-                for (int l = 0; l < N; l++) {
-                    next_chunk();
-                    const double *K = ring + slot * LY::CHD + LY::NT_PAD * 16;
-                    double z1w[KS];
-#pragma unroll
-                    for (int s = 0; s < KS; s++) {
-                        const double z3v = z3n[s], l1 = l1n[s];
-                        if (l + 1 < N) {
-                            z3n[s] = SPCIES_V(Z3, l + 1, s);
-                            l1n[s] = SPCIES_V(LAM, l + 2, s);
-                        }
-                        const double r = SPCIES_K(K, LY::K_RHO, s);
-                        double v = r * (z3v + z2[s]) + l1;
-                        if (l == 0) {
-                            const double l0 = SPCIES_V(LAM, 0, s);
-                            v = v + SPCIES_K(inv_rc, LY::C_RHO0, s) * load_x0(s) - l0;
-                        }
-                        v = v * SPCIES_K(K, LY::K_H1I, s);
-                        v = fmin(fmax(v, SPCIES_K(K, LY::K_LB, s)), SPCIES_K(K, LY::K_UB, s));
-                        z1w[s] = v;
-                        q2[s] += r * (z3v - v) + l1;
-                    }
-                    if (active) {
-#pragma unroll
-                        for (int s = 0; s < KS; s++) SPCIES_VST(Z1, l, s, z1w[s]);
-                    }
-                    if (l == N - 1) {  // z2 = W2 q2 (:145-151) and its part of the exit test (:408-415)
-                        double z2n[KS];
-#pragma unroll
-                        for (int s = 0; s < KS; s++) z2n[s] = 0.0;
-                        int tix = LY::T_W2;
-                        double2 cur;
-                        prod<KS, KS, DENSE>(z2n, q2, lds, ao_l, tix, cur);
-#pragma unroll
-                        for (int s = 0; s < KS; s++) {
-                            res |= fabs(z2[s] - z2n[s]) > tol;
-                            z2[s] = z2n[s];
-                        }
-                    }
-                    commit_chunk();
+                    res |= fabs(z2[s] - z2n[s]) > tol;
+                    Z2O(s) = z2[s];
+                    z2[s] = z2n[s];
                 }
             }
-            // ======================= sweep B: q3, right-hand side, forward substitution =======================
+            // ======================= sweep B: z1, q3, right-hand side, forward substitution =======================
             {
-                double q3c[KS], mup[KX], z1n[KS], ln[KS];
+                double q3c[KS], mup[KX], z3n[KS], ln[KS];
 #pragma unroll
                 for (int s = 0; s < KX; s++) mup[s] = 0.0;
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
-                    z1n[s] = SPCIES_V(Z1, 1, s);
+                    z3n[s] = SPCIES_V(Z3, 1, s);
                     ln[s] = SPCIES_V(LAM, 2, s);
                 }
                 for (int l = 0; l < N; l++) {
@@ -299,19 +295,31 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
 #pragma unroll
                         for (int s = 0; s < KS; s++) {
                             const double l1 = SPCIES_V(LAM, 1, s);
-                            q3c[s] = SPCIES_K(Ka, LY::K_RHO, s) * (z2[s] - SPCIES_V(Z1, 0, s)) + l1;
+                            const double z1v = p1(Ka, s, SPCIES_V(Z3, 0, s), l1,
+                                                  SPCIES_K(inv_rc, LY::C_RHO0, s) * load_x0(s) - SPCIES_V(LAM, 0, s), Z2O(s));
+                            q3c[s] = SPCIES_K(Ka, LY::K_RHO, s) * (z2[s] - z1v) + l1;
                         }
                     }
                     double q3n[KS], t[KS], y[KX];
+                    if (l + 1 < N) {
 #pragma unroll
-                    for (int s = 0; s < KS; s++) {
-                        q3n[s] = SPCIES_K(Kb, LY::K_RHO, s) * (z2[s] - z1n[s]) + ln[s];
-                        if (l + 1 < N) {
-                            z1n[s] = SPCIES_V(Z1, l + 2, s);
-                            ln[s] = SPCIES_V(LAM, l + 3, s);
+                        for (int s = 0; s < KS; s++) {
+                            const double z1v = p1_mid(Kb, s, z3n[s], ln[s], Z2O(s));
+                            q3n[s] = SPCIES_K(Kb, LY::K_RHO, s) * (z2[s] - z1v) + ln[s];
+                            if (l + 2 <= N) {
+                                z3n[s] = SPCIES_V(Z3, l + 2, s);
+                                ln[s] = SPCIES_V(LAM, l + 3, s);
+                            }
                         }
-                        t[s] = SPCIES_K(Ka, LY::K_H3I, s) * q3c[s];
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            const double z1v = p1_N(Kb, s, z3n[s], ln[s], SPCIES_V(LAM, N + 2, s), Z2O(s));
+                            q3n[s] = SPCIES_K(Kb, LY::K_RHO, s) * (z2[s] - z1v) + ln[s];
+                        }
                     }
+#pragma unroll
+                    for (int s = 0; s < KS; s++) t[s] = SPCIES_K(Ka, LY::K_H3I, s) * q3c[s];
 #pragma unroll
                     for (int s = 0; s < KX; s++) y[s] = (4 * s + g < n) ? SPCIES_K(Kb, LY::K_H3I, s) * q3n[s] : 0.0;
                     {
@@ -338,15 +346,31 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                     commit_chunk();
                 }
             }
-            // ======================= sweep C: backward substitution, z3, residuals, duals =======================
+            // ============ sweep C: backward substitution, z1 again, z3, residuals, duals; P1 and q2 of the next iteration ============
             {
                 double mun[KX];
 #pragma unroll
                 for (int s = 0; s < KX; s++) mun[s] = 0.0;
-                // z3_t, residual and lambda_{t+1} of one stage (:289-320, :371-402)
+                // z3_t, residual, lambda_{t+1} of one stage (:289-320, :371-402) and its term of the next q2 (:97-143)
                 auto finish_stage = [&](int t, const double *K, const double (&mu_sub)[KX], const double (&mu_abt)[KX],
-                                        const double (&lam)[KS], const double (&z1v)[KS], const double (&z3o)[KS]) {
-                    double v[KS];
+                                        const double (&lam)[KS], const double (&z3o)[KS]) __attribute__((always_inline)) {
+                    double v[KS], z1v[KS], ex[KS];  // ex: lambda_{N+2} (t = N) / lambda_0 (t = 0)
+                    if (t == N) {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            ex[s] = SPCIES_V(LAM, N + 2, s);
+                            z1v[s] = p1_N(K, s, z3o[s], lam[s], ex[s], Z2O(s));
+                        }
+                    } else if (t == 0) {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            ex[s] = SPCIES_V(LAM, 0, s);
+                            z1v[s] = p1(K, s, z3o[s], lam[s], SPCIES_K(inv_rc, LY::C_RHO0, s) * load_x0(s) - ex[s], Z2O(s));
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) z1v[s] = p1_mid(K, s, z3o[s], lam[s], Z2O(s));
+                    }
 #pragma unroll
                     for (int s = 0; s < KS; s++) {
                         v[s] = SPCIES_K(K, LY::K_RHO, s) * (z2[s] - z1v[s]) + lam[s];
@@ -371,14 +395,53 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                         for (int s = 0; s < KS; s++) {
                             SPCIES_VST(Z3, t, s, v[s]);
                             SPCIES_VST(LAM, t + 1, s, ln_[s]);
+                            if constexpr (WANT_Z1) SPCIES_VST(Z1, t, s, z1v[s]);
+                        }
+                    }
+                    // first / last residual rows and their multipliers (:374-376, 386-388, 391-393, 403-405), then P1 of
+                    // iteration k + 1 from (z3, lambda, z2) of iteration k and this stage's term of q2
+                    if (t == N) {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            const double rN = z2[s] - z1v[s];
+                            ex[s] = ex[s] + SPCIES_K(inv_rc, LY::C_RHOS, s) * rN;
+                            res |= fabs(rN) > tol;
+                            const double r = SPCIES_K(K, LY::K_RHO, s), rs = SPCIES_K(inv_rc, LY::C_RHOS, s);
+                            const double z1n = p1_N(K, s, v[s], ln_[s], ex[s], z2[s]);
+                            q2[s] = r * v[s] - (r + rs) * z1n + ln_[s] + ex[s] + C2.ld(s, voff);
+                        }
+                        if (active) {
+#pragma unroll
+                            for (int s = 0; s < KS; s++) SPCIES_VST(LAM, N + 2, s, ex[s]);
+                        }
+                    } else if (t == 0) {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            const int row = 4 * s + g;
+                            const double x0v = load_x0(s);
+                            const double r0 = (row < n) ? z1v[s] - x0v : 0.0;
+                            ex[s] = ex[s] + SPCIES_K(inv_rc, LY::C_RHO0, s) * r0;  // rows >= n stay 0
+                            res |= fabs(r0) > tol;
+                            if (active && row >= n && row < nm) u_out[inst * m + (row - n)] = z1v[s];  // u_opt (:477), last write wins
+                            const double z1n = p1(K, s, v[s], ln_[s], SPCIES_K(inv_rc, LY::C_RHO0, s) * x0v - ex[s], z2[s]);
+                            q2[s] += SPCIES_K(K, LY::K_RHO, s) * (v[s] - z1n) + ln_[s];
+                        }
+                        if (active) {
+#pragma unroll
+                            for (int s = 0; s < KS; s++) SPCIES_VST(LAM, 0, s, ex[s]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            const double z1n = p1_mid(K, s, v[s], ln_[s], z2[s]);
+                            q2[s] += SPCIES_K(K, LY::K_RHO, s) * (v[s] - z1n) + ln_[s];
                         }
                     }
                 };
-                double lamn[KS], z1vn[KS], z3on[KS], mufn[KX];  // stage l + 1 vectors / mu_l, in flight
+                double lamn[KS], z3on[KS], mufn[KX];  // stage l + 1 vectors / mu_l, in flight
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
                     lamn[s] = SPCIES_V(LAM, N + 1, s);
-                    z1vn[s] = SPCIES_V(Z1, N, s);
                     z3on[s] = SPCIES_V(Z3, N, s);
                 }
 #pragma unroll
@@ -387,26 +450,13 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                     next_chunk();
                     const double *ch = ring + slot * LY::CHD;
                     const double *Ka = ch + LY::NT_PAD * 16, *Kb = Ka + LY::KD;
-                    double lam[KS], z1v[KS], z3o[KS], muf[KX];
+                    double lam[KS], z3o[KS], muf[KX];
 #pragma unroll
                     for (int s = 0; s < KS; s++) {
-#ifdef SPCIES_G4_NOPF
-                        lam[s] = SPCIES_V(LAM, l + 2, s);
-                        z1v[s] = SPCIES_V(Z1, l + 1, s);
-                        z3o[s] = SPCIES_V(Z3, l + 1, s);
-                        if (l == 0) {
-                            lamn[s] = SPCIES_V(LAM, l + 1, s);
-                            z1vn[s] = SPCIES_V(Z1, l, s);
-                            z3on[s] = SPCIES_V(Z3, l, s);
-                        }
-#else
                         lam[s] = lamn[s];
-                        z1v[s] = z1vn[s];
                         z3o[s] = z3on[s];
-                        lamn[s] = SPCIES_V(LAM, l + 1, s);  // stage l: next iteration, or finish_stage(0)
-                        z1vn[s] = SPCIES_V(Z1, l, s);
+                        lamn[s] = SPCIES_V(LAM, l + 1, s);  // stage l: next pass, or finish_stage(0)
                         z3on[s] = SPCIES_V(Z3, l, s);
-#endif
                     }
 #pragma unroll
                     for (int s = 0; s < KX; s++) {
@@ -422,34 +472,16 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                         prod<KX, KX, UPPER>(mu, muf, ch, ao_l, tix, cur);
                         prod<KX, KX, DENSE>(mu, mun, ch, ao_l, tix, cur);
                     }
-                    finish_stage(l + 1, Kb, mu, mun, lam, z1v, z3o);
+                    finish_stage(l + 1, Kb, mu, mun, lam, z3o);
 #pragma unroll
                     for (int s = 0; s < KX; s++) mun[s] = mu[s];
                     if (l == 0) {
                         double zero[KX];
 #pragma unroll
                         for (int s = 0; s < KX; s++) zero[s] = 0.0;
-                        finish_stage(0, Ka, zero, mun, lamn, z1vn, z3on);
+                        finish_stage(0, Ka, zero, mun, lamn, z3on);
                     }
                     commit_chunk();
-                }
-                // first and last residual rows and their multipliers (:374-376, 386-388, 391-393, 403-405)
-                double l0n[KS], l2n[KS];
-#pragma unroll
-                for (int s = 0; s < KS; s++) {
-                    const int row = 4 * s + g;
-                    const double r0 = (row < n) ? SPCIES_V(Z1, 0, s) - load_x0(s) : 0.0;
-                    const double rN = z2[s] - SPCIES_V(Z1, N, s);
-                    l0n[s] = SPCIES_V(LAM, 0, s) + SPCIES_K(inv_rc, LY::C_RHO0, s) * r0;  // rows >= n stay 0
-                    l2n[s] = SPCIES_V(LAM, N + 2, s) + SPCIES_K(inv_rc, LY::C_RHOS, s) * rN;
-                    res |= (fabs(r0) > tol) | (fabs(rN) > tol);
-                }
-                if (active) {
-#pragma unroll
-                    for (int s = 0; s < KS; s++) {
-                        SPCIES_VST(LAM, 0, s, l0n[s]);
-                        SPCIES_VST(LAM, N + 2, s, l2n[s]);
-                    }
                 }
             }
             // ======================= exit (:408-449) =======================
@@ -459,7 +491,6 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
                     const int row = 4 * s + g;
-                    if (row >= n && row < nm) u_out[inst * m + (row - n)] = SPCIES_V(Z1, 0, s);
                     if (z2_out && row < nm) z2_out[inst * nm + row] = z2[s];
                 }
                 if (g == 0) {
@@ -470,8 +501,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
             }
             if (!__syncthreads_or(active ? 1 : 0)) break;
         }
-        // leave the ring at chunk 0 for the next group: sq is 0 again after a whole iteration
     }
+#undef Z2O
 #undef SPCIES_K
 #undef SPCIES_V
 #undef SPCIES_VST
@@ -527,11 +558,15 @@ static int launch_eadmm_g_shape(Plan &pl, const AdmmHost &a, const Args &args, c
     double *Z1 = state, *Z3 = Z1 + tiles * (long)(N + 1) * KS * 64, *LAM = Z3 + tiles * (long)(N + 1) * KS * 64;
     double *MU = LAM + tiles * (long)(N + 3) * KS * 64, *C2 = MU + tiles * (long)N * KX * 64;
     const long wgs = std::min(tiles / 4, (long)pl.num_cu * pick_wgs(tiles / 4, pl.num_cu, WGS));
-    const size_t shmem = LY::LDS_D * sizeof(double);
+    const size_t shmem = (LY::LDS_D + 4 * KS * 64) * sizeof(double);  // + z2 of the previous iteration, per wavefront
     // iteration 1 starts from z3 = lambda = 0 (:85-95); Z3 and LAM are adjacent
     SPCIES_HIP_CHECK(hipMemsetAsync(Z3, 0, (size_t)tiles * (size_t)(2 * N + 4) * KS * 64 * sizeof(double), st));
-    hipLaunchKernelGGL((eadmm_g_kernel<KX, KS, WGS>), dim3((unsigned)wgs), dim3(256), shmem, st, args, pl.d_table, x0, xr, ur,
-                       Z1, Z3, LAM, MU, C2, u, k, e, z2);
+    if (z1)
+        hipLaunchKernelGGL((eadmm_g_kernel<KX, KS, WGS, true>), dim3((unsigned)wgs), dim3(256), shmem, st, args, pl.d_table, x0, xr,
+                           ur, Z1, Z3, LAM, MU, C2, u, k, e, z2);
+    else
+        hipLaunchKernelGGL((eadmm_g_kernel<KX, KS, WGS, false>), dim3((unsigned)wgs), dim3(256), shmem, st, args, pl.d_table, x0, xr,
+                           ur, Z1, Z3, LAM, MU, C2, u, k, e, z2);
     SPCIES_HIP_CHECK(hipGetLastError());
     const long tz = args.B * (long)(N + 1) * nm;
     if (z1)

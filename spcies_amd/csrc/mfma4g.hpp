@@ -203,7 +203,7 @@ struct Stager {
 #pragma unroll
         for (int i = 0; i < NST; i++) {
             const int idx = threadIdx.x + 256 * i;
-            if (idx < CH16) r[i] = s[idx];
+            r[i] = s[idx < CH16 ? idx : CH16 - 1];  // unconditional: a conditionally written r[] is kept in scratch memory
         }
     }
     __device__ __forceinline__ void commit(double *dst) {
