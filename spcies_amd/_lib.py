@@ -18,9 +18,9 @@ EXPORTS = (
     "spcies_hip_closed_loop",
 )
 
-VARIANT_AUTO, VARIANT_STREAM, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4G, VARIANT_TILE, VARIANT_GEMM, VARIANT_BSP, VARIANT_FUSED = 0, 1, 2, 3, 4, 5, 6, 7, 8
+VARIANT_AUTO, VARIANT_STREAM, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4G, VARIANT_TILE, VARIANT_GEMM, VARIANT_BSP, VARIANT_FUSED, VARIANT_MFMA4R = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 VARIANTS = {"auto": VARIANT_AUTO, "stream": VARIANT_STREAM, "mfma": VARIANT_MFMA, "mfma4": VARIANT_MFMA4,
-            "mfma4g": VARIANT_MFMA4G, "tile": VARIANT_TILE, "gemm": VARIANT_GEMM, "bsp": VARIANT_BSP, "fused": VARIANT_FUSED}
+            "mfma4g": VARIANT_MFMA4G, "tile": VARIANT_TILE, "gemm": VARIANT_GEMM, "bsp": VARIANT_BSP, "fused": VARIANT_FUSED, "mfma4r": VARIANT_MFMA4R}
 
 
 class SpciesHipError(RuntimeError):

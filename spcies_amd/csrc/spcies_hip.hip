@@ -21,6 +21,7 @@
 #include "soc_bsp.hpp"
 #include "ellip_bsp.hpp"
 #include "hmpc_fused.hpp"
+#include "fista_r.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -94,6 +95,7 @@ struct Solver {
     rtc::Mfma4Module mfma4_rtc;  // run-time compiled MFMA4 kernel when the shape was not instantiated at build time
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
+    fr::Plan frplan;               // MFMA4R (FISTA with the iteration state in registers + LDS, run-time specialised)
     hfused::Plan hfused;           // FUSED (HMPC split NON_SPARSE path: product + projections in one MFMA kernel)
     std::vector<double> h_M1, h_M2, h_bh_nat;
     bsp::Plan bsp;                 // BSP (ellipMPC soc): block-sparse MFMA program, generated per controller
@@ -679,6 +681,7 @@ static int resolve_variant(const Solver &s) {
     if (s.is_hmpc() && s.hgemm.ok) return SPCIES_VARIANT_GEMM;
     if (s.is_soc() && !s.is_hmpc() && s.bsp.ok) return SPCIES_VARIANT_BSP;
     if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
+    if (s.method == SPCIES_FISTA && s.frplan.ok) return SPCIES_VARIANT_MFMA4R;
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
     if (s.host.gen && s.bsp.ok && s.formulation == SPCIES_LAXMPC) return SPCIES_VARIANT_BSP;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
@@ -1207,13 +1210,23 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
     double *z = f[0], *v = (s.method == SPCIES_FISTA) ? nullptr : f[1], *lam = (s.method == SPCIES_FISTA) ? f[1] : f[2];
     if (s.method == SPCIES_FISTA) {
         const int fv = resolve_variant(s);
+        if (fv == SPCIES_VARIANT_MFMA4R) {
+            if (!s.frplan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant not available: %s", s.frplan.why.c_str());
+            if (!z != !lam) {  // the kernel writes both record fields or none: the missing one goes to handle-owned scratch
+                const size_t need = (size_t)B * (z ? (size_t)s.host.N * s.host.n : (size_t)s.host.dim()) * sizeof(double);
+                int rc = ensure_scratch(s, need);
+                if (rc) return rc;
+                (z ? lam : z) = s.d_scratch;
+            }
+            return fr::launch(s.frplan, s.host.k_max, s.host.tol, x0, xr, ur, ref_stride, B, u, k, e, z, lam, st);
+        }
         if (fv == SPCIES_VARIANT_MFMA4G) {
             if (!s.g4plan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available: %s", s.g4plan.why.c_str());
             int rc = ensure_scratch(s, g4::fista_state_bytes(s.g4plan, s.host, B));
             if (rc) return rc;
             return g4::launch_fista_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, z, lam, st);
         }
-        if (fv != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "FISTA: variants STREAM and MFMA4G are built");
+        if (fv != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "FISTA: variants STREAM, MFMA4G and MFMA4R are built");
         if (!stream_shape_built(s.host.n, s.host.m))
             return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, z || lam));
@@ -1320,6 +1333,7 @@ static void free_solver(Solver *s) {
     if (s->d_recs) hipFree(s->d_recs);
     hgemm::plan_free(s->hgemm);
     hfused::plan_free(s->hfused);
+    fr::plan_free(s->frplan);
     hdense::plan_free(s->hd_plan);
     bsp::plan_free(s->bsp);
     if (s->d_eng) hipFree(s->d_eng);
@@ -1430,6 +1444,18 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         g4::FistaGHost fh{&s->QRi, &s->Td, &s->Ti};
         rc = g4::fista_plan_build(s->g4plan, s->host, fh);
         if (rc) return rc;
+        // MFMA4R: the kernel is specialised for this controller now (hiprtc; SPCIES_HIP_RTC=0 turns it off).  A failure is
+        // not an error: AUTO then runs MFMA4G, and the reason is reported if MFMA4R is asked for.
+        const char *ev = getenv("SPCIES_HIP_RTC");
+        if (ev && ev[0] == '0') {
+            s->frplan.why = "run-time specialisation switched off (SPCIES_HIP_RTC=0)";
+        } else {
+            fr::Host fh2{s->host.n, s->host.m, s->host.N, s->host.k_max, s->host.terminal, s->host.tol, s->host.AB.data(), s->host.Alpha.data(),
+                         s->host.Beta.data(), s->host.Q.data(), s->host.R.data(), s->QRi.data(), s->Td.data(), s->Ti.data(), s->host.LB.data(),
+                         s->host.UB.data()};
+            rc = fr::plan_build(s->frplan, fh2);
+            if (rc) return rc;
+        }
     }
     *out = reinterpret_cast<spcies_hip_handle>(s.release());
     return 0;
@@ -1458,7 +1484,7 @@ int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info) {
 int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
-    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_FUSED) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_MFMA4R) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
     if (variant == SPCIES_VARIANT_FUSED) {
         if (!((s->is_hmpc() || s->is_hdense()) && s->hfused.ok))
             return fail(SPCIES_HIP_ENOSUP, "FUSED variant: built for the HMPC solvers whose blob carries the dense M1, M2 (%s)", s->hfused.why.c_str());
@@ -1499,6 +1525,8 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     }
     if (variant == SPCIES_VARIANT_TILE && !(s->is_soc() && s->tdev.lpi))
         return fail(SPCIES_HIP_ENOSUP, "TILE variant: built for the sparse-KKT solvers (ellipMPC soc, HMPC) whose LDL right-hand side fits the LDS");
+    if (variant == SPCIES_VARIANT_MFMA4R && !s->frplan.ok)
+        return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant not available for this solver: %s", s->frplan.why.c_str());
     if (variant == SPCIES_VARIANT_MFMA4G && !s->g4plan.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available for this solver: %s", s->g4plan.why.c_str());
     if (variant == SPCIES_VARIANT_MFMA4 && !s->mfma4.ok) {

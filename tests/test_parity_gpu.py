@@ -219,7 +219,7 @@ def _compare_fista(variant, got, ref):
     assert (np.abs(sol.lam - lo) / (tol * lscale))[same].max() <= 1.0
 
 
-FISTA_VARIANTS = ["stream", "mfma4g"]
+FISTA_VARIANTS = ["stream", "mfma4g", "mfma4r"]  # mfma4r: specialised per controller at create time (hiprtc)
 
 
 @pytest.mark.parametrize("variant", FISTA_VARIANTS)
@@ -851,7 +851,8 @@ def test_bsp_ellip_admm_arbitrary_shapes(n, m, N):
 
 
 @pytest.mark.parametrize("n,m,N,formulation", [(10, 3, 9, "laxMPC"), (16, 4, 6, "equMPC"), (9, 2, 31, "laxMPC")])
-def test_mfma4g_fista_arbitrary_shapes(n, m, N, formulation):
+@pytest.mark.parametrize("variant", ["mfma4g", "mfma4r"])
+def test_mfma4g_fista_arbitrary_shapes(n, m, N, formulation, variant):
     from oracle import oracle
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
@@ -861,11 +862,11 @@ def test_mfma4g_fista_arbitrary_shapes(n, m, N, formulation):
     cfg.solver_options = dict(tol=1e-6, k_max=300)
     v = benchmarks.ingredients(cfg)
     s = HipSolver(v)
-    s.set_variant("mfma4g")
+    s.set_variant(variant)
     rng = np.random.default_rng(n)
     B = 40
     x0, xr, ur = 0.6 * rng.standard_normal((B, n)), 0.2 * rng.standard_normal((B, n)), 0.1 * rng.standard_normal((B, m))
-    _compare_fista("mfma4g", s(x0, xr, ur), oracle.fista_banded_batch(v, x0, xr, ur))
+    _compare_fista(variant, s(x0, xr, ur), oracle.fista_banded_batch(v, x0, xr, ur))
     s.close()
 
 
