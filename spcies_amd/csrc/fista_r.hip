@@ -165,6 +165,9 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
     return 1;
 }
 
+// build-time instantiations (N, KX, KS, TERMINAL, NW, NLDS; SPCIES_FR_PD = 3): BASELINE configs[2], equMPC-FISTA n = 12, m = 2, N = 30
+#define SPCIES_FR_BUILTIN(X) X(30, 3, 4, false, 4, 68)
+
 #define SPCIES_FR_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 3) X(3, 4) X(4, 4) X(4, 5) X(5, 5) X(5, 6) X(6, 6)
 
 }  // namespace
@@ -192,6 +195,19 @@ int plan_build(Plan &p, const Host &h) {
 #undef X
     if (got < 0) { p.why = "MFMA4R: (ceil(n/4), ceil((n+m)/4)) outside the packer's shapes"; return 0; }
     if (got == 0) return 0;
+    p.builtin = -1;
+    {
+        int idx = 0;
+#define X(NN, KKX, KKS, TT, WW, LL)                                                                                         \
+    if (h.N == NN && KX == KKX && KS == KKS && h.terminal == TT && p.NW == WW && p.NLDS == LL && !getenv("SPCIES_FR_RTC_FLAGS") && \
+        !getenv("SPCIES_FR_PD"))                                                                                             \
+        p.builtin = idx;                                                                                                     \
+    idx++;
+        SPCIES_FR_BUILTIN(X)
+#undef X
+    }
+    p.PD = 3;
+    if (p.builtin < 0) {
     // ---- specialise the kernel for this controller (about ten seconds at N = 30)
     char names[2][160];
     std::vector<std::string> nm;
@@ -228,6 +244,7 @@ int plan_build(Plan &p, const Host &h) {
     p.module = mod;
     p.fn[0] = fns[0];
     p.fn[1] = fns[1];
+    }
     p.table_bytes = tab.size() * sizeof(double);
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_table, p.table_bytes + 64));
     SPCIES_HIP_CHECK(hipMemcpy(p.d_table, tab.data(), p.table_bytes, hipMemcpyHostToDevice));
@@ -256,6 +273,23 @@ int launch(Plan &p, int k_max, double tol, const double *x0, const double *xr, c
     const double *table = p.d_table;
     double *dump = p.d_table + p.table_bytes / sizeof(double);
     double *dscr = p.d_scr;
+    if (p.builtin >= 0) {
+        int idx = 0;
+#define X(NN, KKX, KKS, TT, WW, LL)                                                                                              \
+    if (p.builtin == idx) {                                                                                                       \
+        if (want_sol)                                                                                                             \
+            hipLaunchKernelGGL((fista_r_kernel<NN, KKX, KKS, TT, true, WW, LL>), dim3((unsigned)wgs), dim3(WW * 64), 0, st, args, table, x0, xr, \
+                               ur, u, k, e, z, lam, dump, dscr);                                                                  \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((fista_r_kernel<NN, KKX, KKS, TT, false, WW, LL>), dim3((unsigned)wgs), dim3(WW * 64), 0, st, args, table, x0, xr, \
+                               ur, u, k, e, z, lam, dump, dscr);                                                                  \
+    }                                                                                                                             \
+    idx++;
+        SPCIES_FR_BUILTIN(X)
+#undef X
+        SPCIES_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     void *params[] = {&args, &table, &x0, &xr, &ur, &u, &k, &e, &z, &lam, &dump, &dscr};
     SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 1 : 0], (unsigned)wgs, 1, 1, p.NW * 64, 1, 1, 0, st, params, nullptr));
     return 0;

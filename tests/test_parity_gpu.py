@@ -298,6 +298,7 @@ def test_fista_full_size_properties(variant):
 # ----------------------------------------------------------------------------------------------
 # MPCT EADMM: STREAM variant, reference operation order -> bit-exact; MFMA4G variant -> 1e-10
 # ----------------------------------------------------------------------------------------------
+EADMM_VARIANTS = ["stream", "mfma4g"]
 def _compare_mpct(variant, got, O):
     u, k, e, sol = got
     uo, ko, eo, z1o, z2o, z3o, lo = O
@@ -316,7 +317,7 @@ def _compare_mpct(variant, got, O):
     assert (np.abs(sol.lam - lo) / lscale)[same].max() <= TOL_SPCIES
 
 
-@pytest.mark.parametrize("variant", FISTA_VARIANTS)
+@pytest.mark.parametrize("variant", EADMM_VARIANTS)
 def test_mpct_reference_test_instance(variant, golden_dir):
     from oracle import oracle
     from spcies_amd import benchmarks
@@ -334,7 +335,7 @@ def test_mpct_reference_test_instance(variant, golden_dir):
 
 
 @pytest.mark.parametrize("cfg_name,B,overrides", [("C1_MPCT", 100, {}), ("C4", 130, {}), ("C4", 70, dict(tol=1e-5, k_max=4000))])
-@pytest.mark.parametrize("variant", FISTA_VARIANTS)
+@pytest.mark.parametrize("variant", EADMM_VARIANTS)
 def test_mpct_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
@@ -346,7 +347,7 @@ def test_mpct_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     assert np.array_equal(nosol[0], got[0][:33]) and np.array_equal(nosol[1], got[1][:33]) and nosol[3].z1 is None
 
 
-@pytest.mark.parametrize("variant", FISTA_VARIANTS)
+@pytest.mark.parametrize("variant", EADMM_VARIANTS)
 def test_mpct_vs_reference_template_fixture(variant, golden_dir):
     g = np.load(os.path.join(golden_dir, "template_C4.npz"))
     cfg, v, s = _fista_solver("C4", variant)
