@@ -286,6 +286,30 @@ int spcies_hip_closed_loop(spcies_hip_handle h, const double *AB_plant, const do
                            int ref_stride, long B, int steps, double *x_traj, double *u_traj, int *k_traj, int *e_traj,
                            spcies_hip_timing *timing);
 
+/* ---- several devices from ONE process (no launcher, no torch): what a mex gateway or a plain-C caller binds to use every
+ * GPU of a node (examples/cl_in_C/main_cl_in_C.c:103 use case, batched).  One single-device handle per entry of device_ids
+ * (NULL = 0 .. n_dev-1; n_dev <= 0 = every visible device), all created from the same blob - each device parses and packs
+ * it for itself, no collective; a solve splits the host batch into contiguous shards (spcies_hip_shard_range: sizes differ
+ * by at most one, larger shards first - the split of spcies_amd/distributed.py), one host thread per device, each running
+ * spcies_hip_solve_batch_ex on its shard; results land in the caller's buffers at the shard's offset.  A device may be
+ * listed more than once (two handles on one GPU).  timing: per phase the slowest device, run_time the whole call.        */
+typedef struct spcies_hip_multi_s *spcies_hip_multi_handle;
+int spcies_hip_shard_range(long B, int n_shards, int shard, long *begin, long *count);
+int spcies_hip_create_multi(const void *blob, size_t bytes, const int *device_ids, int n_dev, spcies_hip_multi_handle *out);
+int spcies_hip_multi_destroy(spcies_hip_multi_handle m);
+int spcies_hip_multi_count(spcies_hip_multi_handle m, int *n_dev);
+int spcies_hip_multi_get(spcies_hip_multi_handle m, int i, spcies_hip_handle *single); /* per-device handle (info, reserve) */
+int spcies_hip_multi_set_variant(spcies_hip_multi_handle m, int variant);
+int spcies_hip_multi_set_exit(spcies_hip_multi_handle m, int k_max, double tol);
+int spcies_hip_multi_solve_batch(spcies_hip_multi_handle m, const double *x0, const double *xr, const double *ur, int ref_stride,
+                                 long B, double *u, int *k, int *e_flag, double *z, double *v, double *lambda,
+                                 spcies_hip_timing *timing);
+/* extra_width: doubles per instance in `extra` when extra_stride != 0 (1 for the ellipMPC radius; the packed model of a
+ * time-varying solver) - needed to offset a shard                                                                       */
+int spcies_hip_multi_solve_batch_ex(spcies_hip_multi_handle m, const double *x0, const double *xr, const double *ur, int ref_stride,
+                                    const double *extra, int extra_stride, long extra_width, long B, double *u, int *k,
+                                    int *e_flag, double *const *fields, int n_fields, spcies_hip_timing *timing);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,10 +170,7 @@ class HipSolver:
         arrays = [np.zeros((B, d)) for _, d in self.sol_fields] if want_sol else None
         ptrs = (dp * len(self.sol_fields))(*[_dp(a) for a in arrays]) if want_sol else None
         t = _lib.Timing()
-        _lib.check(self._lib.spcies_hip_solve_batch_ex(
-            self._h, _dp(x0), _dp(xr), _dp(ur), C.c_int(int(per)), _dp(extra) if extra is not None else None,
-            C.c_int(int(extra_stride)), C.c_long(B),
-            _dp(u), _ip(k), _ip(e), ptrs, len(self.sol_fields), C.byref(t)))
+        self._solve_host(x0, xr, ur, per, extra, extra_stride, B, u, k, e, ptrs, t)
         fields = {name: (arrays[i] if want_sol else None) for i, (name, _) in enumerate(self.sol_fields)}
         if single:
             fields = {kf: (a[0] if a is not None else None) for kf, a in fields.items()}
@@ -185,6 +182,12 @@ class HipSolver:
         if single:
             return u[0], int(k[0]), int(e[0]), sol
         return u, k, e, sol
+
+    def _solve_host(self, x0, xr, ur, per, extra, extra_stride, B, u, k, e, ptrs, t):
+        _lib.check(self._lib.spcies_hip_solve_batch_ex(
+            self._h, _dp(x0), _dp(xr), _dp(ur), C.c_int(int(per)), _dp(extra) if extra is not None else None,
+            C.c_int(int(extra_stride)), C.c_long(B),
+            _dp(u), _ip(k), _ip(e), ptrs, len(self.sol_fields), C.byref(t)))
 
     def closed_loop(self, AB, x0, xr, ur, steps):
         """Closed-loop simulation of B plants on the device (``examples/cl_in_C/main_cl_in_C.c:98-117``): at every
@@ -234,3 +237,66 @@ class HipSolver:
         _lib.check(self._lib.spcies_hip_time_device(self._h, ptr(x0), ptr(xr), ptr(ur), C.c_int(per), C.c_long(x0.shape[0]), ptr(u),
                                                    ptr(k), ptr(e_flag), C.c_void_p(stream), int(reps), C.byref(ms)))
         return ms.value
+
+
+class MultiHipSolver(HipSolver):
+    """One controller on several GPUs of one process (``spcies_hip_create_multi``): the host batch is split into
+    contiguous shards, one host thread and one single-device handle per entry of ``devices`` (``None`` = every
+    visible device; a device may be listed more than once).  Same call as :class:`HipSolver`; device-resident
+    entry points are per device: ``self.single(i)``."""
+
+    def __init__(self, vars_or_blob, devices=None, name=None, debug=True):
+        self.blob = vars_or_blob if isinstance(vars_or_blob, (bytes, bytearray)) else _blob.pack(vars_or_blob)
+        lib = _lib.load()
+        mh = C.c_void_p()
+        ids = None if devices is None else (C.c_int * len(devices))(*[int(d) for d in devices])
+        _lib.check(lib.spcies_hip_create_multi(self.blob, len(self.blob), ids, 0 if devices is None else len(devices), C.byref(mh)))
+        self._mh = mh
+        self._lib = lib
+        nd = C.c_int(0)
+        _lib.check(lib.spcies_hip_multi_count(mh, C.byref(nd)))
+        self.n_dev = nd.value
+        self._h = self.single(0)  # info, record layout: the same on every device
+        info = _lib.Info()
+        _lib.check(lib.spcies_hip_get_info(self._h, C.byref(info)))
+        self.n, self.m, self.N, self.dim, self.dim_lambda = info.n, info.m, info.N, info.dim, info.dim_lambda
+        self.method = {v: k for k, v in _blob.METHOD.items()}[info.method]
+        nf, dims, names = C.c_int(0), (C.c_int * 8)(), (C.c_char_p * 8)()
+        _lib.check(lib.spcies_hip_get_sol_layout(self._h, C.byref(nf), dims, names))
+        self.sol_fields = [(names[i].decode(), int(dims[i])) for i in range(nf.value)]
+        self.device = info.device
+        self.formulation = {v: k for k, v in _blob.FORMULATION.items()}[info.formulation]
+        self.submethod = int(info.submethod)
+        self.name = name or self.formulation
+        self.time_varying = bool(int.from_bytes(self.blob[28:32], "little") & 4)
+        self.debug = bool(debug)
+
+    def single(self, i):
+        h = C.c_void_p()
+        _lib.check(self._lib.spcies_hip_multi_get(self._mh, int(i), C.byref(h)))
+        return h
+
+    def close(self):
+        if getattr(self, "_mh", None) is not None and self._mh:
+            self._lib.spcies_hip_multi_destroy(self._mh)
+            self._mh = None
+            self._h = None
+
+    def set_variant(self, name):
+        _lib.check(self._lib.spcies_hip_multi_set_variant(self._mh, _lib.VARIANTS[name]))
+
+    def set_exit(self, k_max=0, tol=-1.0):
+        _lib.check(self._lib.spcies_hip_multi_set_exit(self._mh, int(k_max), float(tol)))
+
+    def reserve(self, B):
+        for i in range(self.n_dev):
+            _lib.check(self._lib.spcies_hip_reserve(self.single(i), C.c_long(-(-int(B) // self.n_dev))))
+
+    def _solve_host(self, x0, xr, ur, per, extra, extra_stride, B, u, k, e, ptrs, t):
+        width = int(extra.size // B) if (extra is not None and extra_stride) else 0
+        _lib.check(self._lib.spcies_hip_multi_solve_batch_ex(
+            self._mh, _dp(x0), _dp(xr), _dp(ur), C.c_int(int(per)), _dp(extra) if extra is not None else None,
+            C.c_int(int(extra_stride)), C.c_long(width), C.c_long(B), _dp(u), _ip(k), _ip(e), ptrs, len(self.sol_fields), C.byref(t)))
+
+    def closed_loop(self, *a, **kw):
+        raise SpciesArgError(f"Spcies:{self.formulation}:closed_loop:multi", "closed_loop runs on one device: use HipSolver")

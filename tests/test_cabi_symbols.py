@@ -131,3 +131,30 @@ def test_blob_parser_rejects_or_accepts_mutations_without_crashing(cfg_name):
         w = int(rng.integers(0, min(words, (blob.HEADER_BYTES + n_arr * blob.ENTRY_BYTES) // 4 + 64)))
         struct.pack_into("<I", b, 4 * w, int(rng.integers(0, 1 << 32)))
         assert create(b) in (-1, -2, -3, -4)
+
+
+def test_shard_range_matches_the_python_partition():
+    """spcies_hip_shard_range (the split spcies_hip_multi_solve_batch applies to a host batch) == distributed.shard_range:
+    contiguous, complete, sizes differ by at most one, larger shards first.  No GPU needed."""
+    from spcies_amd import distributed
+    lib = _lib.load()
+    lo, cnt = C.c_long(), C.c_long()
+    for B in (0, 1, 7, 64, 65536, 524288 + 5):
+        for G in (1, 2, 3, 8):
+            end = 0
+            for g in range(G):
+                assert lib.spcies_hip_shard_range(B, G, g, C.byref(lo), C.byref(cnt)) == 0
+                assert (lo.value, lo.value + cnt.value) == distributed.shard_range(B, G, g) and lo.value == end
+                end += cnt.value
+            assert end == B
+    assert lib.spcies_hip_shard_range(10, 0, 0, C.byref(lo), C.byref(cnt)) != 0
+    assert lib.spcies_hip_shard_range(10, 2, 2, C.byref(lo), C.byref(cnt)) != 0
+    assert b"shard" in lib.spcies_hip_last_error()
+
+
+def test_create_multi_fails_loudly_without_gpu_or_on_bad_blob():
+    lib = _lib.load()
+    h = C.c_void_p()
+    ids = (C.c_int * 2)(0, 0)
+    assert lib.spcies_hip_create_multi(b"x" * 200, 200, ids, 2, C.byref(h)) != 0 and not h
+    assert lib.spcies_hip_multi_destroy(None) == 0

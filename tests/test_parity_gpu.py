@@ -1003,3 +1003,34 @@ def test_partial_record_through_the_c_abi(cfg_name, variant):
             if b is not None:
                 assert np.array_equal(b, ref)
     s.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# One process, several device handles (spcies_hip_create_multi): contiguous shards, one host thread per handle
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg_name,B,devices", [("C2", 1003, [0, 0, 0]), ("C1", 5, [0, 0, 0, 0, 0, 0, 0, 0]), ("C1_soc", 61, [0, 0]),
+                                                ("C1_lax_FISTA", 37, [0, 0])])
+def test_multi_handle_equals_single_handle(cfg_name, B, devices):
+    """The sharded call (ragged shards, empty shards when B < n_dev, record fields, the ellipMPC radius as a per-instance extra
+    input) returns exactly what ONE handle returns for the whole batch - on a one-GPU box every shard runs on device 0."""
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver, MultiHipSolver
+    cfg = benchmarks.config(cfg_name)
+    v = benchmarks.ingredients(cfg)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    extra = ()
+    if cfg_name == "C1_soc":
+        extra = (cfg.param.r * (1.0 + 0.1 * np.arange(B) / B),)
+    with HipSolver(v) as s1, MultiHipSolver(v, devices=devices) as sm:
+        assert sm.n_dev == len(devices) and sm.sol_fields == s1.sol_fields
+        u1, k1, e1, sol1 = s1(x0, xr, ur, *extra)
+        um, km, em, solm = sm(x0, xr, ur, *extra)
+        assert np.array_equal(u1, um) and np.array_equal(k1, km) and np.array_equal(e1, em)
+        for name, _ in s1.sol_fields:
+            assert np.array_equal(getattr(sol1, name if name != "lambda" else "lam"), getattr(solm, name if name != "lambda" else "lam")), name
+        assert solm.run_time > 0 and solm.solve_time > 0
+        un, kn, en, _ = sm(x0, xr, ur, *extra, want_sol=False)
+        assert np.array_equal(un, u1) and np.array_equal(kn, k1)
+        sm.set_exit(k_max=3)
+        _, k3, e3, _ = sm(x0, xr, ur, *extra, want_sol=False)
+        assert (k3 <= 3).all()
