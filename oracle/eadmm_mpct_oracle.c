@@ -2,7 +2,8 @@
  * ORACLE - TEST INFRASTRUCTURE ONLY.  Not part of the product path.
  *
  * CPU restatement (plain C, FP64, one instance per call, runtime dimensions) of the EADMM solver the
- * reference generates for the MPCT formulation, diagonal-Q/R path (IS_DIAG == 1):
+ * reference generates for the MPCT formulation, both the diagonal-Q/R path (IS_DIAG == 1) and the general one
+ * (IS_DIAG == 0, :184-217 and :321-366: dense inverses Q_bi / Q_mi / R_bi / R_mi of the blocks of H3, AB_bi / AB_mi):
  *
  *   formulations/+MPCT/code_MPCT_EADMM_C.c:18-525
  *
@@ -30,7 +31,11 @@ typedef struct {
     const double *Beta;   /* [N][n][n] */
     const double *H1i;    /* [N+1][n+m] */
     const double *W2;     /* [n+m][n+m] */
-    const double *H3i;    /* [N+1][n+m] */
+    const double *H3i;    /* [N+1][n+m]  (IS_DIAG == 1) */
+    int is_diag;
+    const double *Q_bi, *Q_mi; /* [n][n]    (IS_DIAG == 0; cons_MPCT_EADMM_C.m:102-107) */
+    const double *R_bi, *R_mi; /* [m][m]   */
+    const double *AB_bi, *AB_mi; /* [n][n+m] */
 } eadmm_mpct_data;
 
 #define M2(a, l, j) ((a)[(size_t)(l) * nm + (j)])
@@ -104,13 +109,30 @@ int oracle_eadmm_mpct_solve(const eadmm_mpct_data *d, const double *x0_in, const
         /* ---- P3: q3 stored in z3 (:157-172) */
         for (int l = 0; l <= N; l++)
             for (int j = 0; j < nm; j++) M2(z3, l, j) = M2(d->rho, l, j) * (z2[j] - M2(z1, l, j)) + M2(lam, l + 1, j);
-        /* rhs (:176-183) */
-        for (int l = 0; l < N; l++)
+        /* rhs (:176-183; general Q, R :184-217) */
+        if (d->is_diag) {
+            for (int l = 0; l < N; l++)
+                for (int j = 0; j < n; j++) {
+                    double acc = M2(d->H3i, l + 1, j) * M2(z3, l + 1, j);
+                    for (int i = 0; i < nm; i++) acc = acc - ABij(j, i) * M2(d->H3i, l, i) * M2(z3, l, i);
+                    MU(l, j) = acc;
+                }
+        } else {
+            for (int l = 0; l < N - 1; l++)
+                for (int j = 0; j < n; j++) {
+                    MU(l, j) = 0.0;
+                    for (int i = 0; i < n; i++) MU(l, j) += d->Q_bi[(size_t)j * n + i] * M2(z3, l + 1, i);
+                }
             for (int j = 0; j < n; j++) {
-                double acc = M2(d->H3i, l + 1, j) * M2(z3, l + 1, j);
-                for (int i = 0; i < nm; i++) acc = acc - ABij(j, i) * M2(d->H3i, l, i) * M2(z3, l, i);
-                MU(l, j) = acc;
+                MU(N - 1, j) = 0.0;
+                for (int i = 0; i < n; i++) MU(N - 1, j) += d->Q_mi[(size_t)j * n + i] * M2(z3, N, i);
             }
+            for (int j = 0; j < n; j++)
+                for (int i = 0; i < nm; i++) MU(0, j) -= d->AB_mi[(size_t)j * nm + i] * M2(z3, 0, i);
+            for (int l = 1; l < N; l++)
+                for (int j = 0; j < n; j++)
+                    for (int i = 0; i < nm; i++) MU(l, j) -= d->AB_bi[(size_t)j * nm + i] * M2(z3, l, i);
+        }
         /* banded solve (:221-285) */
         for (int l = 0; l < N; l++)
             for (int j = 0; j < n; j++) {
@@ -137,8 +159,23 @@ int oracle_eadmm_mpct_solve(const eadmm_mpct_data *d, const double *x0_in, const
                 for (int i = 0; i < n; i++) M2(z3, l, j) = M2(z3, l, j) + ABij(i, j) * MU(l, i);
         }
         for (int j = 0; j < n; j++) M2(z3, N, j) = M2(z3, N, j) - MU(N - 1, j);
-        for (int l = 0; l <= N; l++)
-            for (int j = 0; j < nm; j++) M2(z3, l, j) = -M2(d->H3i, l, j) * M2(z3, l, j);
+        if (d->is_diag) {
+            for (int l = 0; l <= N; l++)
+                for (int j = 0; j < nm; j++) M2(z3, l, j) = -M2(d->H3i, l, j) * M2(z3, l, j);
+        } else { /* (:321-366): z3 = -H3^-1 z3 block by block; z3p has been compared against already?  no: keep it, use a scratch copy */
+            double *aux = (double *)malloc(sizeof(double) * (size_t)(N + 1) * nm);
+            memcpy(aux, z3, sizeof(double) * (size_t)(N + 1) * nm);
+            memset(z3, 0, sizeof(double) * (size_t)(N + 1) * nm);
+            for (int l = 0; l <= N; l++) {
+                const double *Qi = (l == 0 || l == N) ? d->Q_mi : d->Q_bi;
+                const double *Ri = (l == N) ? d->R_mi : d->R_bi;
+                for (int j = 0; j < n; j++)
+                    for (int i = 0; i < n; i++) M2(z3, l, j) -= Qi[(size_t)j * n + i] * aux[(size_t)l * nm + i];
+                for (int j = 0; j < m; j++)
+                    for (int i = 0; i < m; i++) M2(z3, l, j + n) -= Ri[(size_t)j * m + i] * aux[(size_t)l * nm + i + n];
+            }
+            free(aux);
+        }
         /* ---- residual and lambda (:371-402) */
         for (int j = 0; j < n; j++) M2(res, 0, j) = M2(z1, 0, j) - x0[j];
         for (int l = 0; l <= N; l++)

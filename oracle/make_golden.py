@@ -50,7 +50,7 @@ def main():
                                ("C2_equ", 32, dict(tol=1e-6, k_max=3000)),
                                ("C1_lax_FISTA", 16, {}), ("C1_equ_FISTA", 16, dict(k_max=500)),
                                ("C2_lax_FISTA", 32, {}), ("C2_lax_FISTA", 32, dict(tol=1e-6, k_max=2000)),
-                               ("C2_equ_FISTA", 32, {}), ("C1_MPCT", 16, {}), ("C4", 8, {}),
+                               ("C2_equ_FISTA", 32, {}), ("C1_MPCT", 16, {}), ("C4", 8, {}), ("C1_MPCT_nd", 16, {}), ("C1_MPCT_nd0", 8, {}), ("C4_nd", 6, {}),
                                ("C1_ellip", 12, {}), ("C2_ellip", 8, {}),
                                ("C1_lax_gen", 12, {}), ("C1_equ_gen", 12, dict(k_max=3000)), ("C2_lax_gen", 8, {}),
                                ("C1_soc", 12, {}), ("C5_soc", 8, {}),

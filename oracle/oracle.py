@@ -195,9 +195,13 @@ _EADMM_ARRAYS = (("rho", "rho_mat"), ("rho_0", "rho_0"), ("rho_s", "rho_s"), ("L
                  ("Alpha", "Alpha"), ("Beta", "Beta"), ("H1i", "H1i"), ("W2", "W2"), ("H3i", "H3i"))
 
 
+_EADMM_NONDIAG = ("Q_bi", "Q_mi", "R_bi", "R_mi", "AB_bi", "AB_mi")  # general Q, R (IS_DIAG == 0)
+
+
 class _EadmmData(C.Structure):
     _fields_ = [("n", C.c_int), ("m", C.c_int), ("N", C.c_int), ("k_max", C.c_int), ("tol", C.c_double)] + [
-        (name, C.POINTER(C.c_double)) for name, _ in _EADMM_ARRAYS]
+        (name, C.POINTER(C.c_double)) for name, _ in _EADMM_ARRAYS] + [("is_diag", C.c_int)] + [
+        (name, C.POINTER(C.c_double)) for name in _EADMM_NONDIAG]
 
 
 def eadmm_mpct_batch(v, x0, xr, ur, want_sol=True, quantize=False):
@@ -205,9 +209,12 @@ def eadmm_mpct_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     n, m, N = int(v["n"]), int(v["m"]), int(v["N"])
     nm = n + m
     qz = quantize_like_reference if quantize else (lambda a: a)
-    keep = {k_: np.ascontiguousarray(qz(np.asarray(v[s_], dtype=float))) for k_, s_ in _EADMM_ARRAYS}
+    is_diag = bool(v.get("is_diag", True))
+    keep = {k_: np.ascontiguousarray(qz(np.asarray(v[s_], dtype=float))) for k_, s_ in _EADMM_ARRAYS if not (k_ == "H3i" and not is_diag)}
+    if not is_diag:
+        keep.update({k_: np.ascontiguousarray(qz(np.asarray(v[k_], dtype=float))) for k_ in _EADMM_NONDIAG})
     d = _EadmmData(n=n, m=m, N=N, k_max=int(v["k_max"]), tol=float(qz(v["tol"])) if quantize else float(v["tol"]),
-                   **{k_: _dp(a) for k_, a in keep.items()})
+                   is_diag=int(is_diag), **{k_: _dp(a) for k_, a in keep.items()})
     x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
     B = x0.shape[0]
     xr = np.ascontiguousarray(np.asarray(xr, dtype=float))

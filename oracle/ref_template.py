@@ -123,10 +123,15 @@ def build_admm(v, name):
     elif method == "FISTA":  # cons_laxMPC_FISTA_C.m:94-107 / cons_equMPC_FISTA_C.m
         order = [(k, k) for k in ["LB", "UB", "AB", "Alpha", "Beta", "Q", "R", "QRi"]] \
             + ([("T", "Tdiag"), ("Ti", "Ti")] if v["terminal"] else [])
-    else:  # EADMM, cons_MPCT_EADMM_C.m:82-100 (force_diagonal path: H3i)
+    else:  # EADMM, cons_MPCT_EADMM_C.m:82-108 (force_diagonal path: H3i; general Q, R: no IS_DIAG define, six dense blocks)
         order = [("rho", "rho_mat"), ("rho_0", "rho_0"), ("rho_s", "rho_s"), ("LB", "LB"), ("UB", "UB"), ("LB_0", "LB0"),
                  ("UB_0", "UB0"), ("LB_s", "LBs"), ("UB_s", "UBs"), ("AB", "AB"), ("T", "T"), ("S", "S"),
-                 ("Alpha", "Alpha"), ("Beta", "Beta"), ("H1i", "H1i"), ("W2", "W2"), ("H3i", "H3i")]
+                 ("Alpha", "Alpha"), ("Beta", "Beta"), ("H1i", "H1i"), ("W2", "W2")]
+        if v.get("is_diag", True):
+            order += [("H3i", "H3i")]
+        else:
+            defs.remove("#define IS_DIAG 1")  # Spcies_options.m:669: the define is only printed with force_diagonal
+            order += [(k, k) for k in ("Q_bi", "Q_mi", "R_bi", "R_mi", "AB_bi", "AB_mi")]
     consts = "".join(_decl(cn, v[k]) for cn, k in order)
     with open(os.path.join(REF, "platforms", "+C_code", "generic_solver_struct.c")) as f:
         code = f.read()

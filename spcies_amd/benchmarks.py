@@ -90,6 +90,23 @@ def config(name):
             c.param.N, c.B, c.seed = 20, 1048576, 1204
             c.solver_options.update(k_max=200, tol=0.0)
         return c
+    if name in ("C1_MPCT_nd0", "C1_MPCT_nd", "C4_nd"):
+        # the general-Q/R path of the generated solver (IS_DIAG == 0, compute_MPCT_EADMM_ingredients.m:142-154):
+        # nd0: the tester's diagonal weights with force_diagonal off (same QP, so the reference test's z_opt still applies);
+        # nd / C4_nd: coupled position / velocity weights and coupled inputs
+        c = config("C4" if name == "C4_nd" else "C1_MPCT")
+        c.name = name
+        c.solver_options["force_diagonal"] = False
+        if name != "C1_MPCT_nd0":
+            n, m = c.sys.n, c.sys.m
+            rng = np.random.default_rng(79)
+            Mq, Mr = rng.standard_normal((n, n)), rng.standard_normal((m, m))
+            c.param.Q = c.param.Q + 0.3 * (Mq @ Mq.T) / n
+            c.param.R = c.param.R + 0.05 * (Mr @ Mr.T) / m
+            c.param.T, c.param.S = 10 * c.param.Q, c.param.R
+        if name == "C4_nd":
+            c.B = 131072
+        return c
     if name in ("C1_MPCT_cs", "C1_MPCT_cs_vec", "C2_cs", "C4_cs"):
         # tests/test_MPCT_ADMM.m:6-17 (rho: def_options_MPCT_ADMM_cs.m); C2 / C4 shapes with 200 fixed iterations.  At the C4
         # shape W = Aeq Hhat^-1 Aeq' has a condition number of 1e9: kept for the bit-exact STREAM variant only

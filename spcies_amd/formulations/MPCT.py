@@ -30,8 +30,7 @@ def compute_MPCT_EADMM_ingredients(controller, opt):
     if "rho" in so:  # (:76-79)
         so["rho_base"], so["rho_mult"] = so["rho"], 1
     rho_base, rho_mult = float(so["rho_base"]), float(so["rho_mult"])
-    if not (opt.force_diagonal and _is_diag(Q) and _is_diag(R)):
-        raise NotImplementedError("HIP platform: MPCT-EADMM is built for diagonal Q, R (IS_DIAG path)")
+    is_diag = bool(opt.force_diagonal and _is_diag(Q) and _is_diag(R))  # (:142-148): IS_DIAG of the generated solver
     L = (N + 1) * nm + n + nm
     rho = rho_base * np.ones(L)
     rho[:2 * n] = rho_mult * rho_base          # x_0 = x (6b) and stage-0 state rows of z1 + z2 + z3 = 0
@@ -54,13 +53,23 @@ def compute_MPCT_EADMM_ingredients(controller, opt):
         Az3[j * n:(j + 1) * n, (j + 1) * nm:(j + 1) * nm + n] = -np.eye(n)
     Az3 = np.hstack([Az3, np.vstack([np.zeros(((N - 1) * n, n)), -np.eye(n)]), np.zeros((N * n, m))])
     H3i = 1.0 / np.diag(H3)
-    W3 = (Az3 * H3i[None, :]) @ Az3.T
+    W3 = (Az3 * H3i[None, :]) @ Az3.T if is_diag else Az3 @ np.linalg.inv(H3) @ Az3.T
     W3c = np.linalg.cholesky(W3).T
     eps_x, eps_u = float(so["epsilon_x"]), float(so["epsilon_u"])
     fin = lambda a: np.where(np.isinf(a), np.sign(a) * inf_value, a)
     v = dict(n=n, m=m, N=N, formulation="MPCT", method="EADMM", terminal=True)
     v["H1i"] = H1i.reshape(N + 1, nm).copy()
-    v["H3i"] = H3i.reshape(N + 1, nm).copy()
+    v["is_diag"] = is_diag
+    if is_diag:
+        v["H3i"] = H3i.reshape(N + 1, nm).copy()
+    else:  # (:149-154, :204-211): dense inverses of the two distinct diagonal blocks of H3 and [A B] times them
+        v["Q_mi"] = np.linalg.inv(Q + rho_mult * rho_base * np.eye(n))
+        v["R_mi"] = np.linalg.inv(R + rho_mult * rho_base * np.eye(m))
+        v["Q_bi"] = np.linalg.inv(Q + rho_base * np.eye(n))
+        v["R_bi"] = np.linalg.inv(R + rho_base * np.eye(m))
+        AB_ = np.hstack([A, B])
+        v["AB_bi"] = AB_ @ np.block([[v["Q_bi"], np.zeros((n, m))], [np.zeros((m, n)), v["R_bi"]]])
+        v["AB_mi"] = AB_ @ np.block([[v["Q_mi"], np.zeros((n, m))], [np.zeros((m, n)), v["R_bi"]]])
     v["AB"] = np.hstack([A, B])
     v["W2"] = W2
     v["T"] = -T
