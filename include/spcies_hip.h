@@ -166,7 +166,12 @@ enum spcies_array_id {
     SPCIES_A_AHI_VAL = 80, SPCIES_A_AHI_COL = 81, SPCIES_A_AHI_ROW = 82, /* CSR of -Aeq Hhat^-1  [nrow x dim] */
     SPCIES_A_HIA_VAL = 83, SPCIES_A_HIA_COL = 84, SPCIES_A_HIA_ROW = 85, /* CSR of -Hhat^-1 Aeq' [dim x nrow] */
     SPCIES_A_HI_VAL = 86, SPCIES_A_HI_COL = 87, SPCIES_A_HI_ROW = 88,    /* CSR of -Hhat^-1      [dim x dim]  */
-    SPCIES_A_RHO_CS = 89, SPCIES_A_RHO_I_CS = 90                          /* [dim] (vector rho)               */
+    SPCIES_A_RHO_CS = 89, SPCIES_A_RHO_I_CS = 90,                         /* [dim] (vector rho)               */
+    /* MPCT EADMM with general (non-diagonal) Q, R - header flags bit5; IS_DIAG == 0 of the generated solver
+     * (cons_MPCT_EADMM_C.m:99-108, code_MPCT_EADMM_C.c:184-217, 321-366): these six INSTEAD of H3i (25)          */
+    SPCIES_A_Q_BI = 91, SPCIES_A_Q_MI = 92,   /* [n][n]   (Q + rho_base I)^-1, (Q + rho_mult rho_base I)^-1  */
+    SPCIES_A_R_BI = 93, SPCIES_A_R_MI = 94,   /* [m][m]                                                       */
+    SPCIES_A_AB_BI = 95, SPCIES_A_AB_MI = 96  /* [n][n+m] [A B] blkdiag(Q_bi, R_bi), [A B] blkdiag(Q_mi, R_bi) */
 };
 
 typedef struct {
@@ -176,7 +181,7 @@ typedef struct {
     uint32_t formulation;  /* enum spcies_formulation                        */
     uint32_t method;       /* enum spcies_method                             */
     uint32_t submethod;    /* 0 = none                                       */
-    uint32_t flags;        /* bit0: scalar rho, bit1: use_soc, bit2: time-varying, bit3: in_engineering, bit4: VAR_BOUNDS */
+    uint32_t flags;        /* bit0: scalar rho, bit1: use_soc, bit2: time-varying, bit3: in_engineering, bit4: VAR_BOUNDS, bit5: general Q, R (MPCT EADMM) */
     uint32_t n, m, N, k_max;
     uint32_t n_arrays;
     uint32_t reserved0;

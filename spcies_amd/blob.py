@@ -30,7 +30,8 @@ ARRAY_ID = {"AB": 1, "Alpha": 2, "Beta": 3, "Hi": 4, "Hi_0": 5, "Hi_N": 6, "Q": 
             "rho_v": 61, "rho_N": 62, "rho_i_v": 63, "rho_i_0": 64, "rho_i_N": 65, "LBN": 66, "UBN": 67, "M1": 68, "M2": 69, "bh_nat": 70,
             "C_val": 71, "C_col": 72, "C_row": 73, "Ct_val": 74, "Ct_col": 75, "Ct_row": 76, "d": 77,
             "Tz": 78, "Sz": 79, "AHi_val": 80, "AHi_col": 81, "AHi_row": 82, "HiA_val": 83, "HiA_col": 84, "HiA_row": 85,
-            "Hi_val": 86, "Hi_col": 87, "Hi_row": 88, "rho_cs": 89, "rho_i_cs": 90}
+            "Hi_val": 86, "Hi_col": 87, "Hi_row": 88, "rho_cs": 89, "rho_i_cs": 90,
+            "Q_bi": 91, "Q_mi": 92, "R_bi": 93, "R_mi": 94, "AB_bi": 95, "AB_mi": 96}
 INT_ARRAYS = {"L_col", "L_row", "GhHhi_col", "GhHhi_row", "HhiGh_col", "HhiGh_row", "Hhi_col", "Hhi_row", "idx_x0",
               "C_col", "C_row", "Ct_col", "Ct_row",
               "AHi_col", "AHi_row", "HiA_col", "HiA_row", "Hi_col", "Hi_row"}
@@ -69,7 +70,8 @@ def pack(v):
         off = _align(off + a.nbytes)
     total = off
     flags = (1 if v.get("rho_is_scalar", True) else 0) | (2 if v.get("use_soc", False) else 0) | (
-        4 if v.get("time_varying", False) else 0) | (8 if v.get("in_engineering", False) else 0) | (16 if v.get("var_bounds", False) else 0)
+        4 if v.get("time_varying", False) else 0) | (8 if v.get("in_engineering", False) else 0) | (16 if v.get("var_bounds", False) else 0) | (
+        32 if not v.get("is_diag", True) else 0)
     res = [float(v.get("sigma", 0.0)), float(v.get("sigma_i", 0.0)), float(v.get("tol_d", 0.0)), float(v.get("alpha", 0.0)), float(v.get("r", 0.0))]
     hdr = struct.pack(_HDR, MAGIC, VERSION, HEADER_BYTES, FORMULATION[v["formulation"]], METHOD[v["method"]],
                       SUBMETHOD[v.get("submethod", "")], flags, int(v["n"]), int(v["m"]), int(v["N"]), int(v["k_max"]),
@@ -94,7 +96,7 @@ def unpack(blob):
     inv = lambda d, x: next(k for k, val in d.items() if val == x)
     v = dict(formulation=inv(FORMULATION, form), method=inv(METHOD, meth), n=n, m=m, N=N, k_max=k_max, tol=tol,
              rho=rho, rho_i=rho_i, rho_is_scalar=bool(flags & 1), time_varying=bool(flags & 4),
-             in_engineering=bool(flags & 8), var_bounds=bool(flags & 16))
+             in_engineering=bool(flags & 8), var_bounds=bool(flags & 16), is_diag=not bool(flags & 32))
     v["terminal"] = v["formulation"] != "equMPC"
     for i in range(n_arr):
         aid, dtype, off, count, d0, d1, d2, d3, _p0, _p1 = struct.unpack_from(_ENT, blob, HEADER_BYTES + i * ENTRY_BYTES)

@@ -20,18 +20,24 @@ namespace g4 {
 
 #pragma clang fp contract(fast)  // (the STREAM headers included before this one switch contraction off)
 
-template <int KX, int KS>
+// DIAG: diagonal Q, R (IS_DIAG == 1: H3^-1 is the vector H3i).  !DIAG: general Q, R (code_MPCT_EADMM_C.c:184-217, 321-366) - H3^-1 is
+// block diagonal, blkdiag(Q_mi | Q_bi, R_bi | R_mi) per stage, and three more block products per stage replace the elementwise
+// scalings: the sweep-B chunk of block l carries Qinv_{l+1} (KX x KX) and -AB H3inv_l (KX x KS, the reference's AB_mi / AB_bi),
+// the sweep-C chunk -H3inv_{l+1} (KS x KS); -H3inv_0 sits in the stage-invariant region.
+template <int KX, int KS, bool DIAG = true>
 struct EadmmGLayout {
     static constexpr int RC = 4 * KS;
-    // stage-invariant blocks: -AB (KX x KS), AB' (KS x KX), W2 (KS x KS), blkdiag(T, S) (KS x KS)
-    static constexpr int T_NAB = 0, T_ABT = KX * KS, T_W2 = 2 * KX * KS, T_TS = 2 * KX * KS + KS * KS;
-    static constexpr int INV_TILES = 2 * KX * KS + 2 * KS * KS;
+    // stage-invariant blocks: -AB (KX x KS), AB' (KS x KX), W2 (KS x KS), blkdiag(T, S) (KS x KS) [, -H3inv_0 (KS x KS)]
+    static constexpr int T_NAB = 0, T_ABT = KX * KS, T_W2 = 2 * KX * KS, T_TS = 2 * KX * KS + KS * KS, T_H0 = 2 * KX * KS + 2 * KS * KS;
+    static constexpr int INV_TILES = (2 * KX * KS + 2 * KS * KS + (DIAG ? 0 : KS * KS) + 1) / 2 * 2;
     enum { C_RHO0, C_RHOS, C_COUNT };
     static constexpr int INV_D = INV_TILES * 16 + C_COUNT * RC;
     // per-stage diagonals and bounds
     enum { K_RHO, K_H1I, K_H3I, K_LB, K_UB, K_COUNT };
     static constexpr int KD = K_COUNT * RC;
-    static constexpr int NT = blk_count(KX, KX, LOWER) + KX * KX, NT_PAD = (NT + 1) / 2 * 2;
+    static constexpr int NTS = blk_count(KX, KX, LOWER) + KX * KX;  // triangular + dense block of the substitution
+    static constexpr int NTX_B = KX * KX + KX * KS, NTX_C = KS * KS;  // general Q, R: extra blocks of a sweep-B / sweep-C chunk
+    static constexpr int NT = NTS + (DIAG ? 0 : (NTX_B > NTX_C ? NTX_B : NTX_C)), NT_PAD = (NT + 1) / 2 * 2;
     static constexpr int CHD = NT_PAD * 16 + 2 * KD;  // blocks, K_a, K_b
     static constexpr int LDS_D = INV_D + 2 * CHD;
     static int n_seq(int N) { return 3 * N + 1; }
@@ -40,11 +46,13 @@ struct EadmmGLayout {
 
 struct EadmmGHost {
     const std::vector<double> *rho, *rho0, *rhos, *LB0, *UB0, *LBs, *UBs, *S, *H1i, *W2, *H3i;
+    bool diag = true;
+    const std::vector<double> *Q_bi = nullptr, *Q_mi = nullptr, *R_bi = nullptr, *R_mi = nullptr;  // general Q, R
 };
 
-template <int KX, int KS>
+template <int KX, int KS, bool DIAG>
 inline int eadmm_plan_build_shape(Plan &p, const AdmmHost &a, const EadmmGHost &h) {
-    using LY = EadmmGLayout<KX, KS>;
+    using LY = EadmmGLayout<KX, KS, DIAG>;
     const int n = a.n, m = a.m, N = a.N, nm = n + m;
     std::vector<double> tab(LY::table_doubles(N), 0.0);
     DM AB(n, nm), W2(nm, nm), TS(nm, nm);
@@ -56,6 +64,24 @@ inline int eadmm_plan_build_shape(Plan &p, const AdmmHost &a, const EadmmGHost &
         for (int j = 0; j < n; j++) TS(i, j) = a.T[(size_t)i * n + j];
     for (int i = 0; i < m; i++)
         for (int j = 0; j < m; j++) TS(n + i, n + j) = (*h.S)[(size_t)i * m + j];
+    // H3^-1 of stage l (general Q, R): blkdiag(Q_mi at l = 0 and N, else Q_bi; R_mi at l = N, else R_bi)
+    auto H3inv = [&](int l) {
+        DM M(nm, nm);
+        if (!DIAG) {
+            const std::vector<double> &Qi = (l == 0 || l == N) ? *h.Q_mi : *h.Q_bi, &Ri = (l == N) ? *h.R_mi : *h.R_bi;
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < n; j++) M(i, j) = Qi[(size_t)i * n + j];
+            for (int i = 0; i < m; i++)
+                for (int j = 0; j < m; j++) M(n + i, n + j) = Ri[(size_t)i * m + j];
+        }
+        return M;
+    };
+    auto xblock = [&](const DM &M) {  // the state rows / columns
+        DM X(n, n);
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) X(i, j) = M(i, j);
+        return X;
+    };
     bool ok = true;
     {
         BlockWriter w(tab, 0);
@@ -63,7 +89,8 @@ inline int eadmm_plan_build_shape(Plan &p, const AdmmHost &a, const EadmmGHost &
         w.emit(tr(AB), KS, KX, DENSE);
         w.emit(W2, KS, KS, DENSE);
         w.emit(TS, KS, KS, DENSE);
-        ok = ok && w.structure_ok && w.cursor == LY::INV_TILES;
+        if (!DIAG) w.emit(neg(H3inv(0)), KS, KS, DENSE);
+        ok = ok && w.structure_ok && w.cursor == 2 * KX * KS + 2 * KS * KS + (DIAG ? 0 : KS * KS);
         double *rc = tab.data() + LY::INV_TILES * 16;
         for (int j = 0; j < nm; j++) {
             rc[LY::C_RHO0 * LY::RC + j] = (*h.rho0)[j];
@@ -76,7 +103,7 @@ inline int eadmm_plan_build_shape(Plan &p, const AdmmHost &a, const EadmmGHost &
         for (int j = 0; j < nm; j++) {
             dst[LY::K_RHO * LY::RC + j] = (*h.rho)[(size_t)l * nm + j];
             dst[LY::K_H1I * LY::RC + j] = (*h.H1i)[(size_t)l * nm + j];
-            dst[LY::K_H3I * LY::RC + j] = (*h.H3i)[(size_t)l * nm + j];
+            dst[LY::K_H3I * LY::RC + j] = DIAG ? (*h.H3i)[(size_t)l * nm + j] : 0.0;
             dst[LY::K_LB * LY::RC + j] = lb[j];
             dst[LY::K_UB * LY::RC + j] = ub[j];
         }
@@ -102,20 +129,27 @@ inline int eadmm_plan_build_shape(Plan &p, const AdmmHost &a, const EadmmGHost &
             const DM BiT = tr(Bi[l]);
             w.emit(BiT, KX, KX, LOWER);
             w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
+            if (!DIAG) {
+                w.emit(xblock(H3inv(l + 1)), KX, KX, DENSE);
+                w.emit(neg(mul(AB, H3inv(l))), KX, KS, DENSE);
+            }
             put_K(Ka, l);
             put_K(Kb, l + 1);
+            ok = ok && w.structure_ok && w.cursor == LY::NTS + (DIAG ? 0 : LY::NTX_B);
         } else {  // sweep C: block l
             const int l = 3 * N - s;
             w.emit(Bi[l], KX, KX, UPPER);
             w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : Zero, KX, KX, DENSE);
+            if (!DIAG) w.emit(neg(H3inv(l + 1)), KS, KS, DENSE);
             put_K(Ka, l);
             put_K(Kb, l + 1);
+            ok = ok && w.structure_ok && w.cursor == LY::NTS + (DIAG ? 0 : LY::NTX_C);
         }
-        ok = ok && w.structure_ok && w.cursor == LY::NT;
     }
     if (!ok) { p.why = "MFMA4G packer: block structure mismatch"; return 0; }
     p.KX = KX;
     p.KS = KS;
+    p.general = !DIAG;
     return plan_upload(p, tab);
 }
 
@@ -125,7 +159,7 @@ inline int eadmm_plan_build_shape(Plan &p, const AdmmHost &a, const EadmmGHost &
 // registers - evaluates P1 of iteration k + 1 on the spot to accumulate q2^{k+1}.  The stand-alone P1 sweep ("A") runs
 // once, before iteration 1.  Traffic per iteration and stage: (6 KS + 2 KX) x 512 B (was 10 KS + 2 KX).
 // WANT_Z1: the record's z1 is requested, sweep C then also writes z1^k.
-template <int KX, int KS, int WG_PER_CU, bool WANT_Z1>
+template <int KX, int KS, int WG_PER_CU, bool WANT_Z1, bool DIAG>
 __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const double *__restrict__ tab,
                                                                  const double *__restrict__ x0g,
                                                                  const double *__restrict__ xrg,
@@ -135,7 +169,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                                                                  double *__restrict__ u_out,
                                                                  int *__restrict__ k_out, int *__restrict__ e_out,
                                                                  double *__restrict__ z2_out) {
-    using LY = EadmmGLayout<KX, KS>;
+    using LY = EadmmGLayout<KX, KS, DIAG>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = p.n, m = p.m, nm = n + m, N = p.N;
     for (int i = threadIdx.x; i < LY::INV_D / 2; i += 256)
@@ -318,14 +352,25 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                             q3n[s] = SPCIES_K(Kb, LY::K_RHO, s) * (z2[s] - z1v) + ln[s];
                         }
                     }
+                    if constexpr (DIAG) {
 #pragma unroll
-                    for (int s = 0; s < KS; s++) t[s] = SPCIES_K(Ka, LY::K_H3I, s) * q3c[s];
+                        for (int s = 0; s < KS; s++) t[s] = SPCIES_K(Ka, LY::K_H3I, s) * q3c[s];
 #pragma unroll
-                    for (int s = 0; s < KX; s++) y[s] = (4 * s + g < n) ? SPCIES_K(Kb, LY::K_H3I, s) * q3n[s] : 0.0;
-                    {
+                        for (int s = 0; s < KX; s++) y[s] = (4 * s + g < n) ? SPCIES_K(Kb, LY::K_H3I, s) * q3n[s] : 0.0;
                         int tix = LY::T_NAB;
                         double2 cur;
                         prod<KX, KS, DENSE>(y, t, lds, ao_l, tix, cur);
+                    } else {  // y = Qinv_{l+1} q3_{l+1}[x] - AB H3inv_l q3_l (:184-217; the padded columns of Qinv are zero)
+                        double qx[KX];
+#pragma unroll
+                        for (int s = 0; s < KX; s++) {
+                            y[s] = 0.0;
+                            qx[s] = q3n[s];
+                        }
+                        int tix = LY::NTS;
+                        double2 cur;
+                        prod<KX, KX, DENSE>(y, qx, ch, ao_l, tix, cur);
+                        prod<KX, KS, DENSE>(y, q3c, ch, ao_l, tix, cur);
                     }
                     double mu[KX];
 #pragma unroll
@@ -352,7 +397,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
 #pragma unroll
                 for (int s = 0; s < KX; s++) mun[s] = 0.0;
                 // z3_t, residual, lambda_{t+1} of one stage (:289-320, :371-402) and its term of the next q2 (:97-143)
-                auto finish_stage = [&](int t, const double *K, const double (&mu_sub)[KX], const double (&mu_abt)[KX],
+                auto finish_stage = [&](int t, const double *K, const double *hblk, const double (&mu_sub)[KX], const double (&mu_abt)[KX],
                                         const double (&lam)[KS], const double (&z3o)[KS]) __attribute__((always_inline)) {
                     double v[KS], z1v[KS], ex[KS];  // ex: lambda_{N+2} (t = N) / lambda_0 (t = 0)
                     if (t == N) {
@@ -381,10 +426,26 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                         double2 cur;
                         prod<KS, KX, DENSE>(v, mu_abt, lds, ao_l, tix, cur);
                     }
+                    double z3v[KS];
+                    if constexpr (DIAG) {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) z3v[s] = -SPCIES_K(K, LY::K_H3I, s) * v[s];
+                    } else {  // z3 = -H3inv_t v (:321-366); t = 0 reads the stage-invariant copy
+#pragma unroll
+                        for (int s = 0; s < KS; s++) z3v[s] = 0.0;
+                        double2 cur;
+                        if (t == 0) {
+                            int tix = LY::T_H0;
+                            prod<KS, KS, DENSE>(z3v, v, lds, ao_l, tix, cur);
+                        } else {
+                            int tix = LY::NTS;
+                            prod<KS, KS, DENSE>(z3v, v, hblk, ao_l, tix, cur);
+                        }
+                    }
                     double ln_[KS];
 #pragma unroll
                     for (int s = 0; s < KS; s++) {
-                        const double z3 = -SPCIES_K(K, LY::K_H3I, s) * v[s];
+                        const double z3 = z3v[s];
                         const double r = z2[s] + z3 - z1v[s];
                         ln_[s] = lam[s] + SPCIES_K(K, LY::K_RHO, s) * r;
                         res |= (fabs(r) > tol) | (fabs(z3o[s] - z3) > tol);
@@ -472,14 +533,14 @@ __global__ __launch_bounds__(256, WG_PER_CU) void eadmm_g_kernel(Args p, const d
                         prod<KX, KX, UPPER>(mu, muf, ch, ao_l, tix, cur);
                         prod<KX, KX, DENSE>(mu, mun, ch, ao_l, tix, cur);
                     }
-                    finish_stage(l + 1, Kb, mu, mun, lam, z3o);
+                    finish_stage(l + 1, Kb, ch, mu, mun, lam, z3o);
 #pragma unroll
                     for (int s = 0; s < KX; s++) mun[s] = mu[s];
                     if (l == 0) {
                         double zero[KX];
 #pragma unroll
                         for (int s = 0; s < KX; s++) zero[s] = 0.0;
-                        finish_stage(0, Ka, zero, mun, lamn, z3on);
+                        finish_stage(0, Ka, ch, zero, mun, lamn, z3on);
                     }
                     commit_chunk();
                 }
@@ -532,8 +593,9 @@ inline int eadmm_plan_build(Plan &p, const AdmmHost &a, const EadmmGHost &h) {
     p.ok = false;
     const int KX = (a.n + 3) / 4, KS = (a.n + a.m + 3) / 4;
     if (a.N < 2) { p.why = "N < 2"; return 0; }
-#define X(KKX, KKS) \
-    if (KX == KKX && KS == KKS) return eadmm_plan_build_shape<KKX, KKS>(p, a, h);
+#define X(KKX, KKS)               \
+    if (KX == KKX && KS == KKS)   \
+        return h.diag ? eadmm_plan_build_shape<KKX, KKS, true>(p, a, h) : eadmm_plan_build_shape<KKX, KKS, false>(p, a, h);
     SPCIES_G4_EADMM_SHAPES(X)
 #undef X
     p.why = "MFMA4G EADMM kernel not instantiated for this (ceil(n/4), ceil((n+m)/4))";
@@ -544,11 +606,11 @@ inline size_t eadmm_state_bytes(const Plan &p, const AdmmHost &a, long B) {
     return (size_t)padded_tiles(B) * ((size_t)(3 * a.N + 6) * p.KS + (size_t)a.N * p.KX) * 64 * sizeof(double);
 }
 
-template <int KX, int KS>
+template <int KX, int KS, bool DIAG>
 static int launch_eadmm_g_shape(Plan &pl, const AdmmHost &a, const Args &args, const double *x0, const double *xr,
                                 const double *ur, double *state, double *u, int *k, int *e, double *z1, double *z2,
                                 double *z3, double *lam, hipStream_t st) {
-    using LY = EadmmGLayout<KX, KS>;
+    using LY = EadmmGLayout<KX, KS, DIAG>;
 #ifndef SPCIES_G4_EADMM_WGS_BIG
 #define SPCIES_G4_EADMM_WGS_BIG 2
 #endif
@@ -561,11 +623,15 @@ static int launch_eadmm_g_shape(Plan &pl, const AdmmHost &a, const Args &args, c
     const size_t shmem = (LY::LDS_D + 4 * KS * 64) * sizeof(double);  // + z2 of the previous iteration, per wavefront
     // iteration 1 starts from z3 = lambda = 0 (:85-95); Z3 and LAM are adjacent
     SPCIES_HIP_CHECK(hipMemsetAsync(Z3, 0, (size_t)tiles * (size_t)(2 * N + 4) * KS * 64 * sizeof(double), st));
+    if (shmem > 64 * 1024) {
+        if (z1) SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)eadmm_g_kernel<KX, KS, WGS, true, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        else SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)eadmm_g_kernel<KX, KS, WGS, false, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    }
     if (z1)
-        hipLaunchKernelGGL((eadmm_g_kernel<KX, KS, WGS, true>), dim3((unsigned)wgs), dim3(256), shmem, st, args, pl.d_table, x0, xr,
+        hipLaunchKernelGGL((eadmm_g_kernel<KX, KS, WGS, true, DIAG>), dim3((unsigned)wgs), dim3(256), shmem, st, args, pl.d_table, x0, xr,
                            ur, Z1, Z3, LAM, MU, C2, u, k, e, z2);
     else
-        hipLaunchKernelGGL((eadmm_g_kernel<KX, KS, WGS, false>), dim3((unsigned)wgs), dim3(256), shmem, st, args, pl.d_table, x0, xr,
+        hipLaunchKernelGGL((eadmm_g_kernel<KX, KS, WGS, false, DIAG>), dim3((unsigned)wgs), dim3(256), shmem, st, args, pl.d_table, x0, xr,
                            ur, Z1, Z3, LAM, MU, C2, u, k, e, z2);
     SPCIES_HIP_CHECK(hipGetLastError());
     const long tz = args.B * (long)(N + 1) * nm;
@@ -589,9 +655,10 @@ inline int launch_eadmm_g(Plan &pl, const AdmmHost &a, const double *x0, const d
                           hipStream_t st) {
     if (!pl.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant unavailable: %s", pl.why.c_str());
     Args args{a.n, a.m, a.N, a.k_max, a.tol, B, ref_stride};
-#define X(KKX, KKS)                     \
-    if (pl.KX == KKX && pl.KS == KKS)   \
-        return launch_eadmm_g_shape<KKX, KKS>(pl, a, args, x0, xr, ur, state, u, k, e, z1, z2, z3, lam, st);
+#define X(KKX, KKS)                                                                                                        \
+    if (pl.KX == KKX && pl.KS == KKS)                                                                                      \
+        return pl.general ? launch_eadmm_g_shape<KKX, KKS, false>(pl, a, args, x0, xr, ur, state, u, k, e, z1, z2, z3, lam, st) \
+                          : launch_eadmm_g_shape<KKX, KKS, true>(pl, a, args, x0, xr, ur, state, u, k, e, z1, z2, z3, lam, st);
     SPCIES_G4_EADMM_SHAPES(X)
 #undef X
     return fail(SPCIES_HIP_ENOSUP, "MFMA4G EADMM kernel not instantiated for KX=%d KS=%d", pl.KX, pl.KS);

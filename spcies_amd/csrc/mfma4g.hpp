@@ -117,6 +117,7 @@ struct Plan {
     bool ok = false;
     std::string why = "not built";
     int KX = 0, KS = 0;
+    bool general = false;  // EADMM: general Q, R (IS_DIAG == 0)
     double *d_table = nullptr;
     size_t table_bytes = 0;
     int num_cu = 256;

@@ -52,6 +52,8 @@ struct Solver {
     int *d_idx = nullptr;
     EadmmDev edev{};
     std::vector<double> e_rho, e_rho0, e_rhos, e_LB0, e_UB0, e_LBs, e_UBs, e_S, e_H1i, e_W2, e_H3i;  // EADMM-only
+    bool e_general = false;                                    // EADMM with general Q, R (IS_DIAG == 0): these instead of e_H3i
+    std::vector<double> e_Qbi, e_Qmi, e_Rbi, e_Rmi, e_ABbi, e_ABmi;
     bool is_soc() const { return (formulation == SPCIES_ELLIPMPC && submethod == 1) || is_hmpc(); }  // 6-field (z, s, ...) record
     bool is_hmpc() const { return formulation == SPCIES_HMPC && submethod == 2; }    // split (code_HMPC_ADMM_split_C.c)
     bool is_cs() const { return formulation == SPCIES_MPCT && method == SPCIES_ADMM && submethod == 3; }  // code_MPCT_ADMM_cs_C.c
@@ -529,7 +531,17 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         want.push_back({SPCIES_A_UB_S, nm, &s.e_UBs});
         want.push_back({SPCIES_A_H1I, (N + 1) * nm, &s.e_H1i});
         want.push_back({SPCIES_A_W2, nm * nm, &s.e_W2});
-        want.push_back({SPCIES_A_H3I, (N + 1) * nm, &s.e_H3i});
+        s.e_general = (h.flags & 32u) != 0;
+        if (!s.e_general) {
+            want.push_back({SPCIES_A_H3I, (N + 1) * nm, &s.e_H3i});
+        } else {
+            want.push_back({SPCIES_A_Q_BI, n * n, &s.e_Qbi});
+            want.push_back({SPCIES_A_Q_MI, n * n, &s.e_Qmi});
+            want.push_back({SPCIES_A_R_BI, m * m, &s.e_Rbi});
+            want.push_back({SPCIES_A_R_MI, m * m, &s.e_Rmi});
+            want.push_back({SPCIES_A_AB_BI, n * nm, &s.e_ABbi});
+            want.push_back({SPCIES_A_AB_MI, n * nm, &s.e_ABmi});
+        }
     } else if (h.method == SPCIES_ADMM) {
         want.push_back({SPCIES_A_HI, (N - 1) * nm, &a.Hi});
         want.push_back({SPCIES_A_HI_0, m, &a.Hi_0});
@@ -1201,6 +1213,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
             return g4::launch_eadmm_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f[0], f[1], f[2], f[3], st);
         }
         if (ev != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "EADMM: variants STREAM and MFMA4G are built");
+        if (s.e_general) return fail(SPCIES_HIP_ENOSUP, "EADMM with general Q, R: the MFMA4G variant is built (STREAM covers the diagonal path)");
         if (!eadmm_stream_shape_built(s.host.n, s.host.m))
             return fail(SPCIES_HIP_ENOSUP, "EADMM STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
@@ -1437,6 +1450,8 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     }
     if (s->method == SPCIES_EADMM) {
         g4::EadmmGHost eh{&s->e_rho, &s->e_rho0, &s->e_rhos, &s->e_LB0, &s->e_UB0, &s->e_LBs, &s->e_UBs, &s->e_S, &s->e_H1i, &s->e_W2, &s->e_H3i};
+        eh.diag = !s->e_general;
+        eh.Q_bi = &s->e_Qbi; eh.Q_mi = &s->e_Qmi; eh.R_bi = &s->e_Rbi; eh.R_mi = &s->e_Rmi;
         rc = g4::eadmm_plan_build(s->g4plan, s->host, eh);
         if (rc) return rc;
     }

@@ -356,6 +356,44 @@ def test_mpct_vs_reference_template_fixture(variant, golden_dir):
     assert np.abs(u - g["u"]).max() <= 1e-9 and np.abs(sol.z1 - g["z1"]).max() <= 1e-9
 
 
+# MPCT EADMM with general (non-diagonal) Q, R - IS_DIAG == 0 of the generated solver (code_MPCT_EADMM_C.c:184-217, 321-366)
+def test_mpct_general_qr_reference_test_instance(golden_dir):
+    """The tester's QP through the general-Q/R kernels (force_diagonal off): the reference test's z_opt, and the oracle."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver("C1_MPCT_nd0")
+    assert s.variant == "mfma4g" and not v["is_diag"]
+    st = benchmarks.tester_status(cfg.sys)
+    u, k, e, sol = s(st.x, st.xr, st.ur)
+    with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
+        z_opt = np.array(json.load(f)["test_MPCT_EADMM"])
+    assert e == 1 and np.abs(sol.z1 - z_opt).max() <= TOL_OPT
+    O = oracle.eadmm_mpct_batch(v, st.x[None], st.xr, st.ur)
+    _compare_mpct("mfma4g", (u[None], np.array([k]), np.array([e]),
+                             type(sol)(z1=sol.z1[None], z2=sol.z2[None], z3=sol.z3[None], lam=sol.lam[None])), O)
+    with pytest.raises(Exception, match="general Q, R"):
+        s.set_variant("stream")
+        s(st.x, st.xr, st.ur)
+
+
+@pytest.mark.parametrize("cfg_name,B,overrides", [("C1_MPCT_nd", 100, {}), ("C4_nd", 90, {}), ("C4_nd", 40, dict(tol=1e-5, k_max=4000))])
+def test_mpct_general_qr_seeded_batch_vs_oracle(cfg_name, B, overrides, golden_dir):
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver(cfg_name, "mfma4g", **overrides)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    got = s(x0, xr, ur)
+    _compare_mpct("mfma4g", got, oracle.eadmm_mpct_batch(v, x0, xr, ur))
+    nosol = s(x0[:33], xr[:33], ur[:33], want_sol=False)
+    assert np.array_equal(nosol[0], got[0][:33]) and np.array_equal(nosol[1], got[1][:33])
+    if not overrides:  # and the compiled reference template's outputs on its fixture
+        g = np.load(os.path.join(golden_dir, f"template_{cfg_name}.npz"))
+        u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
+        assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
+        same = k == g["k"]
+        assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z1 - g["z1"])[same].max() <= 1e-9
+
+
 # ----------------------------------------------------------------------------------------------
 # ellipMPC ADMM soc: STREAM variant (CSR SpMV + CSC-LDL solve + SOC projection) -> bit-exact
 # ----------------------------------------------------------------------------------------------
