@@ -195,3 +195,138 @@ int oracle_fista_banded_batch(const fista_banded_data *d, long B, const double *
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * TIME_VARYING == 1: the update phase that computes the solver's ingredients from the model handed in with
+ * every call (code_laxMPC_FISTA_C.c:117-262, code_equMPC_FISTA_C.c:113-248), then the same iteration.
+ * Inputs as the 9-argument gateway: A [n][n] and B [n][m] COLUMN-major, Q [n], R [m] diagonals, LB / UB [n+m].
+ * T (negated diagonal) and Ti = -1/diag(T) are the only controller constants (cons_laxMPC_FISTA_C.m:94-108).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    double *AB, *Alpha, *Beta, *Q, *R, *QRi; /* outputs, sized as in fista_banded_data */
+} fista_tv_out;
+
+void oracle_fista_tv_update(int n, int m, int N, int terminal, const double *A_in, const double *B_in, const double *Q_in,
+                            const double *R_in, const double *Ti, fista_tv_out *o) {
+    const int nm = n + m;
+    double *Q_i = (double *)calloc((size_t)n, sizeof(double));
+    double *R_i = (double *)calloc((size_t)m, sizeof(double));
+    double *AQiAt = (double *)calloc((size_t)n * n, sizeof(double));
+    double *BRiBt = (double *)calloc((size_t)n * n, sizeof(double));
+#define TAB(i, j) (o->AB[(size_t)(i) * nm + (j)])
+#define TALPHA(l, i, j) (o->Alpha[((size_t)(l) * n + (i)) * n + (j)])
+#define TBETA(l, i, j) (o->Beta[((size_t)(l) * n + (i)) * n + (j)])
+    memset(o->Alpha, 0, sizeof(double) * (size_t)(N - 1) * n * n);
+    memset(o->Beta, 0, sizeof(double) * (size_t)N * n * n);
+    /* :107-133 */
+    for (int i = 0; i < n; i++) {
+        o->Q[i] = Q_in[i];
+        Q_i[i] = 1 / (o->Q[i]);
+        for (int j = 0; j < n; j++) TAB(i, j) = A_in[i + j * n];
+        for (int j = 0; j < m; j++) TAB(i, n + j) = B_in[i + j * n];
+    }
+    for (int j = 0; j < m; j++) {
+        o->R[j] = R_in[j];
+        R_i[j] = 1 / (o->R[j]);
+    }
+    for (int i = 0; i < nm; i++) o->QRi[i] = (i < n) ? -Q_i[i] : -R_i[i - n];
+    /* :146-155 */
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            for (int k = 0; k < n; k++) AQiAt[i * n + j] += A_in[i + k * n] * Q_i[k] * A_in[j + k * n];
+            for (int k = 0; k < m; k++) BRiBt[i * n + j] += B_in[i + k * n] * R_i[k] * B_in[j + k * n];
+        }
+    /* Beta{0} :158-176 (the equMPC template also runs j below i: those entries come out zero and are never read) */
+    for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++) {
+            TBETA(0, i, j) = BRiBt[i * n + j];
+            for (int l = 1; l <= i; l++) TBETA(0, i, j) -= TBETA(0, l - 1, i) * TBETA(0, l - 1, j);
+            if (i == j) {
+                TBETA(0, i, i) += Q_i[i];
+                TBETA(0, i, i) = 1 / sqrt(TBETA(0, i, i));
+            } else {
+                TBETA(0, i, j) = TBETA(0, i, j) * TBETA(0, i, i);
+            }
+        }
+    for (int h = 0; h < N - 1; h++) {
+        if (h >= 1) { /* Beta{h} :194-219 */
+            for (int i = 0; i < n; i++)
+                for (int j = i; j < n; j++) {
+                    TBETA(h, i, j) = AQiAt[i * n + j] + BRiBt[i * n + j];
+                    for (int k = 0; k < n; k++) TBETA(h, i, j) -= TALPHA(h - 1, k, i) * TALPHA(h - 1, k, j);
+                    for (int l = 1; l <= i; l++) TBETA(h, i, j) -= TBETA(h, l - 1, i) * TBETA(h, l - 1, j);
+                    if (i == j) {
+                        TBETA(h, i, i) += Q_i[i];
+                        TBETA(h, i, i) = 1 / sqrt(TBETA(h, i, i));
+                    } else {
+                        TBETA(h, i, j) = TBETA(h, i, j) * TBETA(h, i, i);
+                    }
+                }
+        }
+        /* Alpha{h} :179-191, :223-236 */
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                TALPHA(h, i, j) = -Q_i[i] * TAB(j, i);
+                for (int l = 1; l <= i; l++) TALPHA(h, i, j) -= TBETA(h, l - 1, i) * TALPHA(h, l - 1, j);
+                TALPHA(h, i, j) = TALPHA(h, i, j) * TBETA(h, i, i);
+            }
+    }
+    /* Beta{N-1} :241-262 (laxMPC: the diagonal terminal weight enters through Ti = -1/diag(T)) */
+    for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++) {
+            TBETA(N - 1, i, j) = AQiAt[i * n + j] + BRiBt[i * n + j];
+            for (int k = 0; k < n; k++) TBETA(N - 1, i, j) -= TALPHA(N - 2, k, i) * TALPHA(N - 2, k, j);
+            for (int l = 1; l <= i; l++) TBETA(N - 1, i, j) -= TBETA(N - 1, l - 1, i) * TBETA(N - 1, l - 1, j);
+            if (i == j) {
+                if (terminal) TBETA(N - 1, i, i) -= Ti[i];
+                TBETA(N - 1, i, i) = 1 / sqrt(TBETA(N - 1, i, i));
+            } else {
+                TBETA(N - 1, i, j) = TBETA(N - 1, i, j) * TBETA(N - 1, i, i);
+            }
+        }
+    /* :266-271 */
+    for (int i = 0; i < n; i++) o->Q[i] = -o->Q[i];
+    for (int i = 0; i < m; i++) o->R[i] = -o->R[i];
+#undef TAB
+#undef TALPHA
+#undef TBETA
+    free(Q_i); free(R_i); free(AQiAt); free(BRiBt);
+}
+
+/* Batch driver of the time-varying solver.  model is [B][n*n + n*m + n + m + 2(n+m)] = (A, B, Q, R, LB, UB) per instance
+ * when model_stride != 0, else one shared model.  fac_out (optional): instance 0's Alpha then Beta. */
+int oracle_fista_tv_batch(int n, int m, int N, int k_max, int terminal, double tol, const double *T, const double *Ti, long B,
+                          const double *x0, const double *xr, const double *ur, int ref_stride, const double *model,
+                          int model_stride, double *u, int *k, int *e_flag, double *z, double *lam, double *fac_out) {
+    const int nm = n + m;
+    const size_t dim = (size_t)N * nm - (terminal ? 0 : (size_t)n);
+    const size_t msz = (size_t)n * n + (size_t)n * m + n + m + 2 * (size_t)nm;
+    fista_tv_out o;
+    o.AB = (double *)calloc((size_t)n * nm, sizeof(double));
+    o.Alpha = (double *)calloc((size_t)(N - 1) * n * n, sizeof(double));
+    o.Beta = (double *)calloc((size_t)N * n * n, sizeof(double));
+    o.Q = (double *)calloc((size_t)n, sizeof(double));
+    o.R = (double *)calloc((size_t)m, sizeof(double));
+    o.QRi = (double *)calloc((size_t)nm, sizeof(double));
+    int rc = 0;
+    for (long i = 0; i < B && !rc; i++) {
+        const double *mi = model_stride ? model + (size_t)i * msz : model;
+        const double *A_in = mi, *B_in = A_in + (size_t)n * n, *Q_in = B_in + (size_t)n * m, *R_in = Q_in + n,
+                     *LB = R_in + m, *UB = LB + nm;
+        oracle_fista_tv_update(n, m, N, terminal, A_in, B_in, Q_in, R_in, Ti, &o);
+        if (i == 0 && fac_out) {
+            memcpy(fac_out, o.Alpha, sizeof(double) * (size_t)(N - 1) * n * n);
+            memcpy(fac_out + (size_t)(N - 1) * n * n, o.Beta, sizeof(double) * (size_t)N * n * n);
+        }
+        fista_banded_data d;
+        d.n = n; d.m = m; d.N = N; d.k_max = k_max; d.terminal = terminal; d.tol = tol;
+        d.AB = o.AB; d.Alpha = o.Alpha; d.Beta = o.Beta; d.Q = o.Q; d.R = o.R; d.QRi = o.QRi; d.T = T; d.Ti = Ti;
+        d.LB = LB; d.UB = UB;
+        const double *xri = ref_stride ? xr + (size_t)i * n : xr;
+        const double *uri = ref_stride ? ur + (size_t)i * m : ur;
+        rc = oracle_fista_banded_solve(&d, x0 + (size_t)i * n, xri, uri, u + (size_t)i * m, k + i, e_flag + i,
+                                       z ? z + (size_t)i * dim : NULL, lam ? lam + (size_t)i * (size_t)N * n : NULL);
+    }
+    free(o.AB); free(o.Alpha); free(o.Beta); free(o.Q); free(o.R); free(o.QRi);
+    return rc;
+}

@@ -190,6 +190,39 @@ def fista_banded_batch(v, x0, xr, ur, want_sol=True, quantize=False):
     return u, k, e, z, lam
 
 
+def fista_tv_batch(v, x0, xr, ur, model, per_instance, want_sol=True, want_factors=False):
+    """Time-varying lax/equ MPC FISTA (update phase + iteration).  ``v``: the time-varying ingredients (n, m, N, Tdiag, Ti, tol,
+    k_max, terminal); ``model``: rows from :func:`pack_tv_model`.  Returns ``u, k, e_flag, z, lam`` (+ Alpha, Beta of instance 0)."""
+    n, m, N = int(v["n"]), int(v["m"]), int(v["N"])
+    terminal = bool(v.get("terminal", True))
+    x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
+    B = x0.shape[0]
+    xr = np.ascontiguousarray(np.asarray(xr, dtype=float))
+    ur = np.ascontiguousarray(np.asarray(ur, dtype=float))
+    stride = 1 if xr.ndim == 2 else 0
+    T = np.ascontiguousarray(np.asarray(v["Tdiag"], float))
+    Ti = np.ascontiguousarray(np.asarray(v["Ti"], float))
+    model = np.ascontiguousarray(model)
+    dim = N * (n + m) - (0 if terminal else n)
+    u = np.zeros((B, m)); k = np.zeros(B, dtype=np.int32); e = np.zeros(B, dtype=np.int32)
+    z = np.zeros((B, dim)) if want_sol else None
+    lam = np.zeros((B, N * n)) if want_sol else None
+    fac = np.zeros((2 * N - 1) * n * n) if want_factors else None
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    lib = _lib()
+    lib.oracle_fista_tv_batch.restype = C.c_int
+    rc = lib.oracle_fista_tv_batch(C.c_int(n), C.c_int(m), C.c_int(N), C.c_int(int(v["k_max"])), C.c_int(int(terminal)),
+                                   C.c_double(float(v["tol"])), _dp(T), _dp(Ti), C.c_long(B), _dp(x0), _dp(xr), _dp(ur),
+                                   C.c_int(stride), _dp(model), C.c_int(1 if per_instance else 0), _dp(u), ip(k), ip(e),
+                                   _dp(z) if want_sol else None, _dp(lam) if want_sol else None, _dp(fac) if want_factors else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle_fista_tv_batch failed rc={rc}")
+    out = (u, k, e, z, lam)
+    if want_factors:
+        return out + (fac[:(N - 1) * n * n].reshape(N - 1, n, n), fac[(N - 1) * n * n:].reshape(N, n, n))
+    return out
+
+
 _EADMM_ARRAYS = (("rho", "rho_mat"), ("rho_0", "rho_0"), ("rho_s", "rho_s"), ("LB", "LB"), ("UB", "UB"), ("LB_0", "LB0"),
                  ("UB_0", "UB0"), ("LB_s", "LBs"), ("UB_s", "UBs"), ("AB", "AB"), ("T", "T"), ("S", "S"),
                  ("Alpha", "Alpha"), ("Beta", "Beta"), ("H1i", "H1i"), ("W2", "W2"), ("H3i", "H3i"))

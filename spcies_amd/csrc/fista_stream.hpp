@@ -22,7 +22,31 @@ struct FistaDev {
 
 #pragma clang fp contract(off)
 
-template <int n, int m, bool TERMINAL, bool EXACT>
+// Row offsets of the per-instance constants of the time-varying FISTA solvers inside their scratch [row][Bp]
+struct FistaTvLayout {
+    int AB, Alpha, Beta, Q, R, QRi, LB, UB, AQiAt, BRiBt, rows;
+};
+__host__ __device__ inline FistaTvLayout fista_tv_layout(int n, int m, int N) {
+    FistaTvLayout L;
+    const int nm = n + m;
+    int r = 0;
+    L.AB = r; r += n * nm;
+    L.Alpha = r; r += (N - 1) * n * n;
+    L.Beta = r; r += N * n * n;
+    L.Q = r; r += n;
+    L.R = r; r += m;
+    L.QRi = r; r += nm;
+    L.LB = r; r += nm;
+    L.UB = r; r += nm;
+    L.AQiAt = r; r += n * n;
+    L.BRiBt = r; r += n * n;
+    L.rows = r;
+    return L;
+}
+
+// TV: TIME_VARYING == 1 (code_laxMPC_FISTA_C.c:18, 42-56, 83-262): AB, Alpha, Beta, Q, R, QRi, LB, UB are this instance's own rows
+// of the scratch TVS (written by fista_tv_update_kernel), read through a buffer resource; T, Ti stay controller constants.
+template <int n, int m, bool TERMINAL, bool EXACT, bool TV = false>
 __global__ __launch_bounds__(64) void fista_stream_kernel(FistaDev c, const double *__restrict__ C,
                                                           const double *__restrict__ x0g,
                                                           const double *__restrict__ xrg,
@@ -30,14 +54,24 @@ __global__ __launch_bounds__(64) void fista_stream_kernel(FistaDev c, const doub
                                                           long Bp, double *__restrict__ Y, double *__restrict__ LAM,
                                                           double *__restrict__ DL, double *__restrict__ ZS,
                                                           double *__restrict__ u_out, int *__restrict__ k_out,
-                                                          int *__restrict__ e_out) {
+                                                          int *__restrict__ e_out, const double *__restrict__ TVS = nullptr) {
     constexpr int nm = n + m;
     const long t = (long)blockIdx.x * 64 + threadIdx.x;
     if (t >= B) return;
     const int N = c.N;
     const double tol = c.tol;
-    const double *cAB = C + c.AB, *cAlpha = C + c.Alpha, *cBeta = C + c.Beta, *cQ = C + c.Q, *cR = C + c.R,
-                 *cQRi = C + c.QRi, *cT = C + c.T, *cTi = C + c.Ti, *cLB = C + c.LB, *cUB = C + c.UB;
+    const FistaTvLayout tl = fista_tv_layout(n, m, N);
+    auto K = [&](int shared_off, int tv_row) {
+        if constexpr (TV) {
+            return KArr<true>{__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(TVS), 0, -1, 0x00020000), (unsigned)tv_row,
+                              (unsigned)(Bp * 8), (unsigned)(t * 8)};
+        } else {
+            return KArr<false>{C + shared_off};
+        }
+    };
+    const KArr<TV> cAB = K(c.AB, tl.AB), cAlpha = K(c.Alpha, tl.Alpha), cBeta = K(c.Beta, tl.Beta), cQ = K(c.Q, tl.Q), cR = K(c.R, tl.R),
+                   cQRi = K(c.QRi, tl.QRi), cLB = K(c.LB, tl.LB), cUB = K(c.UB, tl.UB);
+    const double *cT = C + c.T, *cTi = C + c.Ti;
 
     // ---- per-instance setup (code_laxMPC_FISTA_C.c:274-289)
     double xr[n], b[n], q[nm], qT[n];
@@ -139,10 +173,11 @@ __global__ __launch_bounds__(64) void fista_stream_kernel(FistaDev c, const doub
                 res = res || (a > tol);
                 d[j] = acc;
             }
-            const double *Bl = cBeta + (long)l * n * n;
-            const double *Al = cAlpha + (long)(l - 1) * n * n;
+            const KArr<TV> Bl = cBeta + (long)l * n * n;
+            const KArr<TV> Al = cAlpha + (long)(l - 1) * n * n;
 #pragma unroll
             for (int j = 0; j < n; j++) {
+                if constexpr (TV) asm volatile("" ::: "memory");  // keeps a whole sweep's per-lane loads from being hoisted (and spilled)
                 double acc = d[j];
                 if (l > 0) {
 #pragma unroll
@@ -177,13 +212,14 @@ __global__ __launch_bounds__(64) void fista_stream_kernel(FistaDev c, const doub
         // ================= backward sweep: d = W^-1 r, lambda, y (:357-385) =================
         double dn[n];
         for (int l = N - 1; l >= 0; l--) {
-            const double *Bl = cBeta + (long)l * n * n;
-            const double *Al = cAlpha + (long)l * n * n;
+            const KArr<TV> Bl = cBeta + (long)l * n * n;
+            const KArr<TV> Al = cAlpha + (long)l * n * n;
             double d[n];
 #pragma unroll
             for (int j = 0; j < n; j++) d[j] = (l == N - 1) ? dp[j] : Dt[((long)l * n + j) * Bp];
 #pragma unroll
             for (int j = n - 1; j >= 0; j--) {
+                if constexpr (TV) asm volatile("" ::: "memory");
                 double acc = d[j];
                 if (l < N - 1) {
 #pragma unroll
@@ -210,6 +246,107 @@ __global__ __launch_bounds__(64) void fista_stream_kernel(FistaDev c, const doub
     for (int j = 0; j < m; j++) u_out[t * m + j] = u0[j];
     k_out[t] = k;
     e_out[t] = flag;
+}
+
+// Update phase of the time-varying FISTA solvers (code_laxMPC_FISTA_C.c:107-271, code_equMPC_FISTA_C.c:105-255): from the model
+// handed in with the call - A [n][n], B [n][m] column-major, Q, R diagonals, LB, UB, packed per instance in `model` (one
+// shared model when model_stride == 0) - to AB, QRi, the banded Cholesky factors Alpha / Beta of W = G H^-1 G' (no rho here) and
+// the negated Q, R, in the instance's rows of the scratch.  One lane per instance, the reference's operation order.
+template <int n, int m, bool TERMINAL>
+__global__ __launch_bounds__(64) void fista_tv_update_kernel(int N, const double *__restrict__ Ti, const double *__restrict__ model,
+                                                             long model_stride, long B, long Bp, double *__restrict__ TVS) {
+    constexpr int nm = n + m;
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    if (t >= B) return;
+    const FistaTvLayout tl = fista_tv_layout(n, m, N);
+    const double *A_in = model + t * model_stride, *B_in = A_in + n * n, *Q_in = B_in + n * m, *R_in = Q_in + n,
+                 *LB_in = R_in + m, *UB_in = LB_in + nm;
+    double *S = TVS + t;
+#define ROW(base, i) S[(long)((base) + (i)) * Bp]
+#define TBETA(h, i, j) ROW(tl.Beta, ((h) * n + (i)) * n + (j))
+#define TALPHA(h, i, j) ROW(tl.Alpha, ((h) * n + (i)) * n + (j))
+    double Q_i[n], R_i[m];
+    for (int i = 0; i < (N - 1) * n * n; i++) ROW(tl.Alpha, i) = 0.0;
+    for (int i = 0; i < N * n * n; i++) ROW(tl.Beta, i) = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        Q_i[i] = 1 / Q_in[i];
+        for (int j = 0; j < n; j++) ROW(tl.AB, i * nm + j) = A_in[i + j * n];
+        for (int j = 0; j < m; j++) ROW(tl.AB, i * nm + n + j) = B_in[i + j * n];
+    }
+#pragma unroll
+    for (int j = 0; j < m; j++) R_i[j] = 1 / R_in[j];
+#pragma unroll
+    for (int j = 0; j < nm; j++) {
+        ROW(tl.QRi, j) = (j < n) ? -Q_i[j < n ? j : 0] : -R_i[j >= n ? j - n : 0];
+        ROW(tl.LB, j) = LB_in[j];
+        ROW(tl.UB, j) = UB_in[j];
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int k = 0; k < n; k++) a += A_in[i + k * n] * Q_i[k] * A_in[j + k * n];
+#pragma unroll
+            for (int k = 0; k < m; k++) b += B_in[i + k * n] * R_i[k] * B_in[j + k * n];
+            ROW(tl.AQiAt, i * n + j) = a;
+            ROW(tl.BRiBt, i * n + j) = b;
+        }
+    for (int i = 0; i < n; i++)  // Beta{0}
+        for (int j = i; j < n; j++) {
+            double v = ROW(tl.BRiBt, i * n + j);
+            for (int l = 1; l <= i; l++) v -= TBETA(0, l - 1, i) * TBETA(0, l - 1, j);
+            if (i == j) {
+                v += Q_i[i];
+                v = 1 / sqrt(v);
+            } else {
+                v = v * TBETA(0, i, i);
+            }
+            TBETA(0, i, j) = v;
+        }
+    for (int h = 0; h < N - 1; h++) {
+        if (h >= 1) {
+            for (int i = 0; i < n; i++)
+                for (int j = i; j < n; j++) {
+                    double v = ROW(tl.AQiAt, i * n + j) + ROW(tl.BRiBt, i * n + j);
+                    for (int k = 0; k < n; k++) v -= TALPHA(h - 1, k, i) * TALPHA(h - 1, k, j);
+                    for (int l = 1; l <= i; l++) v -= TBETA(h, l - 1, i) * TBETA(h, l - 1, j);
+                    if (i == j) {
+                        v += Q_i[i];
+                        v = 1 / sqrt(v);
+                    } else {
+                        v = v * TBETA(h, i, i);
+                    }
+                    TBETA(h, i, j) = v;
+                }
+        }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                double v = -Q_i[i] * ROW(tl.AB, j * nm + i);
+                for (int l = 1; l <= i; l++) v -= TBETA(h, l - 1, i) * TALPHA(h, l - 1, j);
+                TALPHA(h, i, j) = v * TBETA(h, i, i);
+            }
+    }
+    for (int i = 0; i < n; i++)  // Beta{N-1}
+        for (int j = i; j < n; j++) {
+            double v = ROW(tl.AQiAt, i * n + j) + ROW(tl.BRiBt, i * n + j);
+            for (int k = 0; k < n; k++) v -= TALPHA(N - 2, k, i) * TALPHA(N - 2, k, j);
+            for (int l = 1; l <= i; l++) v -= TBETA(N - 1, l - 1, i) * TBETA(N - 1, l - 1, j);
+            if (i == j) {
+                if constexpr (TERMINAL) v -= Ti[i];
+                v = 1 / sqrt(v);
+            } else {
+                v = v * TBETA(N - 1, i, i);
+            }
+            TBETA(N - 1, i, j) = v;
+        }
+#pragma unroll
+    for (int i = 0; i < n; i++) ROW(tl.Q, i) = -Q_in[i];
+#pragma unroll
+    for (int i = 0; i < m; i++) ROW(tl.R, i) = -R_in[i];
+#undef ROW
+#undef TBETA
+#undef TALPHA
 }
 
 }  // namespace spcies

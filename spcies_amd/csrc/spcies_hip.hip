@@ -511,8 +511,12 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     }
     s.tv = (h.flags & 4u) != 0;
     if (s.tv) {
-        if (h.method != SPCIES_ADMM || !banded) return fail(SPCIES_HIP_ENOSUP, "time-varying: built for laxMPC / equMPC ADMM only");
-        want = {{SPCIES_A_T, n * n, &a.T}, {SPCIES_A_T_RHO_I, n * n, &a.Hi_N}};  // Hi_N = T_rho_i (code_laxMPC_ADMM_C.c:123)
+        if ((h.method != SPCIES_ADMM && h.method != SPCIES_FISTA) || !banded || ellip_admm)
+            return fail(SPCIES_HIP_ENOSUP, "time-varying: built for the laxMPC / equMPC ADMM and FISTA solvers");
+        if (h.method == SPCIES_ADMM)
+            want = {{SPCIES_A_T, n * n, &a.T}, {SPCIES_A_T_RHO_I, n * n, &a.Hi_N}};  // Hi_N = T_rho_i (code_laxMPC_ADMM_C.c:123)
+        else  // FISTA: the diagonal terminal weight and its inverse are the only constants (cons_laxMPC_FISTA_C.m:94-108)
+            want = {{SPCIES_A_TDIAG, n, &s.Td}, {SPCIES_A_TI, n, &s.Ti}};
     }
     if (h.method != SPCIES_EADMM && !s.tv) {
         want.push_back({SPCIES_A_Q, n, &a.Q});
@@ -788,6 +792,54 @@ static int launch_fista_nm(Solver &s, const double *x0, const double *xr, const 
         hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, Y, Bp, B, (int)Nn, lam);
     }
     SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Time-varying lax/equ FISTA: update phase (per-instance banded Cholesky, fista_tv_update_kernel) + the STREAM iteration reading
+// the instance's own constants.  Large batches are split so that one launch's constants stay below the 4 GB a buffer
+// resource can address.
+template <int n, int m>
+static int launch_fista_tv_nm(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, const double *model,
+                              int model_stride, long B, double *u, int *k, int *e, double *z, double *lam, hipStream_t st) {
+    const int N = s.host.N;
+    const FistaTvLayout tl = fista_tv_layout(n, m, N);
+    const bool want_sol = (z || lam);
+    const size_t Nn = (size_t)N * n, dim = (size_t)s.host.dim();
+    const size_t rows_stream = 3 * Nn + (want_sol ? dim : 0);
+    long chunk = (long)((3900ull << 20) / ((size_t)tl.rows * 8)) / 64 * 64;
+    if (chunk > B) chunk = (B + 63) / 64 * 64;
+    int rc = ensure_scratch(s, (rows_stream + (size_t)tl.rows) * (size_t)chunk * sizeof(double));
+    if (rc) return rc;
+    for (long b0 = 0; b0 < B; b0 += chunk) {
+        const long Bc = std::min(chunk, B - b0), Bp = (Bc + 63) / 64 * 64;
+        double *Y = s.d_scratch, *LAM = Y + Nn * Bp, *DL = LAM + Nn * Bp;
+        double *ZS = want_sol ? DL + Nn * Bp : nullptr;
+        double *TVS = s.d_scratch + rows_stream * Bp;
+        const double *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
+        const double *mc = model_stride ? model + b0 * (long)model_stride : model;
+        dim3 grid((unsigned)(Bp / 64)), block(64);
+        if (s.host.terminal) {
+            hipLaunchKernelGGL((fista_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride,
+                               Bc, Bp, TVS);
+            hipLaunchKernelGGL((fista_stream_kernel<n, m, true, true, true>), grid, block, 0, st, s.fdev, s.d_consts, x0 + b0 * n, xrc,
+                               urc, ref_stride, Bc, Bp, Y, LAM, DL, ZS, u + b0 * m, k + b0, e + b0, TVS);
+        } else {
+            hipLaunchKernelGGL((fista_tv_update_kernel<n, m, false>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride,
+                               Bc, Bp, TVS);
+            hipLaunchKernelGGL((fista_stream_kernel<n, m, false, true, true>), grid, block, 0, st, s.fdev, s.d_consts, x0 + b0 * n, xrc,
+                               urc, ref_stride, Bc, Bp, Y, LAM, DL, ZS, u + b0 * m, k + b0, e + b0, TVS);
+        }
+        SPCIES_HIP_CHECK(hipGetLastError());
+        if (z) {
+            dim3 tg((unsigned)(Bp / 64), (unsigned)((dim + 63) / 64));
+            hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, ZS, Bp, Bc, (int)dim, z + b0 * dim);
+        }
+        if (lam) {
+            dim3 tg((unsigned)(Bp / 64), (unsigned)((Nn + 63) / 64));
+            hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, Y, Bp, Bc, (int)Nn, lam + b0 * Nn);
+        }
+        SPCIES_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1221,6 +1273,16 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         return launch_eadmm(s, x0, xr, ur, ref_stride, B, u, k, e, f[0], f[1], f[2], f[3], st);
     }
     double *z = f[0], *v = (s.method == SPCIES_FISTA) ? nullptr : f[1], *lam = (s.method == SPCIES_FISTA) ? f[1] : f[2];
+    if (s.method == SPCIES_FISTA && s.tv) {
+        if (!extra) return fail(SPCIES_HIP_EINVAL, "time-varying solvers take A, B, Q, R, LB, UB with every call (extra): Spcies:laxMPC:nrhs:number");
+        if (extra_stride != 0 && extra_stride != s.tv_model_size())
+            return fail(SPCIES_HIP_EINVAL, "time-varying: extra_stride must be 0 (shared model) or %d", s.tv_model_size());
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
+            return fail(SPCIES_HIP_ENOSUP, "time-varying: only the STREAM variant is built");
+        if (s.host.n == 6 && s.host.m == 2) return launch_fista_tv_nm<6, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, lam, st);
+        if (s.host.n == 12 && s.host.m == 2) return launch_fista_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, lam, st);
+        return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
+    }
     if (s.method == SPCIES_FISTA) {
         const int fv = resolve_variant(s);
         if (fv == SPCIES_VARIANT_MFMA4R) {
@@ -1455,7 +1517,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         rc = g4::eadmm_plan_build(s->g4plan, s->host, eh);
         if (rc) return rc;
     }
-    if (s->method == SPCIES_FISTA) {
+    if (s->method == SPCIES_FISTA && !s->tv) {
         g4::FistaGHost fh{&s->QRi, &s->Td, &s->Ti};
         rc = g4::fista_plan_build(s->g4plan, s->host, fh);
         if (rc) return rc;

@@ -194,9 +194,12 @@ def compute_laxMPC_FISTA_ingredients(controller, opt, terminal=True):
     T = np.asarray(_get(param, "T"), dtype=float) if terminal else np.eye(n)
     if not (_is_diag(Q) and _is_diag(R) and _is_diag(T)):
         raise ValueError("Spcies:laxMPC:FISTA:non_diagonal - matrices Q, R and T must be diagonal")
-    if opt.time_varying:
-        raise NotImplementedError("HIP platform: time_varying solvers are not built yet")
     nm = n + m
+    if opt.time_varying:  # (compute_laxMPC_FISTA_ingredients.m:71, 92, 138; cons_laxMPC_FISTA_C.m:94-108): only T, Ti are constants
+        return dict(n=n, m=m, N=N, formulation="laxMPC" if terminal else "equMPC", method="FISTA", terminal=bool(terminal),
+                    time_varying=True, Tdiag=-np.diag(T).copy() if terminal else np.zeros(n),
+                    Ti=-1.0 / np.diag(T) if terminal else np.zeros(n), k_max=int(opt.solver["k_max"]), tol=float(opt.solver["tol"]),
+                    rho=0.0, rho_i=0.0, rho_is_scalar=True, dim=N * nm if terminal else N * nm - n)
     dim = N * nm if terminal else N * nm - n
     hdiag = np.concatenate([np.diag(R)] + [np.concatenate([np.diag(Q), np.diag(R)])] * (N - 1)
                            + ([np.diag(T)] if terminal else []))

@@ -1,4 +1,4 @@
-"""Time-varying lax/equ MPC ADMM (TIME_VARYING == 1 in
+"""Time-varying lax/equ MPC ADMM and FISTA (TIME_VARYING == 1 in
 formulations/+laxMPC/code_laxMPC_ADMM_C.c:117-279, code_equMPC_ADMM_C.c:117-265, tutorial
 examples/t01_time_varying_MPC.m): the model (A, B, Q, R, LB, UB) arrives with every call and the banded
 Cholesky factors are computed on line.
@@ -95,6 +95,73 @@ def test_hip_time_varying_vs_oracle(name, B, overrides):
     u, k, e, sol = s(x0, xr, ur, *models)
     assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
     assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.v, O[4]) and np.array_equal(sol.lam, O[5])
+    nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)
+    assert np.array_equal(nosol[0], O[0][:9]) and np.array_equal(nosol[1], O[1][:9])
+    s.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# Time-varying lax/equ MPC FISTA (TIME_VARYING == 1 in code_laxMPC_FISTA_C.c:18, 42-56, 83-271, code_equMPC_FISTA_C.c)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,test_name", [("C1_lax_FISTA", "test_laxMPC_FISTA"), ("C1_equ_FISTA", "test_equMPC_FISTA"),
+                                            ("C2_lax_FISTA", None)])
+def test_oracle_time_varying_fista_matches_offline(name, test_name, golden_dir):
+    """The on-line factors equal the off-line ones (chol of W = G H^-1 G') to rounding, and a time-varying solve handed the
+    design model reproduces the ordinary solver - hence the reference tests' z_opt."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, vt, design = _setup(name)
+    assert vt["time_varying"] and "Alpha" not in vt and vt["Ti"].shape == (cfg.sys.n,)
+    model, per = oracle.pack_tv_model(*design)
+    x0, xr, ur = benchmarks.sample_batch(cfg, 12)
+    if test_name:
+        st = benchmarks.tester_status(cfg.sys)
+        x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
+    out = oracle.fista_tv_batch(vt, x0, xr, ur, model, per, want_factors=True)
+    ref = oracle.fista_banded_batch(v, x0, xr, ur)
+    assert np.abs(out[5] - v["Alpha"]).max() <= 1e-12
+    assert np.abs(np.triu(out[6]) - np.triu(v["Beta"])).max() <= 1e-11
+    assert np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2])
+    assert np.abs(out[0] - ref[0]).max() <= 1e-10 and np.abs(out[3] - ref[3]).max() <= 1e-8
+    if test_name:
+        with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
+            z_opt = np.array(json.load(f)[test_name])
+        assert out[2][0] == 1 and np.abs(out[3][0] - z_opt).max() <= 1e-4
+
+
+def test_blob_roundtrip_time_varying_fista():
+    from spcies_amd import blob
+    cfg, v, vt, design = _setup("C1_lax_FISTA")
+    w = blob.unpack(blob.pack(vt))
+    assert w["time_varying"] and np.array_equal(w["Ti"], vt["Ti"]) and "AB" not in w and w["method"] == "FISTA"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,overrides", [("C1_lax_FISTA", 70, {}), ("C1_equ_FISTA", 40, dict(k_max=400)), ("C2_lax_FISTA", 130, {}),
+                                              ("C2_equ_FISTA", 50, dict(tol=1e-6, k_max=2000))])
+def test_hip_time_varying_fista_vs_oracle(name, B, overrides):
+    """The HIP path (update phase + STREAM iteration on the instance's own factors) against the oracle, bit for bit."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver, SpciesArgError
+    cfg, v, vt, design = _setup(name)
+    vt = benchmarks.ingredients(cfg, time_varying=True, **overrides)
+    s = HipSolver(vt)
+    assert s.time_varying and s.variant == "stream" and [f for f, _ in s.sol_fields] == ["z", "lambda"]
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    with pytest.raises(SpciesArgError):
+        s(x0, xr, ur)  # nine inputs are required
+    model, per = oracle.pack_tv_model(*design)  # one shared model (the design model)
+    O = oracle.fista_tv_batch(vt, x0, xr, ur, model, per)
+    u, k, e, sol = s(x0, xr, ur, *design)
+    assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+    assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.lam, O[4])
+    models = _perturbed_models(design, B)  # one model per instance
+    model, per = oracle.pack_tv_model(*models)
+    O = oracle.fista_tv_batch(vt, x0, xr, ur, model, per)
+    u, k, e, sol = s(x0, xr, ur, *models)
+    assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+    assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.lam, O[4])
     nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)
     assert np.array_equal(nosol[0], O[0][:9]) and np.array_equal(nosol[1], O[1][:9])
     s.close()
