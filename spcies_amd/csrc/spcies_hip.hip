@@ -159,6 +159,23 @@ static const double *find_farray_any(const uint8_t *blob, size_t bytes, const sp
 // ellipMPC ADMM soc (cons_ellipMPC_ADMM_soc_C.m:66-117): dense Q, R, T, A, PhiP, bounds, and the sparse
 // factors (CSC of L - I, Dinv, three CSR matrices).  Everything is validated here because the kernel
 // follows these indices without further checks.
+// option in_engineering (header flags bit3) of every generated solver: x0, xr, ur arrive in engineering units and are scaled
+// on the way in, u is un-scaled on the way out (code_laxMPC_ADMM_C.c:83-100, 642-646; code_ellipMPC_ADMM_soc_C.c:63-72, 292-297;
+// code_HMPC_ADMM_split_C.c:78-86, 356-360; code_HMPC_ADMM_C.c:64-72, 265-269; code_MPCT_ADMM_cs_C.c:56-64, 226-230)
+static int parse_eng(const uint8_t *blob, size_t bytes, const spcies_blob_header &h, Solver &s) {
+    s.eng = (h.flags & 8u) != 0;
+    if (!s.eng) return 0;
+    const uint32_t ids[5] = {SPCIES_A_SCALING_X, SPCIES_A_OPPOINT_X, SPCIES_A_SCALING_U, SPCIES_A_OPPOINT_U, SPCIES_A_SCALING_I_U};
+    const uint64_t cnt[5] = {h.n, h.n, h.m, h.m, h.m};
+    s.eng_v.clear();
+    for (int i = 0; i < 5; i++) {
+        const double *p = find_array(blob, bytes, h, ids[i], cnt[i]);
+        if (!p) return fail(SPCIES_HIP_EINVAL, "in_engineering: blob array id %u missing or mis-sized", ids[i]);
+        s.eng_v.insert(s.eng_v.end(), p, p + cnt[i]);
+    }
+    return 0;
+}
+
 static int parse_soc(const uint8_t *blob, size_t bytes, const spcies_blob_header &h, Solver &s) {
     s.formulation = (int)h.formulation; s.method = (int)h.method; s.submethod = (int)h.submethod;
     AdmmHost &a = s.host;
@@ -457,8 +474,10 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
                          (h.formulation == SPCIES_LAXMPC || h.formulation == SPCIES_EQUMPC)) || ellip_admm;
     const bool mpct = (h.method == SPCIES_EADMM && h.formulation == SPCIES_MPCT);
     const bool soc = (h.method == SPCIES_ADMM && h.formulation == SPCIES_ELLIPMPC && h.submethod == 1);
-    if ((h.flags & 8u) && ((h.formulation == SPCIES_ELLIPMPC && h.submethod != 0) || h.formulation == SPCIES_HMPC))
-        return fail(SPCIES_HIP_ENOSUP, "in_engineering is built for the lax/equ MPC and MPCT solvers only");
+    if (soc || h.formulation == SPCIES_HMPC || (h.formulation == SPCIES_MPCT && h.method == SPCIES_ADMM)) {
+        int rc = parse_eng(blob, bytes, h, s);
+        if (rc) return rc;
+    }
     if (soc) return parse_soc(blob, bytes, h, s);
     if (h.formulation == SPCIES_HMPC && (h.method == SPCIES_ADMM || h.method == SPCIES_SADMM) && h.submethod == 2)
         return parse_hmpc(blob, bytes, h, s);
@@ -466,7 +485,6 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         return parse_hmpc_dense(blob, bytes, h, s);
     if (h.formulation == SPCIES_MPCT && h.method == SPCIES_ADMM) {
         if (h.submethod != 3) return fail(SPCIES_HIP_ENOSUP, "MPCT ADMM: the 'cs' submethod is built (not 'semiband')");
-        if (h.flags & 8u) return fail(SPCIES_HIP_ENOSUP, "in_engineering is not built for MPCT ADMM cs");
         return parse_mpct_cs(blob, bytes, h, s);
     }
     if (!banded && !mpct)
@@ -482,16 +500,9 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     AdmmHost &a = s.host;
     a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max;
     a.terminal = (h.formulation != SPCIES_EQUMPC);
-    s.eng = (h.flags & 8u) != 0;
-    if (s.eng) {
-        const uint32_t ids[5] = {SPCIES_A_SCALING_X, SPCIES_A_OPPOINT_X, SPCIES_A_SCALING_U, SPCIES_A_OPPOINT_U, SPCIES_A_SCALING_I_U};
-        const uint64_t cnt[5] = {h.n, h.n, h.m, h.m, h.m};
-        s.eng_v.clear();
-        for (int i = 0; i < 5; i++) {
-            const double *p = find_array(blob, bytes, h, ids[i], cnt[i]);
-            if (!p) return fail(SPCIES_HIP_EINVAL, "in_engineering: blob array id %u missing or mis-sized", ids[i]);
-            s.eng_v.insert(s.eng_v.end(), p, p + cnt[i]);
-        }
+    {
+        int rc = parse_eng(blob, bytes, h, s);
+        if (rc) return rc;
     }
     a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
     if (a.k_max <= 0 || (h.method == SPCIES_ADMM && !vec_rho && !(a.rho > 0))) return fail(SPCIES_HIP_EINVAL, "bad rho / k_max");

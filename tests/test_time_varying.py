@@ -201,6 +201,44 @@ def test_blob_roundtrip_in_engineering():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,B", [("C1_soc", 40), ("C1_HMPC_SADMM", 24), ("C1_HMPC_nosplit", 24), ("C1_MPCT_cs", 30), ("C1_ellip", 30)])
+def test_hip_in_engineering_sparse_solvers_vs_oracle(name, B):
+    """in_engineering of the sparse-KKT / dense-M1 solvers and ellipMPC ADMM (code_ellipMPC_ADMM_soc_C.c:63-72, 292-297;
+    code_HMPC_ADMM_split_C.c:78-86, 356-360; code_HMPC_ADMM_C.c:64-72, 265-269; code_MPCT_ADMM_cs_C.c:56-64, 226-230): the STREAM
+    variant (reference operation order) equals the oracle wrapped in the same scaling bit for bit, the default variant to 1e-10."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _eng_cfg(name)
+    v = benchmarks.ingredients(cfg, in_engineering=True)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    x0, xr, ur = x0 / v["scaling_x"] + v["OpPoint_x"], xr / v["scaling_x"] + v["OpPoint_x"], ur / v["scaling_u"] + v["OpPoint_u"]
+    extra, kw = (), {}
+    if name == "C1_soc":
+        extra, kw, fn = (cfg.param.r,), dict(r=cfg.param.r), oracle.admm_soc_batch
+    elif name == "C1_HMPC_SADMM":
+        fn = oracle.admm_hmpc_batch
+    elif name == "C1_HMPC_nosplit":
+        fn = oracle.hmpc_dense_batch
+    elif name == "C1_MPCT_cs":
+        fn = oracle.mpct_cs_batch
+    else:
+        fn = oracle.admm_banded_batch
+    if kw:
+        O = _oracle_eng(lambda vv, a, b, c: fn(vv, a, b, c, kw["r"]), v, x0, xr, ur)
+    else:
+        O = _oracle_eng(fn, v, x0, xr, ur)
+    with HipSolver(v) as s:
+        u, k, e, sol = s(x0, xr, ur, *extra)  # the default variant
+        same = k == O[1]
+        assert same.mean() >= 0.9 and np.array_equal(e[same], O[2][same])
+        assert np.abs(u - O[0])[same].max() <= 1e-9 and np.abs(sol.z - O[3])[same].max() <= 1e-9
+        s.set_variant("stream")
+        u, k, e, sol = s(x0, xr, ur, *extra)
+        assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0]) and np.array_equal(sol.z, O[3])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,variant,B", [("C1_lax", "stream", 60), ("C2_lax", "mfma4", 100), ("C1_equ_FISTA", "stream", 40),
                                             ("C1_MPCT", "stream", 30)])
 def test_hip_in_engineering_vs_oracle(name, variant, B):
