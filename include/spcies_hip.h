@@ -41,8 +41,14 @@
  *  - ONE handle = ONE solve in flight: a handle owns a single set of device scratch, so calls on the same handle are
  *    serialised (internal mutex) and must not be queued on two streams at once; use one handle per stream (handles are
  *    independent and may live on different devices of one process).  A record field left NULL on a variant whose kernel
- *    writes the whole record (MFMA, MFMA4, BSP) lands in handle-owned scratch that is allocated on first use: make
- *    one such call before capturing into a hipGraph.
+ *    writes the whole record (MFMA, MFMA4, BSP, MFMA4R) lands in handle-owned scratch that is allocated on first use:
+ *    make one such call before capturing into a hipGraph.
+ *  - the device-buffer entry points are asynchronous on the caller's stream EXCEPT for the GEMM variant (HMPC, only when
+ *    selected explicitly or when FUSED is unavailable): it copies an "instances still active" count back to the host
+ *    every 16 iterations and synchronises the stream, so it is neither asynchronous nor hipGraph-capturable.
+ *  - run-time specialised variants (MFMA4 for shapes without a build-time kernel, MFMA4R, BSP, FUSED for other shapes)
+ *    compile at spcies_hip_create (seconds); SPCIES_HIP_RTC=0 in the environment switches them off and AUTO then uses
+ *    the generic kernels.  spcies_hip_get_info().variant tells which variant a solve will run.
  */
 #ifndef SPCIES_HIP_H
 #define SPCIES_HIP_H
