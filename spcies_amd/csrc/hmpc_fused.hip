@@ -33,7 +33,9 @@ struct Dims {  // mirrors Shape<> of the kernel file for run-time values
         NUS = (m + 3) / 4;
         NE = mode == 0 ? NXS : 2 * NXS + NUS;
         NK = 4 * NR + NE + 1;
-        JC = (40960 / (NR * 512)) > 0 ? (40960 / (NR * 512)) : 1;
+        int chunk = SPCIES_HFUSED_CHUNK;
+        if (const char *ev = getenv("SPCIES_HFUSED_CHUNK")) chunk = atoi(ev);  // (with SPCIES_HFUSED_RTC=1 and the same -D in SPCIES_HFUSED_FLAGS)
+        JC = (chunk / (NR * 512)) > 0 ? (chunk / (NR * 512)) : 1;
         NCH = (NK + JC - 1) / JC;
         CHB = ((JC * NR * 512 + 1023) / 1024) * 1024;
         o0 = (N - 1) * nm + m;
@@ -54,10 +56,10 @@ template <int n, int m, int N, bool SYM, bool USE_SOC, int MODE>
 int launch_builtin(const Args &a, const double *ME, const double *C, const double *x0, const double *xr, const double *ur, double *u,
                    int *k, int *e, double *const *f, bool want_sol, unsigned grid, hipStream_t st) {
     if (want_sol)
-        hipLaunchKernelGGL((hmpc_fused_kernel<n, m, N, SYM, USE_SOC, MODE, true>), dim3(grid), dim3(512), 0, st, a, ME, C, x0, xr, ur, u, k, e,
+        hipLaunchKernelGGL((hmpc_fused_kernel<n, m, N, SYM, USE_SOC, MODE, true>), dim3(grid), dim3(kNWV * 64), 0, st, a, ME, C, x0, xr, ur, u, k, e,
                            f[0], f[1], f[2], f[3], f[4], f[5]);
     else
-        hipLaunchKernelGGL((hmpc_fused_kernel<n, m, N, SYM, USE_SOC, MODE, false>), dim3(grid), dim3(512), 0, st, a, ME, C, x0, xr, ur, u, k, e,
+        hipLaunchKernelGGL((hmpc_fused_kernel<n, m, N, SYM, USE_SOC, MODE, false>), dim3(grid), dim3(kNWV * 64), 0, st, a, ME, C, x0, xr, ur, u, k, e,
                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     SPCIES_HIP_CHECK(hipGetLastError());
     return 0;
@@ -97,7 +99,7 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
     if (p.builtin < 0) {  // not among the build-time shapes: specialise now (SPCIES_HIP_RTC=0 turns it off)
         const char *ev = getenv("SPCIES_HIP_RTC");
         if (ev && ev[0] == '0') { p.why = "shape not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
-        std::vector<std::string> names, extra;
+        std::vector<std::string> names, extra = {"-mllvm", "-amdgpu-mfma-vgpr-form"};  // (as the build-time instantiations)
         for (int s = 0; s < 2; s++) {
             char nm[160];
             snprintf(nm, sizeof(nm), "spcies::hfused::hmpc_fused_kernel<%d, %d, %d, %s, %s, %d, %s>", n, m, N, symmetric ? "true" : "false",
@@ -342,7 +344,7 @@ int launch(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rh
     }
     double *f0 = ff[0], *f1 = ff[1], *f2 = ff[2], *f3 = ff[3], *f4 = ff[4], *f5 = ff[5];
     void *params[] = {&a, &ME, &C, &x0, &xr, &ur, &u, &k, &e, &f0, &f1, &f2, &f3, &f4, &f5};
-    SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 1 : 0], grid, 1, 1, 512, 1, 1, 0, st, params, nullptr));
+    SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 1 : 0], grid, 1, 1, kNWV * 64, 1, 1, 0, st, params, nullptr));
     return 0;
 }
 
