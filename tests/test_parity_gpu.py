@@ -49,6 +49,10 @@ def _compare(variant, got, ref, v):
         # z (measured on the oracle itself); their bar scales with |lambda|.  Everything else: 1e-10 flat.
         lscale = np.abs(lo).max(axis=1, keepdims=True)
         tol = TOL_SPCIES * np.maximum(1.0, lscale / 100.0)
+        # the slack made visible (pytest -s / -rP): worst ABSOLUTE differences, and how much of the bar the scaling lent
+        print(f"[parity {variant}] B={len(k)} max|du|={np.abs(u - uo)[same].max():.2e} max|dz|={np.abs(sol.z - zo)[same].max():.2e} "
+              f"max|dv|={np.abs(sol.v - vo)[same].max():.2e} max|dlam|={np.abs(sol.lam - lo)[same].max():.2e} "
+              f"max|lam|={lscale.max():.2e} bar_scale_max={float(np.maximum(1.0, lscale / 100.0).max()):.1f} k_differs={int((dk > 0).sum())}")
         assert (np.abs(u - uo) / tol)[same].max() <= 1.0
         assert (np.abs(sol.z - zo) / tol)[same].max() <= 1.0
         assert (np.abs(sol.v - vo) / tol)[same].max() <= 1.0
