@@ -87,6 +87,76 @@ __global__ __launch_bounds__(NT, NT / 256) void k(double *out, unsigned long lon
     if (threadIdx.x == 0) stamps[blockIdx.x] = t1 - t0;
 }
 
+// Do FP64 vector instructions of ONE wavefront overlap with the FP64 MFMAs of ANOTHER wavefront on the same SIMD?
+// 512 threads = two wavefronts per SIMD: wavefronts 0-3 (one per SIMD) run WHAT0, wavefronts 4-7 run WHAT1
+// (0 = nothing, 1 = 4x4x4 MFMA chain x 38 accumulators, 2 = v_fma_f64 x 16 independent chains)
+template <int WHAT0, int WHAT1>
+__global__ __launch_bounds__(512, 2) void k2(double *out, unsigned long long *stamps, int iters, const double *in) {
+    const int lane = threadIdx.x & 63, half = threadIdx.x >> 8;
+    const int what = half ? WHAT1 : WHAT0;
+    double acc[38], f[16];
+#pragma unroll
+    for (int R = 0; R < 38; R++) acc[R] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) f[q] = in[lane + q];
+    const double b0 = in[lane], a0 = in[lane + 64];
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (what == 1) {
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+#pragma unroll
+                for (int R = 0; R < 38; R++) MF4(acc[R], a0, b0);
+        }
+    } else if (what == 2) {
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int r = 0; r < 76; r++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) f[q] = __builtin_fma(f[q], a0, b0);
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double fs = 0;
+#pragma unroll
+    for (int R = 0; R < 38; R++) fs += acc[R];
+#pragma unroll
+    for (int q = 0; q < 16; q++) fs += f[q];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = fs;
+    if ((threadIdx.x & 255) == 0) stamps[blockIdx.x * 2 + half] = t1 - t0;
+}
+
+template <int WHAT0, int WHAT1>
+void run2(const char *name) {
+    const int wg = 256, iters = 300;
+    double *out, *in;
+    unsigned long long *st;
+    hipMalloc(&out, sizeof(double) * wg * 512);
+    hipMalloc(&in, sizeof(double) * 2048);
+    hipMalloc(&st, sizeof(unsigned long long) * wg * 2);
+    std::vector<double> h(2048);
+    for (int i = 0; i < 2048; i++) h[i] = (0.3 + 0.4 * ((i * 2654435761u) % 1000) / 1000.0) * ((i & 1) ? -1 : 1) * 1e-3;
+    hipMemcpy(in, h.data(), 2048 * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL((k2<WHAT0, WHAT1>), dim3(wg), dim3(512), 0, 0, out, st, 20, in);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k2<WHAT0, WHAT1>), dim3(wg), dim3(512), 0, 0, out, st, iters, in);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> hs(wg * 2);
+    hipMemcpy(hs.data(), st, sizeof(unsigned long long) * wg * 2, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> c0, c1;
+    for (int i = 0; i < wg; i++) { c0.push_back(hs[2 * i]); c1.push_back(hs[2 * i + 1]); }
+    std::sort(c0.begin(), c0.end()); std::sort(c1.begin(), c1.end());
+    printf("%-66s %8.3f ms | wave A: %7.1f cycles per 304 MFMA | wave B: %7.1f cycles per 1216 v_fma_f64\n", name, ms,
+           (double)c0[wg / 2] / iters, (double)c1[wg / 2] / iters);
+    hipFree(out); hipFree(in); hipFree(st);
+}
+
 template <int MODE, int NT>
 void run(const char *name, int mfma_per_iter) {
     const int wg = 256, iters = 300;
@@ -124,5 +194,10 @@ int main() {
     run<3, 512>("3 19 ds_read_b64 + 38 MFMA per k-slab, 2 waves/SIMD", SLABS * NR * 2);
     run<2, 512>("2' 19 ds_read_b64 + 19 MFMA per k-slab, 2 waves/SIMD", SLABS * NR);
     run<4, 256>("4 ds_read_b128 per block pair, ring of 4, 12 accumulators", SLABS * NR / 2 * 2);
+    run2<1, 0>("two waves per SIMD: A = MFMA loop, B idle");
+    run2<0, 2>("two waves per SIMD: A idle, B = v_fma_f64 loop");
+    run2<1, 2>("two waves per SIMD: A = MFMA loop, B = v_fma_f64 loop");
+    run2<1, 1>("two waves per SIMD: both MFMA loops");
+    run2<2, 2>("two waves per SIMD: both v_fma_f64 loops");
     return 0;
 }
