@@ -1,54 +1,42 @@
-%% cons_laxMPC_ADMM_HIP
+%% cons_laxMPC_ADMM_HIP - HIP (AMD MI355X) platform constructor of the ADMM-based laxMPC solver
 %
-% Constructor of the HIP (AMD MI355X) platform for the ADMM-based laxMPC solver.
-% Drop-in sibling of cons_laxMPC_ADMM_C.m / cons_laxMPC_ADMM_Matlab.m: spcies_gen_controller
-% reaches it through the usual name-mangled dispatch  cons_<formulation>_<method>_<platform>
-% once 'HIP' is listed in Spcies_options.valid_platform.
-%
-% It reuses the toolbox's own offline computation (laxMPC.compute_laxMPC_ADMM_ingredients), writes
-% the ingredients as a binary problem blob (layout: include/spcies_hip.h) and asks the constructor
-% to build the mex gateway struct_laxMPC_ADMM_HIP_Matlab.c against libspcies_hip.so.
-%
-% INPUTS / OUTPUTS: as cons_laxMPC_ADMM_C.m.
-
+% Drop-in sibling of cons_laxMPC_ADMM_C.m / cons_laxMPC_ADMM_Matlab.m: spcies_gen_controller reaches it through the usual
+% name-mangled dispatch cons_<formulation>_<method>_<platform> once 'HIP' is listed in Spcies_options.valid_platform.
+% It reuses the toolbox's own offline computation (laxMPC.compute_laxMPC_ADMM_ingredients) and ships what
+% cons_laxMPC_ADMM_C.m:82-130 prints as constants, switch by switch:
+%   scalar rho (SCALAR_RHO, :119-122)           header rho / rho_i, flag bit0
+%   vector rho (:123-129)                       rho_0, rho, rho_N, rho_i_0, rho_i, rho_i_N -> ids 17, 61, 62, 64, 63, 65
+%   one bound column per prediction step (VAR_BOUNDS, :82-90)   LB0 / UB0, LB / UB, LBN / UBN -> ids 19, 20, 10, 11, 66, 67; flag bit4
+%   time_varying (:92-109)                      only T and T_rho_i travel (ids 9, 47), flag bit2; the generated function then
+%                                               takes A, B, Q, R, LB, UB with every call (struct_laxMPC_ADMM_C_Matlab.c:29-31)
+%   in_engineering (:110-116)                   added by HIP.cons_generic (ids 48-52, flag bit3)
 function constructor = cons_laxMPC_ADMM_HIP(recipe)
-
-    import sp_utils.add_line
-
-    full_path = mfilename('fullpath');
-    this_path = fileparts(full_path);
-
-    %% Ingredients: exactly what the C platform prints as constants
     vars = laxMPC.compute_laxMPC_ADMM_ingredients(recipe.controller, recipe.options);
-    if ~vars.rho_is_scalar
-        error('Spcies:laxMPC:HIP:vector_rho', 'The HIP platform currently supports scalar rho only');
-    end
+    n = vars.n;
+    hdr = struct('formulation', 1, 'method', 1, 'submethod', 0, 'flags', 0, 'rho', 0, 'rho_i', 0);
     if recipe.options.time_varying
-        error('Spcies:laxMPC:HIP:time_varying', 'The HIP platform does not support time_varying yet');
+        if ~vars.rho_is_scalar
+            error('Spcies:laxMPC:HIP:time_varying', 'time_varying solvers take a scalar rho (cons_laxMPC_ADMM_C.m:50)');
+        end
+        hdr.flags = 1 + 4; hdr.rho = vars.rho; hdr.rho_i = vars.rho_i;
+        arrays = {9, vars.T, false; 47, vars.T_rho_i, false};
+        constructor = HIP.cons_generic(recipe, vars, hdr, arrays, 6, 'laxMPC');
+        return
     end
-    n = vars.n; m = vars.m; N = vars.N;
-
-    %% Write the problem blob
-    save_dir = recipe.options.directory;
-    if strcmp(save_dir, '$SPCIES$'); save_dir = [spcies_get_root_directory '/generated_solvers/']; end
-    blob_path = [save_dir recipe.options.save_name '.spcb'];
-    HIP.write_blob(blob_path, 1, 1, vars, recipe.options.solver.k_max, recipe.options.solver.tol);
-
-    %% Defines consumed by the mex gateway
-    defCell = recipe.options.default_defCell();
-    defCell = add_line(defCell, 'nn_', n, 1, 'uint', 'define');
-    defCell = add_line(defCell, 'mm_', m, 1, 'uint', 'define');
-    defCell = add_line(defCell, 'nm_', n+m, 1, 'uint', 'define');
-    defCell = add_line(defCell, 'NN_', N, 1, 'uint', 'define');
-    defCell = add_line(defCell, 'dim_', N*(n+m), 1, 'uint', 'define');
-
-    %% Constructor
-    constructor = Spcies_constructor;
-    constructor = constructor.new_empty_file('mex_code', recipe.options, 'c');
-    constructor.files.mex_code.blocks = {'$START$', [this_path '/struct_laxMPC_ADMM_HIP_Matlab.c']};
-    constructor.files.mex_code.flags = {'$FORM$', 'laxMPC'; 'BLOB_PATH', ['"' blob_path '"']};
-    constructor.files.mex_code.exec_me = ['mex -silent $INSERT_PATH$$INSERT_NAME$.c -outdir $INSERT_PATH$ ' ...
-        '-I' HIP.engine_root() '/include -L' HIP.engine_root() '/spcies_amd -lspcies_hip'];
-    constructor.data = {'$INSERT_DEFINES$', defCell};
-
+    arrays = {1, vars.AB, false; 2, vars.Alpha, false; 3, vars.Beta, false; 4, vars.Hi, false; 5, vars.Hi_0(:), false; ...
+              6, vars.Hi_N, false; 7, vars.Q(:), false; 8, vars.R(:), false; 9, vars.T, false};
+    if size(vars.LB, 2) > 1
+        hdr.flags = bitor(hdr.flags, 16);
+        arrays = [arrays; {19, vars.LB(n+1:end, 1), false; 20, vars.UB(n+1:end, 1), false; 10, vars.LB(:, 2:end-1)', false; ...
+                           11, vars.UB(:, 2:end-1)', false; 66, vars.LB(1:n, end), false; 67, vars.UB(1:n, end), false}];
+    else
+        arrays = [arrays; {10, vars.LB(:), false; 11, vars.UB(:), false}];
+    end
+    if vars.rho_is_scalar
+        hdr.flags = bitor(hdr.flags, 1); hdr.rho = vars.rho; hdr.rho_i = vars.rho_i;
+    else
+        arrays = [arrays; {17, vars.rho_0(:), false; 61, vars.rho, false; 62, vars.rho_N(:), false; ...
+                           64, vars.rho_i_0(:), false; 63, vars.rho_i, false; 65, vars.rho_i_N(:), false}];
+    end
+    constructor = HIP.cons_generic(recipe, vars, hdr, arrays, 0, 'laxMPC');
 end

@@ -17,7 +17,7 @@ EXPORTS = (
     "spcies_hip_get_sol_layout", "spcies_hip_solve_batch_ex", "spcies_hip_solve_batch_device_ex",
     "spcies_hip_closed_loop",
     "spcies_hip_shard_range", "spcies_hip_create_multi", "spcies_hip_multi_destroy", "spcies_hip_multi_count", "spcies_hip_multi_get",
-    "spcies_hip_multi_set_variant", "spcies_hip_multi_set_exit", "spcies_hip_multi_solve_batch", "spcies_hip_multi_solve_batch_ex",
+    "spcies_hip_get_notes", "spcies_hip_multi_set_variant", "spcies_hip_multi_set_exit", "spcies_hip_multi_solve_batch", "spcies_hip_multi_solve_batch_ex",
 )
 
 VARIANT_AUTO, VARIANT_STREAM, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4G, VARIANT_TILE, VARIANT_GEMM, VARIANT_BSP, VARIANT_FUSED, VARIANT_MFMA4R = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -72,6 +72,7 @@ def load():
     lib.spcies_hip_solve_batch_device_ex.argtypes = [vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_long, vp, vp, vp,
                                                      C.POINTER(vp), C.c_int, vp]
     lib.spcies_hip_time_device.argtypes = [vp, vp, vp, vp, C.c_int, C.c_long, vp, vp, vp, vp, C.c_int, dp]
+    lib.spcies_hip_get_notes.argtypes = [vp, C.POINTER(C.c_char_p)]
     lp = C.POINTER(C.c_long)
     lib.spcies_hip_shard_range.argtypes = [C.c_long, C.c_int, C.c_int, lp, lp]
     lib.spcies_hip_create_multi.argtypes = [C.c_char_p, C.c_size_t, ip, C.c_int, C.POINTER(vp)]

@@ -569,8 +569,22 @@ inline int compile_program(Plan &p, int *scratch, const char *name0 = "soc_bsp_k
     rt.sync_env();
     void *prog = nullptr;
     if (rt.create(&prog, p.src.c_str(), "spcies_soc_bsp.hip", 0, nullptr, nullptr) != 0) return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans"};
-    if (rt.compile(prog, 4, opts) != 0) {
+    std::vector<std::string> extra;  // experiments: SPCIES_BSP_FLAGS holds extra compiler options, blank-separated
+    if (const char *ev = getenv("SPCIES_BSP_FLAGS")) {
+        std::string tok;
+        for (const char *c = ev;; c++) {
+            if (*c == ' ' || *c == '\0') {
+                if (!tok.empty()) extra.push_back(tok);
+                tok.clear();
+                if (!*c) break;
+            } else {
+                tok.push_back(*c);
+            }
+        }
+    }
+    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans"};
+    for (const std::string &e : extra) opts.push_back(e.c_str());
+    if (rt.compile(prog, (int)opts.size(), opts.data()) != 0) {
         size_t ls = 0;
         rt.log_size(prog, &ls);
         std::string lg(ls + 1, '\0');

@@ -97,6 +97,7 @@ struct Solver {
     rtc::Mfma4Module mfma4_rtc;  // run-time compiled MFMA4 kernel when the shape was not instantiated at build time
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
+    std::string notes;             // which faster (run-time specialised) variants AUTO could not use, and why (spcies_hip_get_notes)
     fr::Plan frplan;               // MFMA4R (FISTA with the iteration state in registers + LDS, run-time specialised)
     hfused::Plan hfused;           // FUSED (HMPC split NON_SPARSE path: product + projections in one MFMA kernel)
     std::vector<double> h_M1, h_M2, h_bh_nat;
@@ -1545,7 +1546,22 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
             if (rc) return rc;
         }
     }
+    // what AUTO had to give up (a failed run-time specialisation is not an error, but the caller can ask)
+    auto note = [&](const char *name, bool wanted, bool ok, const std::string &why) {
+        if (wanted && !ok) s->notes += std::string(s->notes.empty() ? "" : "; ") + name + " unavailable: " + why;
+    };
+    note("MFMA4R", s->method == SPCIES_FISTA && !s->tv, s->frplan.ok, s->frplan.why);
+    note("BSP", (s->is_soc() && !s->is_hmpc()) || s->host.ellip, s->bsp.ok, s->bsp.why);
+    note("MFMA4", s->mfma4.needs_rtc, s->mfma4.ok, s->mfma4.why);
+    note("FUSED", s->is_hmpc() || s->is_hdense(), s->hfused.ok, s->hfused.why);
+    if (!s->notes.empty() && getenv("SPCIES_HIP_VERBOSE")) fprintf(stderr, "[spcies_hip] %s\n", s->notes.c_str());
     *out = reinterpret_cast<spcies_hip_handle>(s.release());
+    return 0;
+}
+
+int spcies_hip_get_notes(spcies_hip_handle h, const char **notes) {
+    if (!h || !notes) return fail(SPCIES_HIP_EINVAL, "NULL argument");
+    *notes = reinterpret_cast<Solver *>(h)->notes.c_str();
     return 0;
 }
 

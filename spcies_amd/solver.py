@@ -88,6 +88,13 @@ class HipSolver:
     def set_variant(self, name):
         _lib.check(self._lib.spcies_hip_set_variant(self._h, _lib.VARIANTS[name]))
 
+    @property
+    def notes(self):
+        """Which faster (run-time specialised) variants AUTO could not use for this controller, and why ('' if none)."""
+        p = C.c_char_p()
+        _lib.check(self._lib.spcies_hip_get_notes(self._h, C.byref(p)))
+        return (p.value or b"").decode()
+
     def set_exit(self, k_max=0, tol=-1.0):
         _lib.check(self._lib.spcies_hip_set_exit(self._h, int(k_max), float(tol)))
 

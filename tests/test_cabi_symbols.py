@@ -50,20 +50,6 @@ def test_create_fails_loudly_without_gpu_or_on_bad_blob():
             HipSolver(good)
 
 
-def test_mex_gateway_source_is_valid_c(tmp_path):
-    """Our MATLAB mex gateway (source-only deliverable) must at least be valid C against the real
-    spcies_hip.h; mex.h comes from a test-only stub (tests/mex_stub/mex.h)."""
-    import subprocess
-    src = open(os.path.join(ROOT, "matlab", "formulations", "+laxMPC", "struct_laxMPC_ADMM_HIP_Matlab.c")).read()
-    defs = "\n".join(["#define DEBUG 1", "#define nn_ 12", "#define mm_ 2", "#define nm_ 14", "#define NN_ 15",
-                      "#define dim_ 210", '#define BLOB_PATH "laxMPC.spcb"'])
-    src = src.replace("$INSERT_DEFINES$", defs).replace("$FORM$", "laxMPC").replace("$INSERT_NAME$", "laxMPC")
-    f = tmp_path / "gateway.c"
-    f.write_text(src)
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
-                           "-I", os.path.join(ROOT, "tests", "mex_stub"), str(f)])
-
-
 def test_generic_mex_gateway_source_is_valid_c(tmp_path):
     """The generic gateway (all solvers; 0, 1 or 6 extra inputs) is valid C against the real spcies_hip.h."""
     import subprocess

@@ -1076,3 +1076,16 @@ def test_multi_handle_equals_single_handle(cfg_name, B, devices):
         sm.set_exit(k_max=3)
         _, k3, e3, _ = sm(x0, xr, ur, *extra, want_sol=False)
         assert (k3 <= 3).all()
+
+
+@pytest.mark.gpu
+def test_notes_report_what_auto_gave_up(monkeypatch):
+    """A failed / disabled run-time specialisation is not an error, but it is not silent either: spcies_hip_get_notes."""
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    v = benchmarks.ingredients(benchmarks.config("C1_lax_FISTA"))
+    with HipSolver(v) as s:
+        assert s.variant == "mfma4r" and s.notes == ""
+    monkeypatch.setenv("SPCIES_HIP_RTC", "0")
+    with HipSolver(v) as s:
+        assert s.variant == "mfma4g" and "MFMA4R unavailable" in s.notes and "SPCIES_HIP_RTC" in s.notes
