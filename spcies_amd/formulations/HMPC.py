@@ -146,10 +146,18 @@ def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
     Gh = np.block([[G, np.zeros((n_eq, n_s))], [C, np.eye(n_s)]])
     bh = np.concatenate([b, dsoc])
     nc = n_eq + n_s
+    # order of the constraint rows behind the primal block: the reference takes whatever MATLAB's ldl returns there (:228-234,
+    # idx_x0 tracks the x0 rows); solver option kkt_order = 'rcm' (default, least fill), 'natural', or 'random:<seed>' - any
+    # permutation of a quasi-definite matrix has an L D L' with diagonal D, and the iterates do not depend on it
     perm2 = np.arange(nc)
-    if reorder:
+    order = str(so.get("kkt_order", "rcm" if reorder else "natural"))
+    if order == "rcm":
         S = Gh @ np.linalg.solve(Hh, Gh.T)
         perm2 = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(np.abs(S) > 1e-14), symmetric_mode=True))
+    elif order.startswith("random"):
+        perm2 = np.random.default_rng(int(order.split(":")[1]) if ":" in order else 0).permutation(nc)
+    elif order != "natural":
+        raise ValueError("kkt_order: 'rcm', 'natural' or 'random:<seed>'")
     Ghp = Gh[perm2]
     M = np.block([[Hh, Ghp.T], [Ghp, np.zeros((nc, nc))]])
     L, D = _ldl_nopivot(M)

@@ -491,6 +491,33 @@ def test_hmpc_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
 
 
+def test_hmpc_any_constraint_row_order(golden_dir):
+    """The reference ships the factor of whatever permutation MATLAB's ldl picked for the constraint rows (with idx_x0 tracking the x0
+    rows, compute_HMPC_ADMM_split_ingredients.m:228-234).  The engine's sparse paths are fed a RANDOM order here (much more fill than
+    the default RCM order): STREAM stays bit-exact against the oracle on the same factor, TILE within 1e-10, and the optimum is the
+    one every other order gives."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = benchmarks.config("C1_HMPC_SADMM")
+    v0 = benchmarks.ingredients(cfg)
+    v = benchmarks.ingredients(cfg, kkt_order="random:3")
+    assert len(v["L_val"]) != len(v0["L_val"]) and not np.array_equal(v["idx_x0"], v0["idx_x0"])
+    x0, xr, ur = benchmarks.sample_batch(cfg, 24)
+    O = oracle.admm_hmpc_batch(v, x0, xr, ur)
+    O0 = oracle.admm_hmpc_batch(v0, x0, xr, ur)
+    assert np.abs(O[3] - O0[3]).max() <= 1e-6  # the iterates do not depend on the order (both exit on 1e-7 residuals)
+    with HipSolver(v) as s:
+        for variant in ("stream", "tile"):
+            s.set_variant(variant)
+            u, k, e, sol = s(x0, xr, ur)
+            if variant == "stream":
+                assert np.array_equal(k, O[1]) and np.array_equal(u, O[0]) and np.array_equal(sol.z, O[3]) and np.array_equal(sol.s, O[4])
+            else:
+                same = k == O[1]
+                assert same.mean() >= 0.9 and np.abs(u - O[0])[same].max() <= 1e-10 and np.abs(sol.z - O[3])[same].max() <= 1e-10
+
+
 @pytest.mark.parametrize("variant", SPARSE_VARIANTS)
 def test_hmpc_vs_reference_template_fixture(variant, golden_dir):
     g = np.load(os.path.join(golden_dir, "template_C1_HMPC_SADMM.npz"))
