@@ -187,7 +187,7 @@ typedef struct {
     uint32_t formulation;  /* enum spcies_formulation                        */
     uint32_t method;       /* enum spcies_method                             */
     uint32_t submethod;    /* 0 = none                                       */
-    uint32_t flags;        /* bit0: scalar rho, bit1: use_soc, bit2: time-varying, bit3: in_engineering, bit4: VAR_BOUNDS, bit5: general Q, R (MPCT EADMM) */
+    uint32_t flags;        /* bit0: scalar rho, bit1: use_soc, bit2: time-varying, bit3: in_engineering, bit4: VAR_BOUNDS, bit5: general Q, R (MPCT EADMM), bit6: HMPC coupled output constraints */
     uint32_t n, m, N, k_max;
     uint32_t n_arrays;
     uint32_t reserved0;

@@ -1,5 +1,6 @@
 %% cons_HMPC_ADMM_HIP - HIP platform constructor of the HMPC ADMM / SADMM solver WITHOUT the splitting
-% (sibling of cons_HMPC_ADMM_C.m:47-151 - the reference's default HMPC solver; box constraints).  The dense M1, M2 and
+% (sibling of cons_HMPC_ADMM_C.m:47-151 - the reference's default HMPC solver; box or coupled constraints: LBy / UBy carry
+% n_y entries and LB / UB N n_y with coupled constraints, the engine reads the mode from those counts).  The dense M1, M2 and
 % the CSR forms of C and C' travel as the generator prints them (:113-131, 0-based indices); the engine runs the
 % z-update as one dgemm per iteration for the whole batch.  Solution record: z, s, lambda (header_HMPC_ADMM_C.h:14-22).
 function constructor = cons_HMPC_ADMM_HIP(recipe)
@@ -8,9 +9,6 @@ function constructor = cons_HMPC_ADMM_HIP(recipe)
     end
     vars = HMPC.compute_HMPC_ADMM_ingredients(recipe.controller, recipe.options);
     o = recipe.options.solver;
-    if ~o.box_constraints
-        error('Spcies:HMPC:HIP:coupled', 'The HIP platform supports box constraints only for HMPC');
-    end
     is_sadmm = strcmp(recipe.options.method, 'SADMM');
     alpha = 0; if is_sadmm; alpha = o.alpha; end
     hdr = struct('formulation', 5, 'method', 1 + 3*is_sadmm, 'submethod', 0, 'flags', 1 + 2*o.use_soc, 'rho', vars.rho, ...

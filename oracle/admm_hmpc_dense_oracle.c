@@ -95,7 +95,7 @@ int oracle_hmpc_dense_solve(const hmpc_dense_data *D, const double *x0, const do
         if (D->use_soc) {
             for (int j = 0; j < D->n_soc; j++) proj_SOC3(&s_cone[3 * j], 1.0, 0.0);
         } else {
-            for (int j = 0; j < nm; j++) {
+            for (int j = 0; j < D->n_soc; j++) { /* n_y outputs (:200): n + m with box constraints, the rows of E / F when coupled */
                 proj_SOC3(&s_cone[3 * j], 1.0, D->LBy[j]);
                 proj_SOC3(&s_cone[3 * j], -1.0, D->UBy[j]);
             }

@@ -37,6 +37,8 @@ typedef struct {
     const double *M1;         /* [dim + n_s][dim + n_s]                                               */
     const double *M2;         /* [dim + n_s][dim_M2]                                                  */
     const double *bh_nat;     /* [n_eq + n_s] bh in its natural order (x0 rows first)                 */
+    /* COUPLED_CONSTRAINTS (:65, 233-283): LBy <= E x + F u <= UBy.  s = [N n_y box slacks of the outputs; cone rows], z is free */
+    int coupled, n_y;
 } admm_hmpc_data;
 
 static inline double absd(double x) { return (x > 0.0) ? x : -x; }
@@ -110,17 +112,28 @@ int oracle_admm_hmpc_solve(const admm_hmpc_data *d, const double *x0, const doub
             for (int j = 0; j < n_s; j++) mu[j] += ar * (s_hat[j] - s[j]);
         }
         for (int j = 0; j < dim; j++) z[j] = z_hat[j] + d->sigma_i * lambda[j];
-        for (int j = 0; j < dim - 3 * n - 3 * m; j++) {
-            z[j] = (z[j] > d->LB[j]) ? z[j] : d->LB[j];
-            z[j] = (z[j] > d->UB[j]) ? d->UB[j] : z[j];
-        }
+        if (!d->coupled)
+            for (int j = 0; j < dim - 3 * n - 3 * m; j++) {
+                z[j] = (z[j] > d->LB[j]) ? z[j] : d->LB[j];
+                z[j] = (z[j] > d->UB[j]) ? d->UB[j] : z[j];
+            }
         for (int j = 0; j < n_s; j++) s[j] = s_hat[j] + d->rho_i * mu[j];
+        double *s_cone = s;
+        if (d->coupled) { /* (:262-283) box on the output slacks, stage by stage; the cones sit behind them */
+            for (int j = 0; j < N; j++)
+                for (int i = 0; i < d->n_y; i++) {
+                    double *e = &s[j * d->n_y + i];
+                    *e = (*e > d->LBy[i]) ? *e : d->LBy[i];
+                    *e = (*e > d->UBy[i]) ? d->UBy[i] : *e;
+                }
+            s_cone = s + N * d->n_y;
+        }
         if (d->use_soc) {
-            for (int j = 0; j < d->n_soc; j++) proj_SOC3(&s[3 * j], 1.0, 0.0);
+            for (int j = 0; j < d->n_soc; j++) proj_SOC3(&s_cone[3 * j], 1.0, 0.0);
         } else {
-            for (int j = 0; j < nm; j++) {
-                proj_SOC3(&s[3 * j], 1.0, d->LBy[j]);
-                proj_SOC3(&s[3 * j], -1.0, d->UBy[j]);
+            for (int j = 0; j < (d->coupled ? d->n_y : nm); j++) {
+                proj_SOC3(&s_cone[3 * j], 1.0, d->LBy[j]);
+                proj_SOC3(&s_cone[3 * j], -1.0, d->UBy[j]);
             }
         }
         if (d->symmetric) {

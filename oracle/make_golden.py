@@ -56,8 +56,10 @@ def main():
                                ("C1_soc", 12, {}), ("C5_soc", 8, {}),
                                ("C1_HMPC", 6, {}), ("C1_HMPC_SADMM", 6, {}), ("C1_HMPC_soc", 4, {}),
                                ("C1_HMPC_SADMM_soc", 4, {}), ("C5_HMPC_SADMM", 4, {}),
+                               ("C1_HMPCcc", 6, {}), ("C1_HMPCcc_SADMM", 6, {}), ("C1_HMPCcc_soc", 4, {}),
                                ("C1_HMPC_nosplit", 6, {}), ("C1_HMPC_SADMM_nosplit", 6, {}), ("C1_HMPC_soc_nosplit", 4, {}),
                                ("C1_HMPC_SADMM_soc_nosplit", 4, {}), ("C5_HMPC_SADMM_nosplit", 4, {}),
+                               ("C1_HMPCcc_nosplit", 6, {}), ("C1_HMPCcc_SADMM_nosplit", 6, {}), ("C1_HMPCcc_soc_nosplit", 4, {}),
                                ("C1_MPCT_cs", 8, {}), ("C1_MPCT_cs_vec", 6, {}), ("C2_cs", 6, {}), ("C4_cs", 4, {})):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:  # `python -m oracle.make_golden C1_ellip ...`: only these
             continue

@@ -332,7 +332,7 @@ class _HmpcData(C.Structure):
                 + [("L_val", C.POINTER(C.c_double)), ("L_col", C.POINTER(C.c_int)), ("L_row", C.POINTER(C.c_int)),
                    ("Dinv", C.POINTER(C.c_double)), ("idx_x0", C.POINTER(C.c_int)), ("bh", C.POINTER(C.c_double)),
                    ("non_sparse", C.c_int), ("dim_M2", C.c_int), ("M1", C.POINTER(C.c_double)), ("M2", C.POINTER(C.c_double)),
-                   ("bh_nat", C.POINTER(C.c_double))])
+                   ("bh_nat", C.POINTER(C.c_double)), ("coupled", C.c_int), ("n_y", C.c_int)])
 
 
 def admm_hmpc_batch(v, x0, xr, ur, want_sol=True, quantize=False, sparse=True):
@@ -360,7 +360,8 @@ def admm_hmpc_batch(v, x0, xr, ur, want_sol=True, quantize=False, sparse=True):
     sc = {k_: (float(qz(v[k_])) if quantize else float(v[k_])) for k_ in ("tol_p", "tol_d", "rho", "rho_i", "sigma", "sigma_i")}
     d = _HmpcData(n=n, m=m, N=int(v["N"]), dim=int(v["dim"]), n_s=int(v["n_s"]), n_eq=int(v["n_eq"]), n_soc=int(v["n_soc"]),
                   nrow_M=int(v["nrow_M"]), k_max=int(v["k_max"]), use_soc=int(v["use_soc"]),
-                  symmetric=int(v["method"] == "SADMM"), alpha=float(v["alpha"]), **sc, **fields)
+                  symmetric=int(v["method"] == "SADMM"), alpha=float(v["alpha"]), coupled=int(bool(v.get("coupled", False))),
+                  n_y=int(v.get("n_y", n + m)), **sc, **fields)
     x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))
     B = x0.shape[0]
     xr = np.ascontiguousarray(np.asarray(xr, dtype=float))

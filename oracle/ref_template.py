@@ -305,6 +305,8 @@ def _build_hmpc(v, name, sparse=True):
         defs += [f"#define alpha_SADMM {_fmt(v['alpha'])}", "#define IS_SYMMETRIC 1"]
     if v["use_soc"]:
         defs += ["#define USE_SOC 1"]
+    if v.get("coupled", False):  # cons_HMPC_ADMM_split_C.m:95-97, 108-110
+        defs += [f"#define n_y {int(v['n_y'])}", "#define COUPLED_CONSTRAINTS 1"]
     consts = "".join(_decl_scalar(k, v[k]) for k in ("rho", "rho_i", "sigma", "sigma_i"))
     consts += "".join(_decl(cn, v[k]) for cn, k in (("A", "A"), ("QQ", "Q"), ("Te", "Te"), ("Se", "Se"), ("LB", "LB"),
                                                     ("UB", "UB"), ("LBy", "LBy"), ("UBy", "UBy")))
@@ -371,7 +373,7 @@ def _build_hmpc_nosplit(v, name):
     defs = ["#define DEBUG 1", "#define MEASURE_TIME 1", "#define in_engineering 0", "#define TIME_VARYING 0",
             "#define IS_DIAG 1", f"#define nn_ {n}", f"#define mm_ {m}", f"#define nm_ {n + m}", f"#define NN_ {N}",
             f"#define dim {v['dim']}", f"#define n_s {v['n_s']}", f"#define n_eq {v['n_eq']}", f"#define n_soc {v['n_soc']}",
-            f"#define n_y {n + m}", f"#define n_box {v['n_box']}", f"#define nrow_C {v['n_s']}", f"#define nrow_Ct {v['dim']}",
+            f"#define n_y {int(v.get('n_y', n + m))}", f"#define n_box {v['n_box']}", f"#define nrow_C {v['n_s']}", f"#define nrow_Ct {v['dim']}",
             f"#define k_max {int(v['k_max'])}", f"#define tol_p {_fmt(v['tol_p'])}", f"#define tol_d {_fmt(v['tol_d'])}"]
     if v["method"] == "SADMM":
         defs += [f"#define alpha_SADMM {_fmt(v['alpha'])}", "#define IS_SYMMETRIC 1"]

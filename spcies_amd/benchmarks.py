@@ -151,6 +151,20 @@ def config(name):
             c.param.N, c.param.r, c.B = 15, 0.5, 524288
             c.solver_options.update(k_max=200, tol_p=0.0, tol_d=0.0)
         return c
+    if name.startswith("C1_HMPCcc"):
+        # HMPC with coupled output constraints LBy <= E x + F u <= UBy (COUPLED_CONSTRAINTS, code_HMPC_ADMM_split_C.c:65, 233-283;
+        # compute_HMPC_ADMM_split_ingredients.m:35-46, 147-175): positions, one output mixing a velocity into an input, the other input
+        c = config(name.replace("HMPCcc", "HMPC"))
+        c.name = name
+        n, m = c.sys.n, c.sys.m
+        E = np.zeros((5, n)); F = np.zeros((5, m))
+        E[0, 0] = E[1, 1] = E[2, 2] = 1.0
+        E[3, 3], F[3, 0], F[4, 1] = 0.2, 1.0, 1.0
+        sysd = dict(vars(c.sys))
+        sysd.update(E=E, F=F, LBy=np.array([-1.0, -1.0, -1.0, -0.8, -0.8]), UBy=np.array([0.3, 0.3, 0.3, 0.8, 0.8]))
+        c.sys = SimpleNamespace(**sysd)
+        c.solver_options = dict(c.solver_options, box_constraints=False)
+        return c
     if name.startswith("C1_HMPC") or name.startswith("C5_HMPC"):
         # tests/test_HMPC_ADMM_s.m / test_HMPC_SADMM_s.m:6-22; C5: 12-state, N = 15, 200 fixed iterations
         sys = sp_utils.oscillating_masses_sys(3 if name.startswith("C1") else 6)

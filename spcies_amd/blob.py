@@ -71,7 +71,7 @@ def pack(v):
     total = off
     flags = (1 if v.get("rho_is_scalar", True) else 0) | (2 if v.get("use_soc", False) else 0) | (
         4 if v.get("time_varying", False) else 0) | (8 if v.get("in_engineering", False) else 0) | (16 if v.get("var_bounds", False) else 0) | (
-        32 if not v.get("is_diag", True) else 0)
+        32 if not v.get("is_diag", True) else 0) | (64 if v.get("coupled", False) and v.get("submethod") == "split" else 0)
     res = [float(v.get("sigma", 0.0)), float(v.get("sigma_i", 0.0)), float(v.get("tol_d", 0.0)), float(v.get("alpha", 0.0)), float(v.get("r", 0.0))]
     hdr = struct.pack(_HDR, MAGIC, VERSION, HEADER_BYTES, FORMULATION[v["formulation"]], METHOD[v["method"]],
                       SUBMETHOD[v.get("submethod", "")], flags, int(v["n"]), int(v["m"]), int(v["N"]), int(v["k_max"]),

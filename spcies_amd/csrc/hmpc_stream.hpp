@@ -14,6 +14,11 @@ struct HmpcDev {
     int L_col, L_row, idx_x0;                               // offsets (ints)
     int n, m, N, dim, n_s, n_eq, n_soc, nrow_M, k_max, use_soc, symmetric;
     double tol_p, tol_d, rho, rho_i, sigma, sigma_i, alpha;
+    // COUPLED_CONSTRAINTS (code_HMPC_ADMM_split_C.c:65, 233-283): LBy <= E x + F u <= UBy - z is free, s = [N n_y box slacks of
+    // the outputs (bounds LBy / UBy, stage after stage); cone rows]; n_y = rows of E / F (n + m with box constraints)
+    int coupled, n_y;
+    __host__ __device__ int cone0() const { return dim + (coupled ? N * n_y : 0); }       // first cone row
+    __host__ __device__ int triples() const { return use_soc ? n_soc : (coupled ? n_y : n + m); }
 };
 
 #pragma clang fp contract(off)
@@ -108,19 +113,31 @@ __global__ __launch_bounds__(64) void hmpc_stream_kernel(HmpcDev c, const double
             double lam = AT(DU, j);
             if (c.symmetric) lam += as * (zh - zo);
             double z = zh + sigma_i * lam;
-            if (j < dim - 3 * nm) z = clamp_ref(z, cLB[j], cUB[j]);
+            if (!c.coupled && j < dim - 3 * nm) z = clamp_ref(z, cLB[j], cUB[j]);
             AT(PR, j) = z;
             AT(DU, j) = lam + gz * (zh - z);
             res = res || (fabs(zo - z) > c.tol_d) || (fabs(z - zh) > c.tol_p);
         }
+        // coupled constraints: box on the output slacks (:262-269), same half step / dual step / residuals with rho
+        const int cone0 = c.cone0();
+        for (int j = dim; j < cone0; j++) {
+            const double sh = AT(RH, j), so = AT(PR, j);
+            double mu = AT(DU, j);
+            if (c.symmetric) mu += ar * (sh - so);
+            double sv = sh + rho_i * mu;
+            sv = clamp_ref(sv, cLBy[(j - dim) % c.n_y], cUBy[(j - dim) % c.n_y]);
+            AT(PR, j) = sv;
+            AT(DU, j) = mu + gs * (sh - sv);
+            res = res || (fabs(so - sv) > c.tol_d) || (fabs(sv - sh) > c.tol_p);
+        }
         // s in triples (:241-259): diamond = two shifted cones per signal, or plain cones with use_soc
-        const int triples = c.use_soc ? c.n_soc : nm;
+        const int triples = c.triples();
         for (int j = 0; j < triples; j++) {
             double sh[3], so[3], mu[3], s[3];
             for (int r = 0; r < 3; r++) {
-                sh[r] = AT(RH, dim + 3 * j + r);
-                so[r] = AT(PR, dim + 3 * j + r);
-                mu[r] = AT(DU, dim + 3 * j + r);
+                sh[r] = AT(RH, cone0 + 3 * j + r);
+                so[r] = AT(PR, cone0 + 3 * j + r);
+                mu[r] = AT(DU, cone0 + 3 * j + r);
                 if (c.symmetric) mu[r] += ar * (sh[r] - so[r]);
                 s[r] = sh[r] + rho_i * mu[r];
             }
@@ -131,8 +148,8 @@ __global__ __launch_bounds__(64) void hmpc_stream_kernel(HmpcDev c, const double
                 proj_soc3(s[0], s[1], s[2], -1.0, cUBy[j]);
             }
             for (int r = 0; r < 3; r++) {
-                AT(PR, dim + 3 * j + r) = s[r];
-                AT(DU, dim + 3 * j + r) = mu[r] + gs * (sh[r] - s[r]);
+                AT(PR, cone0 + 3 * j + r) = s[r];
+                AT(DU, cone0 + 3 * j + r) = mu[r] + gs * (sh[r] - s[r]);
                 res = res || (fabs(so[r] - s[r]) > c.tol_d) || (fabs(s[r] - sh[r]) > c.tol_p);
             }
         }

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64 * WAVES) void hmpc_tile_kernel(HmpcDev c, TileDe
     const double *cA = C + c.A, *cQQ = C + c.QQ, *cTe = C + c.Te, *cSe = C + c.Se, *cLB = C + c.LB, *cUB = C + c.UB,
                  *cLBy = C + c.LBy, *cUBy = C + c.UBy, *Dinv = C + c.Dinv, *cbh = C + c.bh;
     const int *ix0 = I + c.idx_x0;
-    const int triples = c.use_soc ? c.n_soc : nm;
+    const int triples = c.triples(), cone0 = c.cone0();  // coupled constraints: N n_y box slacks of the outputs sit before the cones
     // ---- setup (:102-129), by row ownership
     for (int j = g; j < dim; j += LPI) {
         AT(PR, j) = 0.0;
@@ -459,10 +459,14 @@ __global__ __launch_bounds__(64 * WAVES) void hmpc_tile_kernel(HmpcDev c, TileDe
         }
         AT(QV, j) = v;
     }
+    for (int j = dim + g; j < cone0; j += LPI) {  // rows of the box slacks: owner = row % LPI, as in the projection below
+        AT(PR, j) = 0.0;
+        AT(DU, j) = 0.0;
+    }
     for (int j = g; j < triples; j += LPI)
         for (int r = 0; r < 3; r++) {
-            AT(PR, dim + 3 * j + r) = 0.0;
-            AT(DU, dim + 3 * j + r) = 0.0;
+            AT(PR, cone0 + 3 * j + r) = 0.0;
+            AT(DU, cone0 + 3 * j + r) = 0.0;
         }
     for (int j = g; j < nc; j += LPI) {
         double v = cbh[j];
@@ -495,8 +499,9 @@ __global__ __launch_bounds__(64 * WAVES) void hmpc_tile_kernel(HmpcDev c, TileDe
             for (int u = 0; u < U; u++)
                 if (j0 + u * LPI < dim) RH[(j0 + u * LPI) * T + cc] = sigma * pr[u] - q[u] - du[u];
         }
+        for (int j = dim + g; j < cone0; j += LPI) RH[j * T + cc] = rho * AT(PR, j) - AT(DU, j);
         for (int j = g; j < triples; j += LPI)
-            for (int r = 0; r < 3; r++) RH[(dim + 3 * j + r) * T + cc] = rho * AT(PR, dim + 3 * j + r) - AT(DU, dim + 3 * j + r);
+            for (int r = 0; r < 3; r++) RH[(cone0 + 3 * j + r) * T + cc] = rho * AT(PR, cone0 + 3 * j + r) - AT(DU, cone0 + 3 * j + r);
         for (int j = g; j < nc; j += LPI) RH[(np + j) * T + cc] = AT(BH, j);
         // KKT solve through L D L' (:193-209)
         scatter_stream<LPI>(RH, recs + td.fwd.off, td.fwd.steps, g, cc);
@@ -511,8 +516,8 @@ __global__ __launch_bounds__(64 * WAVES) void hmpc_tile_kernel(HmpcDev c, TileDe
                 const int j = j0 + u * LPI;
                 lm[u] = (j < dim) ? AT(DU, j) : 0.0;
                 zo[u] = (j < dim) ? AT(PR, j) : 0.0;
-                lb[u] = (j < dim - 3 * nm) ? cLB[j] : 0.0;
-                ub[u] = (j < dim - 3 * nm) ? cUB[j] : 0.0;
+                lb[u] = (!c.coupled && j < dim - 3 * nm) ? cLB[j] : 0.0;
+                ub[u] = (!c.coupled && j < dim - 3 * nm) ? cUB[j] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(64 * WAVES) void hmpc_tile_kernel(HmpcDev c, TileDe
                     double lam = lm[u];
                     if (c.symmetric) lam += as * (zh - zo[u]);
                     double z = zh + sigma_i * lam;
-                    if (j < dim - 3 * nm) z = fmin(fmax(z, lb[u]), ub[u]);
+                    if (!c.coupled && j < dim - 3 * nm) z = fmin(fmax(z, lb[u]), ub[u]);
                     if (active) {
                         AT(PH, j) = zh;
                         AT(PR, j) = z;
@@ -532,14 +537,28 @@ __global__ __launch_bounds__(64 * WAVES) void hmpc_tile_kernel(HmpcDev c, TileDe
                 }
             }
         }
+        // coupled constraints: box on the output slacks (:262-269)
+        for (int j = dim + g; j < cone0; j += LPI) {
+            const double sh = RH[j * T + cc], so = AT(PR, j);
+            double mu = AT(DU, j);
+            if (c.symmetric) mu += ar * (sh - so);
+            double sv = sh + rho_i * mu;
+            sv = fmin(fmax(sv, cLBy[(j - dim) % c.n_y]), cUBy[(j - dim) % c.n_y]);
+            if (active) {
+                AT(PH, j) = sh;
+                AT(PR, j) = sv;
+                AT(DU, j) = mu + gs * (sh - sv);
+            }
+            res |= (fabs(so - sv) > c.tol_d) | (fabs(sv - sh) > c.tol_p);
+        }
         // s in triples (:241-259)
         for (int j = g; j < triples; j += LPI) {
             double sh[3], so[3], mu[3], s[3];
 #pragma unroll
             for (int r = 0; r < 3; r++) {
-                sh[r] = RH[(dim + 3 * j + r) * T + cc];
-                so[r] = AT(PR, dim + 3 * j + r);
-                mu[r] = AT(DU, dim + 3 * j + r);
+                sh[r] = RH[(cone0 + 3 * j + r) * T + cc];
+                so[r] = AT(PR, cone0 + 3 * j + r);
+                mu[r] = AT(DU, cone0 + 3 * j + r);
                 if (c.symmetric) mu[r] += ar * (sh[r] - so[r]);
                 s[r] = sh[r] + rho_i * mu[r];
             }
@@ -552,9 +571,9 @@ __global__ __launch_bounds__(64 * WAVES) void hmpc_tile_kernel(HmpcDev c, TileDe
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 if (active) {
-                    AT(PH, dim + 3 * j + r) = sh[r];
-                    AT(PR, dim + 3 * j + r) = s[r];
-                    AT(DU, dim + 3 * j + r) = mu[r] + gs * (sh[r] - s[r]);
+                    AT(PH, cone0 + 3 * j + r) = sh[r];
+                    AT(PR, cone0 + 3 * j + r) = s[r];
+                    AT(DU, cone0 + 3 * j + r) = mu[r] + gs * (sh[r] - s[r]);
                 }
                 res |= (fabs(so[r] - s[r]) > c.tol_d) | (fabs(s[r] - sh[r]) > c.tol_p);
             }

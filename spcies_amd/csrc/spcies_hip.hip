@@ -264,7 +264,17 @@ static int parse_hmpc(const uint8_t *blob, size_t bytes, const spcies_blob_heade
     const int n = a.n, m = a.m, N = a.N, nm = n + m;
     HmpcDev &d = s.hdev;
     d.n = n; d.m = m; d.N = N; d.use_soc = (h.flags & 2u) ? 1 : 0; d.symmetric = (h.method == SPCIES_SADMM);
-    d.dim = (N - 1) * nm + m + 3 * nm; d.n_eq = (N + 3) * n; d.n_soc = d.use_soc ? 2 * nm : nm; d.n_s = 3 * d.n_soc;
+    // header flags bit6: coupled output constraints (COUPLED_CONSTRAINTS); n_y = rows of E / F = entries of LBy
+    d.coupled = (h.flags & 64u) ? 1 : 0;
+    d.n_y = nm;
+    if (d.coupled) {
+        uint64_t cnt_lby = 0;
+        if (!find_farray_any(blob, bytes, h, SPCIES_A_LBY, &cnt_lby) || cnt_lby == 0 || cnt_lby > 4096)
+            return fail(SPCIES_HIP_EINVAL, "HMPC coupled constraints: LBy missing or mis-sized");
+        d.n_y = (int)cnt_lby;
+    }
+    d.dim = (N - 1) * nm + m + 3 * nm; d.n_eq = (N + 3) * n; d.n_soc = d.use_soc ? 2 * d.n_y : d.n_y;
+    d.n_s = 3 * d.n_soc + (d.coupled ? N * d.n_y : 0);
     d.nrow_M = d.dim + d.n_s + d.n_eq + d.n_s; d.k_max = a.k_max;
     d.tol_p = h.tol; d.tol_d = h.reserved[2]; d.rho = h.rho; d.rho_i = h.rho_i; d.sigma = h.reserved[0];
     d.sigma_i = h.reserved[1]; d.alpha = h.reserved[3];
@@ -272,8 +282,8 @@ static int parse_hmpc(const uint8_t *blob, size_t bytes, const spcies_blob_heade
     struct F { uint32_t id; uint64_t want; int *off; };
     F fs[] = {{SPCIES_A_A, (uint64_t)n * n, &d.A}, {SPCIES_A_Q, (uint64_t)n * n, &d.QQ}, {SPCIES_A_TE, (uint64_t)n * n, &d.Te},
               {SPCIES_A_SE, (uint64_t)m * m, &d.Se}, {SPCIES_A_LB, (uint64_t)(d.dim - 3 * nm), &d.LB},
-              {SPCIES_A_UB, (uint64_t)(d.dim - 3 * nm), &d.UB}, {SPCIES_A_LBY, (uint64_t)nm, &d.LBy},
-              {SPCIES_A_UBY, (uint64_t)nm, &d.UBy}, {SPCIES_A_L_VAL, 0, &d.L_val}, {SPCIES_A_DINV, (uint64_t)d.nrow_M, &d.Dinv},
+              {SPCIES_A_UB, (uint64_t)(d.dim - 3 * nm), &d.UB}, {SPCIES_A_LBY, (uint64_t)d.n_y, &d.LBy},
+              {SPCIES_A_UBY, (uint64_t)d.n_y, &d.UBy}, {SPCIES_A_L_VAL, 0, &d.L_val}, {SPCIES_A_DINV, (uint64_t)d.nrow_M, &d.Dinv},
               {SPCIES_A_BH, (uint64_t)nc, &d.bh}};
     uint64_t nnz = 0;
     for (auto &f : fs) {
@@ -420,7 +430,15 @@ static int parse_hmpc_dense(const uint8_t *blob, size_t bytes, const spcies_blob
     const int n = a.n, m = a.m, N = a.N, nm = n + m;
     hdense::Host &d = s.hd_host;
     d.n = n; d.m = m; d.N = N; d.use_soc = (h.flags & 2u) ? 1 : 0; d.symmetric = (h.method == SPCIES_SADMM);
-    d.dim = (N - 1) * nm + m + 3 * nm; d.n_eq = (N + 3) * n; d.n_soc = d.use_soc ? 2 * nm : nm; d.n_box = d.dim - 3 * nm;
+    // box constraints: n_y = n + m outputs, n_box = dim - 3(n+m) slacks of the decision variables; coupled output constraints
+    // (compute_HMPC_ADMM_ingredients.m:155-180): n_y = rows of E / F, n_box = N n_y - both read off the array sizes
+    uint64_t cnt_lby = 0, cnt_lb = 0;
+    if (!find_farray_any(blob, bytes, h, SPCIES_A_LBY, &cnt_lby) || !find_farray_any(blob, bytes, h, SPCIES_A_LB, &cnt_lb) || cnt_lby == 0 ||
+        cnt_lby > 4096 || cnt_lb > (uint64_t)(1 << 24))
+        return fail(SPCIES_HIP_EINVAL, "HMPC: LBy / LB missing or mis-sized");
+    const int n_y = (int)cnt_lby;
+    d.dim = (N - 1) * nm + m + 3 * nm; d.n_eq = (N + 3) * n; d.n_soc = d.use_soc ? 2 * n_y : n_y; d.n_box = (int)cnt_lb;
+    if (d.n_box != d.dim - 3 * nm && d.n_box != N * n_y) return fail(SPCIES_HIP_EINVAL, "HMPC: LB has neither dim - 3(n+m) nor N n_y entries");
     d.n_s = d.n_box + 3 * d.n_soc; d.k_max = a.k_max;
     if ((long)d.dim * d.dim > (1L << 28)) return fail(SPCIES_HIP_EINVAL, "HMPC: dim too large for the dense M1");
     d.tol_p = h.tol; d.tol_d = h.reserved[2]; d.rho = h.rho; d.rho_i = h.rho_i;
@@ -429,7 +447,7 @@ static int parse_hmpc_dense(const uint8_t *blob, size_t bytes, const spcies_blob
     F fs[] = {{SPCIES_A_A, (uint64_t)n * n, &d.A, false}, {SPCIES_A_Q, (uint64_t)n * n, &d.QQ, false},
               {SPCIES_A_TE, (uint64_t)n * n, &d.Te, false}, {SPCIES_A_SE, (uint64_t)m * m, &d.Se, false},
               {SPCIES_A_LB, (uint64_t)d.n_box, &d.LB, false}, {SPCIES_A_UB, (uint64_t)d.n_box, &d.UB, false},
-              {SPCIES_A_LBY, (uint64_t)nm, &d.LBy, false}, {SPCIES_A_UBY, (uint64_t)nm, &d.UBy, false},
+              {SPCIES_A_LBY, (uint64_t)n_y, &d.LBy, false}, {SPCIES_A_UBY, (uint64_t)n_y, &d.UBy, false},
               {SPCIES_A_D, (uint64_t)d.n_s, &d.d, !d.use_soc}, {SPCIES_A_C_VAL, 0, &d.C_val, false},
               {SPCIES_A_CT_VAL, 0, &d.Ct_val, false}, {SPCIES_A_M1, (uint64_t)d.dim * d.dim, &d.M1, false},
               {SPCIES_A_M2, (uint64_t)d.dim * n, &d.M2, false}};
@@ -1458,7 +1476,10 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         rc = hfused::plan_build_nosplit(s->hfused, fh);
         if (rc) return rc;
     }
-    if (s->is_hmpc() && !s->h_M1.empty()) {
+    if (s->is_hmpc() && !s->h_M1.empty() && s->hdev.coupled) {
+        // coupled output constraints: the dense variants' projection kernels know cone rows only - AUTO runs TILE
+        s->hgemm.why = s->hfused.why = "coupled output constraints run on the sparse path (TILE / STREAM)";
+    } else if (s->is_hmpc() && !s->h_M1.empty()) {
         const HmpcDev &hd = s->hdev;
         const double *F = s->soc_f64.data();
         rc = hgemm::plan_build(s->hgemm, hd, s->h_M1, s->h_M2, s->h_bh_nat, F + hd.A, F + hd.QQ, F + hd.Te, F + hd.Se, F + hd.LB,

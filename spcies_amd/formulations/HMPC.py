@@ -54,13 +54,20 @@ def _hmpc_problem(controller, opt):
     n, m = B.shape
     nm = n + m
     so = opt.solver
-    if so.get("box_constraints") is False or _get(sys, "E") is not None:
-        raise NotImplementedError("HIP platform: HMPC with coupled output constraints (E, F) is not built")
     use_soc = bool(so.get("use_soc", False))
     LBx, UBx = np.ravel(_get(sys, "LBx")).astype(float), np.ravel(_get(sys, "UBx")).astype(float)
     LBu, UBu = np.ravel(_get(sys, "LBu")).astype(float), np.ravel(_get(sys, "UBu")).astype(float)
-    LBy, UBy = np.concatenate([LBx, LBu]), np.concatenate([UBx, UBu])
-    n_y = nm
+    # box constraints on (x, u), or coupled output constraints LBy <= E x + F u <= UBy (:35-53; cons_HMPC_ADMM_split_C.m:51-56:
+    # the option defaults to "coupled" when the system carries E / F)
+    coupled = so.get("box_constraints") is False or (so.get("box_constraints") is None and _get(sys, "E") is not None)
+    if coupled:
+        E, F = np.atleast_2d(np.asarray(_get(sys, "E"), float)), np.atleast_2d(np.asarray(_get(sys, "F"), float))
+        LBy, UBy = np.ravel(_get(sys, "LBy")).astype(float), np.ravel(_get(sys, "UBy")).astype(float)
+    else:
+        E = np.vstack([np.eye(n), np.zeros((m, n))])
+        F = np.vstack([np.zeros((n, m)), np.eye(m)])
+        LBy, UBy = np.concatenate([LBx, LBu]), np.concatenate([UBx, UBu])
+    n_y = len(LBy)
     N = int(_get(param, "N"))
     w = float(_get(param, "w"))
     Q, R = np.asarray(_get(param, "Q"), float), np.asarray(_get(param, "R"), float)
@@ -106,9 +113,8 @@ def _hmpc_problem(controller, opt):
     G = np.vstack([G, np.hstack([np.zeros((3 * n, G.shape[1] - 3 * nm)), tail])])
     n_eq = G.shape[0]
     b = np.zeros(n_eq)
-    # ---- cone constraints, box case (:183-218)
-    E = np.vstack([np.eye(n), np.zeros((m, n))])
-    F = np.vstack([np.zeros((n, m)), np.eye(m)])
+    # ---- cone constraints (:147-218): the coupled form, rows kron(I3, -E_j) | kron(I3, -F_j) per output j, IS the box form when
+    #      E = [I; 0], F = [0; I] - except that the reference lists the box form's columns blockwise (C_n, C_m), kept below
     if use_soc:
         bd3 = lambda a, b_, c_: np.block([[a, np.zeros_like(a), np.zeros_like(a)], [np.zeros_like(a), b_, np.zeros_like(a)],
                                           [np.zeros_like(a), np.zeros_like(a), c_]])
@@ -119,6 +125,9 @@ def _hmpc_problem(controller, opt):
             rows.append(np.hstack([bd3(-e, -e, -e), bd3(-f, -f, -f)]))
             dsoc += [UBy[j], 0.0, 0.0, -LBy[j], 0.0, 0.0]
         C_aux, dsoc, n_soc = np.vstack(rows), np.array(dsoc), 2 * n_y
+    elif coupled:
+        C_aux = np.vstack([np.hstack([np.kron(np.eye(3), -E[j:j + 1, :]), np.kron(np.eye(3), -F[j:j + 1, :])]) for j in range(n_y)])
+        dsoc, n_soc = np.zeros(3 * n_y), n_y
     else:
         C_n = np.vstack([np.kron(np.eye(3), -np.eye(n)[j:j + 1, :]) for j in range(n)])
         C_m = np.vstack([np.kron(np.eye(3), -np.eye(m)[j:j + 1, :]) for j in range(m)])
@@ -128,8 +137,15 @@ def _hmpc_problem(controller, opt):
     UB = np.concatenate([UBu] + [np.concatenate([UBx, UBu])] * (N - 1))
     if not stage0:
         Q = np.zeros_like(Q)  # QQ of the generated solver: only multiplies x0 (code_HMPC_ADMM_split_C.c:115-124)
+    # coupled: one box slack per output and stage, s_box = -(E x_j + F u_j) ... the reference's C = blkdiag(-F, kron(I, [-E -F]), C_aux)
+    Cbox = None
+    if coupled:
+        Cbox = np.zeros((N * n_y, dim - 3 * nm))
+        Cbox[:n_y, :m] = -F
+        for j in range(1, N):
+            Cbox[j * n_y:(j + 1) * n_y, m + (j - 1) * nm:m + j * nm] = np.hstack([-E, -F])
     return SimpleNamespace(A=A, n=n, m=m, N=N, Q=Q, Te=Te, Se=Se, H=H, G=G, b=b, C_aux=C_aux, dsoc=dsoc, n_soc=n_soc,
-                           use_soc=use_soc, LB=LB, UB=UB, LBy=LBy, UBy=UBy)
+                           use_soc=use_soc, LB=LB, UB=UB, LBy=LBy, UBy=UBy, coupled=coupled, n_y=n_y, Cbox=Cbox)
 
 
 def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
@@ -140,6 +156,9 @@ def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
     so = opt.solver
     rho, sigma = float(so["rho"]), float(so["sigma"])
     C = np.hstack([np.zeros((3 * n_soc, dim - 3 * nm)), C_aux])
+    if P.coupled:  # (:174-175) box slacks of the outputs first, then the cone rows
+        C = np.block([[P.Cbox, np.zeros((P.Cbox.shape[0], 3 * nm))], [C]])
+        dsoc = np.concatenate([np.zeros(P.Cbox.shape[0]), dsoc])
     n_s = C.shape[0]
     # ---- KKT matrix and its L D L' (:221-234)
     Hh = np.block([[H + sigma * np.eye(dim), np.zeros((dim, n_s))], [np.zeros((n_s, dim)), rho * np.eye(n_s)]])
@@ -167,7 +186,7 @@ def compute_HMPC_ADMM_split_ingredients(controller, opt, reorder=True):
     inv = np.empty(nc, dtype=int)
     inv[perm2] = np.arange(nc)
     v = dict(n=n, m=m, N=N, formulation="HMPC", method=opt.method or "ADMM", submethod="split", terminal=True,
-             dim=dim, n_s=n_s, n_eq=n_eq, n_soc=n_soc, use_soc=use_soc, nrow_M=dim + n_s + nc)
+             dim=dim, n_s=n_s, n_eq=n_eq, n_soc=n_soc, use_soc=use_soc, nrow_M=dim + n_s + nc, coupled=P.coupled, n_y=P.n_y)
     v["A"], v["Q"], v["Te"], v["Se"] = A.copy(), Q.copy(), Te.copy(), Se.copy()
     v["LB"], v["UB"] = P.LB, P.UB
     v["LBy"], v["UBy"] = LBy, UBy
@@ -204,6 +223,11 @@ def compute_HMPC_ADMM_ingredients(controller, opt):
     so = opt.solver
     n_box = dim - 3 * nm
     C = np.block([[-np.eye(n_box), np.zeros((n_box, 3 * nm))], [np.zeros((C_aux.shape[0], n_box)), C_aux]])
+    LBbox, UBbox = P.LB, P.UB
+    if P.coupled:  # (compute_HMPC_ADMM_ingredients.m:155-180): N n_y box slacks of the outputs, bounds LBy / UBy per stage
+        n_box = N * P.n_y
+        C = np.block([[P.Cbox, np.zeros((n_box, 3 * nm))], [np.zeros((C_aux.shape[0], dim - 3 * nm)), C_aux]])
+        LBbox, UBbox = np.tile(P.LBy, N), np.tile(P.UBy, N)
     d = np.concatenate([np.zeros(n_box), P.dsoc])
     rho = float(so["rho"])
     Hhi = np.linalg.inv(H + rho * (C.T @ C))
@@ -214,7 +238,8 @@ def compute_HMPC_ADMM_ingredients(controller, opt):
     v = dict(n=n, m=m, N=N, formulation="HMPC", method=opt.method or "ADMM", submethod="", terminal=True, dim=dim,
              n_s=C.shape[0], n_eq=G.shape[0], n_soc=P.n_soc, n_box=n_box, use_soc=P.use_soc)
     v["A"], v["Q"], v["Te"], v["Se"] = P.A.copy(), P.Q.copy(), P.Te.copy(), P.Se.copy()
-    v["LB"], v["UB"], v["LBy"], v["UBy"] = P.LB, P.UB, P.LBy, P.UBy
+    v["LB"], v["UB"], v["LBy"], v["UBy"] = LBbox, UBbox, P.LBy, P.UBy
+    v["coupled"], v["n_y"] = P.coupled, P.n_y
     v["rho"], v["rho_i"] = rho, 1.0 / rho
     v["alpha"] = float(so.get("alpha", 0.95)) if v["method"] == "SADMM" else 1.0  # :256-258
     v["k_max"] = int(so["k_max"])
