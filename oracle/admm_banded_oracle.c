@@ -87,7 +87,7 @@ static void form_qhat(const admm_banded_data *d, const double *q, const double *
         for (int j = 0; j < n; j++) {
             z->t[j] = qT[j];
             for (int i = 0; i < n; i++)
-                z->t[j] = z->t[j] + d->P_half[(size_t)j * n + i] * lam->t[i] - d->P[(size_t)j * n + i] * d->rho * v->t[i];
+                z->t[j] = z->t[j] + d->P_half[(size_t)j * n + i] * lam->t[i] - d->P[(size_t)j * n + i] * RHO_T(i) * v->t[i];
         }
     } else if (d->terminal)
         for (int j = 0; j < n; j++) z->t[j] = qT[j] + lam->t[j] - RHO_T(j) * v->t[j];
@@ -178,13 +178,13 @@ static inline double clampd(double x, double lo, double hi) {
  * (code_ellipMPC_ADMM_C.c:292-386). */
 static void update_v_lambda_ellip(const admm_banded_data *d, const split_vec *z, split_vec *v, split_vec *lam, double *aux) {
     const int n = d->n, m = d->m, nm = n + m, N = d->N;
-    for (int j = 0; j < m; j++) v->h[j] = clampd(z->h[j] + d->rho_i * lam->h[j], d->LBu0[j], d->UBu0[j]);
+    for (int j = 0; j < m; j++) v->h[j] = clampd(z->h[j] + RHOI_H(j) * lam->h[j], d->LBu0[j], d->UBu0[j]);
     for (int l = 0; l < N - 1; l++)
         for (int j = 0; j < nm; j++)
-            MID(*v, l, j) = clampd(MID(*z, l, j) + d->rho_i * MID(*lam, l, j), d->LBz[(size_t)l * nm + j], d->UBz[(size_t)l * nm + j]);
+            MID(*v, l, j) = clampd(MID(*z, l, j) + RHOI_M(l, j) * MID(*lam, l, j), d->LBz[(size_t)l * nm + j], d->UBz[(size_t)l * nm + j]);
     for (int j = 0; j < n; j++) {
         v->t[j] = z->t[j];
-        for (int i = 0; i < n; i++) v->t[j] = v->t[j] + d->Pinv_half[(size_t)j * n + i] * d->rho_i * lam->t[i];
+        for (int i = 0; i < n; i++) v->t[j] = v->t[j] + d->Pinv_half[(size_t)j * n + i] * RHOI_T(i) * lam->t[i];
     }
     for (int j = 0; j < n; j++) {
         aux[j] = 0.0;
@@ -196,11 +196,11 @@ static void update_v_lambda_ellip(const admm_banded_data *d, const split_vec *z,
         vPv = d->r / sqrt(vPv);
         for (int j = 0; j < n; j++) v->t[j] = vPv * (v->t[j] - d->c[j]) + d->c[j];
     }
-    for (int j = 0; j < m; j++) lam->h[j] = lam->h[j] + d->rho * (z->h[j] - v->h[j]);
+    for (int j = 0; j < m; j++) lam->h[j] = lam->h[j] + RHO_H(j) * (z->h[j] - v->h[j]);
     for (int l = 0; l < N - 1; l++)
         for (int j = 0; j < nm; j++)
-            MID(*lam, l, j) = MID(*lam, l, j) + d->rho * (MID(*z, l, j) - MID(*v, l, j));
-    for (int j = 0; j < n; j++) aux[j] = d->rho * (z->t[j] - v->t[j]);
+            MID(*lam, l, j) = MID(*lam, l, j) + RHO_M(l, j) * (MID(*z, l, j) - MID(*v, l, j));
+    for (int j = 0; j < n; j++) aux[j] = RHO_T(j) * (z->t[j] - v->t[j]);
     for (int j = 0; j < n; j++)
         for (int i = 0; i < n; i++) lam->t[j] = lam->t[j] + d->P_half[(size_t)j * n + i] * aux[i];
 }

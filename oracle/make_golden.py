@@ -51,9 +51,9 @@ def main():
                                ("C1_lax_FISTA", 16, {}), ("C1_equ_FISTA", 16, dict(k_max=500)),
                                ("C2_lax_FISTA", 32, {}), ("C2_lax_FISTA", 32, dict(tol=1e-6, k_max=2000)),
                                ("C2_equ_FISTA", 32, {}), ("C1_MPCT", 16, {}), ("C4", 8, {}), ("C1_MPCT_nd", 16, {}), ("C1_MPCT_nd0", 8, {}), ("C4_nd", 6, {}),
-                               ("C1_ellip", 12, {}), ("C2_ellip", 8, {}),
+                               ("C1_ellip", 12, {}), ("C2_ellip", 8, {}), ("C1_ellip_vec", 12, {}), ("C2_ellip_vec", 8, {}), ("C1_ellip_inc", 12, {}),
                                ("C1_lax_gen", 12, {}), ("C1_equ_gen", 12, dict(k_max=3000)), ("C2_lax_gen", 8, {}),
-                               ("C1_soc", 12, {}), ("C5_soc", 8, {}),
+                               ("C1_soc", 12, {}), ("C5_soc", 8, {}), ("C1_soc_inc", 12, {}),
                                ("C1_HMPC", 6, {}), ("C1_HMPC_SADMM", 6, {}), ("C1_HMPC_soc", 4, {}),
                                ("C1_HMPC_SADMM_soc", 4, {}), ("C5_HMPC_SADMM", 4, {}),
                                ("C1_HMPCcc", 6, {}), ("C1_HMPCcc_SADMM", 6, {}), ("C1_HMPCcc_soc", 4, {}),

@@ -103,10 +103,14 @@ def build_admm(v, name):
             "#define IS_DIAG 1", f"#define nn_ {n}", f"#define mm_ {m}", f"#define nm_ {n + m}", f"#define NN_ {N}",
             f"#define k_max {int(v['k_max'])}", f"#define tol {_fmt(v['tol'])}"]
     variables = ""
-    if method == "ADMM" and form == "ellipMPC":  # cons_ellipMPC_ADMM_C.m:74-110
-        defs += ["#define SCALAR_RHO", f"#define rho {_fmt(v['rho'])}", f"#define rho_i {_fmt(v['rho_i'])}"]
+    if method == "ADMM" and form == "ellipMPC":  # cons_ellipMPC_ADMM_C.m:74-118
         order = [(k, k) for k in ["LBu0", "UBu0", "LBz", "UBz", "Hi", "Hi_0", "Hi_N", "AB", "P", "P_half", "Pinv_half",
                                   "Alpha", "Beta", "Q", "R", "T"]]
+        if v.get("rho_is_scalar", True):
+            defs += ["#define SCALAR_RHO", f"#define rho {_fmt(v['rho'])}", f"#define rho_i {_fmt(v['rho_i'])}"]
+        else:  # :111-117
+            order += [("rho", "rho_v"), ("rho_0", "rho_0"), ("rho_N", "rho_N"), ("rho_i", "rho_i_v"), ("rho_i_0", "rho_i_0"),
+                      ("rho_i_N", "rho_i_N")]
         variables = _decl("c", np.asarray(v["c"], float)).replace("const static ", "") \
             + f"double r = {_fmt(v['r'])};\n"
     elif method == "ADMM":  # cons_laxMPC_ADMM_C.m:72-130
@@ -244,7 +248,7 @@ def _build_soc(v, name):
         code = code.replace("$INSERT_SOLVER$", f.read())
     with open(os.path.join(fdir, "header_ellipMPC_ADMM_soc_C.h")) as f:
         header = f.read()
-    code = code.replace("$INSERT_CONSTANTS$", consts).replace("$INSERT_VARIABLES$", variables)
+    code = code.replace("$INSERT_CONSTANTS$", consts).replace("$INSERT_VARIABLES$", "")  # r is an input of this solver
     header = header.replace("$INSERT_DEFINES$", "\n".join(defs))
     code, header = _snippets(code, "c"), _snippets(header, "h")
     code = _unescape(code.replace("$INSERT_NAME$", name))

@@ -126,6 +126,22 @@ def config(name):
             dim = 2 * c.param.N * (c.sys.n + c.sys.m)
             c.solver_options["rho"] = 0.01 * (0.5 + np.random.default_rng(78).random(dim))
         return c
+    if name in ("C1_ellip_vec", "C2_ellip_vec", "C1_ellip_inc", "C1_soc_inc"):
+        # vector rho (compute_ellipMPC_ADMM_ingredients.m:67-77, 163-175): C1 keeps rho_N uniform (the reference's terminal Hessian
+        # block T + diag(rho_N) P and the template's P diag(rho_N) then agree and the optimum is the QP's); C2 draws every entry,
+        # 200 fixed iterations.  _inc: tightened constraints param.incBx / incBu (:101-128), growing along the horizon
+        c = config(name[:-4])
+        c.name = name
+        n, m, N = c.sys.n, c.sys.m, c.param.N
+        if name.endswith("_vec"):
+            rho = 15.0 * (0.5 + np.random.default_rng(77).random(N * (n + m)))
+            if name.startswith("C1"):
+                rho[-n:] = 15.0
+            c.solver_options["rho"] = rho
+        else:
+            c.param.incBx = 0.01 * np.outer(np.linspace(1.0, 2.0, n), np.arange(N + 1))
+            c.param.incBu = 0.004 * np.outer(np.ones(m), np.arange(N + 1))
+        return c
     if name in ("C1_ellip", "C2_ellip"):  # tests/test_ellipMPC_ADMM.m:6-21; C2: 12-state, N = 15, r = 0.5, 200 fixed iterations
         sys = sp_utils.oscillating_masses_sys(3 if name == "C1_ellip" else 6)
         Q, R, T = _weights(sys, "diag")

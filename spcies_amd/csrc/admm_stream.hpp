@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
     const double *cP = C + c.P, *cPh = C + c.P_half, *cPih = C + c.Pinv_half, *cCe = C + c.c_ell, *cLBz = C + c.LBz,
                  *cUBz = C + c.UBz, *cLBu0 = C + c.LBu0, *cUBu0 = C + c.UBu0;
     static_assert(!ELLIP || (TERMINAL && !TV), "ellipMPC ADMM: terminal block, constant model");
-    static_assert(!GEN || (!ELLIP && !TV), "vector rho / VAR_BOUNDS: lax and equ MPC with a constant model");
+    static_assert(!GEN || !TV, "vector rho / VAR_BOUNDS: constant model (with ELLIP: vector rho, cons_ellipMPC_ADMM_C.m:111-117)");
     // GEN: stage-wise penalty and bounds (no SCALAR_RHO / VAR_BOUNDS, code_laxMPC_ADMM_C.c:323-348, 490-568)
     const double *gR0 = C + c.rho_0, *gRv = C + c.rho_v, *gRN = C + c.rho_N, *gRi0 = C + c.rho_i_0, *gRiv = C + c.rho_i_v,
                  *gRiN = C + c.rho_i_N, *gLBN = C + c.LBN, *gUBN = C + c.UBN;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
             if constexpr (ELLIP) {
                 double acc = qT[j];
 #pragma unroll
-                for (int i = 0; i < n; i++) acc = acc + cPh[j * n + i] * lamv[i] - cP[j * n + i] * rho * vold[i];
+                for (int i = 0; i < n; i++) acc = acc + cPh[j * n + i] * lamv[i] - cP[j * n + i] * RT(i) * vold[i];
                 out[j] = acc;
             } else {
                 out[j] = qT[j] + lamv[j] - RT(j) * vold[j];
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                         for (int j = 0; j < n; j++) {
                             double acc = zN[j];
 #pragma unroll
-                            for (int i = 0; i < n; i++) acc = acc + cPih[j * n + i] * rho_i * lamv[i];
+                            for (int i = 0; i < n; i++) acc = acc + cPih[j * n + i] * RIT(i) * lamv[i];
                             vn[j] = acc;
                         }
 #pragma unroll
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
                             for (int j = 0; j < n; j++) vn[j] = vPv * (vn[j] - cCe[j]) + cCe[j];
                         }
 #pragma unroll
-                        for (int j = 0; j < n; j++) pv[j] = rho * (zN[j] - vn[j]);
+                        for (int j = 0; j < n; j++) pv[j] = RT(j) * (zN[j] - vn[j]);
 #pragma unroll
                         for (int j = 0; j < n; j++) {
                             double ln = lamv[j];

@@ -98,11 +98,23 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
                 if (h != 0.0) GH[(size_t)i * dim + j] += g * h;
             }
         }
+    // (ellipMPC with a vector rho: the terminal block of H^-1, inv(T + diag(rho_N) P), is not symmetric, so neither is W; the reference
+    // factorises it with MATLAB's chol, which reads the UPPER triangle - compute_ellipMPC_ADMM_ingredients.m:97-99)
     for (int i = 0; i < nr; i++)
-        for (int j = 0; j < nr; j++) {
+        for (int j = i; j < nr; j++) {
             double s = 0.0;
             for (int k = 0; k < dim; k++) s += GH[(size_t)i * dim + k] * G[(size_t)j * dim + k];
-            W[(size_t)i * nr + j] = s;
+            W[(size_t)i * nr + j] = W[(size_t)j * nr + i] = s;
+        }
+    Dense HGt((size_t)dim * nr, 0.0);  // H^-1 G'
+    for (int j = 0; j < dim; j++)
+        for (int k = 0; k < dim; k++) {
+            const double h = Hinv[(size_t)j * dim + k];
+            if (h == 0.0) continue;
+            for (int i = 0; i < nr; i++) {
+                const double g = G[(size_t)i * dim + k];
+                if (g != 0.0) HGt[(size_t)j * nr + i] += h * g;
+            }
         }
     Dense Ln;
     std::vector<double> Dn;
@@ -112,7 +124,7 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     for (int i = 0; i < nr; i++)
         for (int j = 0; j < dim; j++) {
             Gm[(size_t)i * PR_ + ip(j)] = -GH[(size_t)i * dim + j];
-            HG[(size_t)ip(j) * RR + i] = -GH[(size_t)i * dim + j];  // -H^-1 G' = (-G H^-1)'  (H symmetric)
+            HG[(size_t)ip(j) * RR + i] = -HGt[(size_t)j * nr + i];
         }
     for (int i = 0; i < dim; i++)
         for (int j = 0; j < dim; j++) H[(size_t)ip(i) * PR_ + ip(j)] = -Hinv[(size_t)i * dim + j];
@@ -163,10 +175,12 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         n_mfma++;
     };
     // a dense n x n matrix (scaled) applied to TS slabs: out[k] += sum_j M[k][j] in[j]
-    auto dense_tail = [&](const std::vector<double> &M, double scale, const char *out, const char *in) {
+    // (colscale: vector rho - P diag(rho_N), Pinv_half diag(rho_i_N), code_ellipMPC_ADMM_C.c:152, 328)
+    auto dense_tail = [&](const std::vector<double> &M, double scale, const char *out, const char *in,
+                          const std::vector<double> *colscale = nullptr) {
         Dense Mp((size_t)4 * TS * 4 * TS, 0.0);
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) Mp[(size_t)i * 4 * TS + j] = scale * M[(size_t)i * n + j];
+            for (int j = 0; j < n; j++) Mp[(size_t)i * 4 * TS + j] = scale * M[(size_t)i * n + j] * (colscale ? (*colscale)[j] : 1.0);
         for (int k = 0; k < TS; k++)
             for (int j = 0; j < TS; j++) {
                 double blk[16];
@@ -192,7 +206,8 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     }
     if (!lax) {
         dense_tail(a.P_half, 1.0, "qt", "lamN");
-        dense_tail(a.P, -a.rho, "qt", "vN");
+        if (a.gen) dense_tail(a.P, -1.0, "qt", "vN", &a.rho_N);
+        else dense_tail(a.P, -a.rho, "qt", "vN");
     }
     body += "            SEG;\n            // rhs = (-G H^-1) q_hat - b\n";
     const int bh_slabs = (n + 3) / 4;  // b = -A x0 in the first n rows
@@ -312,7 +327,8 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         body += "              (void)vn; (void)dd; (void)pv; (void)tt; }\n";
     } else {
         body += "              _Pragma(\"unroll\") for (int k_ = 0; k_ < TS_; k_++) vn[k_] = zN[k_];\n";
-        dense_tail(a.Pinv_half, a.rho_i, "vn", "lamN");
+        if (a.gen) dense_tail(a.Pinv_half, 1.0, "vn", "lamN", &a.rho_i_N);
+        else dense_tail(a.Pinv_half, a.rho_i, "vn", "lamN");
         body += "              _Pragma(\"unroll\") for (int k_ = 0; k_ < TS_; k_++) { dd[k_] = vn[k_] - CE(k_); pv[k_] = 0.0; }\n";
         dense_tail(a.P, 1.0, "pv", "dd");
         body += "              EUPD_A;\n";
@@ -575,7 +591,7 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
             const double sc_ = p.r / sqrt(vpv_);                                                 \
             _Pragma("unroll") for (int k_ = 0; k_ < TS_; k_++) vn[k_] = sc_ * dd[k_] + CE(k_);   \
         }                                                                                        \
-        _Pragma("unroll") for (int k_ = 0; k_ < TS_; k_++) tt[k_] = rho * (zN[k_] - vn[k_]);     \
+        _Pragma("unroll") for (int k_ = 0; k_ < TS_; k_++) tt[k_] = RHOT(k_) * (zN[k_] - vn[k_]); \
     } while (0)
         // ... and, after lambda_N += P_half tt, the residuals and the new v_N (:374-386)
 #define EUPD_B                                                                                   \

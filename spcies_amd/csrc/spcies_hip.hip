@@ -509,8 +509,9 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     if (!banded && !mpct)
         return fail(SPCIES_HIP_ENOSUP, "formulation %u / method %u not built in this library", h.formulation, h.method);
     const bool vec_rho = (h.method == SPCIES_ADMM && !(h.flags & 1u)), var_b = (h.flags & 16u) != 0;
-    if ((vec_rho || var_b) && !(h.method == SPCIES_ADMM && (h.formulation == SPCIES_LAXMPC || h.formulation == SPCIES_EQUMPC)))
-        return fail(SPCIES_HIP_ENOSUP, "vector rho / stage-wise bounds are built for the lax/equ MPC ADMM solvers only");
+    if ((vec_rho || var_b) && !(h.method == SPCIES_ADMM && (h.formulation == SPCIES_LAXMPC || h.formulation == SPCIES_EQUMPC)) &&
+        !(ellip_admm && !var_b))  // ellipMPC ADMM: vector rho (cons_ellipMPC_ADMM_C.m:111-117); its bounds are stage-wise already
+        return fail(SPCIES_HIP_ENOSUP, "vector rho / stage-wise bounds are built for the lax/equ/ellip MPC ADMM solvers only");
     if ((vec_rho || var_b) && (h.flags & 4u)) return fail(SPCIES_HIP_EINVAL, "time-varying solvers take a scalar rho and constant bounds");
     if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.N > 100000) return fail(SPCIES_HIP_EINVAL, "bad n/m/N");
     s.formulation = (int)h.formulation;
@@ -613,7 +614,9 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
     }
     a.gen = vec_rho || var_b;
     if (a.gen) {  // keep the stage-wise form of both switches
-        if (var_b) {
+        if (a.ellip) {
+            a.LBN.assign(n, 0.0); a.UBN.assign(n, 0.0);  // (no terminal box: the ellipsoid)
+        } else if (var_b) {
             a.LBz = a.LB; a.UBz = a.UB;
         } else {
             a.LBu0.assign(a.LB.begin() + n, a.LB.end()); a.UBu0.assign(a.UB.begin() + n, a.UB.end());
@@ -633,6 +636,7 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         }
         for (double r : a.rho_0) if (!(r > 0)) return fail(SPCIES_HIP_EINVAL, "bad rho");
         for (double r : a.rho_v) if (!(r > 0)) return fail(SPCIES_HIP_EINVAL, "bad rho");
+        for (double r : a.rho_N) if (!(r > 0)) return fail(SPCIES_HIP_EINVAL, "bad rho");
     }
     if (a.ellip) return bsp::build_ellip(s.bsp, a);  // BSP variant: generate the controller's block program (host only)
     return 0;
@@ -693,9 +697,11 @@ static int upload_consts(Solver &s) {
         s.dev.r_ell = a.r_ell;
     }
     if (a.gen) {
-        s.dev.LBz = (int)offs[11]; s.dev.UBz = (int)offs[12]; s.dev.LBu0 = (int)offs[13]; s.dev.UBu0 = (int)offs[14];
-        s.dev.LBN = (int)offs[15]; s.dev.UBN = (int)offs[16]; s.dev.rho_0 = (int)offs[17]; s.dev.rho_v = (int)offs[18];
-        s.dev.rho_N = (int)offs[19]; s.dev.rho_i_0 = (int)offs[20]; s.dev.rho_i_v = (int)offs[21]; s.dev.rho_i_N = (int)offs[22];
+        const size_t o = a.ellip ? 19 : 11;  // (ellipMPC with a vector rho: after the ellipsoid's arrays)
+        s.dev.LBz = (int)offs[o]; s.dev.UBz = (int)offs[o + 1]; s.dev.LBu0 = (int)offs[o + 2]; s.dev.UBu0 = (int)offs[o + 3];
+        s.dev.LBN = (int)offs[o + 4]; s.dev.UBN = (int)offs[o + 5]; s.dev.rho_0 = (int)offs[o + 6]; s.dev.rho_v = (int)offs[o + 7];
+        s.dev.rho_N = (int)offs[o + 8]; s.dev.rho_i_0 = (int)offs[o + 9]; s.dev.rho_i_v = (int)offs[o + 10];
+        s.dev.rho_i_N = (int)offs[o + 11];
     }
     return 0;
 }
@@ -770,10 +776,14 @@ static int launch_stream_nm(Solver &s, const double *x0, const double *xr, const
     double *Y = LAM + dim * Bp;
     double *ZS = want_sol ? Y + (size_t)s.host.N * n * Bp : nullptr;
     dim3 grid((unsigned)(Bp / 64)), block(64);
-    if constexpr (ELLIP)
-        hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true, false, true>), grid, block, 0, st, s.dev, s.d_consts, x0, xr, ur,
-                           ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e, nullptr);
-    else if constexpr (GEN) {
+    if constexpr (ELLIP) {
+        if (s.host.gen)  // vector rho
+            hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true, false, true, true>), grid, block, 0, st, s.dev, s.d_consts, x0, xr,
+                               ur, ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e, nullptr);
+        else
+            hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true, false, true>), grid, block, 0, st, s.dev, s.d_consts, x0, xr, ur,
+                               ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e, nullptr);
+    } else if constexpr (GEN) {
         if (s.host.terminal)
             hipLaunchKernelGGL((admm_stream_kernel<n, m, true, true, false, false, true>), grid, block, 0, st, s.dev, s.d_consts, x0,
                                xr, ur, ref_stride, B, Bp, V, LAM, Y, ZS, u, k, e, nullptr);

@@ -18,6 +18,15 @@ from .. import sp_utils
 from .laxMPC import _get, _is_diag, build_G
 
 
+def _inc(param, name, rows, N):
+    """``param.incBx`` / ``param.incBu`` as a [rows][N+1] array (compute_ellipMPC_ADMM_ingredients.m:104-123)."""
+    x = _get(param, name)
+    if x is None:
+        return np.zeros((rows, N + 1))
+    x = np.asarray(x, dtype=float)
+    return x.reshape((rows, N + 1), order="F") if min(x.shape or (1,)) == 1 or x.ndim == 1 else x.reshape(rows, N + 1)
+
+
 def compute_ellipMPC_ADMM_soc_ingredients(controller, opt):
     sys, param = _get(controller, "sys"), _get(controller, "param")
     A = np.asarray(_get(sys, "A"), dtype=float)
@@ -32,8 +41,6 @@ def compute_ellipMPC_ADMM_soc_ingredients(controller, opt):
     r = float(_get(param, "r", 1.0))
     if not (_is_diag(Q) and _is_diag(R)):
         raise ValueError("Spcies:ellipMPC:ADMM:non_diagonal - matrices Q and R must be diagonal")
-    if _get(param, "incBx") is not None or _get(param, "incBu") is not None:
-        raise NotImplementedError("HIP platform: incBx / incBu tightening is not built")
     rho, sigma = float(opt.solver["rho"]), float(opt.solver["sigma"])
     dim = N * nm + 1
     H = np.zeros((dim, dim))
@@ -50,10 +57,13 @@ def compute_ellipMPC_ADMM_soc_ingredients(controller, opt):
     Cm = np.hstack([np.zeros((n + 1, dim - n - 1)),
                     np.block([[np.zeros((1, n)), -np.ones((1, 1))], [-P_half, np.zeros((n, 1))]])])
     n_s = n + 1
-    LBx, UBx = np.ravel(_get(sys, "LBx")), np.ravel(_get(sys, "UBx"))
-    LBu, UBu = np.ravel(_get(sys, "LBu")), np.ravel(_get(sys, "UBu"))
-    LB = np.concatenate([LBu] + [np.concatenate([LBx, LBu])] * (N - 1)).astype(float)
-    UB = np.concatenate([UBu] + [np.concatenate([UBx, UBu])] * (N - 1)).astype(float)
+    LBx, UBx = np.ravel(_get(sys, "LBx")).astype(float), np.ravel(_get(sys, "UBx")).astype(float)
+    LBu, UBu = np.ravel(_get(sys, "LBu")).astype(float), np.ravel(_get(sys, "UBu")).astype(float)
+    # tightened constraints (:101-128): param.incBx [n][N+1], param.incBu [m][N+1] (a vector is reshaped column-major, as
+    # MATLAB's reshape does); columns 2..N tighten stages 1..N-1, u_0 keeps the plain input bounds
+    incBx, incBu = _inc(param, "incBx", n, N), _inc(param, "incBu", m, N)
+    LB = np.concatenate([LBu] + [np.concatenate([LBx + incBx[:, i], LBu + incBu[:, i]]) for i in range(1, N)])
+    UB = np.concatenate([UBu] + [np.concatenate([UBx - incBx[:, i], UBu - incBu[:, i]]) for i in range(1, N)])
     Hh = np.block([[H + sigma * np.eye(dim), np.zeros((dim, n_s))], [np.zeros((n_s, dim)), rho * np.eye(n_s)]])
     Gh = np.block([[G, np.zeros((n_eq, n_s))], [Cm, np.eye(n_s)]])
     Hhi = np.linalg.inv(Hh)
@@ -87,7 +97,11 @@ def compute_ellipMPC_ADMM_ingredients(controller, opt):
     """ellipMPC, ADMM with the P-projection onto the terminal ellipsoid (no submethod) - SURVEY section 8f
     rank 2.  Reference: ``formulations/+ellipMPC/compute_ellipMPC_ADMM_ingredients.m:60-247``: the lax
     ingredients with ``H = Hz + rho blkdiag(I, P)``, stage-wise bounds ``LBu0/UBu0, LBz/UBz`` and the terminal
-    constants ``P, P_half = sqrtm(P), Pinv_half = P^-1 P_half, c, r``.  Scalar ``rho`` only."""
+    constants ``P, P_half = sqrtm(P), Pinv_half = P^-1 P_half, c, r``.  Scalar or vector ``rho`` (:67-77, 163-175): with a vector
+    the reference forms ``H = Hz + rho .* blkdiag(I, P)`` - MATLAB broadcasts the column ``rho`` over the ROWS, so the terminal block
+    of ``H`` is ``T + diag(rho_N) P`` - restated as written (the template's terminal ``q_hat`` uses ``P diag(rho_N)``, so the two
+    agree when ``rho_N`` is uniform).  ``force_vector_rho`` with a scalar expands it (the reference's line :69 names an undefined
+    ``options`` there; the intent is taken)."""
     sys, param = _get(controller, "sys"), _get(controller, "param")
     A = np.asarray(_get(sys, "A"), dtype=float)
     B = np.asarray(_get(sys, "B"), dtype=float)
@@ -102,11 +116,12 @@ def compute_ellipMPC_ADMM_ingredients(controller, opt):
     r = float(_get(param, "r", 1.0))
     if not (_is_diag(Q) and _is_diag(R)):
         raise ValueError("Spcies:ellipMPC:ADMM:non_diagonal - matrices Q and R must be diagonal")
-    rho = opt.solver["rho"]
-    if np.ndim(rho) != 0 or opt.solver.get("force_vector_rho", False):
-        raise NotImplementedError("HIP platform: vector rho is not built yet (scalar rho only)")
-    rho = float(rho)
     dim = N * nm
+    rho = opt.solver["rho"]
+    scalar = np.ndim(rho) == 0 and not opt.solver.get("force_vector_rho", False)
+    rho = float(rho) if scalar else (np.full(dim, float(rho)) if np.ndim(rho) == 0 else np.ravel(np.asarray(rho, dtype=float)))
+    if not scalar and rho.shape != (dim,):
+        raise ValueError("ellipMPC ADMM: a vector rho has N (n + m) entries")
     Hz = np.zeros((dim, dim))
     Hz[:m, :m] = R
     for l in range(N - 1):
@@ -117,13 +132,14 @@ def compute_ellipMPC_ADMM_ingredients(controller, opt):
     P_half = np.real(sla.sqrtm(P))
     E = np.eye(dim)
     E[dim - n:, dim - n:] = P
-    H = Hz + rho * E
+    H = Hz + (rho * E if scalar else rho[:, None] * E)
     G = build_G(A, B, N, terminal=True)
     Hinv = np.linalg.inv(H)
     W = G @ Hinv @ G.T
+    if not scalar:  # H (hence W) is not symmetric with a non-uniform rho_N; MATLAB's chol (:99) reads the upper triangle only
+        W = np.triu(W) + np.triu(W, 1).T
     Wc = np.linalg.cholesky(W).T
-    incBx = np.asarray(_get(param, "incBx", np.zeros((n, N + 1))), dtype=float).reshape(n, N + 1)
-    incBu = np.asarray(_get(param, "incBu", np.zeros((m, N + 1))), dtype=float).reshape(m, N + 1)
+    incBx, incBu = _inc(param, "incBx", n, N), _inc(param, "incBu", m, N)
     LBx, UBx = np.ravel(_get(sys, "LBx")).astype(float), np.ravel(_get(sys, "UBx")).astype(float)
     LBu, UBu = np.ravel(_get(sys, "LBu")).astype(float), np.ravel(_get(sys, "UBu")).astype(float)
     LBz = np.array([np.concatenate([LBx + incBx[:, i], LBu + incBu[:, i]]) for i in range(1, N)])
@@ -137,7 +153,12 @@ def compute_ellipMPC_ADMM_ingredients(controller, opt):
     v["P"], v["P_half"], v["Pinv_half"] = P.copy(), P_half, np.linalg.inv(P) @ P_half
     v["Q"], v["R"], v["T"] = -np.diag(Q).copy(), -np.diag(R).copy(), -T
     v["c"], v["r"] = c.copy(), r
-    v["rho"], v["rho_i"], v["rho_is_scalar"] = rho, 1.0 / rho, True
+    if scalar:
+        v["rho"], v["rho_i"], v["rho_is_scalar"] = rho, 1.0 / rho, True
+    else:  # (:167-174) the blob's names for the [N-1][n+m] pair are rho_v / rho_i_v
+        v["rho"], v["rho_i"], v["rho_is_scalar"] = 0.0, 0.0, False
+        v["rho_0"], v["rho_v"], v["rho_N"] = rho[:m].copy(), rho[m:dim - n].reshape(N - 1, nm).copy(), rho[dim - n:].copy()
+        v["rho_i_0"], v["rho_i_v"], v["rho_i_N"] = 1.0 / v["rho_0"], 1.0 / v["rho_v"], 1.0 / v["rho_N"]
     Beta = np.zeros((N, n, n))
     Alpha = np.zeros((N - 1, n, n))
     for i in range(N):

@@ -116,6 +116,7 @@ _CASES = [  # (config, overrides, cons file, extra-flag expectation)
     ("C1_MPCT", {}, "formulations/+MPCT/cons_MPCT_EADMM_HIP.m"),
     ("C1_MPCT_nd", {}, "formulations/+MPCT/cons_MPCT_EADMM_HIP.m"),
     ("C1_ellip", {}, "formulations/+ellipMPC/cons_ellipMPC_ADMM_HIP.m"),
+    ("C1_ellip_vec", {}, "formulations/+ellipMPC/cons_ellipMPC_ADMM_HIP.m"),
 ]
 
 
