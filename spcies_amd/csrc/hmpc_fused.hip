@@ -19,7 +19,7 @@ static const char *const kFusedSource =
 namespace {
 
 struct Dims {  // mirrors Shape<> of the kernel file for run-time values
-    int nm, dim, n_soc, n_s, n_box, NA, NC, NR, NXS, NUS, NE, NK, JC, NCH, CHB, o0;
+    int nm, dim, n_soc, n_s, n_box, NA, NC, NR, NRP, NXS, NUS, NE, NK, JC, NCH, CHB, o0;
     Dims(int n, int m, int N, bool use_soc, int mode) {
         nm = n + m;
         dim = (N - 1) * nm + m + 3 * nm;
@@ -35,9 +35,10 @@ struct Dims {  // mirrors Shape<> of the kernel file for run-time values
         NK = 4 * NR + NE + 1;
         int chunk = SPCIES_HFUSED_CHUNK;
         if (const char *ev = getenv("SPCIES_HFUSED_CHUNK")) chunk = atoi(ev);  // (with SPCIES_HFUSED_RTC=1 and the same -D in SPCIES_HFUSED_FLAGS)
-        JC = (chunk / (NR * 512)) > 0 ? (chunk / (NR * 512)) : 1;
-        NCH = (NK + JC - 1) / JC;
-        CHB = ((JC * NR * 512 + 1023) / 1024) * 1024;
+        NRP = (NR + 1) / 2 * 2;
+        JC = (chunk / (NRP * 512)) > 0 ? (chunk / (NRP * 512)) : 1;
+        NCH = ((NK + JC - 1) / JC + 1) / 2 * 2;
+        CHB = JC * NRP * 512;
         o0 = (N - 1) * nm + m;
     }
 };
@@ -71,7 +72,8 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
     const int ncol = 4 * D.NCH * D.JC;
     for (double x : Mx)
         if (!std::isfinite(x)) { p.why = "non-finite M1 / M2"; return 0; }
-    // the table in issue order: chunk | k-slab in chunk | row register | lane (k = l >> 4, b = (l >> 2) & 3, i = l & 3)
+    // the table in issue order: chunk | k-slab in chunk | pair of row registers | lane (k = l >> 4, b = (l >> 2) & 3, i = l & 3) |
+    // register of the pair
     std::vector<double> tab((size_t)D.NCH * (D.CHB / 8), 0.0);
     for (int c = 0; c < D.NCH; c++)
         for (int jj = 0; jj < D.JC; jj++) {
@@ -79,7 +81,8 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
             for (int R = 0; R < D.NR; R++)
                 for (int l = 0; l < 64; l++) {
                     const int k = l >> 4, b = (l >> 2) & 3, i = l & 3;
-                    tab[(size_t)c * (D.CHB / 8) + (size_t)(jj * D.NR + R) * 64 + l] = Mx[(size_t)(16 * R + 4 * b + i) * ncol + 4 * J + k];
+                    tab[(size_t)c * (D.CHB / 8) + ((size_t)(jj * (D.NRP / 2) + R / 2) * 64 + l) * 2 + (R & 1)] =
+                        Mx[(size_t)(16 * R + 4 * b + i) * ncol + 4 * J + k];
                 }
         }
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_ME, tab.size() * sizeof(double)));
