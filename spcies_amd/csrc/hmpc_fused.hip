@@ -27,7 +27,7 @@ struct Dims {  // mirrors Shape<> of the kernel file for run-time values
         n_box = dim - 3 * nm;
         n_s = mode == 0 ? 3 * n_soc : n_box + 3 * n_soc;
         NA = ((mode == 0 ? dim : n_box) + 15) / 16;
-        NC = (n_soc + 3) / 4;
+        NC = 3 * ((n_soc + 15) / 16);
         NR = NA + NC;
         NXS = (n + 3) / 4;
         NUS = (m + 3) / 4;
@@ -164,8 +164,8 @@ int plan_build_split(Plan &p, const SplitHost &h) {
     const int NP = 16 * D.NR;
     std::vector<int> orig(NP, -1);
     for (int r = 0; r < h.dim; r++) orig[r] = r;
-    for (int t = 0; t < D.n_soc; t++)
-        for (int i = 0; i < 3; i++) orig[16 * D.NA + 4 * t + i] = h.dim + 3 * t + i;
+    for (int t = 0; t < D.n_soc; t++)  // component i of cone t: register NA + 3 (t / 16) + i, row t % 16
+        for (int i = 0; i < 3; i++) orig[16 * (D.NA + 3 * (t / 16) + i) + t % 16] = h.dim + 3 * t + i;
     // extended matrix: hat = -M1 q_hat + M2 bh,  M2 bh = c_const + (-M2[:, :n] A) x0  (:97-104, :174-190)
     const int ncol = 4 * D.NCH * D.JC;
     std::vector<double> Mx((size_t)NP * ncol, 0.0);
@@ -192,8 +192,7 @@ int plan_build_split(Plan &p, const SplitHost &h) {
         ubv[r] = r < D.n_box ? h.UB[r] : 1e300;
     }
     if (!h.use_soc)
-        for (int t = 0; t < D.n_soc; t++)
-            for (int i = 0; i < 4; i++) { d1[4 * t + i] = h.LBy[t]; d2[4 * t + i] = h.UBy[t]; }
+        for (int t = 0; t < D.n_soc; t++) { d1[t] = h.LBy[t]; d2[t] = h.UBy[t]; }
     p.oQQ = put(flat, std::vector<double>(h.QQ, h.QQ + n * n));
     p.oTe = put(flat, std::vector<double>(h.Te, h.Te + n * n));
     p.oSe = put(flat, std::vector<double>(h.Se, h.Se + m * m));
@@ -260,7 +259,7 @@ int plan_build_nosplit(Plan &p, const NosplitHost &h) {
     std::vector<int> orig(NP, -1);
     for (int r = 0; r < D.n_box; r++) orig[r] = r;
     for (int t = 0; t < D.n_soc; t++)
-        for (int i = 0; i < 3; i++) orig[16 * D.NA + 4 * t + i] = D.n_box + 3 * t + i;
+        for (int i = 0; i < 3; i++) orig[16 * (D.NA + 3 * (t / 16) + i) + t % 16] = D.n_box + 3 * t + i;
     const int ncol = 4 * D.NCH * D.JC;
     std::vector<double> Mx((size_t)NP * ncol, 0.0);
     const int cx0 = NP, cxr = NP + 4 * D.NXS, cur = NP + 8 * D.NXS, cone = NP + 4 * D.NE;
@@ -307,8 +306,7 @@ int plan_build_nosplit(Plan &p, const NosplitHost &h) {
     std::vector<double> lbv(16 * D.NA, 0.0), ubv(16 * D.NA, 0.0), d1(16 * D.NC, 0.0), d2(16 * D.NC, 0.0);
     for (int r = 0; r < D.n_box; r++) { lbv[r] = h.LB[r]; ubv[r] = h.UB[r]; }
     if (!h.use_soc)
-        for (int t = 0; t < D.n_soc; t++)
-            for (int i = 0; i < 4; i++) { d1[4 * t + i] = h.LBy[t]; d2[4 * t + i] = h.UBy[t]; }
+        for (int t = 0; t < D.n_soc; t++) { d1[t] = h.LBy[t]; d2[t] = h.UBy[t]; }
     p.oQQ = p.oTe = p.oSe = 0;
     p.oLB = put(flat, lbv);
     p.oUB = put(flat, ubv);
