@@ -21,6 +21,7 @@
 #include "soc_bsp.hpp"
 #include "ellip_bsp.hpp"
 #include "hmpc_fused.hpp"
+#include "cs_fused.hpp"
 #include "fista_r.hpp"
 #include "common.hpp"
 
@@ -103,6 +104,7 @@ struct Solver {
     std::vector<double> h_M1, h_M2, h_bh_nat;
     bsp::Plan bsp;                 // BSP (ellipMPC soc): block-sparse MFMA program, generated per controller
     CsDev cdev{};                  // MPCT ADMM on the extended state space (STREAM, TILE)
+    csfused::Plan csf;             // ... its FUSED variant (dense operator, state in registers)
     hdense::Host hd_host;          // HMPC without the splitting: blob contents, and its GEMM plan
     hdense::Plan hd_plan;
     tile::TileDev tdev{};          // TILE (soc, HMPC): step streams of the sparse operations
@@ -728,7 +730,7 @@ static int resolve_variant(const Solver &s) {
     if (s.host.ellip) return s.bsp.ok ? SPCIES_VARIANT_BSP : SPCIES_VARIANT_STREAM;
     if (s.tv) return SPCIES_VARIANT_STREAM;
     if (s.is_hdense()) return s.hfused.ok ? SPCIES_VARIANT_FUSED : SPCIES_VARIANT_GEMM;
-    if (s.is_cs()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
+    if (s.is_cs()) return s.csf.ok ? SPCIES_VARIANT_FUSED : (s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM);
     if (s.is_hmpc() && s.hfused.ok) return SPCIES_VARIANT_FUSED;
     if (s.is_hmpc() && s.hgemm.ok) return SPCIES_VARIANT_GEMM;
     if (s.is_soc() && !s.is_hmpc() && s.bsp.ok) return SPCIES_VARIANT_BSP;
@@ -1234,13 +1236,15 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         return fail(SPCIES_HIP_EINVAL, "ellipMPC soc solvers take a 4th input r (extra): Spcies:ellipMPC:nrhs:r");
     if (s.is_cs()) {
         s.cdev.k_max = s.host.k_max; s.cdev.tol = s.host.tol;  // set_exit overrides
+        if (resolve_variant(s) == SPCIES_VARIANT_FUSED)
+            return csfused::launch(s.csf, s.cdev.k_max, s.cdev.tol, x0, xr, ur, ref_stride, B, u, k, e, f[0], f[1], f[2], st);
         if (resolve_variant(s) == SPCIES_VARIANT_TILE) {
             if (!s.tdev.lpi) return fail(SPCIES_HIP_ENOSUP, "TILE variant not available: the LDL right-hand side does not fit the LDS");
             int rc = ensure_scratch(s, tile_scratch_bytes(s, B));
             if (rc) return rc;
             return launch_cs_tile(s, x0, xr, ur, ref_stride, B, u, k, e, f, st);
         }
-        if (resolve_variant(s) != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "MPCT ADMM cs: variants STREAM and TILE are built");
+        if (resolve_variant(s) != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "MPCT ADMM cs: variants STREAM, TILE and FUSED are built");
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
         if (rc) return rc;
         return launch_cs_stream(s, x0, xr, ur, ref_stride, B, u, k, e, f, st);
@@ -1448,6 +1452,7 @@ static void free_solver(Solver *s) {
     if (s->d_recs) hipFree(s->d_recs);
     hgemm::plan_free(s->hgemm);
     hfused::plan_free(s->hfused);
+    csfused::plan_free(s->csf);
     fr::plan_free(s->frplan);
     hdense::plan_free(s->hd_plan);
     bsp::plan_free(s->bsp);
@@ -1485,6 +1490,20 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
                                hh.d.empty() ? nullptr : hh.d.data(), hh.C_val.data(), hh.C_row.data(), hh.C_col.data()};
         rc = hfused::plan_build_nosplit(s->hfused, fh);
         if (rc) return rc;
+    }
+    if (s->is_cs()) {  // MPCT ADMM cs: the dense operator of the FUSED variant (cs_fused.hpp)
+        const CsDev &cd = s->cdev;
+        const double *F = s->soc_f64.data();
+        const int *I = s->soc_i32.data();
+        csfused::Host ch{cd.n, cd.m, cd.N, cd.dim, cd.nrow, cd.scalar_rho, cd.rho, cd.scalar_rho ? nullptr : F + cd.rho_v,
+                         F + cd.Tz, F + cd.Sz, F + cd.LB, F + cd.UB, F + cd.L_val, F + cd.Dinv, F + cd.AHi_val, F + cd.HiA_val, F + cd.Hi_val,
+                         I + cd.L_col, I + cd.L_row, I + cd.AHi_col, I + cd.AHi_row, I + cd.HiA_col, I + cd.HiA_row, I + cd.Hi_col, I + cd.Hi_row};
+        const char *ev = getenv("SPCIES_HIP_CSFUSED");
+        if (ev && ev[0] == '0') s->csf.why = "SPCIES_HIP_CSFUSED=0";
+        else {
+            rc = csfused::plan_build(s->csf, ch);
+            if (rc) return rc;
+        }
     }
     if (s->is_hmpc() && !s->h_M1.empty() && s->hdev.coupled) {
         // coupled output constraints: the dense variants' projection kernels know cone rows only - AUTO runs TILE
@@ -1585,6 +1604,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     note("BSP", (s->is_soc() && !s->is_hmpc()) || s->host.ellip, s->bsp.ok, s->bsp.why);
     note("MFMA4", s->mfma4.needs_rtc, s->mfma4.ok, s->mfma4.why);
     note("FUSED", s->is_hmpc() || s->is_hdense(), s->hfused.ok, s->hfused.why);
+    note("FUSED", s->is_cs(), s->csf.ok, s->csf.why);
     if (!s->notes.empty() && getenv("SPCIES_HIP_VERBOSE")) fprintf(stderr, "[spcies_hip] %s\n", s->notes.c_str());
     *out = reinterpret_cast<spcies_hip_handle>(s.release());
     return 0;
@@ -1620,6 +1640,11 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (!h) return fail(SPCIES_HIP_EINVAL, "NULL handle");
     Solver *s = reinterpret_cast<Solver *>(h);
     if (variant < SPCIES_VARIANT_AUTO || variant > SPCIES_VARIANT_MFMA4R) return fail(SPCIES_HIP_EINVAL, "unknown variant %d", variant);
+    if (variant == SPCIES_VARIANT_FUSED && s->is_cs()) {
+        if (!s->csf.ok) return fail(SPCIES_HIP_ENOSUP, "FUSED variant not available: %s", s->csf.why.c_str());
+        s->variant = variant;
+        return 0;
+    }
     if (variant == SPCIES_VARIANT_FUSED) {
         if (!((s->is_hmpc() || s->is_hdense()) && s->hfused.ok))
             return fail(SPCIES_HIP_ENOSUP, "FUSED variant: built for the HMPC solvers whose blob carries the dense M1, M2 (%s)", s->hfused.why.c_str());

@@ -672,8 +672,11 @@ def test_hmpc_coupled_nosplit_vs_oracle(variant, cfg_name, B, golden_dir):
 
 
 # ----------------------------------------------------------------------------------------------
-# MPCT ADMM on the extended state space ('cs'): STREAM bit-exact, TILE 1e-10
+# MPCT ADMM on the extended state space ('cs'): STREAM bit-exact, TILE and FUSED 1e-10
 # ----------------------------------------------------------------------------------------------
+CS_VARIANTS = SPARSE_VARIANTS + ["fused"]  # FUSED: the iteration as one dense contraction, state in registers (cs_fused.hpp)
+
+
 def _compare_cs(variant, got, O, tol=TOL_SPCIES):
     u, k, e, sol = got
     if variant == "stream":
@@ -694,7 +697,7 @@ def _compare_cs(variant, got, O, tol=TOL_SPCIES):
         assert (np.abs(getattr(sol, name) - ref) / scale)[same].max() <= tol, name
 
 
-@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+@pytest.mark.parametrize("variant", CS_VARIANTS)
 def test_mpct_cs_reference_test_instance(variant, golden_dir):
     from oracle import oracle
     from spcies_amd import benchmarks
@@ -712,10 +715,18 @@ def test_mpct_cs_reference_test_instance(variant, golden_dir):
 
 @pytest.mark.parametrize("cfg_name,B,overrides", [("C1_MPCT_cs", 70, {}), ("C1_MPCT_cs_vec", 40, {}), ("C2_cs", 130, {}),
                                                   ("C2_cs", 24, dict(tol=1e-5, k_max=4000)), ("C4_cs", 65, {})])
-@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+@pytest.mark.parametrize("variant", CS_VARIANTS)
 def test_mpct_cs_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     from oracle import oracle
     from spcies_amd import benchmarks
+    if variant == "fused" and cfg_name == "C4_cs":
+        # 2 N (n + m) = 660 rows: past the 30 row registers of the FUSED kernel (and cond(W) = 1e9 there: its build-time check of the
+        # dense operator against the sparse one would refuse it as well) - AUTO stays on TILE and says why
+        cfg, v, s = _fista_solver(cfg_name)
+        assert s.variant == "tile" and "FUSED unavailable" in s.notes
+        with pytest.raises(Exception, match="FUSED"):
+            s.set_variant("fused")
+        return
     # cond(W) = 1e9 at the C4 shape: re-ordered sums differ by cond * eps there (the compiled reference template itself moves by
     # 8e-9 when its constants are printed with 15 digits); STREAM stays bit-exact
     tol = 1e-6 if cfg_name == "C4_cs" else TOL_SPCIES
@@ -727,7 +738,30 @@ def test_mpct_cs_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
 
 
-@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+def test_mpct_cs_fused_exact_fixed_points():
+    """tol = 0 (the fixed-iteration benchmark setting): the reference's exit test is strict (`r > tol`, code_MPCT_ADMM_cs_C.c:196-205), so an
+    instance whose iteration reaches a floating-point FIXED POINT exits with flag 1.  The sparse operation order never gets there within
+    200 iterations on this batch; the w-form of the FUSED kernel does for about one instance in a thousand (k ~ 50).  A fixed point is a
+    fixed point: those instances carry the state every further iteration would reproduce - u, z, v, lambda equal the oracle's after its
+    200 iterations to 1e-10 - and every other instance runs the 200 iterations with flag -1."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver("C2_cs", "fused")
+    assert v["tol"] == 0.0 and v["k_max"] == 200
+    B = 8192
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    u, k, e, sol = s(x0, xr, ur)
+    early = k < 200
+    assert (e[early] == 1).all() and (e[~early] == -1).all() and early.mean() <= 0.01
+    idx = np.concatenate([np.nonzero(early)[0][:48], np.nonzero(~early)[0][:16]])
+    O = oracle.mpct_cs_batch(v, x0[idx], xr[idx], ur[idx])
+    assert (O[1] == 200).all()
+    print(f"exact fixed points: {int(early.sum())} of {B}; max|dz| vs oracle at k = 200: {np.abs(sol.z[idx] - O[3]).max():.2e}")
+    assert np.abs(u[idx] - O[0]).max() <= TOL_SPCIES and np.abs(sol.z[idx] - O[3]).max() <= TOL_SPCIES
+    assert np.abs(sol.v[idx] - O[4]).max() <= TOL_SPCIES and np.abs(sol.lam[idx] - O[5]).max() <= TOL_SPCIES
+
+
+@pytest.mark.parametrize("variant", CS_VARIANTS)
 def test_mpct_cs_vs_reference_template_fixture(variant, golden_dir):
     g = np.load(os.path.join(golden_dir, "template_C1_MPCT_cs.npz"))
     cfg, v, s = _fista_solver("C1_MPCT_cs", variant)
