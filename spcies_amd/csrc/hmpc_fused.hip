@@ -19,7 +19,7 @@ static const char *const kFusedSource =
 namespace {
 
 struct Dims {  // mirrors Shape<> of the kernel file for run-time values
-    int nm, dim, n_soc, n_s, n_box, NA, NC, NR, NRP, NXS, NUS, NE, NK, JC, NCH, CHB, o0;
+    int nm, dim, n_soc, n_s, n_box, NA, NC, NR, NRP, NXS, NUS, NE, NK, JC, NCH, CHB, o0, ncol;
     Dims(int n, int m, int N, bool use_soc, int mode) {
         nm = n + m;
         dim = (N - 1) * nm + m + 3 * nm;
@@ -32,7 +32,8 @@ struct Dims {  // mirrors Shape<> of the kernel file for run-time values
         NXS = (n + 3) / 4;
         NUS = (m + 3) / 4;
         NE = mode == 0 ? NXS : 2 * NXS + NUS;
-        NK = 4 * NR + NE + 1;
+        NK = 4 * NR;
+        ncol = 16 * NR + 4 * (NE + 1);  // columns of the extended matrix: state | inputs | 1
         int chunk = SPCIES_HFUSED_CHUNK;
         if (const char *ev = getenv("SPCIES_HFUSED_CHUNK")) chunk = atoi(ev);  // (with SPCIES_HFUSED_RTC=1 and the same -D in SPCIES_HFUSED_FLAGS)
         NRP = (NR + 1) / 2 * 2;
@@ -54,22 +55,23 @@ int builtin_index(int n, int m, int N, bool sym, bool use_soc, int mode) {
 }
 
 template <int n, int m, int N, bool SYM, bool USE_SOC, int MODE>
-int launch_builtin(const Args &a, const double *ME, const double *C, const double *x0, const double *xr, const double *ur, double *u,
+int launch_builtin(const Args &a, const double *ME, const double *PRO, const double *C, const double *x0, const double *xr, const double *ur, double *u,
                    int *k, int *e, double *const *f, bool want_sol, unsigned grid, hipStream_t st) {
     if (want_sol)
-        hipLaunchKernelGGL((hmpc_fused_kernel<n, m, N, SYM, USE_SOC, MODE, true>), dim3(grid), dim3(kNWV * 64), 0, st, a, ME, C, x0, xr, ur, u, k, e,
+        hipLaunchKernelGGL((hmpc_fused_kernel<n, m, N, SYM, USE_SOC, MODE, true>), dim3(grid), dim3(kNWV * 64), 0, st, a, ME, PRO, C, x0, xr, ur, u, k, e,
                            f[0], f[1], f[2], f[3], f[4], f[5]);
     else
-        hipLaunchKernelGGL((hmpc_fused_kernel<n, m, N, SYM, USE_SOC, MODE, false>), dim3(grid), dim3(kNWV * 64), 0, st, a, ME, C, x0, xr, ur, u, k, e,
+        hipLaunchKernelGGL((hmpc_fused_kernel<n, m, N, SYM, USE_SOC, MODE, false>), dim3(grid), dim3(kNWV * 64), 0, st, a, ME, PRO, C, x0, xr, ur, u, k, e,
                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     SPCIES_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// Common tail of the two plan builders: Mx = the extended matrix [16 NR][4 NCH JC] in internal row / column order
+// Common tail of the two plan builders: Mx = the extended matrix [16 NR][D.ncol] in internal row / column order
+// (columns: state | per-instance inputs in k-slabs of four | the constant)
 int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int symmetric, int mode, const std::vector<double> &Mx,
                 std::vector<double> &flat) {
-    const int ncol = 4 * D.NCH * D.JC;
+    const int ncol = D.ncol, NP = 16 * D.NR;
     for (double x : Mx)
         if (!std::isfinite(x)) { p.why = "non-finite M1 / M2"; return 0; }
     // the table in issue order: chunk | k-slab in chunk | pair of row registers | lane (k = l >> 4, b = (l >> 2) & 3, i = l & 3) |
@@ -78,6 +80,7 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
     for (int c = 0; c < D.NCH; c++)
         for (int jj = 0; jj < D.JC; jj++) {
             const int J = c * D.JC + jj;
+            if (J >= D.NK) continue;  // (zero blocks pad the last chunks)
             for (int R = 0; R < D.NR; R++)
                 for (int l = 0; l < 64; l++) {
                     const int k = l >> 4, b = (l >> 2) & 3, i = l & 3;
@@ -85,8 +88,19 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
                         Mx[(size_t)(16 * R + 4 * b + i) * ncol + 4 * J + k];
                 }
         }
+    // the prologue table: k-slabs of the inputs and the constant slab (column NP + 4 NE, in k = 0)
+    std::vector<double> ptab((size_t)(D.NE + 1) * (D.NRP / 2) * 128, 0.0);
+    for (int J = 0; J <= D.NE; J++)
+        for (int R = 0; R < D.NR; R++)
+            for (int l = 0; l < 64; l++) {
+                const int k = l >> 4, b = (l >> 2) & 3, i = l & 3;
+                if (J == D.NE && k > 0) continue;
+                ptab[((size_t)(J * (D.NRP / 2) + R / 2) * 64 + l) * 2 + (R & 1)] = Mx[(size_t)(16 * R + 4 * b + i) * ncol + NP + 4 * J + k];
+            }
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_ME, tab.size() * sizeof(double)));
     SPCIES_HIP_CHECK(hipMemcpy(p.d_ME, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_PRO, ptab.size() * sizeof(double)));
+    SPCIES_HIP_CHECK(hipMemcpy(p.d_PRO, ptab.data(), ptab.size() * sizeof(double), hipMemcpyHostToDevice));
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_C, flat.size() * sizeof(double)));
     SPCIES_HIP_CHECK(hipMemcpy(p.d_C, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
     p.n = n; p.m = m; p.N = N; p.use_soc = use_soc; p.symmetric = symmetric; p.mode = mode;
@@ -140,9 +154,10 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
 
 void plan_free(Plan &p) {
     if (p.d_ME) hipFree(p.d_ME);
+    if (p.d_PRO) hipFree(p.d_PRO);
     if (p.d_C) hipFree(p.d_C);
     if (p.module) hipModuleUnload((hipModule_t)p.module);
-    p.d_ME = p.d_C = nullptr;
+    p.d_ME = p.d_PRO = p.d_C = nullptr;
     p.module = nullptr;
     p.ok = false;
 }
@@ -167,7 +182,7 @@ int plan_build_split(Plan &p, const SplitHost &h) {
     for (int t = 0; t < D.n_soc; t++)  // component i of cone t: register NA + 3 (t / 16) + i, row t % 16
         for (int i = 0; i < 3; i++) orig[16 * (D.NA + 3 * (t / 16) + i) + t % 16] = h.dim + 3 * t + i;
     // extended matrix: hat = -M1 q_hat + M2 bh,  M2 bh = c_const + (-M2[:, :n] A) x0  (:97-104, :174-190)
-    const int ncol = 4 * D.NCH * D.JC;
+    const int ncol = D.ncol;
     std::vector<double> Mx((size_t)NP * ncol, 0.0);
     for (int ri = 0; ri < NP; ri++) {
         const int ro = orig[ri];
@@ -260,7 +275,7 @@ int plan_build_nosplit(Plan &p, const NosplitHost &h) {
     for (int r = 0; r < D.n_box; r++) orig[r] = r;
     for (int t = 0; t < D.n_soc; t++)
         for (int i = 0; i < 3; i++) orig[16 * (D.NA + 3 * (t / 16) + i) + t % 16] = D.n_box + 3 * t + i;
-    const int ncol = 4 * D.NCH * D.JC;
+    const int ncol = D.ncol;
     std::vector<double> Mx((size_t)NP * ncol, 0.0);
     const int cx0 = NP, cxr = NP + 4 * D.NXS, cur = NP + 8 * D.NXS, cone = NP + 4 * D.NE;
     for (int ri = 0; ri < NP; ri++) {
@@ -333,18 +348,18 @@ int launch(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rh
     for (int i = 0; i < nf; i++) { ff[i] = f[i]; want_sol |= f[i] != nullptr; }
     const long groups = (B + 31) / 32;
     const unsigned grid = (unsigned)std::min<long>(groups, p.num_cu);
-    const double *ME = p.d_ME, *C = p.d_C;
+    const double *ME = p.d_ME, *PRO = p.d_PRO, *C = p.d_C;
     if (p.builtin >= 0) {
         int idx = 0;
 #define X(nn, mm, NN, SS, UU, MM)                                                                                              \
-    if (p.builtin == idx) return launch_builtin<nn, mm, NN, SS, UU, MM>(a, ME, C, x0, xr, ur, u, k, e, ff, want_sol, grid, st); \
+    if (p.builtin == idx) return launch_builtin<nn, mm, NN, SS, UU, MM>(a, ME, PRO, C, x0, xr, ur, u, k, e, ff, want_sol, grid, st); \
     idx++;
         SPCIES_HFUSED_SHAPES(X)
 #undef X
         return fail(SPCIES_HIP_ENOSUP, "FUSED: bad build-time shape index");
     }
     double *f0 = ff[0], *f1 = ff[1], *f2 = ff[2], *f3 = ff[3], *f4 = ff[4], *f5 = ff[5];
-    void *params[] = {&a, &ME, &C, &x0, &xr, &ur, &u, &k, &e, &f0, &f1, &f2, &f3, &f4, &f5};
+    void *params[] = {&a, &ME, &PRO, &C, &x0, &xr, &ur, &u, &k, &e, &f0, &f1, &f2, &f3, &f4, &f5};
     SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 1 : 0], grid, 1, 1, kNWV * 64, 1, 1, 0, st, params, nullptr));
     return 0;
 }

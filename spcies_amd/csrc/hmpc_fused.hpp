@@ -32,7 +32,7 @@ struct Plan {
     std::string why = "not built";
     int n = 0, m = 0, N = 0, use_soc = 0, symmetric = 0, mode = 0;  // mode 0: split, 1: no splitting
     int NR = 0, NK = 0, NCH = 0, CHB = 0;
-    double *d_ME = nullptr, *d_C = nullptr;
+    double *d_ME = nullptr, *d_PRO = nullptr, *d_C = nullptr;  // iteration table, prologue table (inputs | 1), constants
     int oQQ = 0, oTe = 0, oSe = 0, oLB = 0, oUB = 0, oD1 = 0, oD2 = 0, oZcol = 0, oZcoef = 0, oZd = 0;
     int num_cu = 256;
     void *module = nullptr;        // hipModule_t of a run-time specialised kernel (shapes not instantiated at build time)
