@@ -19,16 +19,19 @@ static const char *const kFusedSource =
 namespace {
 
 struct Dims {  // mirrors Shape<> of the kernel file for run-time values
-    int nm, dim, n_soc, n_s, n_box, NA, NC, NR, NRP, NXS, NUS, NE, NK, JC, NCH, CHB, o0, ncol;
-    Dims(int n, int m, int N, bool use_soc, int mode) {
+    int nm, dim, n_y, n_soc, n_s, n_box, n_sb, NA, NB, NC, NR, NRP, NXS, NUS, NE, NK, JC, NCH, CHB, o0, ncol;
+    Dims(int n, int m, int N, bool use_soc, int mode, int ny = 0) {
         nm = n + m;
         dim = (N - 1) * nm + m + 3 * nm;
-        n_soc = use_soc ? 2 * nm : nm;
+        n_y = ny ? ny : nm;
+        n_soc = use_soc ? 2 * n_y : n_y;
         n_box = dim - 3 * nm;
-        n_s = mode == 0 ? 3 * n_soc : n_box + 3 * n_soc;
+        n_sb = ny ? N * ny : 0;
+        n_s = mode == 0 ? n_sb + 3 * n_soc : n_box + 3 * n_soc;
         NA = ((mode == 0 ? dim : n_box) + 15) / 16;
+        NB = (n_sb + 15) / 16;
         NC = 3 * ((n_soc + 15) / 16);
-        NR = NA + NC;
+        NR = NA + NB + NC;
         NXS = (n + 3) / 4;
         NUS = (m + 3) / 4;
         NE = mode == 0 ? NXS : 2 * NXS + NUS;
@@ -70,7 +73,7 @@ int launch_builtin(const Args &a, const double *ME, const double *PRO, const dou
 // Common tail of the two plan builders: Mx = the extended matrix [16 NR][D.ncol] in internal row / column order
 // (columns: state | per-instance inputs in k-slabs of four | the constant)
 int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int symmetric, int mode, const std::vector<double> &Mx,
-                std::vector<double> &flat) {
+                std::vector<double> &flat, int ny = 0) {
     const int ncol = D.ncol, NP = 16 * D.NR;
     for (double x : Mx)
         if (!std::isfinite(x)) { p.why = "non-finite M1 / M2"; return 0; }
@@ -103,14 +106,14 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
     SPCIES_HIP_CHECK(hipMemcpy(p.d_PRO, ptab.data(), ptab.size() * sizeof(double), hipMemcpyHostToDevice));
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_C, flat.size() * sizeof(double)));
     SPCIES_HIP_CHECK(hipMemcpy(p.d_C, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
-    p.n = n; p.m = m; p.N = N; p.use_soc = use_soc; p.symmetric = symmetric; p.mode = mode;
+    p.n = n; p.m = m; p.N = N; p.use_soc = use_soc; p.symmetric = symmetric; p.mode = mode; p.ny = ny;
     p.NR = D.NR; p.NK = D.NK; p.NCH = D.NCH; p.CHB = D.CHB;
     hipDeviceProp_t prop;
     int dev = 0;
     SPCIES_HIP_CHECK(hipGetDevice(&dev));
     SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     p.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    p.builtin = builtin_index(n, m, N, symmetric != 0, use_soc != 0, mode);
+    p.builtin = ny ? -1 : builtin_index(n, m, N, symmetric != 0, use_soc != 0, mode);
     const char *force = getenv("SPCIES_HFUSED_RTC");  // kernel experiments: re-specialise a built-in shape (with SPCIES_HFUSED_FLAGS)
     if (force && force[0] == '1') p.builtin = -1;
     if (p.builtin < 0) {  // not among the build-time shapes: specialise now (SPCIES_HIP_RTC=0 turns it off)
@@ -119,8 +122,8 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
         std::vector<std::string> names, extra = {"-mllvm", "-amdgpu-mfma-vgpr-form"};  // (as the build-time instantiations)
         for (int s = 0; s < 2; s++) {
             char nm[160];
-            snprintf(nm, sizeof(nm), "spcies::hfused::hmpc_fused_kernel<%d, %d, %d, %s, %s, %d, %s>", n, m, N, symmetric ? "true" : "false",
-                     use_soc ? "true" : "false", mode, s ? "true" : "false");
+            snprintf(nm, sizeof(nm), "spcies::hfused::hmpc_fused_kernel<%d, %d, %d, %s, %s, %d, %s, %d>", n, m, N, symmetric ? "true" : "false",
+                     use_soc ? "true" : "false", mode, s ? "true" : "false", ny);
             names.push_back(nm);
         }
         if (const char *fl = getenv("SPCIES_HFUSED_FLAGS")) {
@@ -171,16 +174,18 @@ static int put(std::vector<double> &flat, const std::vector<double> &v) {
 
 int plan_build_split(Plan &p, const SplitHost &h) {
     const int n = h.n, m = h.m, N = h.N;
-    const Dims D(n, m, N, h.use_soc != 0, 0);
+    const int ny = h.coupled ? h.n_y : 0;
+    const Dims D(n, m, N, h.use_soc != 0, 0, ny);
     if (D.dim != h.dim || D.n_s != h.n_s || D.n_soc != h.n_soc) { p.why = "unexpected HMPC dimensions"; return 0; }
-    if (D.NR > 24) { p.why = "FUSED: more than 24 row registers (dim + padded cones > 384 rows)"; return 0; }
+    if (D.NR > 24) { p.why = "FUSED: more than 24 row registers (dim + padded slacks and cones > 384 rows)"; return 0; }
     const int np = h.dim + h.n_s, nc = h.n_eq + h.n_s;
     // internal row -> row of (z, s), or -1 for a pad
     const int NP = 16 * D.NR;
     std::vector<int> orig(NP, -1);
     for (int r = 0; r < h.dim; r++) orig[r] = r;
-    for (int t = 0; t < D.n_soc; t++)  // component i of cone t: register NA + 3 (t / 16) + i, row t % 16
-        for (int i = 0; i < 3; i++) orig[16 * (D.NA + 3 * (t / 16) + i) + t % 16] = h.dim + 3 * t + i;
+    for (int j = 0; j < D.n_sb; j++) orig[16 * D.NA + j] = h.dim + j;  // coupled constraints: the box slacks of the outputs
+    for (int t = 0; t < D.n_soc; t++)  // component i of cone t: register NA + NB + 3 (t / 16) + i, row t % 16
+        for (int i = 0; i < 3; i++) orig[16 * (D.NA + D.NB + 3 * (t / 16) + i) + t % 16] = h.dim + D.n_sb + 3 * t + i;
     // extended matrix: hat = -M1 q_hat + M2 bh,  M2 bh = c_const + (-M2[:, :n] A) x0  (:97-104, :174-190)
     const int ncol = D.ncol;
     std::vector<double> Mx((size_t)NP * ncol, 0.0);
@@ -201,11 +206,12 @@ int plan_build_split(Plan &p, const SplitHost &h) {
     }
     // constants: QQ, Te, Se, bounds per internal z row, cone shifts per internal cone row
     std::vector<double> flat;
-    std::vector<double> lbv(16 * D.NA, 0.0), ubv(16 * D.NA, 0.0), d1(16 * D.NC, 0.0), d2(16 * D.NC, 0.0);
-    for (int r = 0; r < h.dim; r++) {
-        lbv[r] = r < D.n_box ? h.LB[r] : -1e300;
-        ubv[r] = r < D.n_box ? h.UB[r] : 1e300;
+    std::vector<double> lbv(16 * (D.NA + D.NB), 0.0), ubv(16 * (D.NA + D.NB), 0.0), d1(16 * (D.NC / 3), 0.0), d2(16 * (D.NC / 3), 0.0);  // cone shifts, one per cone (sets of sixteen)
+    for (int r = 0; r < h.dim; r++) {  // (coupled constraints: z is free)
+        lbv[r] = (!ny && r < D.n_box) ? h.LB[r] : -1e300;
+        ubv[r] = (!ny && r < D.n_box) ? h.UB[r] : 1e300;
     }
+    for (int j = 0; j < D.n_sb; j++) { lbv[16 * D.NA + j] = h.LBy[j % ny]; ubv[16 * D.NA + j] = h.UBy[j % ny]; }
     if (!h.use_soc)
         for (int t = 0; t < D.n_soc; t++) { d1[t] = h.LBy[t]; d2[t] = h.UBy[t]; }
     p.oQQ = put(flat, std::vector<double>(h.QQ, h.QQ + n * n));
@@ -216,7 +222,7 @@ int plan_build_split(Plan &p, const SplitHost &h) {
     p.oD1 = put(flat, d1);
     p.oD2 = put(flat, d2);
     p.oZcol = p.oZcoef = p.oZd = 0;
-    return finish_plan(p, D, n, m, N, h.use_soc, h.symmetric, 0, Mx, flat);
+    return finish_plan(p, D, n, m, N, h.use_soc, h.symmetric, 0, Mx, flat, ny);
 }
 
 int plan_build_nosplit(Plan &p, const NosplitHost &h) {
@@ -318,7 +324,7 @@ int plan_build_nosplit(Plan &p, const NosplitHost &h) {
         zd[inv[found]] = dv[found];
     }
     std::vector<double> flat;
-    std::vector<double> lbv(16 * D.NA, 0.0), ubv(16 * D.NA, 0.0), d1(16 * D.NC, 0.0), d2(16 * D.NC, 0.0);
+    std::vector<double> lbv(16 * D.NA, 0.0), ubv(16 * D.NA, 0.0), d1(16 * (D.NC / 3), 0.0), d2(16 * (D.NC / 3), 0.0);  // cone shifts, one per cone (sets of sixteen)
     for (int r = 0; r < D.n_box; r++) { lbv[r] = h.LB[r]; ubv[r] = h.UB[r]; }
     if (!h.use_soc)
         for (int t = 0; t < D.n_soc; t++) { d1[t] = h.LBy[t]; d2[t] = h.UBy[t]; }

@@ -13,6 +13,7 @@ namespace hfused {
 
 struct SplitHost {  // what parse_hmpc collected (HMPC ADMM / SADMM split, blob arrays of cons_HMPC_ADMM_split_C.m:121-150)
     int n, m, N, dim, n_s, n_eq, n_soc, use_soc, symmetric, k_max;
+    int coupled, n_y;                                          // COUPLED_CONSTRAINTS: n_y outputs, s = [N n_y box slacks ; cones]
     double tol_p, tol_d, rho, rho_i, sigma, sigma_i, alpha;
     const double *M1, *M2, *bh_nat;                            // [np][np], [np][n_eq + n_s], [n_eq + n_s]
     const double *A, *QQ, *Te, *Se, *LB, *UB, *LBy, *UBy;     // dense small matrices and bounds
@@ -30,7 +31,7 @@ struct NosplitHost {  // what parse_hmpc_dense collected (HMPC ADMM / SADMM with
 struct Plan {
     bool ok = false;
     std::string why = "not built";
-    int n = 0, m = 0, N = 0, use_soc = 0, symmetric = 0, mode = 0;  // mode 0: split, 1: no splitting
+    int n = 0, m = 0, N = 0, use_soc = 0, symmetric = 0, mode = 0, ny = 0;  // mode 0: split, 1: no splitting; ny > 0: coupled constraints
     int NR = 0, NK = 0, NCH = 0, CHB = 0;
     double *d_ME = nullptr, *d_PRO = nullptr, *d_C = nullptr;  // iteration table, prologue table (inputs | 1), constants
     int oQQ = 0, oTe = 0, oSe = 0, oLB = 0, oUB = 0, oD1 = 0, oD2 = 0, oZcol = 0, oZcoef = 0, oZd = 0;

@@ -1505,18 +1505,17 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
             if (rc) return rc;
         }
     }
-    if (s->is_hmpc() && !s->h_M1.empty() && s->hdev.coupled) {
-        // coupled output constraints: the dense variants' projection kernels know cone rows only - AUTO runs TILE
-        s->hgemm.why = s->hfused.why = "coupled output constraints run on the sparse path (TILE / STREAM)";
-    } else if (s->is_hmpc() && !s->h_M1.empty()) {
+    if (s->is_hmpc() && !s->h_M1.empty()) {
         const HmpcDev &hd = s->hdev;
         const double *F = s->soc_f64.data();
-        rc = hgemm::plan_build(s->hgemm, hd, s->h_M1, s->h_M2, s->h_bh_nat, F + hd.A, F + hd.QQ, F + hd.Te, F + hd.Se, F + hd.LB,
-                               hd.dim - 3 * (hd.n + hd.m), F + hd.UB, F + hd.LBy, F + hd.UBy);
-        if (rc) return rc;
-        const int nb = hd.dim - 3 * (hd.n + hd.m);
-        (void)nb;
-        hfused::SplitHost fh{hd.n, hd.m, hd.N, hd.dim, hd.n_s, hd.n_eq, hd.n_soc, hd.use_soc, hd.symmetric, hd.k_max,
+        if (hd.coupled) {  // coupled output constraints: the GEMM variant's projection kernel knows z and cone rows only
+            s->hgemm.why = "coupled output constraints: FUSED, TILE and STREAM are built";
+        } else {
+            rc = hgemm::plan_build(s->hgemm, hd, s->h_M1, s->h_M2, s->h_bh_nat, F + hd.A, F + hd.QQ, F + hd.Te, F + hd.Se, F + hd.LB,
+                                   hd.dim - 3 * (hd.n + hd.m), F + hd.UB, F + hd.LBy, F + hd.UBy);
+            if (rc) return rc;
+        }
+        hfused::SplitHost fh{hd.n, hd.m, hd.N, hd.dim, hd.n_s, hd.n_eq, hd.n_soc, hd.use_soc, hd.symmetric, hd.k_max, hd.coupled, hd.n_y,
                              hd.tol_p, hd.tol_d, hd.rho, hd.rho_i, hd.sigma, hd.sigma_i, hd.alpha,
                              s->h_M1.data(), s->h_M2.data(), s->h_bh_nat.data(),
                              F + hd.A, F + hd.QQ, F + hd.Te, F + hd.Se, F + hd.LB, F + hd.UB, F + hd.LBy, F + hd.UBy};

@@ -623,10 +623,11 @@ def test_hmpc_nosplit_vs_reference_template_fixture(golden_dir):
 
 # ----------------------------------------------------------------------------------------------
 # HMPC with coupled output constraints LBy <= E x + F u <= UBy (COUPLED_CONSTRAINTS, code_HMPC_ADMM_split_C.c:65, 233-283;
-# compute_HMPC_ADMM_ingredients.m:155-180): split on the sparse path (STREAM bit-exact, TILE 1e-10), non-split on GEMM / STREAM
+# compute_HMPC_ADMM_ingredients.m:155-180): split on FUSED (AUTO, 1e-10; a third row class - the output slacks - between z and the
+# cones) and on the sparse path (STREAM bit-exact, TILE 1e-10), non-split on GEMM / STREAM
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg_name,B", [("C1_HMPCcc", 40), ("C1_HMPCcc_SADMM", 70), ("C1_HMPCcc_soc", 33)])
-@pytest.mark.parametrize("variant", SPARSE_VARIANTS)
+@pytest.mark.parametrize("variant", SPARSE_VARIANTS + ["fused"])
 def test_hmpc_coupled_split_vs_oracle(variant, cfg_name, B, golden_dir):
     from oracle import oracle
     from spcies_amd import benchmarks
@@ -636,7 +637,7 @@ def test_hmpc_coupled_split_vs_oracle(variant, cfg_name, B, golden_dir):
     st = benchmarks.tester_status(cfg.sys)
     x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
     got = s(x0, xr, ur)
-    _compare_sparse(variant, got, oracle.admm_hmpc_batch(v, x0, xr, ur))
+    _compare_sparse(variant, got, oracle.admm_hmpc_batch(v, x0, xr, ur, sparse=(variant != "fused")))
     g = np.load(os.path.join(golden_dir, f"template_{cfg_name}.npz"))  # the compiled reference template on the same constants
     u, k, e, sol = s(g["x0"], g["xr"], g["ur"])
     assert np.array_equal(e, g["e_flag"]) and np.abs(k.astype(int) - g["k"]).max() <= 1
@@ -644,13 +645,13 @@ def test_hmpc_coupled_split_vs_oracle(variant, cfg_name, B, golden_dir):
     assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-8 and np.abs(sol.s - g["s"])[same].max() <= 1e-8
 
 
-def test_hmpc_coupled_split_dense_variants_refuse():
-    """GEMM / FUSED projection kernels know cone rows only: a coupled split solver resolves AUTO to TILE and says why."""
+def test_hmpc_coupled_split_variants():
+    """A coupled split solver resolves AUTO to FUSED (specialised with hiprtc: no build-time shape carries output slacks); the
+    GEMM variant's projection kernel knows z and cone rows only and says so."""
     cfg, v, s = _fista_solver("C1_HMPCcc")
-    assert s.variant == "tile"
-    for variant in ("gemm", "fused"):
-        with pytest.raises(Exception, match="coupled"):
-            s.set_variant(variant)
+    assert s.variant == "fused"
+    with pytest.raises(Exception, match="coupled"):
+        s.set_variant("gemm")
 
 
 @pytest.mark.parametrize("cfg_name,B", [("C1_HMPCcc_nosplit", 40), ("C1_HMPCcc_SADMM_nosplit", 70), ("C1_HMPCcc_soc_nosplit", 33)])
