@@ -433,6 +433,10 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
             asm volatile("" : "+v"(go));
             LAUNDER4(lbm); LAUNDER4(ubm);
             bool res = false;
+            // once every instance of the wavefront has a residual above tol the remaining checks of this iteration cannot change
+            // the outcome (the reference leaves its residual loops at the first hit, code_laxMPC_ADMM_C.c:575-620): skipped under a
+            // wave-uniform branch - a quarter of the iteration's FP64 vector instructions while the batch is far from converged
+            bool all_hit = false;
             auto stage_z = [&](int t, d4 &cwt) -> d4 {
                 d4 z;
                 const d4 qq = qhat(t, cwt);
@@ -453,9 +457,15 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
                 const d4 wn = z + fz * (w[t] - cwt);  // z + lambda/rho
                 const d4 vn = clampv(wn, LBt(t), UBt(t));
                 // v_old = fz * clamp(w_old); the product folds into the subtraction (exact: fz is 0 or 1)
+                if (!all_hit) {
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    res |= (fabs(__builtin_fma(fz, cwt[r], -vn[r])) > tol) | (fabs(z[r] - vn[r]) > tol);
+                    for (int r = 0; r < 4; r++)
+                        res |= (fabs(__builtin_fma(fz, cwt[r], -vn[r])) > tol) | (fabs(z[r] - vn[r]) > tol);
+                    unsigned long long hb = __ballot(res);
+                    hb |= hb >> 32;
+                    hb |= hb >> 16;
+                    all_hit = (hb & 0xFFFFull) == 0xFFFFull;
+                }
                 w[t] = wn;
                 if constexpr (WANT_SOL) {
                     const int off = (t == 0) ? -n : (m + (t - 1) * nm);
