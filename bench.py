@@ -459,8 +459,8 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)  # 0.73 s timed region at C2: long enough for an outside sampler to see the GPU busy
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--variant", default="auto", choices=["auto", "stream", "mfma", "mfma4"])
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances of the CPU baseline (0: about 12 s of work, sized by a probe)")
