@@ -159,13 +159,12 @@ int plan_build(Plan &p, const Host &h) {
     if (!h.scalar_rho)
         for (int j = 0; j < dim; j++) rho[j] = h.rho_v[j];
     // ---- iteration table: ME = Mz diag(rho), internal rows / columns = natural order, pads zero
-    const int ncol = 4 * D.NCH * D.JC;
     std::vector<double> tab((size_t)D.NCH * (D.CHB / 8), 0.0);
     auto me = [&](int r, int c) { return (r < dim && c < dim) ? Mz[(size_t)r * dim + c] * rho[c] : 0.0; };
     for (int c = 0; c < D.NCH; c++)
         for (int jj = 0; jj < D.JC; jj++) {
             const int J = c * D.JC + jj;
-            if (4 * J >= ncol) continue;
+            if (J >= D.NK) continue;  // (zero blocks pad the last chunks)
             for (int R = 0; R < D.NR; R++)
                 for (int l = 0; l < 64; l++) {
                     const int k = l >> 4, b = (l >> 2) & 3, i = l & 3;
