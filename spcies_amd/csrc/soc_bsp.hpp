@@ -268,6 +268,7 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
         }
         snprintf(line, sizeof(line), "              ZUPD(%d, ph); }\n", Ib);
         body += line;
+        if (Ib == 0) body += "/*SPLIT*/";  // the rest of the iteration exists twice: with and without residual checks (below)
         if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
     }
     if (SS > 8) { p.why = "more than 32 cone rows"; return 0; }
@@ -306,6 +307,21 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
         for (int t = nb; t < n_pad; t++) refill(t);
         out += "\n";
         body.swap(out);
+    }
+    {  // Once the first slab's check has put every instance of the wavefront above its tolerance, no later check of this iteration
+       // can change the outcome (the reference leaves its residual loops at the first hit): the rest of the iteration runs in a copy
+       // without the checks (ZUPD_L / SUPD_L), chosen by ONE wave-uniform branch - a branch per slab would cut the straight-line
+       // program into basic blocks the scheduler cannot interleave MFMA chains across (measured: slower than no branch at all)
+        const size_t cut = body.find("/*SPLIT*/");
+        if (cut != std::string::npos && !getenv("SPCIES_BSP_NOSPLIT")) {
+            const std::string head = body.substr(0, cut), tail = body.substr(cut + 9);
+            std::string light = tail;
+            for (const char *nm : {"ZUPD(", "SUPD("}) {
+                const std::string from = nm, to = std::string(nm).insert(4, "_L");
+                for (size_t i = light.find(from); i != std::string::npos; i = light.find(from, i + to.size())) light.replace(i, from.size(), to);
+            }
+            body = head + "            HITUPD;\n            if (all_hit) {\n" + light + "            } else {\n" + tail + "            }\n";
+        }
     }
     // ---- LB / UB rows of the z slabs (rows past dim - n - 1 are free; pads are pinned to 0 by 0 <= z <= 0)
     const int rc_lb = (int)tab.size();
@@ -445,9 +461,24 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
 #define LBR(I) ldsr[4 * (I) + go]
 #define UBR(I) ldsr[4 * ZS_ + 4 * (I) + go]
 #define QHZ(J) (qv[QI_##J] + sigma * (w[J] - 2.0 * fmin(fmax(w[J], LBR(J)), UBR(J))))
-        bool active = valid, res = false;
+        bool active = valid, res = false, all_hit = false;
+#define HITUPD                                                                                   \
+    do {                                                                                         \
+        unsigned long long hb_ = __ballot(res);                                                  \
+        hb_ |= hb_ >> 32;                                                                        \
+        hb_ |= hb_ >> 16;                                                                        \
+        all_hit = (hb_ & 0xFFFFull) == 0xFFFFull;                                                \
+    } while (0)
         int kk = 0;
         RING_INIT
+        // ... without the residual check (every instance of the wavefront is above its tolerance already)
+#define ZUPD_L(I, zh)                                                                            \
+    do {                                                                                         \
+        const double lb_ = LBR(I), ub_ = UBR(I);                                                 \
+        const double wo_ = w[I], zo_ = fmin(fmax(wo_, lb_), ub_);                                \
+        w[I] = (zh) + (wo_ - zo_);                                                               \
+        if (WANT_SOL) *((4 * (I) + 3 < DIM_ || 4 * (I) + g < DIM_) ? zhp + 4 * (I) : dump) = (zh); \
+    } while (0)
         // z rows of slab I: box, lambda, residuals (:209-217, 246-248, 256-267)
 #define ZUPD(I, zh)                                                                              \
     do {                                                                                         \
@@ -482,6 +513,32 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
             sc[k_] = v;                                                                          \
             mu[k_] = mu_ + rho * ((sh)[k_] - v);                                                 \
             res |= (fabs(so_ - v) > tol_d) | (fabs(v - (sh)[k_]) > tol_p);                       \
+            if (WANT_SOL) *((4 * k_ + 3 < NSC_ || 4 * k_ + g < NSC_) ? shp + 4 * k_ : dump) = (sh)[k_]; \
+        }                                                                                        \
+    } while (0)
+#define SUPD_L(sh)                                                                                \
+    do {                                                                                         \
+        double v_[SS_], nrm_ = 0.0;                                                              \
+        _Pragma("unroll") for (int k_ = 0; k_ < SS_; k_++) {                                     \
+            v_[k_] = (sh)[k_] + rho_i * mu[k_];                                                  \
+            nrm_ += (k_ == 0 && g == 0) ? 0.0 : v_[k_] * v_[k_];                                 \
+        }                                                                                        \
+        nrm_ += __shfl_xor(nrm_, 16);                                                            \
+        nrm_ += __shfl_xor(nrm_, 32);                                                            \
+        const double s_norm_ = sqrt(nrm_), s0_ = __shfl(v_[0], c);                               \
+        _Pragma("unroll") for (int k_ = 0; k_ < SS_; k_++) {                                     \
+            double v = v_[k_];                                                                   \
+            if (s_norm_ <= s0_) {                                                                \
+            } else if (s_norm_ <= -s0_) {                                                        \
+                v = 0.0;                                                                         \
+            } else {                                                                             \
+                const double step_ = (s0_ + s_norm_) / (2 * s_norm_);                            \
+                v = (k_ == 0 && g == 0) ? step_ * s_norm_ : step_ * v;                           \
+            }                                                                                    \
+            const double so_ = sc[k_], mu_ = mu[k_];                                             \
+            sc[k_] = v;                                                                          \
+            mu[k_] = mu_ + rho * ((sh)[k_] - v);                                                 \
+            (void)so_;                                                                           \
             if (WANT_SOL) *((4 * k_ + 3 < NSC_ || 4 * k_ + g < NSC_) ? shp + 4 * k_ : dump) = (sh)[k_]; \
         }                                                                                        \
     } while (0)
