@@ -672,6 +672,33 @@ def test_hmpc_coupled_nosplit_vs_oracle(variant, cfg_name, B, golden_dir):
     assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-8
 
 
+@pytest.mark.parametrize("cfg_name", ["C1_HMPC_SADMM", "C1_HMPC_nosplit", "C1_HMPCcc", "C1_MPCT_cs"])
+def test_fused_edge_batches_and_reference_modes(cfg_name):
+    """The FUSED kernels (32 instances per workgroup, four per wavefront group): ragged batch sizes around those strides, the empty
+    batch, one reference for the whole batch - each instance's result does not depend on who shares its wavefront."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver(cfg_name, "fused")
+    x0, xr, ur = benchmarks.sample_batch(cfg, 67)
+    full = s(x0, xr, ur)
+    for B in (1, 3, 5, 31, 33, 64):
+        part = s(x0[:B], xr[:B], ur[:B])
+        assert np.array_equal(part[0], full[0][:B]) and np.array_equal(part[1], full[1][:B]) and np.array_equal(part[2], full[2][:B])
+        assert np.array_equal(part[3].z, full[3].z[:B])
+    u, k, e, sol = s(np.zeros((0, cfg.sys.n)), xr[0], ur[0])
+    assert u.shape == (0, cfg.sys.m) and k.shape == (0,)
+    shared = s(x0[:9], xr[0], ur[0])
+    if cfg_name == "C1_MPCT_cs":
+        O = oracle.mpct_cs_batch(v, x0[:9], xr[0], ur[0])
+    elif "nosplit" in cfg_name:
+        O = oracle.hmpc_dense_batch(v, x0[:9], xr[0], ur[0])
+    else:
+        O = oracle.admm_hmpc_batch(v, x0[:9], xr[0], ur[0], sparse=False)
+    dk = np.abs(shared[1].astype(int) - O[1].astype(int))
+    assert dk.max() <= 1
+    assert np.abs(shared[0] - O[0])[dk == 0].max() <= TOL_SPCIES and np.abs(shared[3].z - O[3])[dk == 0].max() <= TOL_SPCIES
+
+
 # ----------------------------------------------------------------------------------------------
 # MPCT ADMM on the extended state space ('cs'; SURVEY section 8f rank 4): STREAM bit-exact, TILE and FUSED 1e-10
 # ----------------------------------------------------------------------------------------------
