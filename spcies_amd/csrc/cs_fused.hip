@@ -30,8 +30,9 @@ struct Dims {  // mirrors Shape<> of the kernel file
         NE = 2 * NXS + NUS;
         NK = 4 * NR;
         JC = (SPCIES_CSFUSED_CHUNK / (NRP * 512)) > 0 ? (SPCIES_CSFUSED_CHUNK / (NRP * 512)) : 1;
-        NCH = ((NK + JC - 1) / JC + 1) / 2 * 2;
-        CHB = JC * NRP * 512;
+        while (JC > 1 && 3 * ((JC * NRP * 512 + 4095) / 4096 * 4096) + 2 * 16 * NR * 8 > 160 * 1024) JC--;  // (as Shape::pick_jc)
+        NCH = ((NK + JC - 1) / JC + 2) / 3 * 3;
+        CHB = (JC * NRP * 512 + 4095) / 4096 * 4096;
     }
 };
 
@@ -111,7 +112,7 @@ int plan_build(Plan &p, const Host &h) {
     p.ok = false;
     if (D.dim != h.dim) { p.why = "unexpected MPCT-cs dimensions"; return 0; }
     if (D.NR > 30) { p.why = "FUSED: more than 30 row registers (2 N (n + m) > 480)"; return 0; }
-    if (2 * D.CHB + 2 * 16 * D.NR * 8 > 160 * 1024) { p.why = "FUSED: chunk buffers exceed the LDS"; return 0; }
+    if (3 * D.CHB + 2 * 16 * D.NR * 8 > 160 * 1024) { p.why = "FUSED: chunk buffers exceed the LDS"; return 0; }
     const int dim = h.dim, dnm = D.dnm, NP = 16 * D.NR;
     // ---- dense operator, column by column: Mz = d z / d q_hat  [dim][dim],  Kb = d z / d x0  [dim][n]
     Operator op(h);
@@ -218,7 +219,7 @@ int plan_build(Plan &p, const Host &h) {
     if (p.builtin < 0) {
         const char *ev = getenv("SPCIES_HIP_RTC");
         if (ev && ev[0] == '0') { p.why = "shape not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
-        std::vector<std::string> names, extra = {"-mllvm", "-amdgpu-mfma-vgpr-form"};
+        std::vector<std::string> names, extra = {"-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-pragma-unroll-threshold=1000000"};
         for (int s = 0; s < 2; s++) {
             char nm[160];
             snprintf(nm, sizeof(nm), "spcies::csfused::cs_fused_kernel<%d, %d, %d, %s>", n, m, N, s ? "true" : "false");

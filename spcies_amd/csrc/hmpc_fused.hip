@@ -41,8 +41,10 @@ struct Dims {  // mirrors Shape<> of the kernel file for run-time values
         if (const char *ev = getenv("SPCIES_HFUSED_CHUNK")) chunk = atoi(ev);  // (with SPCIES_HFUSED_RTC=1 and the same -D in SPCIES_HFUSED_FLAGS)
         NRP = (NR + 1) / 2 * 2;
         JC = (chunk / (NRP * 512)) > 0 ? (chunk / (NRP * 512)) : 1;
-        NCH = ((NK + JC - 1) / JC + 1) / 2 * 2;
-        CHB = JC * NRP * 512;
+        const int lds_tables = 2 * 16 * (NA + NB) * 8 + 2 * 16 * (NC / 3) * 8;
+        while (JC > 1 && 3 * ((JC * NRP * 512 + 4095) / 4096 * 4096) + lds_tables > 160 * 1024) JC--;  // (as Shape::pick_jc)
+        NCH = ((NK + JC - 1) / JC + 2) / 3 * 3;
+        CHB = (JC * NRP * 512 + 4095) / 4096 * 4096;
         o0 = (N - 1) * nm + m;
     }
 };
@@ -119,7 +121,9 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
     if (p.builtin < 0) {  // not among the build-time shapes: specialise now (SPCIES_HIP_RTC=0 turns it off)
         const char *ev = getenv("SPCIES_HIP_RTC");
         if (ev && ev[0] == '0') { p.why = "shape not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
-        std::vector<std::string> names, extra = {"-mllvm", "-amdgpu-mfma-vgpr-form"};  // (as the build-time instantiations)
+        // (as the build-time instantiations; the unroll threshold: clang otherwise leaves the chunk loop of the larger shapes rolled and
+        // indexes the state arrays at run time - scratch memory)
+        std::vector<std::string> names, extra = {"-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-pragma-unroll-threshold=1000000"};
         for (int s = 0; s < 2; s++) {
             char nm[160];
             snprintf(nm, sizeof(nm), "spcies::hfused::hmpc_fused_kernel<%d, %d, %d, %s, %s, %d, %s, %d>", n, m, N, symmetric ? "true" : "false",
