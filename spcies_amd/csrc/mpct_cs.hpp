@@ -150,6 +150,10 @@ __global__ __launch_bounds__(64 * WAVES) void cs_tile_kernel(CsDev c, TileDev td
         }
         AT(QV, j) = v;
     }
+    // The setup above writes per-instance rows (q, b) that OTHER lane groups of the instance read in the first iteration: without
+    // this fence such a read can overtake the store and pick up whatever the scratch allocation held (a NaN there ends the solve
+    // at k = 2 with flag 1: clamp(NaN) is a bound, NaN > tol is false) - seen once in a full test run, never in isolation
+    __syncthreads();
     int k = 0;
     bool active = valid;
     while (true) {

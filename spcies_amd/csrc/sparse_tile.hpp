@@ -306,6 +306,10 @@ __global__ __launch_bounds__(64 * WAVES) void soc_tile_kernel(SocDev c, TileDev 
     }
     const double rho = c.rho, rho_i = c.rho_i, sigma = c.sigma, sigma_i = c.sigma_i;
 
+    // The setup above writes per-instance rows (q, bh) that OTHER lane groups of the instance read in the first iteration: without
+    // this fence such a read can overtake the store and pick up whatever the scratch allocation held (a NaN there ends the solve
+    // at k = 2 with flag 1: clamp(NaN) is a bound, NaN > tol is false) - seen once in a full test run, never in isolation
+    __syncthreads();
     int k = 0;
     bool active = valid;
     while (true) {
@@ -481,6 +485,10 @@ __global__ __launch_bounds__(64 * WAVES) void hmpc_tile_kernel(HmpcDev c, TileDe
     const double as = c.alpha * c.sigma, ar = c.alpha * c.rho;
     const double gz = c.symmetric ? as : sigma, gs = c.symmetric ? ar : rho;
 
+    // The setup above writes per-instance rows (q, bh) that OTHER lane groups of the instance read in the first iteration: without
+    // this fence such a read can overtake the store and pick up whatever the scratch allocation held (a NaN there ends the solve
+    // at k = 2 with flag 1: clamp(NaN) is a bound, NaN > tol is false) - seen once in a full test run, never in isolation
+    __syncthreads();
     int k = 0;
     bool active = valid;
     while (true) {
