@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
         // A-operand stream: a ring of block pairs kept PF pairs ahead of the MFMA that consumes them (the LDS
         // round trip is ~130 cycles = 8 small MFMAs); it carries over from one iteration to the next.
 #ifndef SPCIES_MFMA4_PF
-#define SPCIES_MFMA4_PF 6
+#define SPCIES_MFMA4_PF 8  // (measured at C2 after the residual short-circuit: 6 -> 7.31 ms, 8 -> 7.21, 10 -> 7.31, 12 -> 7.35)
 #endif
         constexpr int NP = LL.stream_pairs(), PF = SPCIES_MFMA4_PF;
         static_assert(NP > PF, "ring");
