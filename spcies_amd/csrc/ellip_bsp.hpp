@@ -134,7 +134,9 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         Dinv[i] = Dn[i];
     }
     const BlockList bG = blocks_of(Gm, RR, PR_), bHG = blocks_of(HG, PR_, RR), bH = blocks_of(H, PR_, PR_), bL = blocks_of(L, RR, RR);
-    int SEG_EVERY = 4, PF = 8;  // (a 12-deep ring leaves 116 B of scratch at the C2 shape)
+    // ring depth: measured at the C2 shape (ms, scratch B per lane): 8: 10.5 / 0, 12: 9.94 / 116, 16: 9.77 / 148, 20: 9.58 / 156, 24: 9.29 / 280
+    // (the laxMPC programs do not care: 12.5 ms and no scratch at any depth)
+    int SEG_EVERY = 4, PF = 24;
     if (const char *ev = getenv("SPCIES_BSP_SEG")) SEG_EVERY = std::max(1, atoi(ev));
     if (const char *ev = getenv("SPCIES_BSP_PF")) PF = std::min(64, std::max(2, atoi(ev)));
     if (pf_request > 0) PF = pf_request;
@@ -684,8 +686,8 @@ inline int finish_ellip(Plan &p, const AdmmHost &a) {
     int rc = compile_program(p, &scratch, "ellip_bsp_kernel", "ellip_bsp_kernel_sol");
     if (rc) return rc;
     if (!getenv("SPCIES_BSP_PF"))
-        for (int pf : {4}) {
-            if (scratch == 0) break;
+        for (int pf : {12, 8, 4}) {  // (a compiler that spills far more than the one this was tuned with gets a shorter ring)
+            if (scratch <= 640) break;
             rc = build_ellip(p, a, pf);
             if (rc) return rc;
             if (p.src.empty()) return fail(SPCIES_HIP_ENOSUP, "BSP program: %s", p.why.c_str());

@@ -103,7 +103,9 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     const BlockList bG = blocks_of(G, RR, PR_), bHG = blocks_of(HG, PR_, RR), bH = blocks_of(H, PR_, PR_), bL = blocks_of(L, RR, RR);
     // ---- table + program text
     // scheduling fences every SEG_EVERY block rows / columns: without them the compiler hoists the LDS reads of whole phases
-    int SEG_EVERY = 4, PF = 12;  // (16 is 4 % faster at C5 but leaves 44 B of scratch there: finish_soc would recompile)
+    // ring depth: measured at C5 with the split tail (ms, scratch B per lane): 4: 11.51 / 236, 8: 11.13 / 300, 12: 10.71 / 356, 16: 10.36 / 412,
+    // 20: 10.12 / 504, 24: 10.49 / 540, 32: 10.60 / 684 - the deep ring pays for the spills it causes (they sit in the cold copy of the tail)
+    int SEG_EVERY = 4, PF = 20;
     if (const char *ev = getenv("SPCIES_BSP_PF")) PF = std::min(64, std::max(2, atoi(ev)));
     if (pf_request > 0) PF = pf_request;
     p.src.clear();
@@ -673,9 +675,11 @@ inline int finish_soc(Plan &p, const SocDev &c, const double *F, const int *I) {
     int scratch = 0;
     int rc = compile_program(p, &scratch);
     if (rc) return rc;
+    // a compiler that spills far more than the one this was tuned with (an older comgr loaded first: 1 KB and more, 77-99 ms) gets a
+    // shorter ring
     if (!getenv("SPCIES_BSP_PF"))
-        for (int pf : {8, 4}) {
-            if (scratch == 0) break;
+        for (int pf : {12, 8, 4}) {
+            if (scratch <= 640) break;
             rc = build_soc(p, c, F, I, pf);
             if (rc) return rc;
             if (p.src.empty()) return fail(SPCIES_HIP_ENOSUP, "BSP program: %s", p.why.c_str());
