@@ -1,7 +1,8 @@
 """CPU: the BSP variant's code generator (spcies_amd/csrc/soc_bsp.hpp).  `spcies_hip_create` generates the controller's block
 program while it parses the blob - before it needs a device - so the generated HIP source can be captured here
-(SPCIES_BSP_DUMP), compiled for gfx950 with the installed hiprtc (which runs without a GPU) and inspected: it must compile,
-keep its state in registers (no scratch memory in the no-record kernel) and issue exactly one MFMA per table block."""
+(SPCIES_BSP_DUMP), compiled for gfx950 with the installed hiprtc (which runs without a GPU) and inspected: it must compile, stay
+under the spill bound finish_soc accepts (640 B of scratch per lane; the plain program without the split tail and with the 12-deep
+ring keeps everything in registers) and issue exactly one MFMA per table block on either path through the iteration."""
 import ctypes as C
 import os
 import re
@@ -64,19 +65,28 @@ def test_bsp_program_is_generated_compiles_and_keeps_state_in_registers(cfg_name
     if not (os.path.exists(HIPRTC) and os.path.exists(READELF)):
         pytest.skip("needs the ROCm installation's hiprtc and llvm-readelf")
     src = _generate(cfg_name, tmp_path / "prog.hip", monkeypatch)
-    assert "soc_bsp_kernel" in src and len(re.findall(r"\bMF\(", src)) == n_blocks + 1  # + the macro definition
-    # every table block is consumed by exactly one MFMA, and refilled into the ring exactly once per iteration
-    assert len(re.findall(r"= BLK\(blk\d, \d+\);", src)) >= n_blocks
+    assert "soc_bsp_kernel" in src
+    # the iteration: a head, then ONE wave-uniform branch `if (all_hit) { tail without residual checks } else { tail }` (soc_bsp.hpp);
+    # every table block is consumed by exactly one MFMA on either path, and refilled into the ring once
+    body = src[src.index("while (true)"):]
+    i_if, i_else = body.index("if (all_hit) {"), body.index("} else {", body.index("if (all_hit) {"))
+    head, light, full = body[:i_if], body[i_if:i_else], body[i_else:]
+    n_mf = lambda t: len(re.findall(r"\bMF\(", t))
+    assert n_mf(head) + n_mf(light) == n_blocks and n_mf(light) == n_mf(full)
+    assert "ZUPD_L(" in light and "ZUPD(" not in light.replace("ZUPD_L(", "") and "ZUPD(" in full and "ZUPD_L(" not in full
+    assert len(re.findall(r"= BLK\(blk\d, \d+\);", head + full)) >= n_blocks
     kernels, lds = _compile(tmp_path / "prog.hip", tmp_path / "prog.co")
     assert set(kernels) == {"soc_bsp_kernel", "soc_bsp_kernel_sol"}
     assert lds and max(lds) <= 160 * 1024
-    assert int(kernels["soc_bsp_kernel"]) == 0  # the default 12-deep ring: no scratch at either size
+    assert int(kernels["soc_bsp_kernel"]) <= 640  # the default 20-deep ring: within the bound finish_soc accepts (0 at C1, 504 B at C5)
 
 
-def test_bsp_shallower_ring_has_no_scratch_at_c5(tmp_path, monkeypatch):
+def test_bsp_plain_program_has_no_scratch_at_c5(tmp_path, monkeypatch):
     if not (os.path.exists(HIPRTC) and os.path.exists(READELF)):
         pytest.skip("needs the ROCm installation's hiprtc and llvm-readelf")
-    monkeypatch.setenv("SPCIES_BSP_PF", "8")  # (finish_soc falls back to 8, then 4, if a program spills)
+    monkeypatch.setenv("SPCIES_BSP_PF", "12")     # the round-1 program: one copy of the tail, 12-deep ring
+    monkeypatch.setenv("SPCIES_BSP_NOSPLIT", "1")
     src = _generate("C5_soc", tmp_path / "prog.hip", monkeypatch)
+    assert "if (all_hit) {" not in src and len(re.findall(r"\bMF\(", src)) == 1015 + 1  # + the macro definition
     kernels, _ = _compile(tmp_path / "prog.hip", tmp_path / "prog.co")
     assert int(kernels["soc_bsp_kernel"]) == 0
