@@ -69,6 +69,26 @@ def traffic_from_profile(variant):
     return None, None
 
 
+_PROFILE_OF = {"C3": "r02_C3_mfma4r", "C4": "r02_C4_mfma4g", "C5_soc": "r02_C5soc_bsp", "C5_hmpc": "r02_C5hmpc_fused"}
+
+
+def design_traffic(key):
+    """HBM bytes per launch of a configuration's kernel from its committed rocprofv3 PMC passes (profiles/r02_<config>_pmc_summary.txt,
+    FETCH_SIZE x 2 + WRITE_SIZE, KB) - the DESIGN traffic, a constant read from the repository like `roofline.traffic` above."""
+    path = os.path.join(ROOT, "profiles", _PROFILE_OF.get(key, "") + "_pmc_summary.txt")
+    if not os.path.exists(path):
+        return None, None
+    fetch = write = None
+    for line in open(path):
+        if line.startswith("FETCH_SIZE"):
+            fetch = float(line.split("mean=")[1].split()[0])
+        elif line.startswith("WRITE_SIZE"):
+            write = float(line.split("mean=")[1].split()[0])
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.relpath(path, ROOT)
+
+
 def host_threads():
     """Threads the CPU baseline may use: the affinity mask, capped by the cgroup CPU quota when there is one."""
     n = len(os.sched_getaffinity(0))
@@ -212,7 +232,7 @@ def _oracle_check(cfg, v, x0, xr, ur, u_gpu, k_gpu, count=32):
             "k_equal": bool(np.array_equal(k_gpu[:count], o[1]))}
 
 
-def bench_config(spec, dev, steps, warmup):
+def bench_config(spec, dev, steps, warmup, key=""):
     import torch
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
@@ -253,6 +273,9 @@ def bench_config(spec, dev, steps, warmup):
                         "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_MFMA_TFLOPS,
                         "flop_per_solve": spec["flop"], "algorithmic_io_gbs": gbs, "hbm_frac_algorithmic": gbs / PEAK_HBM_GBS},
            "oracle_check": _oracle_check(cfg, v, x0, xr, ur, tu[:32].cpu().numpy(), tk[:32].cpu().numpy())}
+    traffic, src = design_traffic(key)
+    if traffic is not None:  # what the kernel really moves through HBM (design bytes, not algorithmic ones) against the 8 TB/s peak
+        out["roofline"].update(traffic=traffic, traffic_source=src, hbm_frac_design=traffic / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS)
     solver.close()
     return out
 
@@ -431,7 +454,7 @@ def run_rank(args):
                         continue
                     t = time.perf_counter()
                     try:
-                        out["configs"][key] = bench_config(spec, dev, args.config_steps, 1)
+                        out["configs"][key] = bench_config(spec, dev, args.config_steps, 1, key)
                     except Exception as ex:  # a failing side configuration must not lose the headline line
                         out["configs"][key] = {"error": f"{type(ex).__name__}: {ex}"}
                     out["configs"][key]["wall_s"] = time.perf_counter() - t
