@@ -256,6 +256,8 @@ int plan_build(Plan &p, const Host &h) {
     // d scratch: one slot per resident wavefront (fista_r_kernel.inc)
     const size_t slot = (size_t)std::max(h.N - p.PD, 1) * KX * 512;
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_scr, slot * p.num_cu * p.NW));
+    if (const char *ev = getenv("SPCIES_HIP_POISON"))  // (test runs: see ensure_scratch in spcies_hip.hip)
+        if (ev[0] == '1') SPCIES_HIP_CHECK(hipMemset(p.d_scr, 0xFF, slot * p.num_cu * p.NW));
     p.ok = true;
     p.why.clear();
     return 0;

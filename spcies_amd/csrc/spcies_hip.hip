@@ -764,6 +764,13 @@ static int ensure_scratch(Solver &s, size_t need) {
     s.scratch_bytes = 0;
     SPCIES_HIP_CHECK(hipMalloc((void **)&s.d_scratch, need));
     s.scratch_bytes = need;
+    // Scratch is never zeroed: a kernel that reads a row before it wrote it gets whatever the allocation held.  SPCIES_HIP_POISON=1
+    // (test runs) fills it with NaNs so that such a read shows in the results instead of depending on the memory's history.
+    if (const char *ev = getenv("SPCIES_HIP_POISON"))
+        if (ev[0] == '1') {
+            SPCIES_HIP_CHECK(hipMemset(s.d_scratch, 0xFF, need));
+            SPCIES_HIP_CHECK(hipDeviceSynchronize());
+        }
     return 0;
 }
 
