@@ -191,22 +191,218 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _out_dir():
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _tail(path, nbytes=2000):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, os.SEEK_END)
+            f.seek(max(0, f.tell() - nbytes))
+            return f.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
+def _stop(procs, grace=5.0):
+    """Terminate the children this process started (exact PIDs, never a pattern), then kill what ignores the signal."""
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    deadline = time.monotonic() + grace
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.0, deadline - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+
+
 def launch_ranks(args, argv):
     """Parent of a self-launched multi-GPU run.  It makes NO GPU call (a process that initialised the GPU must not be
     replaced or forked on this pool): it starts N fresh children of this script with RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_ADDR / MASTER_PORT set, relays rank 0's stdout (the JSON line) and returns the worst exit code."""
+    MASTER_ADDR / MASTER_PORT set and WATCHES them: every rank's stderr goes to gpurun_out/rank<r>.err, rank 0's stdout (the
+    JSON line) to gpurun_out/rank0.out; the first rank that exits non-zero - or the overall --launch-timeout - ends the
+    others (they would otherwise sit in the RCCL rendezvous or a barrier until its watchdog fires), the failing rank's last
+    stderr lines are relayed and the parent exits non-zero.  On success rank 0's line is relayed, with the one-process
+    `multi` leg (spcies_hip_create_multi over the same N devices, run afterwards in a fresh child) merged in."""
     port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
-    procs = []
+    out_dir = _out_dir()
+    procs, files = [], []
+    out0 = os.path.join(out_dir, "rank0.out")
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", SPCIES_BENCH_SELF_LAUNCHED="1")
+        ferr = open(os.path.join(out_dir, f"rank{r}.err"), "w")
+        fout = open(out0, "w") if r == 0 else subprocess.DEVNULL
+        files += [ferr] + ([fout] if r == 0 else [])
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=fout, stderr=ferr))
+    deadline = time.monotonic() + args.launch_timeout
+    failed, why = None, ""
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed, why = bad[0], f"rank {bad[0]} exited with code {codes[bad[0]]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failed = next(r for r, c in enumerate(codes) if c is None)
+            why = f"--launch-timeout {args.launch_timeout:.0f} s passed; ranks still running: {[r for r, c in enumerate(codes) if c is None]}"
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        _stop(procs)
+    for f in files:
+        f.close()
+    if failed is not None:
+        sys.stderr.write(f"bench.py: {why}; the other ranks were stopped.  Last lines of gpurun_out/rank{failed}.err:\n"
+                         f"{_tail(os.path.join(out_dir, f'rank{failed}.err'))}\n")
+        sys.stderr.flush()
+        rc = procs[failed].returncode
+        return abs(rc) if rc not in (None, 0) else 124
+    out = open(out0).read()
+    if not args.no_multi_leg and not args.dry_run:
+        out = _merge_multi_leg(out, run_multi_leg_child(args))
     sys.stdout.write(out)
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return 0
+
+
+def _merge_multi_leg(out, leg):
+    lines = out.splitlines()
+    for i in range(len(lines) - 1, -1, -1):
+        if lines[i].startswith("{"):
+            try:
+                d = json.loads(lines[i])
+            except ValueError:
+                continue
+            d["multi_launch"] = leg
+            lines[i] = json.dumps(d)
+            break
+    return "\n".join(lines) + "\n"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "launch": "multi" - ONE process, N devices through spcies_hip_create_multi (what a mex or plain-C caller has: no launcher,
+# no torch), host batch of N x B instances in page-locked buffers, split into contiguous shards by the library
+# ---------------------------------------------------------------------------------------------------------------------
+def run_multi_leg_child(args, timeout=240.0):
+    """Run the multi leg in a FRESH child (the caller may hold a GPU context; it is never re-exec'ed) and return its JSON."""
+    out_dir = _out_dir()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT",
+                                                          "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.abspath(__file__), "--launch", "multi", "--gpus", str(args.gpus), "--steps", str(max(1, min(args.steps, 20))),
+           "--warmup", str(max(1, min(args.warmup, 3))), "--batch", str(args.batch)]
+    err_path = os.path.join(out_dir, "multi_leg.err")
+    try:
+        with open(err_path, "w") as ferr:
+            p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=ferr, text=True)
+            try:
+                out, _ = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                _stop([p])
+                return {"error": f"multi leg did not finish within {timeout:.0f} s", "stderr_tail": _tail(err_path, 600)}
+        if p.returncode != 0:
+            return {"error": f"multi leg exited with code {p.returncode}", "stderr_tail": _tail(err_path, 600)}
+        for line in reversed(out.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": "multi leg printed no JSON line"}
+    except Exception as ex:  # the headline line must survive a failing side leg
+        return {"error": f"{type(ex).__name__}: {ex}"}
+
+
+def run_multi(args):
+    """One process, --gpus devices, spcies_hip_create_multi.  Wall-clock per call of spcies_hip_multi_solve_batch over the whole
+    host batch (H2D + solve + D2H on every device side by side): a PCIe-inclusive rate, reported next to the RCCL leg's
+    device-resident `value`, never instead of it.  --dry-run: the sharding arithmetic only (no device)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from spcies_amd import _lib, benchmarks, blob as blobmod
+    lib = _lib.load()
+    cfg = benchmarks.config("C2")
+    G, B = args.gpus, args.batch
+    total = G * B
+    shards = []
+    for g in range(G):
+        lo, cnt = C.c_long(), C.c_long()
+        _lib.check(lib.spcies_hip_shard_range(total, G, g, C.byref(lo), C.byref(cnt)))
+        shards.append((lo.value, cnt.value))
+    out = {"launch": "multi", "n_gpus": G, "batch_total": total, "shards": shards, "unit": "solves/s",
+           "note": "one process, spcies_hip_create_multi over n_gpus devices, page-locked host buffers, wall time per "
+                   "spcies_hip_multi_solve_batch call (H2D + solve + D2H), u / k / e_flag out"}
+    if args.dry_run:
+        out["dry_run"] = True
+        assert sum(c for _, c in shards) == total and all(shards[i][0] + shards[i][1] == shards[i + 1][0] for i in range(G - 1))
+        print(json.dumps(out), flush=True)
+        return
+    ndev = C.c_int(0)
+    _lib.check(lib.spcies_hip_device_count(C.byref(ndev)))
+    if ndev.value < G:
+        raise SystemExit(f"--launch multi --gpus {G}: only {ndev.value} device(s) visible")
+    v = benchmarks.ingredients(cfg)
+    blob = blobmod.pack(v)
+    t = time.perf_counter()
+    mh = C.c_void_p()
+    ids = (C.c_int * G)(*range(G))
+    _lib.check(lib.spcies_hip_create_multi(blob, len(blob), ids, G, C.byref(mh)))
+    out["create_s"] = time.perf_counter() - t
+    n, m = cfg.sys.n, cfg.sys.m
+
+    def pinned(shape, dtype):
+        p = C.c_void_p()
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        _lib.check(lib.spcies_hip_host_alloc(nbytes, C.byref(p)))
+        arr = np.frombuffer((C.c_char * nbytes).from_address(p.value), dtype=dtype).reshape(shape)
+        return p, arr
+    bufs = {}
+    for name, shape, dt in (("x0", (total, n), np.float64), ("xr", (total, n), np.float64), ("ur", (total, m), np.float64),
+                            ("u", (total, m), np.float64), ("k", (total,), np.int32), ("e", (total,), np.int32)):
+        bufs[name] = pinned(shape, dt)
+    from spcies_amd import distributed as spdist
+    for g, (lo, cnt) in enumerate(shards):  # the instances rank g of the RCCL leg draws
+        x0, xr, ur = spdist.shard_inputs(cfg, cnt, g)
+        bufs["x0"][1][lo:lo + cnt], bufs["xr"][1][lo:lo + cnt], bufs["ur"][1][lo:lo + cnt] = x0, xr, ur
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    cast = lambda name, ty: C.cast(bufs[name][0], ty)
+    tim = _lib.Timing()
+
+    def step():
+        _lib.check(lib.spcies_hip_multi_solve_batch(mh, cast("x0", dp), cast("xr", dp), cast("ur", dp), 1, total, cast("u", dp),
+                                                    cast("k", ip), cast("e", ip), None, None, None, C.byref(tim)))
+    for _ in range(args.warmup):
+        step()
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dt = time.perf_counter() - t
+    k, e = bufs["k"][1], bufs["e"][1]
+    out.update(value=total * args.steps / dt, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
+               last_call_ms={"h2d": tim.update_time, "solve": tim.solve_time, "d2h": tim.polish_time, "run": tim.run_time},
+               all_k_200_eflag_m1=bool((k == 200).all() and (e == -1).all()))
+    hits, misses = C.c_long(), C.c_long()
+    lib.spcies_hip_rtc_cache_stats(C.byref(hits), C.byref(misses))
+    out["rtc_cache"] = {"hits": hits.value, "misses": misses.value}
+    # the first shard against a single-device handle on device 0 (same instances): identical results
+    from spcies_amd.solver import HipSolver
+    s0 = HipSolver(blob, device=0)
+    lo, cnt = shards[-1]
+    cnt = min(cnt, 4096)
+    u1, k1, e1, _ = s0(bufs["x0"][1][lo:lo + cnt].copy(), bufs["xr"][1][lo:lo + cnt].copy(), bufs["ur"][1][lo:lo + cnt].copy(), want_sol=False)
+    out["last_shard_equals_single_device"] = bool(np.array_equal(u1, bufs["u"][1][lo:lo + cnt]) and np.array_equal(k1, k[lo:lo + cnt]))
+    s0.close()
+    lib.spcies_hip_multi_destroy(mh)
+    for p, _ in bufs.values():
+        lib.spcies_hip_host_free(p)
+    print(json.dumps(out), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -300,6 +496,8 @@ def pcie_inclusive(solver, cfg, B, reps=5):
 
 # ---------------------------------------------------------------------------------------------------------------------
 def run_rank(args):
+    from datetime import timedelta
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -311,11 +509,16 @@ def run_rank(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.fail_rank == rank:  # tests/test_bench_contract.py: a rank that dies at start-up
+        sys.stderr.write(f"rank {rank}: --fail-rank\n")
+        raise SystemExit(3)
+    if args.fail_rank == -2 and rank == 0:  # ... and a rank that hangs before the rendezvous
+        time.sleep(3600)
     dry = args.dry_run
     if dry:  # CPU rehearsal of the launch / rendezvous / timing plumbing (tests/test_bench_contract.py): no solver, no GPU
         dev = torch.device("cpu")
         if world > 1:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=args.init_timeout))
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
@@ -324,7 +527,8 @@ def run_rank(args):
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         if world > 1:
-            dist.init_process_group("nccl", device_id=dev)
+            # a finite rendezvous / collective timeout: a rank that died at start-up must not leave the others waiting for minutes
+            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=args.init_timeout))
 
     def sync():
         if not dry:
@@ -454,7 +658,7 @@ def run_rank(args):
                         continue
                     t = time.perf_counter()
                     try:
-                        out["configs"][key] = bench_config(spec, dev, args.config_steps, 1, key)
+                        out["configs"][key] = bench_config(spec, dev, args.config_steps, 2, key)
                     except Exception as ex:  # a failing side configuration must not lose the headline line
                         out["configs"][key] = {"error": f"{type(ex).__name__}: {ex}"}
                     out["configs"][key]["wall_s"] = time.perf_counter() - t
@@ -470,12 +674,19 @@ def run_rank(args):
                                                   "cores": tmpl["cores"], "note": tmpl["sample"] + "; constants printed by this "
                                                   "repository's generator under the reference's dec_var.m rules, not by MATLAB"}
                 out["cpu_baseline"] = port
-        print(json.dumps(out), flush=True)
     if solver is not None:
         solver.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # Under a launcher (torchrun: the driver's N > 1 contract) rank 0 also reports the one-process leg: the other ranks
+        # are past their last collective and exiting, the leg runs in a FRESH child process (this one keeps its idle context on
+        # GPU 0 and is never replaced), bounded by a timeout; its failure is reported inside `multi_launch`, the line survives.
+        # Self-launched runs do this in the parent instead (launch_ranks).
+        if world > 1 and not dry and not args.no_multi_leg and not os.environ.get("SPCIES_BENCH_SELF_LAUNCHED"):
+            out["multi_launch"] = run_multi_leg_child(args)
+        print(json.dumps(out), flush=True)
 
 
 def main(argv=None):
@@ -491,12 +702,23 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations (N = 1 runs them by default)")
     ap.add_argument("--configs", default="", help="comma-separated subset of " + ",".join(EXTRA_CONFIGS))
-    ap.add_argument("--config-steps", type=int, default=3)
+    ap.add_argument("--config-steps", type=int, default=10)  # timed launches per side configuration (after 2 warm-ups)
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank plumbing: no solver, no GPU")
+    ap.add_argument("--launch", default="ranks", choices=["ranks", "multi"],
+                    help="ranks: one process per GPU under torch.distributed (default, the driver's contract); multi: ONE process, "
+                         "--gpus devices through spcies_hip_create_multi from page-locked host buffers")
+    ap.add_argument("--no-multi-leg", action="store_true", help="N > 1: skip the one-process create_multi leg reported as `multi_launch`")
+    ap.add_argument("--launch-timeout", type=float, default=540.0, help="self-launched ranks: overall limit in seconds before the parent stops them")
+    ap.add_argument("--init-timeout", type=float, default=120.0, help="torch.distributed rendezvous / collective timeout in seconds")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: this rank exits 3 before the rendezvous
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.launch == "multi":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        run_multi(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # must be set before any rank touches the GPU (ROCr reads it at initialisation): the children inherit it
         os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"

@@ -219,6 +219,12 @@ typedef struct spcies_hip_solver_s *spcies_hip_handle;
 #define SPCIES_VARIANT_BSP 7    /* ellipMPC ADMM / soc: the KKT iteration as a per-controller program of 4x4 MFMA blocks */
 #define SPCIES_VARIANT_FUSED 8  /* HMPC dense paths and MPCT ADMM cs: product, projections, duals and exit test in one v_mfma_f64_4x4x4 kernel */
 #define SPCIES_VARIANT_MFMA4R 9 /* FISTA: v_mfma_f64_4x4x4, unrolled on the horizon, iteration state in registers + LDS  */
+/* Integer outputs.  STREAM runs the reference's operation order and returns its k / e_flag bit for bit.  The other variants
+ * re-associate sums (1e-10 on the iterates): an exit test decided within rounding may fire one iteration apart on < 0.1 % of
+ * instances.  tol = 0 is the reference tests' fixed-iteration setting (k = k_max, e_flag = -1): MPCT ADMM cs FUSED, whose
+ * w-form reaches an exact floating-point fixed point the reference order does not, switches its exit test off after the first
+ * iteration when tol <= 0, so it returns (k_max, -1) like the reference (code_MPCT_ADMM_cs_C.c:196-215); the all-zero instance
+ * still returns (1, 1) as there. */
 
 typedef struct {
     int formulation, method, submethod;
@@ -285,6 +291,26 @@ int spcies_hip_solve_batch_device_ex(spcies_hip_handle h, const double *x0, cons
                                      int ref_stride, const double *extra, int extra_stride, long B, double *u, int *k,
                                      int *e_flag, double *const *fields, int n_fields, void *stream);
 
+/* Doubles per instance of the `extra` input when extra_stride != 0: 1 (ellipMPC radius), or the packed model
+ * (A, B, Q, R, LB, UB; struct_laxMPC_ADMM_C_Matlab.c:57-103) of a time-varying solver. */
+int spcies_hip_get_extra_width(spcies_hip_handle h, long *doubles_per_instance);
+
+/* Page-locked host buffers visible to every device of the process (hipHostMalloc, portable): what a gateway hands the
+ * host-buffer entry points when it wants the H2D / D2H copies at full PCIe rate and overlapped across devices. */
+int spcies_hip_host_alloc(size_t bytes, void **ptr);
+int spcies_hip_host_free(void *ptr);
+
+/* Run-time specialised kernels (hiprtc) are compiled once per process and controller: code objects served from /
+ * added to the process-wide cache so far (the N handles of spcies_hip_create_multi compile once). */
+int spcies_hip_rtc_cache_stats(long *hits, long *misses);
+
+/* Batch statistics of a solve (the batch counterpart of the dense MATLAB solvers' genHist record,
+ * platforms/Matlab/spcies_laxMPC_ADMM_solver.m:253-261): k, e_flag are DEVICE arrays [B] as a device solve left them;
+ * hist[b], b < n_bins, counts the instances with b k_max / n_bins < k <= (b + 1) k_max / n_bins (host array);
+ * counts[0..3] = { e_flag > 0, e_flag == -1, other, sum of k } (host array of 4). */
+int spcies_hip_k_histogram_device(spcies_hip_handle h, const int *k, const int *e_flag, long B, int n_bins, long *hist, long *counts,
+                                  void *stream);
+
 /* Time `reps` back-to-back device solves with hipEvents recorded on `stream` (the stream the
  * kernel is launched on); returns the mean milliseconds per launch in *ms_per_launch. */
 int spcies_hip_time_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,
@@ -319,8 +345,9 @@ int spcies_hip_multi_set_exit(spcies_hip_multi_handle m, int k_max, double tol);
 int spcies_hip_multi_solve_batch(spcies_hip_multi_handle m, const double *x0, const double *xr, const double *ur, int ref_stride,
                                  long B, double *u, int *k, int *e_flag, double *z, double *v, double *lambda,
                                  spcies_hip_timing *timing);
-/* extra_width: doubles per instance in `extra` when extra_stride != 0 (1 for the ellipMPC radius; the packed model of a
- * time-varying solver) - needed to offset a shard                                                                       */
+/* extra_width: doubles per instance in `extra` when extra_stride != 0 - spcies_hip_get_extra_width's value (1 for the
+ * ellipMPC radius; the packed model of a time-varying solver); <= 0 means "that value", anything else that differs from it is
+ * rejected with SPCIES_HIP_EINVAL.  NULL x0 / xr / ur / u / k / e_flag are rejected like in the single-device entry point. */
 int spcies_hip_multi_solve_batch_ex(spcies_hip_multi_handle m, const double *x0, const double *xr, const double *ur, int ref_stride,
                                     const double *extra, int extra_stride, long extra_width, long B, double *u, int *k,
                                     int *e_flag, double *const *fields, int n_fields, spcies_hip_timing *timing);

@@ -12,6 +12,11 @@
 //
 // NN_MODEL_ is 0, 1 (extra input r) or 6 (time-varying model); the blob is written next to the mex by the
 // constructor (HIP.cons_generic) and loaded on the first call; the engine handle lives until the mex is cleared.
+//
+// Device selection (read once, at the first call; `clear <mex>` to change it):
+//     SPCIES_HIP_DEVICE=<i>            one GPU, device i (default 0)
+//     SPCIES_HIP_DEVICES=all | i,j,... several GPUs from this one MATLAB process (spcies_hip_create_multi: one host thread and one
+//                                      handle per device, the batch split into contiguous shards, no collective)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -21,11 +26,14 @@
 
 $INSERT_DEFINES$ /* nn_, mm_, N_EXTRA_ (0, 1 or 6) and BLOB_PATH, as HIP.cons_generic prints them */
 
-static spcies_hip_handle g_handle = NULL;
+static spcies_hip_handle g_handle = NULL;      /* device 0 of g_multi when several devices are used */
+static spcies_hip_multi_handle g_multi = NULL; /* SPCIES_HIP_DEVICES */
 
 static void at_exit(void) {
-    if (g_handle) spcies_hip_destroy(g_handle);
+    if (g_multi) spcies_hip_multi_destroy(g_multi);
+    else if (g_handle) spcies_hip_destroy(g_handle);
     g_handle = NULL;
+    g_multi = NULL;
 }
 
 static void ensure_handle(void) {
@@ -41,9 +49,36 @@ static void ensure_handle(void) {
         mexErrMsgIdAndTxt("Spcies:$FORM$:HIP:blob", "short read on %s", BLOB_PATH);
     }
     fclose(f);
-    int rc = spcies_hip_create(blob, (size_t)bytes, 0, &g_handle);
+    int rc;
+    const char *many = getenv("SPCIES_HIP_DEVICES"), *one = getenv("SPCIES_HIP_DEVICE");
+    if (many && *many) {
+        int ids[64], n_ids = 0;
+        if (strcmp(many, "all") != 0) {
+            const char *c = many;
+            while (*c && n_ids < 64) {
+                char *end = NULL;
+                long d = strtol(c, &end, 10);
+                if (end == c || d < 0) {
+                    mxFree(blob);
+                    mexErrMsgIdAndTxt("Spcies:$FORM$:HIP:devices", "SPCIES_HIP_DEVICES must be 'all' or a comma-separated list of device indices");
+                }
+                ids[n_ids++] = (int)d;
+                c = (*end == ',') ? end + 1 : end;
+                if (*end && *end != ',') break;
+            }
+        }
+        rc = spcies_hip_create_multi(blob, (size_t)bytes, n_ids ? ids : NULL, n_ids, &g_multi);
+        if (!rc) rc = spcies_hip_multi_get(g_multi, 0, &g_handle);
+    } else {
+        rc = spcies_hip_create(blob, (size_t)bytes, (one && *one) ? atoi(one) : 0, &g_handle);
+    }
     mxFree(blob);
-    if (rc) mexErrMsgIdAndTxt("Spcies:$FORM$:HIP:create", "%s", spcies_hip_last_error());
+    if (rc) {
+        if (g_multi) spcies_hip_multi_destroy(g_multi);
+        g_multi = NULL;
+        g_handle = NULL;
+        mexErrMsgIdAndTxt("Spcies:$FORM$:HIP:create", "%s", spcies_hip_last_error());
+    }
     mexAtExit(at_exit);
 }
 
@@ -126,14 +161,16 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     }
 #endif
     spcies_hip_timing t;
-    int rc = spcies_hip_solve_batch_ex(g_handle, mxGetPr(prhs[0]), mxGetPr(prhs[1]), mxGetPr(prhs[2]), per_instance, extra,
-                                       extra_stride, B, mxGetPr(plhs[0]), k, e,
 #ifdef DEBUG
-                                       fields,
+    double *const *fields_arg = fields;
 #else
-                                       NULL,
+    double *const *fields_arg = NULL;
 #endif
-                                       n_fields, &t);
+    int rc = g_multi ? spcies_hip_multi_solve_batch_ex(g_multi, mxGetPr(prhs[0]), mxGetPr(prhs[1]), mxGetPr(prhs[2]), per_instance, extra,
+                                                       extra_stride, 0 /* the solver's own width */, B, mxGetPr(plhs[0]), k, e,
+                                                       fields_arg, n_fields, &t)
+                     : spcies_hip_solve_batch_ex(g_handle, mxGetPr(prhs[0]), mxGetPr(prhs[1]), mxGetPr(prhs[2]), per_instance, extra,
+                                                 extra_stride, B, mxGetPr(plhs[0]), k, e, fields_arg, n_fields, &t);
     if (extra_owned) mxFree(extra);
     if (rc) mexErrMsgIdAndTxt("Spcies:$FORM$:HIP:solve", "%s", spcies_hip_last_error());
     for (long i = 0; i < B; i++) { mxGetPr(k_d)[i] = (double)k[i]; mxGetPr(e_d)[i] = (double)e[i]; }

@@ -29,62 +29,17 @@ inline void module_free(Mfma4Module &m) {
 
 // compile admm_mfma4_kernel<N, KX, KS, TERMINAL, false / true> for gfx950
 inline int compile_mfma4(Mfma4Module &out, int N, int KX, int KS, bool terminal) {
-    Hiprtc &rt = hiprtc();
-    int rc = rt.open();
+    std::vector<std::string> names;
+    for (int s = 0; s < 2; s++) {
+        char nm[128];
+        snprintf(nm, sizeof(nm), "spcies::admm_mfma4_kernel<%d, %d, %d, %s, %s>", N, KX, KS, terminal ? "true" : "false", s ? "true" : "false");
+        names.push_back(nm);
+    }
+    std::vector<std::string> extra = {"-DSPCIES_RTC_STATIC_LDS=1"};
+    // experiments: SPCIES_MFMA4_RTC_FLAGS holds extra options, blank-separated
+    for (const std::string &e : split_flags(getenv("SPCIES_MFMA4_RTC_FLAGS"))) extra.push_back(e);
+    int rc = compile_module(kMfma4Source, "spcies_mfma4_rtc.hip", names, extra, &out.module, out.fn);  // cached per process
     if (rc) return rc;
-    rt.sync_env();
-    void *prog = nullptr;
-    if (rt.create(&prog, kMfma4Source, "spcies_mfma4_rtc.hip", 0, nullptr, nullptr) != 0)
-        return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");
-    char names[2][128];
-    for (int s = 0; s < 2; s++) {
-        snprintf(names[s], sizeof(names[s]), "spcies::admm_mfma4_kernel<%d, %d, %d, %s, %s>", N, KX, KS, terminal ? "true" : "false",
-                 s ? "true" : "false");
-        if (rt.add_name(prog, names[s]) != 0) {
-            rt.destroy(&prog);
-            return fail(SPCIES_HIP_EHIP, "hiprtcAddNameExpression failed");
-        }
-    }
-    std::vector<std::string> extra;  // experiments: SPCIES_MFMA4_RTC_FLAGS holds extra options, blank-separated
-    if (const char *ev = getenv("SPCIES_MFMA4_RTC_FLAGS")) {
-        std::string tok;
-        for (const char *c = ev;; c++) {
-            if (*c == ' ' || *c == '\0') {
-                if (!tok.empty()) extra.push_back(tok);
-                tok.clear();
-                if (!*c) break;
-            } else {
-                tok.push_back(*c);
-            }
-        }
-    }
-    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans", "-DSPCIES_RTC_STATIC_LDS=1"};
-    for (const std::string &e : extra) opts.push_back(e.c_str());
-    const int crc = rt.compile(prog, (int)opts.size(), opts.data());
-    if (crc != 0) {
-        size_t ls = 0;
-        rt.log_size(prog, &ls);
-        std::string lg(ls + 1, '\0');
-        if (ls) rt.log(prog, &lg[0]);
-        rt.destroy(&prog);
-        return fail(SPCIES_HIP_EHIP, "hiprtcCompileProgram failed: %.400s", lg.c_str());
-    }
-    size_t cs = 0;
-    rt.code_size(prog, &cs);
-    std::vector<char> code(cs);
-    rt.code(prog, code.data());
-    std::string lowered[2];
-    for (int s = 0; s < 2; s++) {
-        const char *ln = nullptr;
-        if (rt.lowered(prog, names[s], &ln) != 0 || !ln) {
-            rt.destroy(&prog);
-            return fail(SPCIES_HIP_EHIP, "hiprtcGetLoweredName failed");
-        }
-        lowered[s] = ln;
-    }
-    rt.destroy(&prog);
-    SPCIES_HIP_CHECK(hipModuleLoadData(&out.module, code.data()));
-    for (int s = 0; s < 2; s++) SPCIES_HIP_CHECK(hipModuleGetFunction(&out.fn[s], out.module, lowered[s].c_str()));
     out.ok = true;
     return 0;
 }

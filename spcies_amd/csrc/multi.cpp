@@ -39,19 +39,35 @@ int spcies_hip_create_multi(const void *blob, size_t bytes, const int *device_id
         n_dev = cnt;
         device_ids = nullptr;
     }
+    // The first handle is built on the calling thread: whatever it specialises at run time (hiprtc: MFMA4 shapes, BSP / FUSED /
+    // MFMA4R programs, seconds each) lands in the process-wide code-object cache (rtc_common.hpp).  The others are then built
+    // side by side, one host thread per device, and take their code objects from the cache - N devices cost one compilation.
     spcies_hip_multi_s *m = new spcies_hip_multi_s;
-    for (int i = 0; i < n_dev; i++) {
-        const int d = device_ids ? device_ids[i] : i;
-        spcies_hip_handle h = nullptr;
-        int rc = spcies_hip_create(blob, bytes, d, &h);
-        if (rc) {
-            for (spcies_hip_handle x : m->h) spcies_hip_destroy(x);
-            delete m;
-            return rc;  // last_error set by spcies_hip_create
-        }
-        m->h.push_back(h);
-        m->dev.push_back(d);
+    m->h.assign(n_dev, nullptr);
+    m->dev.resize(n_dev);
+    for (int i = 0; i < n_dev; i++) m->dev[i] = device_ids ? device_ids[i] : i;
+    std::vector<int> rcs(n_dev, 0);
+    std::vector<std::string> errs(n_dev);
+    auto build = [&](int i) {
+        rcs[i] = spcies_hip_create(blob, bytes, m->dev[i], &m->h[i]);
+        if (rcs[i]) errs[i] = spcies_hip_last_error();  // thread-local: carried to the caller below
+    };
+    build(0);
+    if (rcs[0] == 0) {
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_dev; i++) th.emplace_back(build, i);
+        for (std::thread &t : th) t.join();
     }
+    for (int i = 0; i < n_dev; i++)
+        if (rcs[i]) {
+            const int rc = rcs[i];
+            const std::string why = errs[i];
+            for (spcies_hip_handle x : m->h)
+                if (x) spcies_hip_destroy(x);
+            const int d = m->dev[i];
+            delete m;
+            return spcies::fail(rc, "device %d (handle %d of %d): %s", d, i, n_dev, why.c_str());
+        }
     *out = m;
     return 0;
 }
@@ -104,6 +120,8 @@ int spcies_hip_multi_solve_batch_ex(spcies_hip_multi_handle m, const double *x0,
     if (B < 0) return spcies::fail(SPCIES_HIP_EINVAL, "negative batch");
     if (timing) *timing = spcies_hip_timing{0, 0, 0, 0};
     if (B == 0) return 0;
+    // (checked here: a NULL would turn into a non-NULL pointer once a shard's offset is added)
+    if (!x0 || !xr || !ur || !u || !k || !e_flag) return spcies::fail(SPCIES_HIP_EINVAL, "NULL buffer");
     spcies_hip_info info;
     int rc = spcies_hip_get_info(m->h[0], &info);
     if (rc) return rc;
@@ -112,7 +130,13 @@ int spcies_hip_multi_solve_batch_ex(spcies_hip_multi_handle m, const double *x0,
     rc = spcies_hip_get_sol_layout(m->h[0], &nf, dims, names);
     if (rc) return rc;
     if (fields && n_fields != nf) return spcies::fail(SPCIES_HIP_EINVAL, "this solver's record has %d fields", nf);
-    if (extra && extra_stride && extra_width <= 0) extra_width = 1;
+    if (extra && extra_stride) {  // a shard's offset into `extra` is the width the single-device entry point derives for itself
+        long w = 1;
+        rc = spcies_hip_get_extra_width(m->h[0], &w);
+        if (rc) return rc;
+        if (extra_width <= 0) extra_width = w;
+        if (extra_width != w) return spcies::fail(SPCIES_HIP_EINVAL, "extra_width = %ld, this solver's per-instance extra input is %ld doubles", extra_width, w);
+    }
     const int G = (int)m->h.size();
     std::vector<int> rcs(G, 0);
     std::vector<std::string> errs(G);

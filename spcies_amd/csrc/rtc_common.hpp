@@ -6,6 +6,11 @@
 #include <link.h>
 #include <unistd.h>
 
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+
 #include "common.hpp"
 
 namespace spcies {
@@ -81,47 +86,110 @@ inline Hiprtc &hiprtc() {  // one binding (and one link namespace) per process
     return rt;
 }
 
+// Everything that touches the binding - open(), the environment sync of the private link namespace, the compiler itself - runs
+// under ONE process-wide lock: handles may be created from several host threads (spcies_hip_create_multi does: one per device).
+inline std::mutex &rtc_mutex() {
+    static std::mutex mu;
+    return mu;
+}
 
-// Compile `src` for gfx950 and load it: `names` are name expressions (template instantiations) resolved to functions
-inline int compile_module(const char *src, const char *fname, const std::vector<std::string> &names, const std::vector<std::string> &extra_opts,
-                          hipModule_t *module, hipFunction_t *fns) {
-    Hiprtc &rt = hiprtc();
-    int rc = rt.open();
-    if (rc) return rc;
-    rt.sync_env();
-    void *prog = nullptr;
-    if (rt.create(&prog, src, fname, 0, nullptr, nullptr) != 0) return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");
-    for (const std::string &nm : names)
-        if (rt.add_name(prog, nm.c_str()) != 0) {
-            rt.destroy(&prog);
-            return fail(SPCIES_HIP_EHIP, "hiprtcAddNameExpression failed");
-        }
-    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans"};
-    for (const std::string &e : extra_opts) opts.push_back(e.c_str());
-    if (rt.compile(prog, (int)opts.size(), opts.data()) != 0) {
-        size_t ls = 0;
-        rt.log_size(prog, &ls);
-        std::string lg(ls + 1, '\0');
-        if (ls) rt.log(prog, &lg[0]);
-        rt.destroy(&prog);
-        return fail(SPCIES_HIP_EHIP, "hiprtcCompileProgram failed: %.400s", lg.c_str());
-    }
-    size_t cs = 0;
-    rt.code_size(prog, &cs);
-    std::vector<char> code(cs);
-    rt.code(prog, code.data());
+// Code objects compiled in this process, keyed by (source, file name, name expressions, options): the N handles of
+// spcies_hip_create_multi - and any later handle for the same controller - compile once (4-10 s for a BSP / MFMA4R program) and
+// load the same code object on their own device.  Entries are immutable once inserted and live as long as the process.
+struct CodeObject {
+    std::vector<char> code;
     std::vector<std::string> lowered;
-    for (const std::string &nm : names) {
-        const char *ln = nullptr;
-        if (rt.lowered(prog, nm.c_str(), &ln) != 0 || !ln) {
-            rt.destroy(&prog);
-            return fail(SPCIES_HIP_EHIP, "hiprtcGetLoweredName failed");
+};
+inline std::map<std::string, std::shared_ptr<const CodeObject>> &code_cache() {
+    static std::map<std::string, std::shared_ptr<const CodeObject>> cache;
+    return cache;
+}
+struct CacheStats { long hits = 0, misses = 0; };
+inline CacheStats &cache_stats() {
+    static CacheStats st;
+    return st;
+}
+
+
+inline std::vector<std::string> split_flags(const char *ev) {  // blank-separated compiler options of an experiment variable
+    std::vector<std::string> out;
+    std::string tok;
+    for (const char *c = ev; c;) {
+        if (*c == ' ' || *c == '\0') {
+            if (!tok.empty()) out.push_back(tok);
+            tok.clear();
+            if (!*c) break;
+        } else {
+            tok.push_back(*c);
         }
-        lowered.push_back(ln);
+        c++;
     }
-    rt.destroy(&prog);
-    SPCIES_HIP_CHECK(hipModuleLoadData(module, code.data()));
-    for (size_t i = 0; i < lowered.size(); i++) SPCIES_HIP_CHECK(hipModuleGetFunction(&fns[i], *module, lowered[i].c_str()));
+    return out;
+}
+
+// Compile `src` for gfx950 (or take the code object this process compiled before) and load it on the current device: `names`
+// are name expressions (template instantiations) resolved to functions
+inline int compile_module(const char *src, const char *fname, const std::vector<std::string> &names, const std::vector<std::string> &extra_opts,
+                          hipModule_t *module, hipFunction_t *fns, bool names_are_symbols = false) {
+    // names_are_symbols: `names` are extern "C" kernels of the source (a generated program), taken as they are
+    std::shared_ptr<const CodeObject> co;
+    {
+        std::lock_guard<std::mutex> lk(rtc_mutex());
+        // the key holds the full text: a hash collision must not hand a controller somebody else's program
+        std::string key = std::string(fname) + '\x1f';
+        for (const std::string &nm : names) key += nm + '\x1e';
+        key += '\x1f';
+        for (const std::string &e : extra_opts) key += e + '\x1e';
+        key += '\x1f';
+        key += src;
+        auto it = getenv("SPCIES_HIP_RTC_NOCACHE") ? code_cache().end() : code_cache().find(key);
+        if (it != code_cache().end()) {
+            co = it->second;
+            cache_stats().hits++;
+        } else {
+            Hiprtc &rt = hiprtc();
+            int rc = rt.open();
+            if (rc) return rc;
+            rt.sync_env();
+            void *prog = nullptr;
+            if (rt.create(&prog, src, fname, 0, nullptr, nullptr) != 0) return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");
+            for (const std::string &nm : names)
+                if (!names_are_symbols && rt.add_name(prog, nm.c_str()) != 0) {
+                    rt.destroy(&prog);
+                    return fail(SPCIES_HIP_EHIP, "hiprtcAddNameExpression failed");
+                }
+            std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans"};
+            for (const std::string &e : extra_opts) opts.push_back(e.c_str());
+            if (rt.compile(prog, (int)opts.size(), opts.data()) != 0) {
+                size_t ls = 0;
+                rt.log_size(prog, &ls);
+                std::string lg(ls + 1, '\0');
+                if (ls) rt.log(prog, &lg[0]);
+                rt.destroy(&prog);
+                return fail(SPCIES_HIP_EHIP, "hiprtcCompileProgram failed: %.400s", lg.c_str());
+            }
+            auto fresh = std::make_shared<CodeObject>();
+            size_t cs = 0;
+            rt.code_size(prog, &cs);
+            fresh->code.resize(cs);
+            rt.code(prog, fresh->code.data());
+            for (const std::string &nm : names) {
+                const char *ln = names_are_symbols ? nm.c_str() : nullptr;
+                if (!names_are_symbols && (rt.lowered(prog, nm.c_str(), &ln) != 0 || !ln)) {
+                    rt.destroy(&prog);
+                    return fail(SPCIES_HIP_EHIP, "hiprtcGetLoweredName failed");
+                }
+                fresh->lowered.push_back(ln);
+            }
+            rt.destroy(&prog);
+            cache_stats().misses++;
+            co = fresh;
+            if (!getenv("SPCIES_HIP_RTC_NOCACHE")) code_cache().emplace(std::move(key), co);
+        }
+    }
+    // loading is per device (the caller has made its device current) and needs no lock
+    SPCIES_HIP_CHECK(hipModuleLoadData(module, co->code.data()));
+    for (size_t i = 0; i < co->lowered.size(); i++) SPCIES_HIP_CHECK(hipModuleGetFunction(&fns[i], *module, co->lowered[i].c_str()));
     return 0;
 }
 

@@ -622,43 +622,11 @@ extern "C" __global__ __launch_bounds__(256, 1) void soc_bsp_kernel_sol(Args p, 
 inline int compile_program(Plan &p, int *scratch, const char *name0 = "soc_bsp_kernel", const char *name1 = "soc_bsp_kernel_sol") {
     if (p.module) hipModuleUnload(p.module);
     p.module = nullptr;
-    rtc::Hiprtc &rt = rtc::hiprtc();
-    int rc = rt.open();
+    // experiments: SPCIES_BSP_FLAGS holds extra compiler options, blank-separated
+    const std::vector<std::string> extra = rtc::split_flags(getenv("SPCIES_BSP_FLAGS"));
+    // (cached per process: the handles spcies_hip_create_multi builds for the same controller print the same program)
+    int rc = rtc::compile_module(p.src.c_str(), "spcies_soc_bsp.hip", {name0, name1}, extra, &p.module, p.fn, true);
     if (rc) return rc;
-    rt.sync_env();
-    void *prog = nullptr;
-    if (rt.create(&prog, p.src.c_str(), "spcies_soc_bsp.hip", 0, nullptr, nullptr) != 0) return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");
-    std::vector<std::string> extra;  // experiments: SPCIES_BSP_FLAGS holds extra compiler options, blank-separated
-    if (const char *ev = getenv("SPCIES_BSP_FLAGS")) {
-        std::string tok;
-        for (const char *c = ev;; c++) {
-            if (*c == ' ' || *c == '\0') {
-                if (!tok.empty()) extra.push_back(tok);
-                tok.clear();
-                if (!*c) break;
-            } else {
-                tok.push_back(*c);
-            }
-        }
-    }
-    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans"};
-    for (const std::string &e : extra) opts.push_back(e.c_str());
-    if (rt.compile(prog, (int)opts.size(), opts.data()) != 0) {
-        size_t ls = 0;
-        rt.log_size(prog, &ls);
-        std::string lg(ls + 1, '\0');
-        if (ls) rt.log(prog, &lg[0]);
-        rt.destroy(&prog);
-        return fail(SPCIES_HIP_EHIP, "BSP program: hiprtcCompileProgram failed: %.600s", lg.c_str());
-    }
-    size_t cs = 0;
-    rt.code_size(prog, &cs);
-    std::vector<char> code(cs);
-    rt.code(prog, code.data());
-    rt.destroy(&prog);
-    SPCIES_HIP_CHECK(hipModuleLoadData(&p.module, code.data()));
-    SPCIES_HIP_CHECK(hipModuleGetFunction(&p.fn[0], p.module, name0));
-    SPCIES_HIP_CHECK(hipModuleGetFunction(&p.fn[1], p.module, name1));
     int local = 0;
     if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, p.fn[0]) != hipSuccess) local = 0;
     *scratch = local;

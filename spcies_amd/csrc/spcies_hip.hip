@@ -1429,6 +1429,27 @@ __global__ __launch_bounds__(256) void plant_step_kernel(const double *__restric
 
 using namespace spcies;
 
+// batch histogram of the iteration counts (what the dense MATLAB solvers' `genHist` gives a user per solve,
+// spcies_laxMPC_ADMM_solver.m:253-261, for a batch): bin b counts the instances with (b) k_max / n_bins < k <= (b + 1) k_max / n_bins;
+// counts[0..2] = instances with e_flag > 0 (converged), == -1 (k_max reached), anything else; counts[3] = sum of k
+__global__ void k_histogram_kernel(const int *__restrict__ k, const int *__restrict__ e, long B, int k_max, int n_bins,
+                                   unsigned long long *__restrict__ hist, unsigned long long *__restrict__ counts) {
+    extern __shared__ unsigned long long s_h[];
+    for (int i = threadIdx.x; i < n_bins + 4; i += blockDim.x) s_h[i] = 0ull;
+    __syncthreads();
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < B; i += (long)gridDim.x * blockDim.x) {
+        const int kk = k[i], ee = e[i];
+        long b = kk <= 0 ? 0 : ((long)(kk - 1) * n_bins) / (k_max > 0 ? k_max : 1);
+        if (b >= n_bins) b = n_bins - 1;
+        atomicAdd(&s_h[b], 1ull);
+        atomicAdd(&s_h[n_bins + (ee > 0 ? 0 : (ee == -1 ? 1 : 2))], 1ull);
+        atomicAdd(&s_h[n_bins + 3], (unsigned long long)(kk > 0 ? kk : 0));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_bins + 4; i += blockDim.x)
+        if (s_h[i]) atomicAdd(i < n_bins ? &hist[i] : &counts[i - n_bins], s_h[i]);
+}
+
 extern "C" {
 
 int spcies_hip_abi_version(void) { return SPCIES_HIP_ABI_VERSION; }
@@ -1619,6 +1640,65 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
 int spcies_hip_get_notes(spcies_hip_handle h, const char **notes) {
     if (!h || !notes) return fail(SPCIES_HIP_EINVAL, "NULL argument");
     *notes = reinterpret_cast<Solver *>(h)->notes.c_str();
+    return 0;
+}
+
+int spcies_hip_get_extra_width(spcies_hip_handle h, long *doubles_per_instance) {
+    if (!h || !doubles_per_instance) return fail(SPCIES_HIP_EINVAL, "NULL argument");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    *doubles_per_instance = s->tv ? (long)s->tv_model_size() : 1;
+    return 0;
+}
+
+int spcies_hip_host_alloc(size_t bytes, void **ptr) {
+    if (!ptr) return fail(SPCIES_HIP_EINVAL, "NULL argument");
+    *ptr = nullptr;
+    if (bytes == 0) return 0;
+    SPCIES_HIP_CHECK(hipHostMalloc(ptr, bytes, hipHostMallocPortable));  // page-locked, visible to every device of the process
+    return 0;
+}
+
+int spcies_hip_host_free(void *ptr) {
+    if (ptr) SPCIES_HIP_CHECK(hipHostFree(ptr));
+    return 0;
+}
+
+int spcies_hip_rtc_cache_stats(long *hits, long *misses) {
+    std::lock_guard<std::mutex> lk(rtc::rtc_mutex());
+    if (hits) *hits = rtc::cache_stats().hits;
+    if (misses) *misses = rtc::cache_stats().misses;
+    return 0;
+}
+
+int spcies_hip_k_histogram_device(spcies_hip_handle h, const int *k, const int *e_flag, long B, int n_bins, long *hist, long *counts,
+                                  void *stream) {
+    if (!h || !hist || !counts) return fail(SPCIES_HIP_EINVAL, "NULL argument");
+    if (n_bins < 1 || n_bins > 1024) return fail(SPCIES_HIP_EINVAL, "k_histogram: 1 <= n_bins <= 1024");
+    if (B < 0) return fail(SPCIES_HIP_EINVAL, "negative batch");
+    for (int i = 0; i < n_bins; i++) hist[i] = 0;
+    for (int i = 0; i < 4; i++) counts[i] = 0;
+    if (B == 0) return 0;
+    if (!k || !e_flag) return fail(SPCIES_HIP_EINVAL, "NULL buffer");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    std::lock_guard<std::mutex> lk(s->mu);
+    SPCIES_HIP_CHECK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *d = nullptr;
+    SPCIES_HIP_CHECK(hipMalloc((void **)&d, (n_bins + 4) * sizeof(unsigned long long)));
+    hipError_t er = hipMemsetAsync(d, 0, (n_bins + 4) * sizeof(unsigned long long), st);
+    if (er == hipSuccess) {
+        long blocks = (B + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        k_histogram_kernel<<<(unsigned)blocks, 256, (n_bins + 4) * sizeof(unsigned long long), st>>>(k, e_flag, B, s->host.k_max, n_bins, d, d + n_bins);
+        er = hipGetLastError();
+    }
+    std::vector<unsigned long long> hst(n_bins + 4);
+    if (er == hipSuccess) er = hipMemcpyAsync(hst.data(), d, (n_bins + 4) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+    if (er == hipSuccess) er = hipStreamSynchronize(st);
+    hipFree(d);
+    if (er != hipSuccess) return fail(SPCIES_HIP_EHIP, "k_histogram: %s", hipGetErrorString(er));
+    for (int i = 0; i < n_bins; i++) hist[i] = (long)hst[i];
+    for (int i = 0; i < 4; i++) counts[i] = (long)hst[n_bins + i];
     return 0;
 }
 

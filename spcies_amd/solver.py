@@ -236,6 +236,19 @@ class HipSolver:
                                                              C.c_int(int(extra_stride)), C.c_long(x0.shape[0]), ptr(u), ptr(k),
                                                              ptr(e_flag), fp, nf, C.c_void_p(stream)))
 
+    def k_histogram(self, k, e_flag, n_bins=10, stream=0):
+        """Batch statistics of a device solve (the batch counterpart of the MATLAB solvers' ``genHist`` record):
+        ``k``, ``e_flag`` are the int32 DEVICE arrays a device solve wrote.  Returns ``SimpleNamespace(hist, converged,
+        k_max_reached, other, mean_k)`` - ``hist[b]`` counts instances with ``b k_max / n_bins < k <= (b + 1) k_max / n_bins``."""
+        ptr = lambda a: C.c_void_p(a if isinstance(a, int) else a.data_ptr())
+        B = int(k.shape[0])
+        hist = (C.c_long * int(n_bins))()
+        counts = (C.c_long * 4)()
+        _lib.check(self._lib.spcies_hip_k_histogram_device(self._h, ptr(k), ptr(e_flag), C.c_long(B), int(n_bins), hist, counts,
+                                                          C.c_void_p(stream)))
+        return SimpleNamespace(hist=np.array(hist[:], dtype=np.int64), converged=int(counts[0]), k_max_reached=int(counts[1]),
+                               other=int(counts[2]), mean_k=(counts[3] / B if B else 0.0))
+
     def time_device(self, x0, xr, ur, u, k, e_flag, stream=0, reps=1):
         """Mean ms per launch over ``reps`` back-to-back solves, hipEvents on ``stream``."""
         ptr = lambda a: C.c_void_p(a.data_ptr())

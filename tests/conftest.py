@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))  # tests/_margins.py
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -17,3 +20,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Worst differences seen by the parity helpers -> gpurun_out/parity_margins.json (tests/_margins.py)."""
+    import _margins
+    _margins.dump(ROOT)

@@ -55,6 +55,53 @@ def test_bench_under_torch_distributed_run_dry_run():
     assert out["n_gpus"] == 2 and out["rccl_ranks_seen"] == 2 and out["config"]["launch"] == "torchrun"
 
 
+def test_bench_parent_stops_everything_when_a_rank_dies():
+    """A rank that dies before the rendezvous must not leave the others waiting in it: the self-launching parent polls its
+    children, stops the survivors (fresh child processes, by PID), says which rank failed and returns non-zero - well inside
+    30 s, not after a collective timeout."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    t = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64",
+                        "--dry-run", "--fail-rank", "1"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    dt = time.monotonic() - t
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert dt < 30.0, dt
+    assert "rank 1 exited with code 3" in r.stderr and "--fail-rank" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # no JSON line from a failed run
+    assert "--fail-rank" in open(os.path.join(ROOT, "gpurun_out", "rank1.err")).read()
+
+
+def test_bench_parent_enforces_the_launch_timeout():
+    """Rank 0 missing: rank 1 sits in the rendezvous; the parent's overall limit ends it and the exit code says so."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    t = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "64",
+                        "--dry-run", "--fail-rank", "-2", "--launch-timeout", "8", "--init-timeout", "60"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0 and time.monotonic() - t < 40.0
+    assert "--launch-timeout" in r.stderr
+
+
+def test_bench_multi_launch_dry_run():
+    """`--launch multi`: one process, N devices through spcies_hip_create_multi.  Dry run = the shard arithmetic the library
+    applies (spcies_hip_shard_range), no device."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launch", "multi", "--gpus", "8", "--batch", "1000", "--dry-run"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["launch"] == "multi" and out["n_gpus"] == 8 and out["batch_total"] == 8000
+    assert out["shards"] == [[1000 * g, 1000] for g in range(8)]
+
+
+def test_merge_multi_leg_into_the_json_line():
+    import bench
+    merged = bench._merge_multi_leg('noise\n{"value": 1.0, "n_gpus": 2}\n', {"launch": "multi", "value": 2.0})
+    out = _json_line(merged)
+    assert out["value"] == 1.0 and out["multi_launch"]["value"] == 2.0 and merged.count("\n{") == 1
+
+
 def test_bench_gpus_mismatch_is_an_error():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,

@@ -13,6 +13,8 @@ import os
 import numpy as np
 import pytest
 
+import _margins
+
 pytestmark = pytest.mark.gpu
 
 TOL_SPCIES = 1e-10
@@ -53,6 +55,14 @@ def _compare(variant, got, ref, v):
         print(f"[parity {variant}] B={len(k)} max|du|={np.abs(u - uo)[same].max():.2e} max|dz|={np.abs(sol.z - zo)[same].max():.2e} "
               f"max|dv|={np.abs(sol.v - vo)[same].max():.2e} max|dlam|={np.abs(sol.lam - lo)[same].max():.2e} "
               f"max|lam|={lscale.max():.2e} bar_scale_max={float(np.maximum(1.0, lscale / 100.0).max()):.1f} k_differs={int((dk > 0).sum())}")
+        _margins.record("_compare", variant, du=np.abs(u - uo)[same].max(), dz=np.abs(sol.z - zo)[same].max(),
+                        dv=np.abs(sol.v - vo)[same].max(), dlam=np.abs(sol.lam - lo)[same].max(), lam_scale=lscale.max(),
+                        k_differs=(dk > 0).sum(), bar=TOL_SPCIES,
+                        frac_of_bar=max((np.abs(u - uo) / tol)[same].max(), (np.abs(sol.z - zo) / tol)[same].max(),
+                                        (np.abs(sol.v - vo) / tol)[same].max(),
+                                        (np.abs(sol.lam - lo) / (tol * (1.0 + lscale)))[same].max()),
+                        frac_of_flat_bar=max(np.abs(u - uo)[same].max(), np.abs(sol.z - zo)[same].max(),
+                                             np.abs(sol.v - vo)[same].max()) / TOL_SPCIES)
         assert (np.abs(u - uo) / tol)[same].max() <= 1.0
         assert (np.abs(sol.z - zo) / tol)[same].max() <= 1.0
         assert (np.abs(sol.v - vo) / tol)[same].max() <= 1.0
@@ -219,6 +229,11 @@ def _compare_fista(variant, got, ref):
     # the same allowance as in _compare)
     lscale = np.maximum(1.0, np.abs(lo).max(axis=1, keepdims=True))
     tol = TOL_SPCIES * np.maximum(1.0, lscale / 100.0)
+    _margins.record("_compare_fista", variant, du=np.abs(u - uo)[same].max(), dz=np.abs(sol.z - zo)[same].max(),
+                    dlam=np.abs(sol.lam - lo)[same].max(), lam_scale=lscale.max(), k_differs=(dk > 0).sum(), bar=TOL_SPCIES,
+                    frac_of_bar=max((np.abs(u - uo) / tol)[same].max(), (np.abs(sol.z - zo) / tol)[same].max(),
+                                    (np.abs(sol.lam - lo) / (tol * lscale))[same].max()),
+                    frac_of_flat_bar=max(np.abs(u - uo)[same].max(), np.abs(sol.z - zo)[same].max()) / TOL_SPCIES)
     assert (np.abs(u - uo) / tol)[same].max() <= 1.0 and (np.abs(sol.z - zo) / tol)[same].max() <= 1.0
     assert (np.abs(sol.lam - lo) / (tol * lscale))[same].max() <= 1.0
 
@@ -316,6 +331,11 @@ def _compare_mpct(variant, got, O):
     same = dk == 0
     assert np.array_equal(e[same], eo[same])
     lscale = np.maximum(1.0, np.abs(lo).max(axis=1, keepdims=True))
+    worst = max(np.abs(a - b)[same].max() for a, b in ((u, uo), (sol.z1, z1o), (sol.z2, z2o), (sol.z3, z3o)))
+    _margins.record("_compare_mpct", variant, du=np.abs(u - uo)[same].max(), dz=worst, dlam=np.abs(sol.lam - lo)[same].max(),
+                    lam_scale=lscale.max(), k_differs=(dk > 0).sum(), bar=TOL_SPCIES,
+                    frac_of_bar=max(worst, (np.abs(sol.lam - lo) / lscale)[same].max()) / TOL_SPCIES,
+                    frac_of_flat_bar=worst / TOL_SPCIES)
     for a, b in ((u, uo), (sol.z1, z1o), (sol.z2, z2o), (sol.z3, z3o)):
         assert np.abs(a - b)[same].max() <= TOL_SPCIES
     assert (np.abs(sol.lam - lo) / lscale)[same].max() <= TOL_SPCIES
@@ -419,7 +439,16 @@ def _compare_sparse(variant, got, O):
     assert np.array_equal(np.asarray(e)[same], O[2][same])
     assert np.abs(u - O[0])[same].max() <= TOL_SPCIES
     if sol.z is None:
+        _margins.record("_compare_sparse", variant, du=np.abs(u - O[0])[same].max(), k_differs=(dk > 0).sum(), bar=TOL_SPCIES,
+                        frac_of_bar=np.abs(u - O[0])[same].max() / TOL_SPCIES)
         return
+    _w = {name: np.abs(getattr(sol, name) - ref)[same].max() for name, ref in zip(_SOC_FIELDS, O[3:])}
+    _ws = max((np.abs(getattr(sol, name) - ref) / (np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True)) if name in ("lam", "mu") else 1.0))[same].max()
+              for name, ref in zip(_SOC_FIELDS, O[3:]))
+    _margins.record("_compare_sparse", variant, du=np.abs(u - O[0])[same].max(), dz=max(v_ for n_, v_ in _w.items() if n_ not in ("lam", "mu")),
+                    dlam=max([v_ for n_, v_ in _w.items() if n_ in ("lam", "mu")] or [0.0]), k_differs=(dk > 0).sum(), bar=TOL_SPCIES,
+                    frac_of_bar=max(_ws, np.abs(u - O[0])[same].max()) / TOL_SPCIES,
+                    frac_of_flat_bar=max(v_ for n_, v_ in _w.items() if n_ not in ("lam", "mu")) / TOL_SPCIES)
     for name, ref in zip(_SOC_FIELDS, O[3:]):
         scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True)) if name in ("lam", "mu") else 1.0
         assert (np.abs(getattr(sol, name) - ref) / scale)[same].max() <= TOL_SPCIES, name
@@ -491,6 +520,39 @@ def test_hmpc_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     _compare_sparse(variant, got, oracle.admm_hmpc_batch(v, x0, xr, ur, sparse=(variant not in ("gemm", "fused"))))
     nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
     assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
+
+
+def test_hmpc_fused_more_than_sixteen_inputs():
+    """m > 16: u = z[0 .. m) spans more than one row register of the FUSED layout (sixteen rows per register) - every one of
+    them has to reach u_out (round-2 advisor finding: only register 0 was written)."""
+    from types import SimpleNamespace
+
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    n, m, N = 2, 18, 3
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((n, n))
+    A *= 0.9 / max(abs(np.linalg.eigvals(A)))
+    sysm = SimpleNamespace(A=A, B=rng.standard_normal((n, m)) / np.sqrt(m), n=n, m=m, LBx=-1.0 - rng.random(n), UBx=1.0 + rng.random(n),
+                           LBu=-0.5 - rng.random(m), UBu=0.5 + rng.random(m))
+    Q, R = np.diag(1.0 + 4 * rng.random(n)), np.diag(0.1 + rng.random(m))
+    cfg = SimpleNamespace(name="hmpc_2_18_3", sys=sysm, formulation="HMPC", method="SADMM", submethod="split",
+                          param=SimpleNamespace(N=N, w=0.7, Q=Q, R=R, Te=10 * N * Q, Th=10 * N * Q, Se=R, Sh=0.5 * R),
+                          solver_options=dict(rho=2, sigma=20, k_max=300, tol_p=1e-6, tol_d=1e-6, sparse=True, use_soc=False,
+                                              box_constraints=True), B=1, seed=5)
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    s.set_variant("fused")
+    B = 37
+    x0, xr, ur = 0.3 * rng.standard_normal((B, n)), 0.1 * rng.standard_normal((B, n)), 0.05 * rng.standard_normal((B, m))
+    got = s(x0, xr, ur)
+    O = oracle.admm_hmpc_batch(v, x0, xr, ur, sparse=False)
+    assert np.abs(O[0][:, 16:]).max() > 1e-3  # the inputs past the first register are not trivially zero
+    _compare_sparse("fused", got, O)
+    nosol = s(x0, xr, ur, want_sol=False)
+    assert np.array_equal(nosol[0], got[0])
+    s.close()
 
 
 def test_hmpc_any_constraint_row_order(golden_dir):
@@ -579,7 +641,16 @@ def _compare_hmpc_nosplit(got, O, variant="gemm"):
     assert np.array_equal(np.asarray(e)[same], O[2][same])
     assert np.abs(u - O[0])[same].max() <= TOL_SPCIES
     if sol.z is None:
+        _margins.record("_compare_hmpc_nosplit", variant, du=np.abs(u - O[0])[same].max(), k_differs=(dk > 0).sum(), bar=TOL_SPCIES,
+                        frac_of_bar=np.abs(u - O[0])[same].max() / TOL_SPCIES)
         return
+    _w = {name: np.abs(getattr(sol, name) - ref)[same].max() for name, ref in zip(("z", "s", "lam"), O[3:])}
+    _ws = max((np.abs(getattr(sol, name) - ref) / (np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True)) if name in ("lam", "mu") else 1.0))[same].max()
+              for name, ref in zip(("z", "s", "lam"), O[3:]))
+    _margins.record("_compare_hmpc_nosplit", variant, du=np.abs(u - O[0])[same].max(), dz=max(v_ for n_, v_ in _w.items() if n_ not in ("lam", "mu")),
+                    dlam=max([v_ for n_, v_ in _w.items() if n_ in ("lam", "mu")] or [0.0]), k_differs=(dk > 0).sum(), bar=TOL_SPCIES,
+                    frac_of_bar=max(_ws, np.abs(u - O[0])[same].max()) / TOL_SPCIES,
+                    frac_of_flat_bar=max(v_ for n_, v_ in _w.items() if n_ not in ("lam", "mu")) / TOL_SPCIES)
     for name, ref in zip(("z", "s", "lam"), O[3:]):
         scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True)) if name == "lam" else 1.0
         assert (np.abs(getattr(sol, name) - ref) / scale)[same].max() <= TOL_SPCIES, name
@@ -719,7 +790,16 @@ def _compare_cs(variant, got, O, tol=TOL_SPCIES):
     assert np.array_equal(np.asarray(e)[same], O[2][same])
     assert np.abs(u - O[0])[same].max() <= tol
     if sol.z is None:
+        _margins.record("_compare_cs", variant, du=np.abs(u - O[0])[same].max(), k_differs=(dk > 0).sum(), bar=tol,
+                        frac_of_bar=np.abs(u - O[0])[same].max() / tol)
         return
+    _w = {name: np.abs(getattr(sol, name) - ref)[same].max() for name, ref in zip(("z", "v", "lam"), O[3:])}
+    _ws = max((np.abs(getattr(sol, name) - ref) / (np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True)) if name in ("lam", "mu") else 1.0))[same].max()
+              for name, ref in zip(("z", "v", "lam"), O[3:]))
+    _margins.record("_compare_cs", variant, du=np.abs(u - O[0])[same].max(), dz=max(v_ for n_, v_ in _w.items() if n_ not in ("lam", "mu")),
+                    dlam=max([v_ for n_, v_ in _w.items() if n_ in ("lam", "mu")] or [0.0]), k_differs=(dk > 0).sum(), bar=tol,
+                    frac_of_bar=max(_ws, np.abs(u - O[0])[same].max()) / tol,
+                    frac_of_flat_bar=max(v_ for n_, v_ in _w.items() if n_ not in ("lam", "mu")) / TOL_SPCIES)
     for name, ref in zip(("z", "v", "lam"), O[3:]):
         scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True)) if name == "lam" else 1.0
         assert (np.abs(getattr(sol, name) - ref) / scale)[same].max() <= tol, name
@@ -766,12 +846,11 @@ def test_mpct_cs_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
 
 
-def test_mpct_cs_fused_exact_fixed_points():
-    """tol = 0 (the fixed-iteration benchmark setting): the reference's exit test is strict (`r > tol`, code_MPCT_ADMM_cs_C.c:196-205), so an
-    instance whose iteration reaches a floating-point FIXED POINT exits with flag 1.  The sparse operation order never gets there within
-    200 iterations on this batch; the w-form of the FUSED kernel does for about one instance in a thousand (k ~ 50).  A fixed point is a
-    fixed point: those instances carry the state every further iteration would reproduce - u, z, v, lambda equal the oracle's after its
-    200 iterations to 1e-10 - and every other instance runs the 200 iterations with flag -1."""
+def test_mpct_cs_fused_fixed_iteration_count():
+    """tol = 0 (the fixed-iteration benchmark setting): k = k_max and e_flag = -1 for EVERY instance, as the reference's
+    operation order returns (code_MPCT_ADMM_cs_C.c:196-215; its strict test `r > tol` never passes within 200 iterations on this
+    batch).  The w-form of the FUSED kernel reaches an exact floating-point fixed point for about one instance in a thousand
+    (k ~ 50); with tol <= 0 its exit test is off, so those instances report (200, -1) too and carry the state of iteration 200."""
     from oracle import oracle
     from spcies_amd import benchmarks
     cfg, v, s = _fista_solver("C2_cs", "fused")
@@ -779,14 +858,20 @@ def test_mpct_cs_fused_exact_fixed_points():
     B = 8192
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
     u, k, e, sol = s(x0, xr, ur)
-    early = k < 200
-    assert (e[early] == 1).all() and (e[~early] == -1).all() and early.mean() <= 0.01
-    idx = np.concatenate([np.nonzero(early)[0][:48], np.nonzero(~early)[0][:16]])
+    assert (k == 200).all() and (e == -1).all()
+    # the same through AUTO (what a caller gets by default)
+    cfg, v, sa = _fista_solver("C2_cs", None)
+    ua, ka, ea, _ = sa(x0[:4096], xr[:4096], ur[:4096], want_sol=False)
+    assert (ka == 200).all() and (ea == -1).all(), sa.variant
+    # the one case in which the reference leaves at tol = 0: all-zero inputs, residuals exactly zero in iteration 1 -> (1, 1)
+    z0 = np.zeros((5, cfg.sys.n)), np.zeros((5, cfg.sys.n)), np.zeros((5, cfg.sys.m))
+    Oz = oracle.mpct_cs_batch(v, *z0)
+    uz, kz, ez, _ = s(*z0)
+    assert np.array_equal(kz, Oz[1]) and np.array_equal(ez, Oz[2]) and (kz == 1).all() and (ez == 1).all() and not uz.any()
+    idx = np.arange(0, B, B // 64)
     O = oracle.mpct_cs_batch(v, x0[idx], xr[idx], ur[idx])
-    assert (O[1] == 200).all()
-    print(f"exact fixed points: {int(early.sum())} of {B}; max|dz| vs oracle at k = 200: {np.abs(sol.z[idx] - O[3]).max():.2e}")
-    assert np.abs(u[idx] - O[0]).max() <= TOL_SPCIES and np.abs(sol.z[idx] - O[3]).max() <= TOL_SPCIES
-    assert np.abs(sol.v[idx] - O[4]).max() <= TOL_SPCIES and np.abs(sol.lam[idx] - O[5]).max() <= TOL_SPCIES
+    assert (O[1] == 200).all() and (O[2] == -1).all()
+    _compare_cs("fused", (u[idx], k[idx], e[idx], type("S", (), dict(z=sol.z[idx], v=sol.v[idx], lam=sol.lam[idx]))()), O)
 
 
 @pytest.mark.parametrize("variant", CS_VARIANTS)
@@ -1232,3 +1317,27 @@ def test_notes_report_what_auto_gave_up(monkeypatch):
     monkeypatch.setenv("SPCIES_HIP_RTC", "0")
     with HipSolver(v) as s:
         assert s.variant == "mfma4g" and "MFMA4R unavailable" in s.notes and "SPCIES_HIP_RTC" in s.notes
+
+
+def test_k_histogram_of_a_device_solve():
+    """the batch histogram of k and the exit-flag counts, computed on the device from the arrays a device solve wrote."""
+    import torch
+    cfg, v, s = _solver("C1", "mfma4")
+    from spcies_amd import benchmarks
+    B = 3000
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    s.set_exit(k_max=800, tol=1e-5)  # about 7 % of this batch reach k_max, the rest converge between k = 440 and 800
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tu = torch.empty((B, cfg.sys.m), dtype=torch.float64, device=dev)
+    tk = torch.empty(B, dtype=torch.int32, device=dev)
+    te = torch.empty(B, dtype=torch.int32, device=dev)
+    s.solve_device(t(x0), t(xr), t(ur), tu, tk, te)
+    torch.cuda.synchronize()
+    h = s.k_histogram(tk, te, n_bins=10)
+    k, e = tk.cpu().numpy(), te.cpu().numpy()
+    want = np.bincount(np.minimum((np.maximum(k, 1) - 1) * 10 // 800, 9), minlength=10)
+    assert np.array_equal(h.hist, want) and h.hist.sum() == B
+    assert h.converged == int((e > 0).sum()) and h.k_max_reached == int((e == -1).sum()) and h.other == 0
+    assert abs(h.mean_k - k.mean()) < 1e-9 and 0 < h.converged < B  # both outcomes occur on this batch
+    s.close()
