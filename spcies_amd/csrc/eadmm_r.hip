@@ -1,0 +1,303 @@
+// Host side of the MFMA4R variant of MPCT EADMM (eadmm_r.hpp): table packer for the "H" lane layout, kernel specialisation
+// (hiprtc / build-time), launch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/spcies_hip.h"
+#include "eadmm_r.hpp"
+#include "eadmm_r_kernel.inc"
+#include "rtc_common.hpp"
+
+namespace spcies {
+namespace er {
+
+static const char *const kSource =
+#include "eadmm_r_src.inc"
+    ;
+
+namespace {
+
+struct DM {
+    int r = 0, c = 0;
+    std::vector<double> a;
+    DM() {}
+    DM(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
+    double &operator()(int i, int j) { return a[(size_t)i * c + j]; }
+    double operator()(int i, int j) const { return a[(size_t)i * c + j]; }
+};
+DM mul(const DM &A, const DM &B) {
+    DM C(A.r, B.c);
+    for (int i = 0; i < A.r; i++)
+        for (int k = 0; k < A.c; k++) {
+            const double v = A(i, k);
+            if (v == 0.0) continue;
+            for (int j = 0; j < B.c; j++) C(i, j) += v * B(k, j);
+        }
+    return C;
+}
+DM tr(const DM &A) {
+    DM T(A.c, A.r);
+    for (int i = 0; i < A.r; i++)
+        for (int j = 0; j < A.c; j++) T(j, i) = A(i, j);
+    return T;
+}
+DM neg(DM A) {
+    for (auto &x : A.a) x = -x;
+    return A;
+}
+DM scale_cols(DM A, const double *d) {
+    for (int i = 0; i < A.r; i++)
+        for (int j = 0; j < A.c; j++) A(i, j) *= d[j];
+    return A;
+}
+// inverse of the upper-triangular Beta block as the reference stores it (reciprocal diagonal)
+DM beta_inverse(const double *beta, int n) {
+    DM U(n, n), X(n, n);
+    for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++) U(i, j) = (i == j) ? 1.0 / beta[i * n + j] : beta[i * n + j];
+    for (int j = 0; j < n; j++) {
+        X(j, j) = 1.0 / U(j, j);
+        for (int i = j - 1; i >= 0; i--) {
+            double s = 0.0;
+            for (int k = i + 1; k <= j; k++) s += U(i, k) * X(k, j);
+            X(i, j) = -s / U(i, i);
+        }
+    }
+    return X;
+}
+// Appends the MFMA records of M (KI row slabs x KJ k-slabs) in issue order - J outer, register R inner, the rule of mf_nz - to a
+// stream of pair records: MFMA c, element (k, r, i) = M[4 (2 R + r) + i][4 J + k] at 64 (c / 2) + 2 (4 (2 k + r) + i) + c % 2.
+// pair = false: single records of 32 doubles (header products).
+struct RecordWriter {
+    double *base;
+    bool pair;
+    int cursor = 0;
+    bool structure_ok = true;
+    RecordWriter(double *b, bool pr) : base(b), pair(pr) {}
+    void emit(const DM &M, int KI, int KJ, int pat) {
+        auto at = [&](int i, int j) { return (i < M.r && j < M.c) ? M(i, j) : 0.0; };
+        for (int J = 0; J < KJ; J++)
+            for (int R = 0; R < (KI + 1) / 2; R++) {
+                if (!mf_nz(R, J, KI, pat)) {
+                    for (int r = 0; r < 2; r++)
+                        for (int i = 0; i < 4; i++)
+                            for (int k = 0; k < 4; k++)
+                                if (at(4 * (2 * R + r) + i, 4 * J + k) != 0.0) structure_ok = false;
+                    continue;
+                }
+                double *t = pair ? base + (size_t)(cursor / 2) * 64 + (cursor % 2) : base + (size_t)cursor * 32;
+                for (int k = 0; k < 4; k++)
+                    for (int r = 0; r < 2; r++)
+                        for (int i = 0; i < 4; i++) {
+                            // a block outside the pattern that shares its MFMA with one inside must be structurally zero too
+                            const bool inside = 2 * R + r < KI && blk_nz(2 * R + r, J, pat);
+                            const double v = at(4 * (2 * R + r) + i, 4 * J + k);
+                            if (!inside && v != 0.0) structure_ok = false;
+                            t[(pair ? 2 : 1) * (4 * (2 * k + r) + i)] = inside ? v : 0.0;
+                        }
+                cursor++;
+            }
+    }
+};
+
+template <int KX, int KS>
+int pack(Plan &p, const Host &h, std::vector<double> &tab) {
+    using LY = Layout<KX, KS>;
+    const int n = h.n, m = h.m, N = h.N, nm = n + m;
+    tab.assign((size_t)LY::table_doubles(N), 0.0);
+    DM AB(n, nm), W2(nm, nm), TS(nm, nm);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < nm; j++) AB(i, j) = h.AB[(size_t)i * nm + j];
+    for (int i = 0; i < nm; i++)
+        for (int j = 0; j < nm; j++) W2(i, j) = h.W2[(size_t)i * nm + j];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) TS(i, j) = h.T[(size_t)i * n + j];
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < m; j++) TS(n + i, n + j) = h.S[(size_t)i * m + j];
+    for (int l = 0; l <= N; l++) {
+        const double *lb = (l == 0) ? h.LB0 : (l == N ? h.LBs : h.LB), *ub = (l == 0) ? h.UB0 : (l == N ? h.UBs : h.UB);
+        for (int j = 0; j < nm; j++) {
+            tab[LY::k_off(l, LY::K_RHO) + j] = h.rho[(size_t)l * nm + j];
+            tab[LY::k_off(l, LY::K_H1I) + j] = h.H1i[(size_t)l * nm + j];
+            tab[LY::k_off(l, LY::K_NH3I) + j] = -h.H3i[(size_t)l * nm + j];
+            tab[LY::k_off(l, LY::K_LB) + j] = lb[j];
+            tab[LY::k_off(l, LY::K_UB) + j] = ub[j];
+        }
+    }
+    for (int j = 0; j < nm; j++) {
+        tab[LY::c_off(N, LY::C_RHO0) + j] = h.rho0[j];
+        tab[LY::c_off(N, LY::C_RHOS) + j] = h.rhos[j];
+    }
+    bool ok = true;
+    {
+        RecordWriter w(tab.data() + LY::inv_off(N), false);
+        w.emit(W2, KS, KS, DENSE);
+        w.emit(TS, KS, KS, DENSE);
+        ok = ok && w.structure_ok && w.cursor == 2 * LY::M_W2;
+    }
+    std::vector<DM> Bi(N), Al(N - 1);
+    for (int l = 0; l < N; l++) Bi[l] = beta_inverse(h.Beta + (size_t)l * n * n, n);
+    for (int l = 0; l < N - 1; l++) {
+        Al[l] = DM(n, n);
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) Al[l](i, j) = h.Alpha[((size_t)l * n + i) * n + j];
+    }
+    const DM Zero(n, n), ABt = tr(AB);
+    for (int s = 0; s < 2 * N; s++) {
+        RecordWriter w(tab.data() + LY::chunk_off(s, N), true);
+        if (s < N) {  // forward chunk of block l: y_l = F1 q3_{l+1}[x] + F2 q3_l + F3 y_{l-1}
+            const int l = s;
+            const DM BiT = tr(Bi[l]);
+            w.emit(scale_cols(BiT, h.H3i + (size_t)(l + 1) * nm), KX, KX, LOWER);
+            w.emit(neg(mul(BiT, scale_cols(AB, h.H3i + (size_t)l * nm))), KX, KS, DENSE);
+            w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
+            ok = ok && w.structure_ok && w.cursor == LY::MF;
+        } else {  // backward chunk of block l = 2N-1-s: mu_l = B1 y_l + B2 mu_{l+1}; AB' for stage l + 1 (and again for stage 0)
+            const int l = 2 * N - 1 - s;
+            w.emit(Bi[l], KX, KX, UPPER);
+            w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : Zero, KX, KX, DENSE);
+            w.emit(ABt, KS, KX, DENSE);
+            if (l == 0) w.emit(ABt, KS, KX, DENSE);
+            ok = ok && w.structure_ok && w.cursor == (l == 0 ? LY::MB0 : LY::MB);
+        }
+    }
+    if (!ok) { p.why = "MFMA4R packer: block structure mismatch"; return 0; }
+    for (double x : tab)
+        if (!std::isfinite(x)) { p.why = "non-finite folded constant (singular Beta block?)"; return 0; }
+    p.KX = KX;
+    p.KS = KS;
+    // registers: z3, lambda ((2 N + 4) RS), z2 (2 RS), q2 (RS), y ((N - NYL) RX); LDS: header, four chunk slots, per-wavefront
+    // x0 / c2, y of the first NYL blocks
+    const int RX = LY::RX, RS = LY::RS;
+    int max_reg = 200;  // doubles per lane the register allocator places without spilling (of 256)
+    if (const char *ev = getenv("SPCIES_ER_MAX_REG")) max_reg = atoi(ev);
+    const int fixed = (2 * N + 4) * RS + 3 * RS;
+    const long lds_free = 163840 - 8L * (LY::hdr_d(N) + 4 * LY::CMAX + 2 * RS * 256) - 1024;
+    if (lds_free < 0) { p.why = "MFMA4R: header and chunk ring exceed the LDS"; return 0; }
+    const int nyl_max = (int)std::min<long>(N, lds_free / (8L * RX * 256));
+    int nyl = std::max(0, (fixed + N * RX - max_reg + RX - 1) / RX);
+    if (const char *ev = getenv("SPCIES_ER_NYL")) nyl = atoi(ev);
+    if (nyl > nyl_max || nyl < 0) { p.why = "MFMA4R: the iteration state does not fit registers + LDS (use MFMA4G)"; return 0; }
+    p.NYL = nyl;
+    return 1;
+}
+
+// build-time instantiations (N, KX, KS, NYL): BASELINE configs[3], MPCT-EADMM n = 20, m = 2, N = 20
+#ifndef SPCIES_ER_BUILTIN
+#define SPCIES_ER_BUILTIN(X) X(20, 5, 6, 8)
+#endif
+
+#define SPCIES_ER_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 3) X(3, 4) X(4, 4) X(4, 5) X(5, 5) X(5, 6) X(6, 6)
+
+}  // namespace
+
+void plan_free(Plan &p) {
+    if (p.d_table) hipFree(p.d_table);
+    p.d_table = nullptr;
+    if (p.module) hipModuleUnload((hipModule_t)p.module);
+    p.module = nullptr;
+    p.ok = false;
+}
+
+int plan_build(Plan &p, const Host &h) {
+    p.ok = false;
+    p.n = h.n; p.m = h.m; p.N = h.N;
+    if (h.N < 2) { p.why = "N < 2"; return 0; }
+    if (const char *ev = getenv("SPCIES_ER_DISABLE"))
+        if (ev[0] == '1') { p.why = "disabled (SPCIES_ER_DISABLE=1)"; return 0; }
+    const int KX = (h.n + 3) / 4, KS = (h.n + h.m + 3) / 4;
+    std::vector<double> tab;
+    int got = -1;
+#define X(KKX, KKS) \
+    if (KX == KKX && KS == KKS) got = pack<KKX, KKS>(p, h, tab);
+    SPCIES_ER_SHAPES(X)
+#undef X
+    if (got < 0) { p.why = "MFMA4R: (ceil(n/4), ceil((n+m)/4)) outside the packer's shapes"; return 0; }
+    if (got == 0) return 0;
+    p.builtin = -1;
+    {
+        int idx = 0;
+#define X(NN, KKX, KKS, YY)                                                                                   \
+    if (h.N == NN && KX == KKX && KS == KKS && p.NYL == YY && !getenv("SPCIES_ER_RTC_FLAGS")) p.builtin = idx; \
+    idx++;
+        SPCIES_ER_BUILTIN(X)
+#undef X
+    }
+    if (p.builtin < 0) {
+        const char *ev = getenv("SPCIES_HIP_RTC");
+        if (ev && ev[0] == '0') { p.why = "shape not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
+        std::vector<std::string> nm;
+        for (int s = 0; s < 2; s++) {
+            char name[160];
+            snprintf(name, sizeof(name), "spcies::er::eadmm_r_kernel<%d, %d, %d, %s, %d>", h.N, KX, KS, s ? "true" : "false", p.NYL);
+            nm.push_back(name);
+        }
+        // the horizon is unrolled by #pragma unroll: lift the size limit under which clang honours the pragma; MFMA results in
+        // either register file (the state beyond 256 architectural registers would otherwise be spilled to scratch memory)
+        std::vector<std::string> extra = {"-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form"};
+        for (const std::string &e : rtc::split_flags(getenv("SPCIES_ER_RTC_FLAGS"))) extra.push_back(e);
+        hipModule_t mod = nullptr;
+        hipFunction_t fns[2] = {nullptr, nullptr};
+        int rc = rtc::compile_module(kSource, "spcies_eadmm_r_rtc.hip", nm, extra, &mod, fns);
+        if (rc) { p.why = std::string("MFMA4R: run-time specialisation failed: ") + spcies_hip_last_error(); return 0; }
+        int scratch = 0;
+        if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fns[0]) != hipSuccess) scratch = 0;
+        if (getenv("SPCIES_ER_VERBOSE")) fprintf(stderr, "[spcies eadmm_r] N=%d KX=%d KS=%d NYL=%d scratch=%d B per lane\n", h.N, KX, KS, p.NYL, scratch);
+        p.module = mod;
+        p.fn[0] = fns[0];
+        p.fn[1] = fns[1];
+    }
+    p.table_bytes = tab.size() * sizeof(double);
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_table, p.table_bytes + 64));
+    SPCIES_HIP_CHECK(hipMemcpy(p.d_table, tab.data(), p.table_bytes, hipMemcpyHostToDevice));
+    hipDeviceProp_t prop;
+    int dev = 0;
+    SPCIES_HIP_CHECK(hipGetDevice(&dev));
+    SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    p.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    p.ok = true;
+    p.why.clear();
+    return 0;
+}
+
+int launch(Plan &p, int k_max, double tol, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u,
+           int *k, int *e, double *z1, double *z2, double *z3, double *lam, hipStream_t st) {
+    if (!p.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant unavailable: %s", p.why.c_str());
+    const bool want_sol = (z1 || z2 || z3 || lam);
+    if (want_sol && !(z1 && z2 && z3 && lam)) return fail(SPCIES_HIP_EINVAL, "MFMA4R variant: pass all of z1, z2, z3, lambda or none");
+    Args args{p.n, p.m, k_max, ref_stride, tol, B};
+    const long n_groups = (B + 31) / 32;
+    const long wgs = std::min<long>(n_groups, p.num_cu);
+    if (wgs <= 0) return 0;
+    // the reference copies only the first n entries of every multiplier block out, contiguously (code_MPCT_EADMM_C.c:495-513): the
+    // rest of the (N + 3)(n + m) record is zero
+    if (want_sol) SPCIES_HIP_CHECK(hipMemsetAsync(lam, 0, (size_t)B * (size_t)(p.N + 3) * (p.n + p.m) * sizeof(double), st));
+    const double *table = p.d_table;
+    if (p.builtin >= 0) {
+        int idx = 0;
+#define X(NN, KKX, KKS, YY)                                                                                                          \
+    if (p.builtin == idx) {                                                                                                          \
+        if (want_sol)                                                                                                                \
+            hipLaunchKernelGGL((eadmm_r_kernel<NN, KKX, KKS, true, YY>), dim3((unsigned)wgs), dim3(256), 0, st, args, table, x0, xr, ur, u, k, e, \
+                               z1, z2, z3, lam);                                                                                     \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((eadmm_r_kernel<NN, KKX, KKS, false, YY>), dim3((unsigned)wgs), dim3(256), 0, st, args, table, x0, xr, ur, u, k, e, \
+                               z1, z2, z3, lam);                                                                                     \
+    }                                                                                                                                \
+    idx++;
+        SPCIES_ER_BUILTIN(X)
+#undef X
+        SPCIES_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    void *params[] = {&args, &table, &x0, &xr, &ur, &u, &k, &e, &z1, &z2, &z3, &lam};
+    SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 1 : 0], 256 > 0 ? (unsigned)wgs : 0, 1, 1, 256, 1, 1, 0, st, params, nullptr));
+    return 0;
+}
+
+}  // namespace er
+}  // namespace spcies
