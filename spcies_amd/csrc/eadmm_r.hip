@@ -104,9 +104,9 @@ struct RecordWriter {
     }
 };
 
-template <int KX, int KS>
+template <int KX, int KS, bool MIDSAME>
 int pack(Plan &p, const Host &h, std::vector<double> &tab) {
-    using LY = Layout<KX, KS>;
+    using LY = Layout<KX, KS, MIDSAME>;
     const int n = h.n, m = h.m, N = h.N, nm = n + m;
     tab.assign((size_t)LY::table_doubles(N), 0.0);
     DM AB(n, nm), W2(nm, nm), TS(nm, nm);
@@ -121,11 +121,11 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
     for (int l = 0; l <= N; l++) {
         const double *lb = (l == 0) ? h.LB0 : (l == N ? h.LBs : h.LB), *ub = (l == 0) ? h.UB0 : (l == N ? h.UBs : h.UB);
         for (int j = 0; j < nm; j++) {
-            tab[LY::k_off(l, LY::K_RHO) + j] = h.rho[(size_t)l * nm + j];
-            tab[LY::k_off(l, LY::K_H1I) + j] = h.H1i[(size_t)l * nm + j];
-            tab[LY::k_off(l, LY::K_NH3I) + j] = -h.H3i[(size_t)l * nm + j];
-            tab[LY::k_off(l, LY::K_LB) + j] = lb[j];
-            tab[LY::k_off(l, LY::K_UB) + j] = ub[j];
+            tab[LY::k_off(l, N, LY::K_RHO) + j] = h.rho[(size_t)l * nm + j];  // (MIDSAME: the middle stages write the same table)
+            tab[LY::k_off(l, N, LY::K_H1I) + j] = h.H1i[(size_t)l * nm + j];
+            tab[LY::k_off(l, N, LY::K_NH3I) + j] = -h.H3i[(size_t)l * nm + j];
+            tab[LY::k_off(l, N, LY::K_LB) + j] = lb[j];
+            tab[LY::k_off(l, N, LY::K_UB) + j] = ub[j];
         }
     }
     for (int j = 0; j < nm; j++) {
@@ -133,11 +133,13 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
         tab[LY::c_off(N, LY::C_RHOS) + j] = h.rhos[j];
     }
     bool ok = true;
+    const DM ABt = tr(AB);
     {
         RecordWriter w(tab.data() + LY::inv_off(N), false);
         w.emit(W2, KS, KS, DENSE);
         w.emit(TS, KS, KS, DENSE);
-        ok = ok && w.structure_ok && w.cursor == 2 * LY::M_W2;
+        w.emit(ABt, KS, KX, DENSE);  // stage 0 reads AB' from the header
+        ok = ok && w.structure_ok && w.cursor == 2 * LY::M_W2 + LY::MG;
     }
     std::vector<DM> Bi(N), Al(N - 1);
     for (int l = 0; l < N; l++) Bi[l] = beta_inverse(h.Beta + (size_t)l * n * n, n);
@@ -146,23 +148,22 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) Al[l](i, j) = h.Alpha[((size_t)l * n + i) * n + j];
     }
-    const DM Zero(n, n), ABt = tr(AB);
+    const DM Zero(n, n);
     for (int s = 0; s < 2 * N; s++) {
         RecordWriter w(tab.data() + LY::chunk_off(s, N), true);
         if (s < N) {  // forward chunk of block l: y_l = F1 q3_{l+1}[x] + F2 q3_l + F3 y_{l-1}
             const int l = s;
             const DM BiT = tr(Bi[l]);
-            w.emit(scale_cols(BiT, h.H3i + (size_t)(l + 1) * nm), KX, KX, LOWER);
-            w.emit(neg(mul(BiT, scale_cols(AB, h.H3i + (size_t)l * nm))), KX, KS, DENSE);
+            w.emit(neg(mul(BiT, scale_cols(AB, h.H3i + (size_t)l * nm))), KX, KS, DENSE);  // F2, F3 first: they do not wait for q3_{l+1}
             w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
+            w.emit(scale_cols(BiT, h.H3i + (size_t)(l + 1) * nm), KX, KX, LOWER);
             ok = ok && w.structure_ok && w.cursor == LY::MF;
-        } else {  // backward chunk of block l = 2N-1-s: mu_l = B1 y_l + B2 mu_{l+1}; AB' for stage l + 1 (and again for stage 0)
+        } else {  // backward chunk of block l = 2N-1-s: mu_l = B1 y_l + B2 mu_{l+1}; AB' for stage l + 1
             const int l = 2 * N - 1 - s;
             w.emit(Bi[l], KX, KX, UPPER);
             w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : Zero, KX, KX, DENSE);
             w.emit(ABt, KS, KX, DENSE);
-            if (l == 0) w.emit(ABt, KS, KX, DENSE);
-            ok = ok && w.structure_ok && w.cursor == (l == 0 ? LY::MB0 : LY::MB);
+            ok = ok && w.structure_ok && w.cursor == LY::MB;
         }
     }
     if (!ok) { p.why = "MFMA4R packer: block structure mismatch"; return 0; }
@@ -170,25 +171,26 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
         if (!std::isfinite(x)) { p.why = "non-finite folded constant (singular Beta block?)"; return 0; }
     p.KX = KX;
     p.KS = KS;
-    // registers: z3, lambda ((2 N + 4) RS), z2 (2 RS), q2 (RS), y ((N - NYL) RX); LDS: header, four chunk slots, per-wavefront
-    // x0 / c2, y of the first NYL blocks
+    // LDS: header, four chunk slots, per-wavefront x0 / c2, and z3 / lambda of the first NLS stages; the other stages' z3 / lambda in
+    // registers (2 RS doubles per stage and lane) next to lambda_0, lambda_{N+2}, z2 (old and new), q2 and the y in flight
     const int RX = LY::RX, RS = LY::RS;
-    int max_reg = 200;  // doubles per lane the register allocator places without spilling (of 256)
+    int max_reg = 84;  // doubles per lane of z3 / lambda the register allocator places without spilling (measured at configs[3]: 96 spill)
     if (const char *ev = getenv("SPCIES_ER_MAX_REG")) max_reg = atoi(ev);
-    const int fixed = (2 * N + 4) * RS + 3 * RS;
-    const long lds_free = 163840 - 8L * (LY::hdr_d(N) + 4 * LY::CMAX + 2 * RS * 256) - 1024;
+    const long lds_free = 163840 - 8L * (LY::hdr_d(N) + 4 * LY::CMAX + 2 * RS * 256) - 512;
     if (lds_free < 0) { p.why = "MFMA4R: header and chunk ring exceed the LDS"; return 0; }
-    const int nyl_max = (int)std::min<long>(N, lds_free / (8L * RX * 256));
-    int nyl = std::max(0, (fixed + N * RX - max_reg + RX - 1) / RX);
-    if (const char *ev = getenv("SPCIES_ER_NYL")) nyl = atoi(ev);
-    if (nyl > nyl_max || nyl < 0) { p.why = "MFMA4R: the iteration state does not fit registers + LDS (use MFMA4G)"; return 0; }
-    p.NYL = nyl;
+    const int nls_max = (int)std::min<long>(N + 1, lds_free / (8L * 2 * RS * 256));
+    int nls = std::max(0, ((N + 1) * 2 * RS - max_reg + 2 * RS - 1) / (2 * RS));
+    if (const char *ev = getenv("SPCIES_ER_NLS")) nls = atoi(ev);
+    if (nls > nls_max || nls < 0) { p.why = "MFMA4R: the iteration state does not fit registers + LDS (use MFMA4G)"; return 0; }
+    p.NLS = nls;
+    p.midsame = MIDSAME;
+    p.RX = RX;
     return 1;
 }
 
-// build-time instantiations (N, KX, KS, NYL): BASELINE configs[3], MPCT-EADMM n = 20, m = 2, N = 20
+// build-time instantiations (N, KX, KS, NLS, MIDSAME): BASELINE configs[3], MPCT-EADMM n = 20, m = 2, N = 20
 #ifndef SPCIES_ER_BUILTIN
-#define SPCIES_ER_BUILTIN(X) X(20, 5, 6, 8)
+#define SPCIES_ER_BUILTIN(X) X(20, 5, 6, 7, true)
 #endif
 
 #define SPCIES_ER_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 3) X(3, 4) X(4, 4) X(4, 5) X(5, 5) X(5, 6) X(6, 6)
@@ -198,6 +200,8 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
 void plan_free(Plan &p) {
     if (p.d_table) hipFree(p.d_table);
     p.d_table = nullptr;
+    if (p.d_yscr) hipFree(p.d_yscr);
+    p.d_yscr = nullptr;
     if (p.module) hipModuleUnload((hipModule_t)p.module);
     p.module = nullptr;
     p.ok = false;
@@ -210,10 +214,21 @@ int plan_build(Plan &p, const Host &h) {
     if (const char *ev = getenv("SPCIES_ER_DISABLE"))
         if (ev[0] == '1') { p.why = "disabled (SPCIES_ER_DISABLE=1)"; return 0; }
     const int KX = (h.n + 3) / 4, KS = (h.n + h.m + 3) / 4;
+    // one table of row constants for the stages 1 .. N - 1 when they are all the same (one rho, one pair of bounds: the usual case)
+    bool midsame = true;
+    {
+        const int nm = h.n + h.m;
+        for (int l = 2; l < h.N && midsame; l++)
+            for (int j = 0; j < nm; j++)
+                if (h.rho[(size_t)l * nm + j] != h.rho[(size_t)nm + j] || h.H1i[(size_t)l * nm + j] != h.H1i[(size_t)nm + j] ||
+                    h.H3i[(size_t)l * nm + j] != h.H3i[(size_t)nm + j])
+                    midsame = false;
+        if (getenv("SPCIES_ER_NO_MIDSAME")) midsame = false;
+    }
     std::vector<double> tab;
     int got = -1;
 #define X(KKX, KKS) \
-    if (KX == KKX && KS == KKS) got = pack<KKX, KKS>(p, h, tab);
+    if (KX == KKX && KS == KKS) got = midsame ? pack<KKX, KKS, true>(p, h, tab) : pack<KKX, KKS, false>(p, h, tab);
     SPCIES_ER_SHAPES(X)
 #undef X
     if (got < 0) { p.why = "MFMA4R: (ceil(n/4), ceil((n+m)/4)) outside the packer's shapes"; return 0; }
@@ -221,8 +236,8 @@ int plan_build(Plan &p, const Host &h) {
     p.builtin = -1;
     {
         int idx = 0;
-#define X(NN, KKX, KKS, YY)                                                                                   \
-    if (h.N == NN && KX == KKX && KS == KKS && p.NYL == YY && !getenv("SPCIES_ER_RTC_FLAGS")) p.builtin = idx; \
+#define X(NN, KKX, KKS, LL, MM)                                                                                                  \
+    if (h.N == NN && KX == KKX && KS == KKS && p.NLS == LL && p.midsame == MM && !getenv("SPCIES_ER_RTC_FLAGS")) p.builtin = idx; \
     idx++;
         SPCIES_ER_BUILTIN(X)
 #undef X
@@ -233,7 +248,8 @@ int plan_build(Plan &p, const Host &h) {
         std::vector<std::string> nm;
         for (int s = 0; s < 2; s++) {
             char name[160];
-            snprintf(name, sizeof(name), "spcies::er::eadmm_r_kernel<%d, %d, %d, %s, %d>", h.N, KX, KS, s ? "true" : "false", p.NYL);
+            snprintf(name, sizeof(name), "spcies::er::eadmm_r_kernel<%d, %d, %d, %s, %d, %s>", h.N, KX, KS, s ? "true" : "false", p.NLS,
+                     p.midsame ? "true" : "false");
             nm.push_back(name);
         }
         // the horizon is unrolled by #pragma unroll: lift the size limit under which clang honours the pragma; MFMA results in
@@ -246,7 +262,8 @@ int plan_build(Plan &p, const Host &h) {
         if (rc) { p.why = std::string("MFMA4R: run-time specialisation failed: ") + spcies_hip_last_error(); return 0; }
         int scratch = 0;
         if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fns[0]) != hipSuccess) scratch = 0;
-        if (getenv("SPCIES_ER_VERBOSE")) fprintf(stderr, "[spcies eadmm_r] N=%d KX=%d KS=%d NYL=%d scratch=%d B per lane\n", h.N, KX, KS, p.NYL, scratch);
+        if (getenv("SPCIES_ER_VERBOSE"))
+            fprintf(stderr, "[spcies eadmm_r] N=%d KX=%d KS=%d NLS=%d midsame=%d scratch=%d B per lane\n", h.N, KX, KS, p.NLS, (int)p.midsame, scratch);
         p.module = mod;
         p.fn[0] = fns[0];
         p.fn[1] = fns[1];
@@ -259,6 +276,11 @@ int plan_build(Plan &p, const Host &h) {
     SPCIES_HIP_CHECK(hipGetDevice(&dev));
     SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     p.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // y scratch: one slot per resident wavefront (eadmm_r_kernel.inc; SPCIES_ER_PD = 3 blocks stay in registers)
+    const size_t slot = (size_t)std::max(h.N - 3, 1) * p.RX * 512;
+    SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_yscr, slot * p.num_cu * 4));
+    if (const char *ev = getenv("SPCIES_HIP_POISON"))  // (test runs: see ensure_scratch in spcies_hip.hip)
+        if (ev[0] == '1') SPCIES_HIP_CHECK(hipMemset(p.d_yscr, 0xFF, slot * p.num_cu * 4));
     p.ok = true;
     p.why.clear();
     return 0;
@@ -277,25 +299,26 @@ int launch(Plan &p, int k_max, double tol, const double *x0, const double *xr, c
     // rest of the (N + 3)(n + m) record is zero
     if (want_sol) SPCIES_HIP_CHECK(hipMemsetAsync(lam, 0, (size_t)B * (size_t)(p.N + 3) * (p.n + p.m) * sizeof(double), st));
     const double *table = p.d_table;
+    double *yscr = p.d_yscr;
     if (p.builtin >= 0) {
         int idx = 0;
-#define X(NN, KKX, KKS, YY)                                                                                                          \
-    if (p.builtin == idx) {                                                                                                          \
-        if (want_sol)                                                                                                                \
-            hipLaunchKernelGGL((eadmm_r_kernel<NN, KKX, KKS, true, YY>), dim3((unsigned)wgs), dim3(256), 0, st, args, table, x0, xr, ur, u, k, e, \
-                               z1, z2, z3, lam);                                                                                     \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((eadmm_r_kernel<NN, KKX, KKS, false, YY>), dim3((unsigned)wgs), dim3(256), 0, st, args, table, x0, xr, ur, u, k, e, \
-                               z1, z2, z3, lam);                                                                                     \
-    }                                                                                                                                \
+#define X(NN, KKX, KKS, LL, MM)                                                                                                          \
+    if (p.builtin == idx) {                                                                                                              \
+        if (want_sol)                                                                                                                    \
+            hipLaunchKernelGGL((eadmm_r_kernel<NN, KKX, KKS, true, LL, MM>), dim3((unsigned)wgs), dim3(256), 0, st, args, table, x0, xr, ur, u, k, e, \
+                               z1, z2, z3, lam, yscr);                                                                                   \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((eadmm_r_kernel<NN, KKX, KKS, false, LL, MM>), dim3((unsigned)wgs), dim3(256), 0, st, args, table, x0, xr, ur, u, k, e, \
+                               z1, z2, z3, lam, yscr);                                                                                   \
+    }                                                                                                                                    \
     idx++;
         SPCIES_ER_BUILTIN(X)
 #undef X
         SPCIES_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    void *params[] = {&args, &table, &x0, &xr, &ur, &u, &k, &e, &z1, &z2, &z3, &lam};
-    SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 1 : 0], 256 > 0 ? (unsigned)wgs : 0, 1, 1, 256, 1, 1, 0, st, params, nullptr));
+    void *params[] = {&args, &table, &x0, &xr, &ur, &u, &k, &e, &z1, &z2, &z3, &lam, &yscr};
+    SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 1 : 0], (unsigned)wgs, 1, 1, 256, 1, 1, 0, st, params, nullptr));
     return 0;
 }
 

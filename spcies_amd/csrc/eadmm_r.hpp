@@ -1,5 +1,5 @@
 // Variant MFMA4R of the MPCT EADMM solver (diagonal Q, R): unrolled on the horizon, the whole iteration state (z3, lambda,
-// the forward-substituted y) resident in registers (+ LDS for part of y), eight instances per wavefront in the "H" lane layout,
+// y through an L2-resident scratch slot) resident in registers + LDS, eight instances per wavefront in the "H" lane layout,
 // the controller's 4x4 blocks streamed L2 -> LDS by LDS-DMA (eadmm_r_kernel.inc has the design).  Specialised per controller:
 // hiprtc at create time (Spcies prints one solver per controller; so does this), a build-time instantiation for BASELINE configs[3].
 #pragma once
@@ -18,8 +18,10 @@ struct Host {  // what parse_banded collected for the MPCT EADMM solver (cons_MP
 struct Plan {
     bool ok = false;
     std::string why = "not built";
-    int n = 0, m = 0, N = 0, KX = 0, KS = 0, NYL = 0;
+    int n = 0, m = 0, N = 0, KX = 0, KS = 0, RX = 0, NLS = 0;  // NLS: stages whose z3 / lambda live in LDS
+    bool midsame = false;                                     // one table of row constants for the stages 1 .. N - 1
     double *d_table = nullptr;
+    double *d_yscr = nullptr;  // per-wavefront scratch slots of the forward-substituted y
     size_t table_bytes = 0;
     int num_cu = 256;
     void *module = nullptr;            // hipModule_t of the run-time specialised kernel

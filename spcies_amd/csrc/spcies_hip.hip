@@ -23,6 +23,7 @@
 #include "hmpc_fused.hpp"
 #include "cs_fused.hpp"
 #include "fista_r.hpp"
+#include "eadmm_r.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -100,6 +101,7 @@ struct Solver {
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
     std::string notes;             // which faster (run-time specialised) variants AUTO could not use, and why (spcies_hip_get_notes)
     fr::Plan frplan;               // MFMA4R (FISTA with the iteration state in registers + LDS, run-time specialised)
+    er::Plan erplan;               // MFMA4R (MPCT EADMM, diagonal Q, R: the whole iteration state on the chip, run-time specialised)
     hfused::Plan hfused;           // FUSED (HMPC split NON_SPARSE path: product + projections in one MFMA kernel)
     std::vector<double> h_M1, h_M2, h_bh_nat;
     bsp::Plan bsp;                 // BSP (ellipMPC soc): block-sparse MFMA program, generated per controller
@@ -736,6 +738,7 @@ static int resolve_variant(const Solver &s) {
     if (s.is_soc() && !s.is_hmpc() && s.bsp.ok) return SPCIES_VARIANT_BSP;
     if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.method == SPCIES_FISTA && s.frplan.ok) return SPCIES_VARIANT_MFMA4R;
+    if (s.method == SPCIES_EADMM && s.erplan.ok) return SPCIES_VARIANT_MFMA4R;
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
     if (s.host.gen && s.bsp.ok && s.formulation == SPCIES_LAXMPC) return SPCIES_VARIANT_BSP;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
@@ -1309,13 +1312,17 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
     }
     if (s.method == SPCIES_EADMM) {
         const int ev = resolve_variant(s);
+        if (ev == SPCIES_VARIANT_MFMA4R) {
+            if (!s.erplan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant not available: %s", s.erplan.why.c_str());
+            return er::launch(s.erplan, s.host.k_max, s.host.tol, x0, xr, ur, ref_stride, B, u, k, e, f[0], f[1], f[2], f[3], st);
+        }
         if (ev == SPCIES_VARIANT_MFMA4G) {
             if (!s.g4plan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available: %s", s.g4plan.why.c_str());
             int rc = ensure_scratch(s, g4::eadmm_state_bytes(s.g4plan, s.host, B));
             if (rc) return rc;
             return g4::launch_eadmm_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f[0], f[1], f[2], f[3], st);
         }
-        if (ev != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "EADMM: variants STREAM and MFMA4G are built");
+        if (ev != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "EADMM: variants STREAM, MFMA4G and MFMA4R are built");
         if (s.e_general) return fail(SPCIES_HIP_ENOSUP, "EADMM with general Q, R: the MFMA4G variant is built (STREAM covers the diagonal path)");
         if (!eadmm_stream_shape_built(s.host.n, s.host.m))
             return fail(SPCIES_HIP_ENOSUP, "EADMM STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
@@ -1482,6 +1489,7 @@ static void free_solver(Solver *s) {
     hfused::plan_free(s->hfused);
     csfused::plan_free(s->csf);
     fr::plan_free(s->frplan);
+    er::plan_free(s->erplan);
     hdense::plan_free(s->hd_plan);
     bsp::plan_free(s->bsp);
     if (s->d_eng) hipFree(s->d_eng);
@@ -1605,6 +1613,17 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         eh.Q_bi = &s->e_Qbi; eh.Q_mi = &s->e_Qmi; eh.R_bi = &s->e_Rbi; eh.R_mi = &s->e_Rmi;
         rc = g4::eadmm_plan_build(s->g4plan, s->host, eh);
         if (rc) return rc;
+        // MFMA4R: the whole iteration state on the chip, the kernel specialised for this controller (hiprtc unless the shape was
+        // instantiated at build time).  A failure is not an error: AUTO then runs MFMA4G.
+        if (s->e_general) {
+            s->erplan.why = "general Q, R (IS_DIAG == 0): MFMA4G carries that path";
+        } else {
+            er::Host eh2{s->host.n, s->host.m, s->host.N, s->host.k_max, s->host.tol, s->host.AB.data(), s->host.Alpha.data(), s->host.Beta.data(),
+                         s->host.T.data(), s->e_S.data(), s->e_rho.data(), s->e_rho0.data(), s->e_rhos.data(), s->host.LB.data(), s->host.UB.data(),
+                         s->e_LB0.data(), s->e_UB0.data(), s->e_LBs.data(), s->e_UBs.data(), s->e_H1i.data(), s->e_W2.data(), s->e_H3i.data()};
+            rc = er::plan_build(s->erplan, eh2);
+            if (rc) return rc;
+        }
     }
     if (s->method == SPCIES_FISTA && !s->tv) {
         g4::FistaGHost fh{&s->QRi, &s->Td, &s->Ti};
@@ -1628,6 +1647,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         if (wanted && !ok) s->notes += std::string(s->notes.empty() ? "" : "; ") + name + " unavailable: " + why;
     };
     note("MFMA4R", s->method == SPCIES_FISTA && !s->tv, s->frplan.ok, s->frplan.why);
+    note("MFMA4R", s->method == SPCIES_EADMM, s->erplan.ok, s->erplan.why);
     note("BSP", (s->is_soc() && !s->is_hmpc()) || s->host.ellip, s->bsp.ok, s->bsp.why);
     note("MFMA4", s->mfma4.needs_rtc, s->mfma4.ok, s->mfma4.why);
     note("FUSED", s->is_hmpc() || s->is_hdense(), s->hfused.ok, s->hfused.why);
@@ -1771,7 +1791,9 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     }
     if (variant == SPCIES_VARIANT_TILE && !(s->is_soc() && s->tdev.lpi))
         return fail(SPCIES_HIP_ENOSUP, "TILE variant: built for the sparse-KKT solvers (ellipMPC soc, HMPC) whose LDL right-hand side fits the LDS");
-    if (variant == SPCIES_VARIANT_MFMA4R && !s->frplan.ok)
+    if (variant == SPCIES_VARIANT_MFMA4R && s->method == SPCIES_EADMM && !s->erplan.ok)
+        return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant not available for this solver: %s", s->erplan.why.c_str());
+    if (variant == SPCIES_VARIANT_MFMA4R && s->method != SPCIES_EADMM && !s->frplan.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant not available for this solver: %s", s->frplan.why.c_str());
     if (variant == SPCIES_VARIANT_MFMA4G && !s->g4plan.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available for this solver: %s", s->g4plan.why.c_str());

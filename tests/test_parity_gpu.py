@@ -317,7 +317,7 @@ def test_fista_full_size_properties(variant):
 # ----------------------------------------------------------------------------------------------
 # MPCT EADMM: STREAM variant, reference operation order -> bit-exact; MFMA4G variant -> 1e-10
 # ----------------------------------------------------------------------------------------------
-EADMM_VARIANTS = ["stream", "mfma4g"]
+EADMM_VARIANTS = ["stream", "mfma4g", "mfma4r"]  # mfma4r: whole iteration state on the chip, specialised per controller (eadmm_r.hpp)
 def _compare_mpct(variant, got, O):
     u, k, e, sol = got
     uo, ko, eo, z1o, z2o, z3o, lo = O
@@ -1141,8 +1141,9 @@ def test_mfma4g_fista_arbitrary_shapes(n, m, N, formulation, variant):
     s.close()
 
 
-@pytest.mark.parametrize("n,m,N", [(10, 3, 9), (16, 4, 6), (5, 1, 14)])
-def test_mfma4g_eadmm_arbitrary_shapes(n, m, N):
+@pytest.mark.parametrize("variant", ["mfma4g", "mfma4r"])
+@pytest.mark.parametrize("n,m,N", [(10, 3, 9), (16, 4, 6), (5, 1, 14), (7, 2, 11), (12, 1, 5)])  # odd / even slab counts, n % 4 != 0
+def test_mfma4g_eadmm_arbitrary_shapes(n, m, N, variant):
     from oracle import oracle
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
@@ -1152,11 +1153,14 @@ def test_mfma4g_eadmm_arbitrary_shapes(n, m, N):
     cfg.solver_options = dict(rho_base=2, rho_mult=20, k_max=300, tol=1e-6)
     v = benchmarks.ingredients(cfg)
     s = HipSolver(v)
-    s.set_variant("mfma4g")
+    s.set_variant(variant)
     rng = np.random.default_rng(n)
-    B = 40
+    B = 45  # (not a multiple of the 8 / 16 instances of a wavefront, nor of the 32 / 64 of a workgroup)
     x0, xr, ur = 0.5 * rng.standard_normal((B, n)), 0.2 * rng.standard_normal((B, n)), 0.1 * rng.standard_normal((B, m))
-    _compare_mpct("mfma4g", s(x0, xr, ur), oracle.eadmm_mpct_batch(v, x0, xr, ur))
+    got = s(x0, xr, ur)
+    _compare_mpct(variant, got, oracle.eadmm_mpct_batch(v, x0, xr, ur))
+    nosol = s(x0, xr, ur, want_sol=False)
+    assert np.array_equal(nosol[0], got[0]) and np.array_equal(nosol[1], got[1])
     s.close()
 
 
