@@ -137,9 +137,11 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
     {
         RecordWriter w(tab.data() + LY::inv_off(N), false);
         w.emit(W2, KS, KS, DENSE);
-        w.emit(TS, KS, KS, DENSE);
         w.emit(ABt, KS, KX, DENSE);  // stage 0 reads AB' from the header
-        ok = ok && w.structure_ok && w.cursor == 2 * LY::M_W2 + LY::MG;
+        ok = ok && w.structure_ok && w.cursor == LY::M_W2 + LY::MG;
+        RecordWriter w2(tab.data() + LY::ts_off(N), false);  // setup only: read from L2, not kept in LDS
+        w2.emit(TS, KS, KS, DENSE);
+        ok = ok && w2.structure_ok && w2.cursor == LY::M_W2;
     }
     std::vector<DM> Bi(N), Al(N - 1);
     for (int l = 0; l < N; l++) Bi[l] = beta_inverse(h.Beta + (size_t)l * n * n, n);
@@ -171,12 +173,13 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
         if (!std::isfinite(x)) { p.why = "non-finite folded constant (singular Beta block?)"; return 0; }
     p.KX = KX;
     p.KS = KS;
-    // LDS: header, four chunk slots, per-wavefront x0 / c2, and z3 / lambda of the first NLS stages; the other stages' z3 / lambda in
-    // registers (2 RS doubles per stage and lane) next to lambda_0, lambda_{N+2}, z2 (old and new), q2 and the y in flight
+    // LDS: header, four chunk slots, per-wavefront x0, three y blocks per wavefront on their way back from the scratch slot, and z3 /
+    // lambda of the first NLS stages; the other stages' z3 / lambda in registers (2 RS doubles per stage and lane) next to lambda_0,
+    // lambda_{N+2}, z2 (old and new), q2, c2, the middle stages' row constants and the last two y blocks
     const int RX = LY::RX, RS = LY::RS;
-    int max_reg = 84;  // doubles per lane of z3 / lambda the register allocator places without spilling (measured at configs[3]: 96 spill)
+    int max_reg = 90;  // doubles per lane of z3 / lambda the register allocator places without spilling (measured at configs[3])
     if (const char *ev = getenv("SPCIES_ER_MAX_REG")) max_reg = atoi(ev);
-    const long lds_free = 163840 - 8L * (LY::hdr_d(N) + 4 * LY::CMAX + 2 * RS * 256) - 512;
+    const long lds_free = 163840 - 8L * (LY::hdr_lds(N) + 4 * LY::CMAX + RS * 256 + 3 * 4 * ((RX + 1) / 2) * 128) - 512;
     if (lds_free < 0) { p.why = "MFMA4R: header and chunk ring exceed the LDS"; return 0; }
     const int nls_max = (int)std::min<long>(N + 1, lds_free / (8L * 2 * RS * 256));
     int nls = std::max(0, ((N + 1) * 2 * RS - max_reg + 2 * RS - 1) / (2 * RS));
@@ -190,7 +193,7 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
 
 // build-time instantiations (N, KX, KS, NLS, MIDSAME): BASELINE configs[3], MPCT-EADMM n = 20, m = 2, N = 20
 #ifndef SPCIES_ER_BUILTIN
-#define SPCIES_ER_BUILTIN(X) X(20, 5, 6, 7, true)
+#define SPCIES_ER_BUILTIN(X) X(20, 5, 6, 6, true)
 #endif
 
 #define SPCIES_ER_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 3) X(3, 4) X(4, 4) X(4, 5) X(5, 5) X(5, 6) X(6, 6)
@@ -276,8 +279,8 @@ int plan_build(Plan &p, const Host &h) {
     SPCIES_HIP_CHECK(hipGetDevice(&dev));
     SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     p.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    // y scratch: one slot per resident wavefront (eadmm_r_kernel.inc; SPCIES_ER_PD = 3 blocks stay in registers)
-    const size_t slot = (size_t)std::max(h.N - 3, 1) * p.RX * 512;
+    // y scratch: one slot per resident wavefront (eadmm_r_kernel.inc; the last kYKeep = 2 blocks stay in registers)
+    const size_t slot = (size_t)std::max(h.N - kYKeep, 1) * p.RX * 512;
     SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_yscr, slot * p.num_cu * 4));
     if (const char *ev = getenv("SPCIES_HIP_POISON"))  // (test runs: see ensure_scratch in spcies_hip.hip)
         if (ev[0] == '1') SPCIES_HIP_CHECK(hipMemset(p.d_yscr, 0xFF, slot * p.num_cu * 4));
