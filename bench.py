@@ -69,24 +69,26 @@ def traffic_from_profile(variant):
     return None, None
 
 
-_PROFILE_OF = {"C3": "r02_C3_mfma4r", "C4": "r02_C4_mfma4g", "C5_soc": "r02_C5soc_bsp", "C5_hmpc": "r02_C5hmpc_fused"}
+_PROFILE_TAG = {"C3": "C3", "C4": "C4", "C5_soc": "C5soc", "C5_hmpc": "C5hmpc"}
 
 
-def design_traffic(key):
-    """HBM bytes per launch of a configuration's kernel from its committed rocprofv3 PMC passes (profiles/r02_<config>_pmc_summary.txt,
-    FETCH_SIZE x 2 + WRITE_SIZE, KB) - the DESIGN traffic, a constant read from the repository like `roofline.traffic` above."""
-    path = os.path.join(ROOT, "profiles", _PROFILE_OF.get(key, "") + "_pmc_summary.txt")
-    if not os.path.exists(path):
-        return None, None
-    fetch = write = None
-    for line in open(path):
-        if line.startswith("FETCH_SIZE"):
-            fetch = float(line.split("mean=")[1].split()[0])
-        elif line.startswith("WRITE_SIZE"):
-            write = float(line.split("mean=")[1].split()[0])
-    if fetch is None or write is None:
-        return None, None
-    return (2.0 * fetch + write) * 1024.0, os.path.relpath(path, ROOT)
+def design_traffic(key, variant):
+    """HBM bytes per launch of a configuration's kernel from its committed rocprofv3 PMC passes (profiles/rNN_<config>_<variant>_pmc_summary.txt,
+    newest round first; FETCH_SIZE x 2 + WRITE_SIZE, KB) - the DESIGN traffic, a constant read from the repository like `roofline.traffic`
+    above.  Only a profile of the SAME variant counts."""
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{_PROFILE_TAG.get(key, key)}_{variant}_pmc_summary.txt")
+        if not os.path.exists(path):
+            continue
+        fetch = write = None
+        for line in open(path):
+            if line.startswith("FETCH_SIZE"):
+                fetch = float(line.split("mean=")[1].split()[0])
+            elif line.startswith("WRITE_SIZE"):
+                write = float(line.split("mean=")[1].split()[0])
+        if fetch is not None and write is not None:
+            return (2.0 * fetch + write) * 1024.0, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def host_threads():
@@ -465,11 +467,11 @@ def bench_config(spec, dev, steps, warmup, key=""):
     variant = solver.variant
     out = {"workload": spec["what"], "batch": B, "variant": variant, "steps": steps, "kernel_ms": ms,
            "solves_per_s": B / (ms * 1e-3),
-           "roofline": {"bound": "hbm" if variant in ("mfma4g", "stream", "tile") else "mfma",
+           "roofline": {"bound": "hbm" if variant in ("mfma4g", "stream", "tile") else "mfma",  # (what binds the DESIGN; `achieved` is algorithmic flop either way)
                         "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_MFMA_TFLOPS,
                         "flop_per_solve": spec["flop"], "algorithmic_io_gbs": gbs, "hbm_frac_algorithmic": gbs / PEAK_HBM_GBS},
            "oracle_check": _oracle_check(cfg, v, x0, xr, ur, tu[:32].cpu().numpy(), tk[:32].cpu().numpy())}
-    traffic, src = design_traffic(key)
+    traffic, src = design_traffic(key, variant)
     if traffic is not None:  # what the kernel really moves through HBM (design bytes, not algorithmic ones) against the 8 TB/s peak
         out["roofline"].update(traffic=traffic, traffic_source=src, hbm_frac_design=traffic / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS)
     solver.close()
