@@ -173,13 +173,13 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
         if (!std::isfinite(x)) { p.why = "non-finite folded constant (singular Beta block?)"; return 0; }
     p.KX = KX;
     p.KS = KS;
-    // LDS: header, four chunk slots, per-wavefront x0, three y blocks per wavefront on their way back from the scratch slot, and z3 /
+    // LDS: header, four chunk slots, per-wavefront x0 and c2, three y blocks per wavefront on their way back from the scratch slot, and z3 /
     // lambda of the first NLS stages; the other stages' z3 / lambda in registers (2 RS doubles per stage and lane) next to lambda_0,
-    // lambda_{N+2}, z2 (old and new), q2, c2, the middle stages' row constants and the last two y blocks
+    // lambda_{N+2}, z2 (old and new), q2, the middle stages' row constants and the last two y blocks
     const int RX = LY::RX, RS = LY::RS;
     int max_reg = 90;  // doubles per lane of z3 / lambda the register allocator places without spilling (measured at configs[3])
     if (const char *ev = getenv("SPCIES_ER_MAX_REG")) max_reg = atoi(ev);
-    const long lds_free = 163840 - 8L * (LY::hdr_lds(N) + 4 * LY::CMAX + RS * 256 + 3 * 4 * ((RX + 1) / 2) * 128) - 512;
+    const long lds_free = 163840 - 8L * (LY::hdr_lds(N) + 4 * LY::CMAX + 2 * RS * 256 + 3 * 4 * RX * 64) - 512;
     if (lds_free < 0) { p.why = "MFMA4R: header and chunk ring exceed the LDS"; return 0; }
     const int nls_max = (int)std::min<long>(N + 1, lds_free / (8L * 2 * RS * 256));
     int nls = std::max(0, ((N + 1) * 2 * RS - max_reg + 2 * RS - 1) / (2 * RS));
