@@ -2,7 +2,7 @@
 # Round profile: kernel-trace stats + FETCH/WRITE passes (+ SQ counters) for the BASELINE configurations' default variants.
 # usage (GPU box): tools/profile_round.sh r02 [tag ...]   -> gpurun_out/prof_<round>_<tag>/, summaries in gpurun_out/profiles_<round>/
 # (with tags: only those configurations)
-R=${GRAFT_REPO_ROOT:-/root/repo}; RD=${1:-r02}; shift; ONLY=" $* "
+R=${GRAFT_REPO_ROOT:-/root/repo}; RD=${1:-r03}; shift; ONLY=" $* "
 OUT=$R/gpurun_out/profiles_$RD; mkdir -p $OUT
 prof() {  # tag config B variant kernel-substring
   if [ "$ONLY" != "  " ] && [[ "$ONLY" != *" $1 "* ]]; then return; fi
@@ -14,6 +14,7 @@ prof() {  # tag config B variant kernel-substring
 }
 prof C2_mfma4 C2 65536 mfma4 admm_mfma4
 prof C3_mfma4r C3 262144 mfma4r fista_r
+prof C4_mfma4r C4 131072 mfma4r eadmm_r
 prof C4_mfma4g C4 131072 mfma4g eadmm_g
 prof C5soc_bsp C5_soc 65536 bsp bsp
 prof C5hmpc_fused C5_HMPC_SADMM 65536 fused hmpc_fused
