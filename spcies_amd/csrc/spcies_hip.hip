@@ -7,6 +7,7 @@
 #include "admm_mfma4.hpp"
 #include "mfma4_rtc.hpp"
 #include "admm_stream.hpp"
+#include "admm_tvw.hpp"
 #include "fista_stream.hpp"
 #include "fista_mfma4g.hpp"
 #include "admm_mfma4g.hpp"
@@ -727,10 +728,24 @@ static int ensure_mfma4_rtc(Solver &s) {
     return 0;
 }
 
+// Time-varying lax/equ ADMM, variant TILE (admm_tvw.hpp: one wavefront per instance, the instance's factors in LDS): wavefronts
+// (instances) per workgroup the LDS holds, 0 when the variant does not apply
+static int tvw_waves(const Solver &s) {
+    if (!s.tv || s.method != SPCIES_ADMM) return 0;
+    const int n = s.host.n, m = s.host.m, N = s.host.N;
+    if (!((n == 6 || n == 12) && m == 2) || N < 2 || N + 1 > 32) return 0;
+    if (const char *ev = getenv("SPCIES_TVW_DISABLE"))
+        if (ev[0] == '1') return 0;
+    const long per = 8L * tvw::lds_doubles_per_wave(n, m, N);
+    return (int)std::min<long>(4, (160 * 1024) / per);
+}
+
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
     if (s.host.ellip) return s.bsp.ok ? SPCIES_VARIANT_BSP : SPCIES_VARIANT_STREAM;
-    if (s.tv) return SPCIES_VARIANT_STREAM;
+    // (time-varying ADMM also has TILE - one wavefront per instance, admm_tvw.hpp - on request: measured 0.157 M solves/s against
+    // STREAM's 0.279 M at the configs[1] shape, so AUTO stays on STREAM)
+    if (s.tv) return (s.variant == SPCIES_VARIANT_TILE && tvw_waves(s) > 0) ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.is_hdense()) return s.hfused.ok ? SPCIES_VARIANT_FUSED : SPCIES_VARIANT_GEMM;
     if (s.is_cs()) return s.csf.ok ? SPCIES_VARIANT_FUSED : (s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM);
     if (s.is_hmpc() && s.hfused.ok) return SPCIES_VARIANT_FUSED;
@@ -958,7 +973,8 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
     const TvLayout tl = tv_layout(n, m, N);
     const bool want_sol = (z || v || lam);
     const size_t dim = (size_t)s.host.dim();
-    const size_t rows_stream = 2 * dim + (size_t)N * n + (want_sol ? dim : 0);
+    const int nw = resolve_variant(s) == SPCIES_VARIANT_TILE ? tvw_waves(s) : 0;  // TILE: one wavefront per instance (admm_tvw.hpp)
+    const size_t rows_stream = nw ? 0 : 2 * dim + (size_t)N * n + (want_sol ? dim : 0);
     long chunk = (long)((3900ull << 20) / ((size_t)tl.rows * 8)) / 64 * 64;
     if (chunk > B) chunk = (B + 63) / 64 * 64;
     int rc = ensure_scratch(s, (rows_stream + (size_t)tl.rows) * (size_t)chunk * sizeof(double));
@@ -971,6 +987,43 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
         const double *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
         const double *mc = model_stride ? model + b0 * (long)model_stride : model;
         dim3 grid((unsigned)(Bp / 64)), block(64);
+        if (nw) {  // update phase as before (the reference's operation order, one lane per instance), then one wavefront per instance
+            if (s.host.terminal)
+                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
+                                   (long)model_stride, Bc, Bp, TVS);
+            else
+                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, false>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
+                                   (long)model_stride, Bc, Bp, TVS);
+            SPCIES_HIP_CHECK(hipGetLastError());
+            tvw::Args ta{N, s.host.k_max, ref_stride, s.host.rho, s.host.rho_i, s.host.tol, Bc, Bp};
+            const size_t shmem = (size_t)nw * tvw::lds_doubles_per_wave(n, m, N) * sizeof(double);
+            hipDeviceProp_t prop;
+            SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, s.device));
+            const long wgs = std::min<long>((Bc + nw - 1) / nw, (long)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256));
+            const double *hin = s.d_consts + s.dev.Hi_N, *tt = s.d_consts + s.dev.T;
+            double *zo = z ? z + b0 * dim : nullptr, *vo = v ? v + b0 * dim : nullptr, *lo = lam ? lam + b0 * dim : nullptr;
+#define SPCIES_TVW_LAUNCH(TT, RR)                                                                                                        \
+    do {                                                                                                                                 \
+        if (shmem > 64 * 1024)                                                                                                           \
+            SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)tvw::admm_tvw_kernel<n, m, TT, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                 (int)shmem));                                                                           \
+        hipLaunchKernelGGL((tvw::admm_tvw_kernel<n, m, TT, RR>), dim3((unsigned)wgs), dim3(64 * nw), shmem, st, ta, hin, tt, TVS, x0 + b0 * n, xrc, \
+                           urc, u + b0 * m, k + b0, e + b0, zo, vo, lo);                                                                 \
+    } while (0)
+#define SPCIES_TVW_CASE(RR)                                 \
+    case RR:                                                \
+        if (s.host.terminal) SPCIES_TVW_LAUNCH(true, RR);   \
+        else SPCIES_TVW_LAUNCH(false, RR);                  \
+        break;
+            switch ((N + 4) / 4) {
+                SPCIES_TVW_CASE(1) SPCIES_TVW_CASE(2) SPCIES_TVW_CASE(3) SPCIES_TVW_CASE(4) SPCIES_TVW_CASE(5) SPCIES_TVW_CASE(6) SPCIES_TVW_CASE(7) SPCIES_TVW_CASE(8)
+                default: return fail(SPCIES_HIP_ENOSUP, "time-varying TILE variant: N + 1 > 32");
+            }
+#undef SPCIES_TVW_CASE
+#undef SPCIES_TVW_LAUNCH
+            SPCIES_HIP_CHECK(hipGetLastError());
+            continue;
+        }
         if (s.host.terminal) {
             hipLaunchKernelGGL((admm_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
                                (long)model_stride, Bc, Bp, TVS);
@@ -1370,8 +1423,8 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (!extra) return fail(SPCIES_HIP_EINVAL, "time-varying solvers take A, B, Q, R, LB, UB with every call (extra): Spcies:laxMPC:nrhs:number");
         if (extra_stride != 0 && extra_stride != s.tv_model_size())
             return fail(SPCIES_HIP_EINVAL, "time-varying: extra_stride must be 0 (shared model) or %d", s.tv_model_size());
-        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
-            return fail(SPCIES_HIP_ENOSUP, "time-varying: only the STREAM variant is built");
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM && !(s.variant == SPCIES_VARIANT_TILE && tvw_waves(s) > 0))
+            return fail(SPCIES_HIP_ENOSUP, "time-varying ADMM: variants STREAM and TILE (one wavefront per instance, when the factors fit the LDS) are built");
         if (s.host.n == 6 && s.host.m == 2) return launch_tv_nm<6, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         if (s.host.n == 12 && s.host.m == 2) return launch_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
@@ -1786,6 +1839,10 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (s->is_cs()) {
         if (variant != SPCIES_VARIANT_AUTO && variant != SPCIES_VARIANT_STREAM && !(variant == SPCIES_VARIANT_TILE && s->tdev.lpi))
             return fail(SPCIES_HIP_ENOSUP, "MPCT ADMM cs: variants STREAM and TILE (when the right-hand side fits the LDS) are built");
+        s->variant = variant;
+        return 0;
+    }
+    if (variant == SPCIES_VARIANT_TILE && s->tv && tvw_waves(*s) > 0) {  // time-varying ADMM: one wavefront per instance (admm_tvw.hpp)
         s->variant = variant;
         return 0;
     }
