@@ -1164,6 +1164,31 @@ def test_mfma4g_eadmm_arbitrary_shapes(n, m, N, variant):
     s.close()
 
 
+@pytest.mark.parametrize("env", [dict(SPCIES_ER_NO_MIDSAME="1"), dict(SPCIES_ER_NLS="0"), dict(SPCIES_ER_NLS="3"),
+                                 dict(SPCIES_ER_NO_MIDSAME="1", SPCIES_ER_NLS="2")])
+def test_eadmm_mfma4r_state_placements(env, monkeypatch):
+    """The specialisation switches of the on-chip EADMM kernel (eadmm_r.hip): one table of row constants per stage instead of
+    the shared middle table (a controller whose middle stages differ takes that path), and the number of stages whose z3 / lambda
+    live in LDS instead of registers - the same results whichever way the state is placed."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    cfg = _random_cfg(9, 2, 8, seed=77)
+    cfg.formulation, cfg.method = "MPCT", "EADMM"
+    cfg.param.T, cfg.param.S = 10 * cfg.param.Q, cfg.param.R.copy()
+    cfg.solver_options = dict(rho_base=2, rho_mult=20, k_max=250, tol=1e-6)
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    s.set_variant("mfma4r")
+    rng = np.random.default_rng(3)
+    B = 37
+    x0, xr, ur = 0.5 * rng.standard_normal((B, 9)), 0.2 * rng.standard_normal((B, 9)), 0.1 * rng.standard_normal((B, 2))
+    _compare_mpct("mfma4r", s(x0, xr, ur), oracle.eadmm_mpct_batch(v, x0, xr, ur))
+    s.close()
+
+
 # ----------------------------------------------------------------------------------------------
 # lax/equ MPC ADMM with vector rho and stage-wise bounds (SURVEY section 8f rank 3: no SCALAR_RHO, VAR_BOUNDS)
 # ----------------------------------------------------------------------------------------------
