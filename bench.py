@@ -382,12 +382,17 @@ def run_multi(args):
                                                     cast("k", ip), cast("e", ip), None, None, None, C.byref(tim)))
     for _ in range(args.warmup):
         step()
-    t = time.perf_counter()
+    calls = []
     for _ in range(args.steps):
+        t = time.perf_counter()
         step()
-    dt = time.perf_counter() - t
+        calls.append(time.perf_counter() - t)
+    # (a synchronous host call per step: the median is the steady rate - the first calls on fresh page-locked buffers and a cold
+    # clock can take several times as long; mean and extremes are reported next to it)
+    dt = float(np.median(calls)) * args.steps
     k, e = bufs["k"][1], bufs["e"][1]
     out.update(value=total * args.steps / dt, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
+               ms_per_step_mean=float(np.mean(calls)) * 1e3, ms_per_step_min=float(np.min(calls)) * 1e3, ms_per_step_max=float(np.max(calls)) * 1e3,
                last_call_ms={"h2d": tim.update_time, "solve": tim.solve_time, "d2h": tim.polish_time, "run": tim.run_time},
                all_k_200_eflag_m1=bool((k == 200).all() and (e == -1).all()))
     hits, misses = C.c_long(), C.c_long()
