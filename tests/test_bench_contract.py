@@ -102,6 +102,17 @@ def test_merge_multi_leg_into_the_json_line():
     assert out["value"] == 1.0 and out["multi_launch"]["value"] == 2.0 and merged.count("\n{") == 1
 
 
+def test_design_traffic_reads_only_a_profile_of_the_same_variant():
+    """`roofline.traffic` of a side configuration comes from the committed PMC summary of the SAME (config, variant) - a profile of
+    another kernel for the same configuration (C4: MFMA4G, 857 GB per launch) must not be quoted for the default one (MFMA4R)."""
+    import bench
+    t4r, src = bench.design_traffic("C4", "mfma4r")
+    t4g, srcg = bench.design_traffic("C4", "mfma4g")
+    assert src and "C4_mfma4r" in src and srcg and "C4_mfma4g" in srcg
+    assert 0.05 * t4g < t4r < 0.2 * t4g  # the on-chip kernel moves about an eighth of the streaming one's bytes
+    assert bench.design_traffic("C4", "stream") == (None, None)
+
+
 def test_bench_gpus_mismatch_is_an_error():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
