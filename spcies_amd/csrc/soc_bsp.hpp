@@ -259,8 +259,15 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
             MF(acc, emit_block(blk), a2);
         }
     };
+    // (round 3: the bounds of a slab are requested from LDS BEFORE its products - one wavefront per SIMD has nothing else to hide the
+    // read behind; measured 10.05 -> 9.92 ms at C5.  Also tried: two accumulators per block row of the substitutions, used in turn - a
+    // chain of v_mfma_f64_4x4x4 on one accumulator issues every 22 cycles, several chains every 16.8 - with the nearest dependence
+    // last: 11.4 ms against 9.9 - slower, and so was the same program with the second accumulator left unused.)
+    const bool early_bounds = !getenv("SPCIES_BSP_LATE_BOUNDS");
     for (int Ib = 0; Ib < ZS; Ib++) {
-        body += "            { double ph = 0.0;\n";
+        if (early_bounds) snprintf(line, sizeof(line), "            { double ph = 0.0; const double lbx = LBR(%d), ubx = UBR(%d);\n", Ib, Ib);
+        else snprintf(line, sizeof(line), "            { double ph = 0.0; const double lbx = 0.0, ubx = 0.0; (void)lbx; (void)ubx;\n");
+        body += line;
         prim_row(Ib, "ph");
         if (saved.count(Ib)) {
             char e[128];
@@ -359,6 +366,7 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     std::string s;
     auto def = [&](const char *name, long v) { snprintf(line, sizeof(line), "#define %s %ld\n", name, v); s += line; };
     def("ZS_", ZS); def("SS_", SS); def("NP_", NP); def("NR_", NR); def("NQ_", (long)qrow.size()); def("NSV_", (long)std::max<size_t>(saved.size(), 1));
+    if (early_bounds) s += "#define EARLY_BOUNDS_ 1\n";
     def("TAB_DOUBLES_", (long)tab.size()); def("RC_LB_", rc_lb); def("RC_UB_", rc_ub); def("DIM_", dim); def("NSC_", n_s);
     s += "#define RING_INIT";
     for (int i = 0; i < PF; i++) { snprintf(line, sizeof(line), " double a%d = BLK(blk%d, %d);", i, (i % p.n_blocks) / 512, (i % p.n_blocks) % 512); s += line; }
@@ -462,6 +470,13 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
         int go = g;  // (laundered once per iteration like ao: keeps LICM from hoisting every bound read out of the loop)
 #define LBR(I) ldsr[4 * (I) + go]
 #define UBR(I) ldsr[4 * ZS_ + 4 * (I) + go]
+#ifdef EARLY_BOUNDS_  // the slab's bounds were read at the top of its block (lbx, ubx)
+#define BND_LB(I) lbx
+#define BND_UB(I) ubx
+#else
+#define BND_LB(I) LBR(I)
+#define BND_UB(I) UBR(I)
+#endif
 #define QHZ(J) (qv[QI_##J] + sigma * (w[J] - 2.0 * fmin(fmax(w[J], LBR(J)), UBR(J))))
         bool active = valid, res = false, all_hit = false;
 #define HITUPD                                                                                   \
@@ -476,7 +491,7 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
         // ... without the residual check (every instance of the wavefront is above its tolerance already)
 #define ZUPD_L(I, zh)                                                                            \
     do {                                                                                         \
-        const double lb_ = LBR(I), ub_ = UBR(I);                                                 \
+        const double lb_ = BND_LB(I), ub_ = BND_UB(I);                                           \
         const double wo_ = w[I], zo_ = fmin(fmax(wo_, lb_), ub_);                                \
         w[I] = (zh) + (wo_ - zo_);                                                               \
         if (WANT_SOL) *((4 * (I) + 3 < DIM_ || 4 * (I) + g < DIM_) ? zhp + 4 * (I) : dump) = (zh); \
@@ -484,7 +499,7 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
         // z rows of slab I: box, lambda, residuals (:209-217, 246-248, 256-267)
 #define ZUPD(I, zh)                                                                              \
     do {                                                                                         \
-        const double lb_ = LBR(I), ub_ = UBR(I);                                                 \
+        const double lb_ = BND_LB(I), ub_ = BND_UB(I);                                           \
         const double wo_ = w[I], zo_ = fmin(fmax(wo_, lb_), ub_);                                \
         const double wn_ = (zh) + (wo_ - zo_), z_ = fmin(fmax(wn_, lb_), ub_);                   \
         w[I] = wn_;                                                                              \
