@@ -1142,7 +1142,7 @@ def test_mfma4g_fista_arbitrary_shapes(n, m, N, formulation, variant):
 
 
 @pytest.mark.parametrize("variant", ["mfma4g", "mfma4r"])
-@pytest.mark.parametrize("n,m,N", [(10, 3, 9), (16, 4, 6), (5, 1, 14), (7, 2, 11), (12, 1, 5)])  # odd / even slab counts, n % 4 != 0
+@pytest.mark.parametrize("n,m,N", [(10, 3, 9), (16, 4, 6), (5, 1, 14), (7, 2, 11), (12, 1, 5), (6, 2, 2), (8, 4, 3)])  # odd / even slab counts, n % 4 != 0, the shortest horizons
 def test_mfma4g_eadmm_arbitrary_shapes(n, m, N, variant):
     from oracle import oracle
     from spcies_amd import benchmarks
