@@ -25,13 +25,13 @@ struct Dims {  // mirrors Shape<> of the kernel file for run-time values
         dim = (N - 1) * nm + m + 3 * nm;
         n_y = ny ? ny : nm;
         n_soc = use_soc ? 2 * n_y : n_y;
-        n_box = dim - 3 * nm;
-        n_sb = ny ? N * ny : 0;
+        n_box = (mode == 1 && ny) ? N * ny : dim - 3 * nm;
+        n_sb = (mode == 0 && ny) ? N * ny : 0;
         n_s = mode == 0 ? n_sb + 3 * n_soc : n_box + 3 * n_soc;
         NA = ((mode == 0 ? dim : n_box) + 15) / 16;
         NB = (n_sb + 15) / 16;
         NC = 3 * ((n_soc + 15) / 16);
-        NR = NA + NB + NC;
+        NR = NA + NB + NC + ((mode == 1 && ny) ? 1 : 0);  // (+ the u row register of the coupled solver without the splitting)
         NXS = (n + 3) / 4;
         NUS = (m + 3) / 4;
         NE = mode == 0 ? NXS : 2 * NXS + NUS;
@@ -41,7 +41,7 @@ struct Dims {  // mirrors Shape<> of the kernel file for run-time values
         if (const char *ev = getenv("SPCIES_HFUSED_CHUNK")) chunk = atoi(ev);  // (with SPCIES_HFUSED_RTC=1 and the same -D in SPCIES_HFUSED_FLAGS)
         NRP = (NR + 1) / 2 * 2;
         JC = (chunk / (NRP * 512)) > 0 ? (chunk / (NRP * 512)) : 1;
-        const int lds_tables = 2 * 16 * (NA + NB) * 8 + 2 * 16 * (NC / 3) * 8;
+        const int lds_tables = 2 * 16 * (NA + NB) * 8 + 2 * 16 * (NC / 3) * 8;  // (NC from the line above: cones only)
         while (JC > 1 && 3 * ((JC * NRP * 512 + 4095) / 4096 * 4096) + lds_tables > 160 * 1024) JC--;  // (as Shape::pick_jc)
         NCH = ((NK + JC - 1) / JC + 2) / 3 * 3;
         CHB = (JC * NRP * 512 + 4095) / 4096 * 4096;
@@ -231,9 +231,19 @@ int plan_build_split(Plan &p, const SplitHost &h) {
 
 int plan_build_nosplit(Plan &p, const NosplitHost &h) {
     const int n = h.n, m = h.m, N = h.N;
-    const Dims D(n, m, N, h.use_soc != 0, 1);
+    // coupled output constraints (COUPLED_CONSTRAINTS): the box-type slack rows are the N n_y output slacks, not one per decision variable
+    int ny = 0;
+    {
+        const int nm = n + m, dim0 = (N - 1) * nm + m + 3 * nm;
+        if (h.n_box != dim0 - 3 * nm) {
+            if (h.n_box <= 0 || h.n_box % N != 0) { p.why = "unexpected HMPC dimensions"; return 0; }
+            ny = h.n_box / N;
+        }
+    }
+    const Dims D(n, m, N, h.use_soc != 0, 1, ny);
     if (D.dim != h.dim || D.n_s != h.n_s || D.n_soc != h.n_soc || D.n_box != h.n_box) { p.why = "unexpected HMPC dimensions"; return 0; }
     if (D.NR > 24) { p.why = "FUSED: more than 24 row registers"; return 0; }
+    if (ny && m > 16) { p.why = "FUSED, coupled constraints: m > 16"; return 0; }
     const int dim = h.dim, n_s = h.n_s, NP = 16 * D.NR;
     // dense C [n_s][dim] from its CSR form
     std::vector<double> Cd((size_t)n_s * dim, 0.0);
@@ -309,12 +319,29 @@ int plan_build_nosplit(Plan &p, const NosplitHost &h) {
         }
         row[cone] = cst;
     }
+    if (ny) {  // u = z[0 .. m) = (M2 b + M1 q)[0 .. m) + G1[0 .. m) (rho (s - d) + lambda): the last row register
+        for (int jr = 0; jr < m; jr++) {
+            double *row = &Mx[(size_t)(16 * (D.NR - 1) + jr) * ncol];
+            double cst = 0.0;
+            for (int ci = 0; ci < NP; ci++)
+                if (orig[ci] >= 0) {
+                    row[ci] = G1[(size_t)jr * n_s + orig[ci]];
+                    cst -= h.rho * G1[(size_t)jr * n_s + orig[ci]] * dv[orig[ci]];
+                }
+            for (int q = 0; q < n; q++) {
+                row[cx0 + q] = L[(size_t)jr * nin + q];
+                row[cxr + q] = L[(size_t)jr * nin + n + q];
+            }
+            for (int q = 0; q < m; q++) row[cur + q] = L[(size_t)jr * nin + 2 * n + q];
+            row[cone] = cst;
+        }
+    }
     // z of the last product from C z - d: one slack row per decision variable whose row of C holds that entry alone
     std::vector<double> zcol(NP, -1.0), zcoef(NP, 0.0), zd(NP, 0.0);
     std::vector<int> inv(n_s, -1);
     for (int ri = 0; ri < NP; ri++)
         if (orig[ri] >= 0) inv[orig[ri]] = ri;
-    for (int c = 0; c < dim; c++) {
+    for (int c = 0; c < dim && !ny; c++) {  // (coupled constraints: u comes from its own row register, the z record from the GEMM variant)
         int found = -1;
         for (int i = 0; i < n_s && found < 0; i++) {
             if (Cd[(size_t)i * dim + c] == 0.0 || zcol[inv[i]] >= 0) continue;
@@ -340,7 +367,7 @@ int plan_build_nosplit(Plan &p, const NosplitHost &h) {
     p.oZcol = put(flat, zcol);
     p.oZcoef = put(flat, zcoef);
     p.oZd = put(flat, zd);
-    return finish_plan(p, D, n, m, N, h.use_soc, h.symmetric, 1, Mx, flat);
+    return finish_plan(p, D, n, m, N, h.use_soc, h.symmetric, 1, Mx, flat, ny);
 }
 
 int launch(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rho_i, double sigma, double sigma_i, double alpha,
@@ -356,6 +383,8 @@ int launch(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rh
     double *ff[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool want_sol = false;
     for (int i = 0; i < nf; i++) { ff[i] = f[i]; want_sol |= f[i] != nullptr; }
+    if (p.mode == 1 && p.ny > 0 && f[0])
+        return fail(SPCIES_HIP_ENOSUP, "FUSED, HMPC without the splitting and with coupled constraints: the z record comes from the GEMM variant");
     const long groups = (B + 31) / 32;
     const unsigned grid = (unsigned)std::min<long>(groups, p.num_cu);
     const double *ME = p.d_ME, *PRO = p.d_PRO, *C = p.d_C;

@@ -743,6 +743,35 @@ def test_hmpc_coupled_nosplit_vs_oracle(variant, cfg_name, B, golden_dir):
     assert np.abs(u - g["u"])[same].max() <= 1e-9 and np.abs(sol.z - g["z"])[same].max() <= 1e-8
 
 
+@pytest.mark.parametrize("cfg_name,B", [("C1_HMPCcc_nosplit", 40), ("C1_HMPCcc_SADMM_nosplit", 70), ("C1_HMPCcc_soc_nosplit", 33)])
+def test_hmpc_coupled_nosplit_fused(cfg_name, B):
+    """HMPC without the splitting and WITH coupled output constraints on the hand-written FUSED kernel (round 3; rocBLAS before): no
+    decision variable has a slack row of its own there, so u rides in one more row register of the slack-space product.  AUTO is
+    FUSED for the control action and GEMM for a call that asks for the z record; FUSED by name refuses the record."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _fista_solver(cfg_name, None)
+    assert v["coupled"] and s.variant == "fused", s.notes
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    st = benchmarks.tester_status(cfg.sys)
+    x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
+    O = oracle.hmpc_dense_batch(v, x0, xr, ur)
+    u, k, e, sol = s(x0, xr, ur, want_sol=False)  # the FUSED kernel
+    assert sol.z is None
+    dk = np.abs(k.astype(int) - O[1].astype(int))
+    assert dk.max() <= 1 and (dk > 0).mean() <= 0.03 and np.array_equal(e[dk == 0], O[2][dk == 0])
+    assert np.abs(u - O[0])[dk == 0].max() <= TOL_SPCIES
+    _margins.record("hmpc_coupled_nosplit_fused", "fused", du=np.abs(u - O[0])[dk == 0].max(), k_differs=(dk > 0).sum(), bar=TOL_SPCIES,
+                    frac_of_bar=np.abs(u - O[0])[dk == 0].max() / TOL_SPCIES)
+    _compare_hmpc_nosplit(s(x0, xr, ur), O, "gemm")  # the record: AUTO hands this call to GEMM
+    s.set_variant("fused")
+    with pytest.raises(Exception, match="z record"):
+        s(x0, xr, ur)
+    u2, k2, _, _ = s(x0, xr, ur, want_sol=False)
+    assert np.array_equal(u2, u) and np.array_equal(k2, k)
+    s.close()
+
+
 @pytest.mark.parametrize("cfg_name", ["C1_HMPC_SADMM", "C1_HMPC_nosplit", "C1_HMPCcc", "C1_MPCT_cs"])
 def test_fused_edge_batches_and_reference_modes(cfg_name):
     """The FUSED kernels (32 instances per workgroup, four per wavefront group): ragged batch sizes around those strides, the empty
