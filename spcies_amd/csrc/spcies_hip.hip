@@ -1707,6 +1707,12 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     note("FUSED", s->is_hmpc() || s->is_hdense(), s->hfused.ok, s->hfused.why);
     note("FUSED", s->is_cs(), s->csf.ok, s->csf.why);
     if (!s->notes.empty() && getenv("SPCIES_HIP_VERBOSE")) fprintf(stderr, "[spcies_hip] %s\n", s->notes.c_str());
+    // SPCIES_HIP_STRICT=1: a faster variant that could not be built (hiprtc missing, compile error, state too large) is an error instead
+    // of a silent 2-12x slower default - for deployments that must notice
+    if (!s->notes.empty()) {
+        const char *strict = getenv("SPCIES_HIP_STRICT");
+        if (strict && strict[0] == '1') return fail(SPCIES_HIP_ENOSUP, "SPCIES_HIP_STRICT: %s", s->notes.c_str());
+    }
     *out = reinterpret_cast<spcies_hip_handle>(s.release());
     return 0;
 }

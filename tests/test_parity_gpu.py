@@ -1399,3 +1399,18 @@ def test_k_histogram_of_a_device_solve():
     assert h.converged == int((e > 0).sum()) and h.k_max_reached == int((e == -1).sum()) and h.other == 0
     assert abs(h.mean_k - k.mean()) < 1e-9 and 0 < h.converged < B  # both outcomes occur on this batch
     s.close()
+
+
+def test_strict_mode_turns_a_missing_fast_variant_into_an_error(monkeypatch):
+    """SPCIES_HIP_STRICT=1: AUTO silently landing on a slower variant (here: run-time specialisation switched off, so FISTA would fall from
+    MFMA4R to MFMA4G) is an error of create; without it the handle exists and `notes` says what is missing."""
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    v = benchmarks.ingredients(benchmarks.config("C1_equ_FISTA"))
+    monkeypatch.setenv("SPCIES_HIP_RTC", "0")
+    s = HipSolver(v)
+    assert s.variant == "mfma4g" and "MFMA4R unavailable" in s.notes
+    s.close()
+    monkeypatch.setenv("SPCIES_HIP_STRICT", "1")
+    with pytest.raises(Exception, match="SPCIES_HIP_STRICT: MFMA4R unavailable"):
+        HipSolver(v)
