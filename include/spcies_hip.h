@@ -216,7 +216,8 @@ typedef struct spcies_hip_solver_s *spcies_hip_handle;
 #define SPCIES_VARIANT_MFMA4G 4 /* v_mfma_f64_4x4x4 with a rolled stage loop: any N, state streamed through HBM   */
 #define SPCIES_VARIANT_TILE 5   /* sparse-KKT solvers: 4-64 lanes per instance, LDL right-hand side in LDS          */
 #define SPCIES_VARIANT_GEMM 6   /* HMPC (split NON_SPARSE path; no-split solver): one dgemm per iteration for the batch */
-#define SPCIES_VARIANT_BSP 7    /* ellipMPC ADMM / soc: the KKT iteration as a per-controller program of 4x4 MFMA blocks */
+#define SPCIES_VARIANT_BSP 7    /* ellipMPC ADMM / soc: the KKT iteration as a per-controller program of 4x4 MFMA blocks; also laxMPC / equMPC ADMM
+                                 * (AUTO's choice there with vector rho or stage-wise bounds, on request otherwise) */
 #define SPCIES_VARIANT_FUSED 8  /* HMPC dense paths and MPCT ADMM cs: product, projections, duals and exit test in one v_mfma_f64_4x4x4 kernel */
 #define SPCIES_VARIANT_MFMA4R 9 /* FISTA: v_mfma_f64_4x4x4, unrolled on the horizon, iteration state in registers + LDS  */
 /* Integer outputs.  STREAM runs the reference's operation order and returns its k / e_flag bit for bit.  The other variants

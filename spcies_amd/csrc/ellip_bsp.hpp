@@ -43,15 +43,18 @@ inline bool dense_ldl(const Dense &W, int n, Dense &L, std::vector<double> &Dinv
 }
 
 inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
-    const int n = a.n, m = a.m, nm = n + m, N = a.N, dim = N * nm, dz = m + (N - 1) * nm, nr = N * n;
-    const int ZS = (dz + 3) / 4, TS = (n + 3) / 4, NP = ZS + TS, NR = (nr + 3) / 4, PR_ = 4 * NP, RR = 4 * NR;
+    // equ mode (equMPC ADMM, code_equMPC_ADMM_C.c): no terminal variable - the last block row of G reads A x_{N-1} + B u_{N-1} = xr - so
+    // the program has no terminal slabs (TS = 0) and the reference enters the right-hand side of its last n rows
+    const bool equ = !a.terminal;
+    const int n = a.n, m = a.m, nm = n + m, N = a.N, dz = m + (N - 1) * nm, dim = equ ? dz : N * nm, nr = N * n;
+    const int ZS = (dz + 3) / 4, TS = equ ? 0 : (n + 3) / 4, NP = ZS + TS, NR = (nr + 3) / 4, PR_ = 4 * NP, RR = 4 * NR;
     p.ok = false;
     p.src.clear();
     p.ZS = ZS; p.SS = TS; p.NR = NR;
     // lax mode: the same program for the laxMPC ADMM solver (scalar or vector rho, constant or stage-wise bounds): the terminal
     // block is a box like the others, its dense weight inv(T + rho I) stays inside the terminal slabs
     const bool lax = !a.ellip;
-    if (!a.terminal) { p.why = "no terminal block (equMPC): not built"; return 0; }
+    if (equ && (a.ellip || N < 2)) { p.why = "no terminal block"; return 0; }
     std::vector<double> rho_row(dim, a.rho), lb_row(dim, 0.0), ub_row(dim, 0.0);
     for (int r = 0; r < dim; r++) {
         const int e = (r < m) ? -1 : (r < dz ? (r - m) % nm : -2);
@@ -76,8 +79,9 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
             const int r = m + l * nm + j;
             Hinv[(size_t)r * dim + r] = a.Hi[(size_t)l * nm + j];
         }
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) Hinv[(size_t)(dz + i) * dim + dz + j] = a.Hi_N[(size_t)i * n + j];
+    if (!equ)
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) Hinv[(size_t)(dz + i) * dim + dz + j] = a.Hi_N[(size_t)i * n + j];
     for (int i = 0; i < n; i++) {  // block 0: B u0 - x1 = -A x0
         for (int j = 0; j < m; j++) G[(size_t)i * dim + j] = a.AB[(size_t)i * nm + n + j];
         G[(size_t)i * dim + m + i] = -1.0;
@@ -86,7 +90,7 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         for (int i = 0; i < n; i++) {
             const int row = l * n + i, c0 = m + (l - 1) * nm;
             for (int j = 0; j < nm; j++) G[(size_t)row * dim + c0 + j] = a.AB[(size_t)i * nm + j];
-            G[(size_t)row * dim + (l < N - 1 ? m + l * nm + i : dz + i)] = -1.0;
+            if (l < N - 1 || !equ) G[(size_t)row * dim + (l < N - 1 ? m + l * nm + i : dz + i)] = -1.0;  // (equ: x_N = xr sits in b)
         }
     Dense GH((size_t)nr * dim, 0.0), W((size_t)nr * nr, 0.0);
     for (int i = 0; i < nr; i++)
@@ -200,7 +204,7 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         else snprintf(out, cap, "qt[%d]", J - ZS);
     };
     // ---- terminal q_hat in P-coordinates (:146-156)
-    body += "            // q_hat_N = qT + P_half lambda_N - rho P v_N  (lax: qT + lambda_N - rho v_N)\n            double qt[TS_];\n";
+    if (!equ) body += "            // q_hat_N = qT + P_half lambda_N - rho P v_N  (lax: qT + lambda_N - rho v_N)\n            double qt[TS_];\n";
     for (int k = 0; k < TS; k++) {
         if (lax) snprintf(line, sizeof(line), "            qt[%d] = qTv[%d] + RHOT(%d) * (wN[%d] - 2.0 * fmin(fmax(wN[%d], LBT(%d)), UBT(%d)));\n", k, k, k, k, k, k, k);
         else snprintf(line, sizeof(line), "            qt[%d] = qTv[%d];\n", k, k);
@@ -213,8 +217,11 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     }
     body += "            SEG;\n            // rhs = (-G H^-1) q_hat - b\n";
     const int bh_slabs = (n + 3) / 4;  // b = -A x0 in the first n rows
+    const int bt_first = equ ? ((N - 1) * n) / 4 : NR;  // equ: b = xr in the last n rows (code_equMPC_ADMM_C.c:337-352)
     for (int Ib = 0; Ib < NR; Ib++) {
-        if (Ib < bh_slabs) snprintf(line, sizeof(line), "            rh[%d] = -bh[%d];\n", Ib, Ib);
+        if (Ib < bh_slabs && Ib >= bt_first) snprintf(line, sizeof(line), "            rh[%d] = -bh[%d] - bt[%d];\n", Ib, Ib, Ib - bt_first);
+        else if (Ib < bh_slabs) snprintf(line, sizeof(line), "            rh[%d] = -bh[%d];\n", Ib, Ib);
+        else if (Ib >= bt_first) snprintf(line, sizeof(line), "            rh[%d] = -bt[%d];\n", Ib, Ib - bt_first);
         else snprintf(line, sizeof(line), "            rh[%d] = 0.0;\n", Ib);
         body += line;
     }
@@ -317,14 +324,15 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
     }
     // ---- terminal block (:318-386)
-    body += "            SEG;\n            { double zN[TS_], vn[TS_], dd[TS_], pv[TS_], tt[TS_];\n";
+    if (!equ) body += "            SEG;\n            { double zN[TS_], vn[TS_], dd[TS_], pv[TS_], tt[TS_];\n";
     for (int k = 0; k < TS; k++) {
         snprintf(line, sizeof(line), "              zN[%d] = 0.0;\n", k);
         body += line;
         snprintf(a1, sizeof(a1), "zN[%d]", k);
         prim_row(ZS + k, a1);
     }
-    if (lax) {
+    if (equ) {
+    } else if (lax) {
         body += "              _Pragma(\"unroll\") for (int k_ = 0; k_ < TS_; k_++) ZUPDT(k_, zN[k_]);\n";
         body += "              (void)vn; (void)dd; (void)pv; (void)tt; }\n";
     } else {
@@ -377,7 +385,11 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         if (!std::isfinite(x)) { p.why = "non-finite block"; return 0; }
     }
     if (tab.size() * sizeof(double) > 160 * 1024 - 1024 || p.n_blocks > 1536) { p.why = "block table exceeds the LDS"; return 0; }
-    if (p.n_blocks <= PF) { p.why = "fewer blocks than the prefetch ring"; return 0; }
+    if (p.n_blocks <= PF) {  // a very small controller: a shorter ring
+        if (p.n_blocks >= 6 && pf_request != p.n_blocks / 2) return build_ellip(p, a, p.n_blocks / 2);
+        p.why = "fewer blocks than the prefetch ring";
+        return 0;
+    }
     // ---- q: slabs with the same row pattern share one register
     std::map<std::vector<int>, int> sig_index;
     std::vector<int> qi(ZS), qrow;
@@ -399,8 +411,10 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     std::string s;
     auto def = [&](const char *name, long v) { snprintf(line, sizeof(line), "#define %s %ld\n", name, v); s += line; };
     def("LAX_", lax ? 1 : 0);
+    def("EQU_", equ ? 1 : 0);
     def("RHO_SCALAR_", a.gen ? 0 : 1);
-    def("ZS_", ZS); def("TS_", TS); def("NR_", NR); def("NQ_", (long)qrow.size()); def("NBH_", bh_slabs);
+    def("ZS_", ZS); def("TS_", TS); def("TSA_", std::max(TS, 1)); def("NR_", NR); def("NQ_", (long)qrow.size()); def("NBH_", bh_slabs);
+    def("NBT_", std::max(NR - bt_first, 1)); def("BT_ROW0_", equ ? (long)(N - 1) * n : (long)4 * NR); def("BT_FIRST_", bt_first);
     def("TAB_DOUBLES_", (long)tab.size()); def("RC_", rc_lb); def("DIM_", dim); def("DZ_", dz); def("NN_", n);
     s += "#define RING_INIT";
     for (int i = 0; i < PF; i++) { snprintf(line, sizeof(line), " double a%d = BLK(blk%d, %d);", i, (i % p.n_blocks) / 512, (i % p.n_blocks) % 512); s += line; }
@@ -488,7 +502,15 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
                 for (int i = 0; i < n; i++) v -= cA[row * n + i] * x0[i];
             bh[I] = v;
         }
-        double qv[NQ_], qTv[TS_];
+#if EQU_
+        double bt[NBT_];  // equMPC: b = xr in the last n rows
+#pragma unroll
+        for (int I = 0; I < NBT_; I++) {
+            const int row = 4 * (BT_FIRST_ + I) + g - BT_ROW0_;
+            bt[I] = (row >= 0 && row < n) ? xr[row] : 0.0;
+        }
+#endif
+        double qv[NQ_], qTv[TSA_];
 #pragma unroll
         for (int u = 0; u < NQ_; u++) {
             const int j = QROW_[u] + g;
@@ -514,7 +536,7 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
             qTv[k] = v;
         }
         // state: w = v + lambda / rho per z slab (v = clamp(w), lambda = rho (w - v)); the terminal slabs keep v_N, lambda_N
-        double w[ZS_], vN[TS_], lamN[TS_], wN[TS_], rh[NR_];  // (lax: wN; ellip: vN, lamN - the unused ones fold away)
+        double w[ZS_], vN[TSA_], lamN[TSA_], wN[TSA_], rh[NR_];  // (lax: wN; ellip: vN, lamN - the unused ones fold away)
 #pragma unroll
         for (int I = 0; I < ZS_; I++) w[I] = 0.0;
 #pragma unroll
@@ -705,7 +727,7 @@ inline int finish_ellip(Plan &p, const AdmmHost &a) {
     for (int i = 0; i < n; i++) {
         for (int j = 0; j < n; j++) {
             cA[i * n + j] = a.AB[(size_t)i * nm + j];
-            cT[i * n + j] = a.T[(size_t)i * n + j];
+            cT[i * n + j] = a.terminal ? a.T[(size_t)i * n + j] : 0.0;
         }
         cQ[i * n + i] = a.Q[i];
     }
@@ -728,7 +750,7 @@ inline int launch_ellip(Plan &p, const AdmmHost &a, const double *x0, const doub
     if (!p.ok) return fail(SPCIES_HIP_ENOSUP, "BSP variant not available: %s", p.why.c_str());
     const bool any = z || v || lam;
     if (any && !(z && v && lam)) return fail(SPCIES_HIP_EINVAL, "BSP variant: pass all of z, v, lambda or none");
-    EArgs ar{a.n, a.m, a.N, a.N * (a.n + a.m), a.k_max, ref_stride, a.tol, a.rho, a.rho_i, a.r_ell * a.r_ell, a.r_ell, B};
+    EArgs ar{a.n, a.m, a.N, a.N * (a.n + a.m) - (a.terminal ? 0 : a.n), a.k_max, ref_stride, a.tol, a.rho, a.rho_i, a.r_ell * a.r_ell, a.r_ell, B};
     const long n_tiles = (B + 15) / 16;
     long wgs = (n_tiles + 3) / 4;
     if (wgs > p.num_cu) wgs = p.num_cu;

@@ -755,7 +755,7 @@ static int resolve_variant(const Solver &s) {
     if (s.method == SPCIES_FISTA && s.frplan.ok) return SPCIES_VARIANT_MFMA4R;
     if (s.method == SPCIES_EADMM && s.erplan.ok) return SPCIES_VARIANT_MFMA4R;
     if (s.method == SPCIES_FISTA || s.method == SPCIES_EADMM) return s.g4plan.ok ? SPCIES_VARIANT_MFMA4G : SPCIES_VARIANT_STREAM;
-    if (s.host.gen && s.bsp.ok && s.formulation == SPCIES_LAXMPC) return SPCIES_VARIANT_BSP;
+    if (s.host.gen && s.bsp.ok && (s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC)) return SPCIES_VARIANT_BSP;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
     if (s.mfma.ok) return SPCIES_VARIANT_MFMA;
     if (s.g4plan.ok) return SPCIES_VARIANT_MFMA4G;
@@ -1620,7 +1620,8 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     }
     // laxMPC ADMM with vector rho / stage-wise bounds: the register-resident MFMA4 kernels do not take them, and the block
     // program is 1.4x faster than MFMA4G there (12.5 against 17.4 ms at the C2 shape)
-    if (s->formulation == SPCIES_LAXMPC && s->method == SPCIES_ADMM && s->host.gen && !s->tv && !s->eng && !s->host.ellip) {
+    if ((s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC) && s->method == SPCIES_ADMM && s->host.gen && !s->tv && !s->eng &&
+        !s->host.ellip) {
         const char *ev = getenv("SPCIES_HIP_BSP");
         if (!(ev && ev[0] == '0')) {
             rc = bsp::build_ellip(s->bsp, s->host);
@@ -1819,9 +1820,9 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     }
     if (variant == SPCIES_VARIANT_BSP) {
         const bool soc = s->is_soc() && !s->is_hmpc();
-        const bool lax = s->formulation == SPCIES_LAXMPC && s->method == SPCIES_ADMM && !s->tv && !s->eng;
+        const bool lax = (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC) && s->method == SPCIES_ADMM && !s->tv && !s->eng;
         if (!soc && !s->host.ellip && !lax)
-            return fail(SPCIES_HIP_ENOSUP, "BSP variant: built for the ellipMPC solvers (ADMM and ADMM soc) and, on request, laxMPC ADMM");
+            return fail(SPCIES_HIP_ENOSUP, "BSP variant: built for the ellipMPC solvers (ADMM and ADMM soc) and, on request, laxMPC / equMPC ADMM");
         if (lax && !s->bsp.ok && s->bsp.src.empty()) {  // laxMPC ADMM: the program is only generated when it is asked for
             int rc = bsp::build_ellip(s->bsp, s->host);
             if (rc) return rc;

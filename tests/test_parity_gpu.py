@@ -1121,6 +1121,51 @@ def test_bsp_lax_admm_on_request(cfg_name, B, overrides):
     assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
 
 
+@pytest.mark.parametrize("cfg_name,B,overrides,auto", [("C1_equ", 70, {}, False), ("C2_equ", 100, {}, False),
+                                                       ("C2_equ", 40, dict(tol=1e-6, k_max=3000), False),
+                                                       ("C1_equ_gen", 40, dict(k_max=3000), True), ("C2_equ_gen", 64, {}, True)])
+def test_bsp_equ_admm(cfg_name, B, overrides, auto):
+    """The banded block program in its equ mode (no terminal variable, `x_N = xr` in the right-hand side of the last block row,
+    code_equMPC_ADMM_C.c:337-352): the default for equMPC ADMM with vector rho / stage-wise bounds, on request otherwise."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = benchmarks.config(cfg_name)
+    v = benchmarks.ingredients(cfg, **overrides)
+    s = HipSolver(v)
+    if auto:
+        assert s.variant == "bsp", s.notes
+    else:
+        s.set_variant("bsp")
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    got = s(x0, xr, ur)
+    _compare("bsp", got, oracle.admm_banded_batch(v, x0, xr, ur), v)
+    nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
+    assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
+    s.close()
+
+
+@pytest.mark.parametrize("n,m,N", [(5, 2, 6), (7, 3, 9), (3, 2, 2), (9, 4, 11), (3, 2, 3), (2, 2, 2)])
+def test_bsp_equ_admm_arbitrary_shapes(n, m, N):
+    """equ mode on shapes whose last block row does not start on a slab boundary ((N - 1) n not a multiple of 4; N = 2 with the `-A x0`
+    and the `xr` rows in the same slab)."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=500 + n)
+    cfg.formulation = "equMPC"
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    s.set_variant("bsp")
+    rng = np.random.default_rng(13 * n + m)
+    B = 50
+    x0 = 0.6 * rng.standard_normal((B, n))
+    xr = 0.2 * rng.standard_normal((B, n))
+    ur = 0.1 * rng.standard_normal((B, m))
+    _compare("bsp", s(x0, xr, ur), oracle.admm_banded_batch(v, x0, xr, ur), v)
+    s.close()
+
+
 @pytest.mark.parametrize("n,m,N", [(6, 2, 7), (5, 3, 6), (8, 1, 10), (10, 4, 5), (7, 2, 13)])
 def test_bsp_ellip_admm_arbitrary_shapes(n, m, N):
     """ellipMPC ADMM through its block program on shapes no STREAM kernel is instantiated for: partial last slabs of the box and
