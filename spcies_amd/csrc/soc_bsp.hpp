@@ -13,8 +13,12 @@
 // inverted on the host:  x_I = Linv_II rhs_I - sum_{J<I} (Linv_II L_IJ) x_J ;  y_I = (Uinv_II Dinv_I) x_I - sum_{J>I}
 // (Uinv_II U_IJ) y_J  (U = L').  Sums run in another order than the reference's loops: parity 1e-10, not bit-exact.
 #pragma once
+#include <algorithm>
+#include <cstdarg>
 #include <map>
+#include <numeric>
 
+#include "bsp_sched.hpp"
 #include "mfma4_rtc.hpp"
 #include "soc_stream.hpp"
 
@@ -33,6 +37,8 @@ struct Plan {
     std::string src;             // generated kernel source
     std::vector<double> table;   // blocks in issue order, then LB / UB rows (internal layout)
     int n_blocks = 0, ZS = 0, SS = 0, NR = 0, n_mfma = 0;
+    bool legacy_order = false;   // ask build_soc for the round-2 form (finish_soc: the scheduled program spilled in this compiler)
+    bool scheduled = false;      // the iteration was ordered by bsp_sched.hpp: compiled with LLVM's machine scheduler off
     double *d_table = nullptr, *d_consts = nullptr;  // d_consts: A | Q | R | T | PhiP (dense, for the per-instance setup)
     hipModule_t module = nullptr;
     hipFunction_t fn[2] = {nullptr, nullptr};
@@ -106,6 +112,11 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     // ring depth: measured at C5 with the split tail (ms, scratch B per lane): 4: 11.51 / 236, 8: 11.13 / 300, 12: 10.71 / 356, 16: 10.36 / 412,
     // 20: 10.12 / 504, 24: 10.49 / 540, 32: 10.60 / 684 - the deep ring pays for the spills it causes (they sit in the cold copy of the tail)
     int SEG_EVERY = 4, PF = 20;
+    const bool use_sched = !p.legacy_order && !(getenv("SPCIES_BSP_SCHED") && getenv("SPCIES_BSP_SCHED")[0] == '0');
+    // scheduled program: the ring holds block PAIRS read by ds_read_b128 (PF counts pairs; SPCIES_BSP_PAIRS=0: single blocks) - a
+    // ds_read_b64 per block keeps the LDS pipe busier than the matrix pipe (measured at C5: 9.18 -> 8.42 ms)
+    const bool pairs = use_sched && !(getenv("SPCIES_BSP_PAIRS") && getenv("SPCIES_BSP_PAIRS")[0] == '0');
+    if (use_sched) PF = pairs ? 6 : 12;  // (measured at C5: pairs 4: 7.95 ms, 6: 7.8, 8: 8.1; single blocks 12: 9.14-9.24, 20: 9.29-9.8, 32: 11.1)
     if (const char *ev = getenv("SPCIES_BSP_PF")) PF = std::min(64, std::max(2, atoi(ev)));
     if (pf_request > 0) PF = pf_request;
     p.src.clear();
@@ -154,9 +165,323 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
         if (J < ZS) snprintf(out, cap, "QHZ(%d)", J);
         else snprintf(out, cap, "(mu[%d] - rho * sc[%d])", J - ZS, J - ZS);
     };
+    // bound rows of the z slabs (rows past dim - n - 1 are free; pads are pinned to 0 by 0 <= z <= 0) and their distinct patterns: with
+    // stage-invariant bounds a handful of (LB, UB) slab patterns repeat along the horizon - the scheduled program keeps them in registers
+    // (the LDS pipe is the busiest unit of the iteration: every product's A operand comes through it)
+    std::vector<double> lb_rows(4 * ZS), ub_rows(4 * ZS);
+    for (int r = 0; r < 4 * ZS; r++) {
+        lb_rows[r] = r < dim - n - 1 ? F[c.LB + r] : (r < dim ? -1e300 : 0.0);
+        ub_rows[r] = r < dim - n - 1 ? F[c.UB + r] : (r < dim ? 1e300 : 0.0);
+    }
+    std::vector<int> bnd_of(ZS), bnd_slab;
+    {
+        std::map<std::vector<double>, int> pat;
+        for (int J = 0; J < ZS; J++) {
+            std::vector<double> key(lb_rows.begin() + 4 * J, lb_rows.begin() + 4 * J + 4);
+            key.insert(key.end(), ub_rows.begin() + 4 * J, ub_rows.begin() + 4 * J + 4);
+            auto it = pat.find(key);
+            if (it == pat.end()) { it = pat.emplace(key, (int)bnd_slab.size()).first; bnd_slab.push_back(J); }
+            bnd_of[J] = it->second;
+        }
+    }
+    int bnd_regs_max = 16;
+    if (const char *ev = getenv("SPCIES_BSP_BND_REGS")) bnd_regs_max = atoi(ev);
+    const bool bnd_in_regs = use_sched && (int)bnd_slab.size() <= bnd_regs_max;
+    std::vector<double> kreg_blocks;  // (scheduled program) the register-resident blocks, 16 doubles each in A-operand order
+    std::vector<int> bh_slabs;  // slabs of the right-hand side that hold a row of bh: -A x0, r, -PhiP xr (:97-131)
+    std::map<int, int> saved;   // (row-order program) slab -> index into sv[]
+    const bool early_bounds = !getenv("SPCIES_BSP_LATE_BOUNDS");
+    if (SS > 8) { p.why = "more than 32 cone rows"; return 0; }
+    // The iteration as a list of micro-operations ordered by bsp_sched.hpp (SPCIES_BSP_SCHED=0: the program in the generator's
+    // own order, left to LLVM's scheduler - the round-2 form)
+    p.scheduled = use_sched;
+    if (use_sched) {
+        sched::Program P;
+        auto F_ = [](const char *fmt, ...) -> std::string {
+            char buf[1024];
+            va_list ap;
+            va_start(ap, fmt);
+            vsnprintf(buf, sizeof(buf), fmt, ap);
+            va_end(ap);
+            return std::string(buf);
+        };
+        auto R = [&](const char *base, int i) { return F_("%s_%d", base, i); };
+        // ---- right-hand side: rh_I = -bh (the slabs that hold a row of bh) + G q_hat, column by column
+        std::vector<char> started(NR, 0);
+        for (int Ib = 0; Ib < NR; Ib++) {
+            bool any = false;
+            for (int r = 4 * Ib; r < 4 * Ib + 4; r++) any |= (r < n) || (r == n_eq - 1) || (r > n_eq && r <= n_eq + n);
+            if (any) {
+                P.stmt(sched::K_VALU, F_("double rh_%d = -bh[%d];", Ib, (int)bh_slabs.size()), "", {}, {R("rh", Ib)}, 1, false);
+                bh_slabs.push_back(Ib);
+                started[Ib] = 1;
+            }
+        }
+        // q_hat of primal slab J from the current state, as micro-operations; `ph`: "g" (right-hand side) or "p" (primal phase)
+        auto qhat_ops = [&](int J, const char *ph) {
+            if (J < ZS) {
+                const bool prim = ph[0] == 'p';
+                const std::string lb = F_("lb%s_%d", ph, J), ub = F_("ub%s_%d", ph, J), c1 = F_("c1%s_%d", ph, J), cc = F_("c%s_%d", ph, J),
+                                  tt = F_("t%s_%d", ph, J), q = F_("q%s_%d", ph, J), w = R("w", J), gov = prim ? "go_p" : "go_g";
+                // (the primal phase forms the same q_hat from the same state and the same bounds: without the laundered copy of w
+                // and the laundered row index LLVM keeps the first phase's clamp and bounds alive across both solves - two values per slab)
+                std::string wx = F_("w[%d]", J);
+                if (prim) {
+                    wx = F_("wp_%d", J);
+                    P.stmt(sched::K_VALU, F_("double wp_%d = w[%d]; asm volatile(\"\" : \"+v\"(wp_%d));", J, J, J), "", {w}, {wx}, 0, false);
+                }
+                const std::string wv = prim ? wx : w;
+                if (bnd_in_regs) {  // (plain aliases: no instruction)
+                    P.stmt(sched::K_VALU, F_("const double %s = lbv[%d], %s = ubv[%d];", lb.c_str(), bnd_of[J], ub.c_str(), bnd_of[J]), "", {}, {lb, ub}, 0, false);
+                } else {
+                    P.stmt(sched::K_LDS, F_("const double %s = LBR(%d);", lb.c_str(), J), "", {gov}, {lb}, 1);
+                    P.stmt(sched::K_LDS, F_("const double %s = UBR(%d);", ub.c_str(), J), "", {gov}, {ub}, 1);
+                }
+                P.stmt(sched::K_VALU, F_("const double %s = fmax(%s, %s);", c1.c_str(), wx.c_str(), lb.c_str()), "", {wv, lb}, {c1}, 1);
+                P.stmt(sched::K_VALU, F_("const double %s = fmin(%s, %s);", cc.c_str(), c1.c_str(), ub.c_str()), "", {c1, ub}, {cc}, 1);
+                P.stmt(sched::K_VALU, F_("const double %s = __builtin_fma(-2.0, %s, %s);", tt.c_str(), cc.c_str(), wx.c_str()), "", {cc, wv}, {tt}, 1);
+                P.stmt(sched::K_VALU, F_("const double %s = __builtin_fma(sigma, %s, qv[QI_%d]);", q.c_str(), tt.c_str(), J), "", {tt}, {q}, 1);
+            } else {
+                const int k = J - ZS;
+                P.stmt(sched::K_VALU, F_("const double q%s_%d = __builtin_fma(-rho, sc[%d], mu[%d]);", ph, J, k, k), "", {R("sc", k), R("mu", k)},
+                       {F_("q%s_%d", ph, J)}, 1);
+            }
+        };
+        auto product = [&](const std::string &acc, std::vector<char> *st, int idx, const double *blk, const std::string &x) {
+            const bool first = st && !(*st)[idx];
+            if (st) (*st)[idx] = 1;
+            P.mfma(acc, first, blk, x);
+        };
+        for (int J = 0; J < NP; J++) {
+            if (bG.by_col[J].empty()) continue;
+            qhat_ops(J, "g");
+            for (int Ib : bG.by_col[J]) {
+                double blk[16];
+                block_of(G, PR_, Ib, J, blk);
+                product(R("rh", Ib), &started, Ib, blk, R("qg", J));
+            }
+        }
+        for (int Ib = 0; Ib < NR; Ib++)
+            if (!started[Ib]) P.stmt(sched::K_VALU, F_("double rh_%d = 0.0;", Ib), "", {}, {R("rh", Ib)}, 1, false);
+        // ---- W mu = rhs in column order: xf_J = Linv_JJ rh_J, rh_I -= L_IJ xf_J (I > J); then xb_J = (Uinv_JJ Dinv_J) xf_J,
+        // xf_I -= D_I U_IJ xb_J (I < J).  Program order: the dependent chain D_J -> U_{J+1,J} -> D_{J+1} with the other updates
+        // between its links; the scheduler refines it
+        std::vector<std::vector<double>> Linv(NR, std::vector<double>(16));
+        for (int Ib = 0; Ib < NR; Ib++) {
+            double d[16];
+            block_of(L, RR, Ib, Ib, d);
+            inv_unit_lower(d, Linv[Ib].data());
+        }
+        struct Pend { int I, J; };
+        auto run_columns = [&](bool forward) {
+            std::vector<Pend> queue;
+            auto pop_front = [&]() { Pend q = queue.front(); queue.erase(queue.begin()); return q; };
+            auto update = [&](const Pend &q) {
+                double lj[16], o[16];
+                if (forward) {
+                    block_of(L, RR, q.I, q.J, lj);
+                    for (int e = 0; e < 16; e++) o[e] = -lj[e];
+                    product(R("rh", q.I), nullptr, 0, o, R("xf", q.J));
+                } else {
+                    block_of(L, RR, q.J, q.I, lj);
+                    for (int i = 0; i < 4; i++)
+                        for (int k = 0; k < 4; k++) o[i * 4 + k] = -lj[k * 4 + i] / Dinv[4 * q.I + i];
+                    product(R("xf", q.I), nullptr, 0, o, R("xb", q.J));
+                }
+            };
+            for (int J = forward ? 0 : NR - 1; forward ? J < NR : J >= 0; J += forward ? 1 : -1) {
+                const int nxt = forward ? J + 1 : J - 1;
+                double d[16];
+                if (forward) {
+                    for (int e = 0; e < 16; e++) d[e] = Linv[J][e];
+                    P.mfma(R("xf", J), true, d, R("rh", J));
+                } else {
+                    for (int i = 0; i < 4; i++)
+                        for (int k = 0; k < 4; k++) d[i * 4 + k] = Linv[J][k * 4 + i] * Dinv[4 * J + k];
+                    P.mfma(R("xb", J), true, d, R("xf", J));
+                }
+                bool any = false, crit = false;
+                while (!queue.empty() && queue.front().I == nxt) { update(pop_front()); any = true; }
+                if (!any && !queue.empty()) update(pop_front());
+                if (forward) { for (int I : bL.by_col[J]) if (I > J) { if (I == nxt) crit = true; else queue.push_back(Pend{I, J}); } }
+                else { for (int I : bL.by_row[J]) if (I < J) { if (I == nxt) crit = true; else queue.push_back(Pend{I, J}); } }
+                std::stable_sort(queue.begin(), queue.end(), [&](const Pend &x, const Pend &y) { return forward ? x.I < y.I : x.I > y.I; });
+                if (crit) update(Pend{nxt, J});
+                bool one = false;
+                while ((queue.size() > 1 || (!one && !queue.empty())) && queue.front().I != nxt) { update(pop_front()); one = true; }
+            }
+            while (!queue.empty()) update(pop_front());
+        };
+        run_columns(true);
+        run_columns(false);
+        P.stmt(sched::K_VALU, "asm volatile(\"\" : \"+v\"(go));", "", {}, {"go_g", "go_p"}, 0, false);
+        // ---- primal_hat = (-Hh^-1) q_hat + (-Hh^-1 Gh') mu row by row; each row is consumed by the update of its slab.  q_hat of a
+        // slab is a value of its own (formed before the slab's state is overwritten: the dependences say so), so a row that needs
+        // the q_hat of another slab (the dense terminal weight) simply reads it
+        std::vector<char> qp_done(NP, 0);
+        auto need_qp = [&](int J) {
+            if (!qp_done[J]) qhat_ops(J, "p");
+            qp_done[J] = 1;
+        };
+        auto prim_row = [&](int Ib, const std::string &acc) {
+            bool first = true;
+            for (int J : bH.by_row[Ib]) need_qp(J);
+            for (int J : bH.by_row[Ib]) {
+                double blk[16];
+                block_of(H, PR_, Ib, J, blk);
+                P.mfma(acc, first, blk, R("qp", J));
+                first = false;
+            }
+            for (int J : bHG.by_row[Ib]) {
+                double blk[16];
+                block_of(HG, RR, Ib, J, blk);
+                P.mfma(acc, first, blk, R("xb", J));
+                first = false;
+            }
+            if (first) P.stmt(sched::K_VALU, "double " + acc + " = 0.0;", "", {}, {acc}, 1, false);
+        };
+        for (int Ib = 0; Ib < ZS; Ib++) {
+            need_qp(Ib);  // (its clamp, bounds and w - clamp(w) are the update's too)
+            const std::string ph = R("ph", Ib), w = R("w", Ib), cc = R("cp", Ib), lb = R("lbp", Ib), ub = R("ubp", Ib), dd = R("dp", Ib);
+            P.stmt(sched::K_VALU, F_("const double dp_%d = wp_%d - cp_%d;", Ib, Ib, Ib), "", {R("wp", Ib), cc}, {dd}, 1);
+            prim_row(Ib, ph);
+            const std::string store = F_(" if (WANT_SOL) *((4 * %d + 3 < DIM_ || 4 * %d + g < DIM_) ? zhp + 4 * %d : dump) = ph_%d;", Ib, Ib, Ib, Ib);
+            const std::string light = F_("w[%d] = ph_%d + dp_%d;", Ib, Ib, Ib) + store;
+            const std::string full0 =
+                F_("{ const double wn_ = ph_%d + dp_%d, z_ = fmin(fmax(wn_, lbp_%d), ubp_%d); w[%d] = wn_; res |= (fabs(cp_%d - z_) > tol_d) | "
+                   "(fabs(z_ - ph_%d) > tol_p); }", Ib, Ib, Ib, Ib, Ib, Ib, Ib) + store;
+            // (the checks of the other slabs: running maxima pinned per slab - an or-chain is sunk to the end of the iteration by LLVM with
+            // every operand kept alive until then; fmax drops a NaN exactly like the reference's comparison)
+            const std::string full =
+                F_("{ const double wn_ = ph_%d + dp_%d, z_ = fmin(fmax(wn_, lbp_%d), ubp_%d); w[%d] = wn_; rd_ = fmax(rd_, fabs(cp_%d - z_)); "
+                   "rp_ = fmax(rp_, fabs(z_ - ph_%d)); asm volatile(\"\" : \"+v\"(rd_), \"+v\"(rp_)); }", Ib, Ib, Ib, Ib, Ib, Ib, Ib) + store;
+            if (Ib == 0) {
+                P.stmt(sched::K_VALU, full0, "", {ph, dd, cc, lb, ub}, {w, "res"}, 8);
+                // one wave-uniform branch: once the first slab's check has put every instance of the wavefront above its tolerance no
+                // later check of this iteration can change the outcome - the rest of the iteration exists with and without the checks
+                P.mark = P.stmt(sched::K_MARK, "", "", {"res"}, {"branch"}, 2, false);
+            } else {
+                sched::Op &o = P.ops[P.stmt(sched::K_VALU, light, full, {ph, dd, cc, lb, ub, "branch"}, {w}, 2)];
+                (void)o;
+            }
+        }
+        {
+            std::string args;
+            sched::Op o;
+            o.kind = sched::K_VALU;
+            for (int k = 0; k < SS; k++) {
+                prim_row(ZS + k, R("sh", k));
+                args += (k ? ", sh_" : "sh_") + std::to_string(k);
+            }
+            o.text[0] = "{ double sh_[SS_] = {" + args + "}; SUPD_L(sh_); }";
+            o.text[1] = "{ double sh_[SS_] = {" + args + "}; SUPD(sh_); }";
+            for (int k = 0; k < SS; k++) {
+                for (const std::string &v : {R("sh", k), R("mu", k), R("sc", k)}) o.reads.push_back(P.id(v));
+                for (const std::string &v : {R("mu", k), R("sc", k)}) o.writes.push_back(P.id(v));
+            }
+            o.reads.push_back(P.id("branch"));
+            o.cost = 10 * SS + 12;
+            o.order = (int)P.ops.size();
+            if (SS > 0) P.ops.push_back(o);
+        }
+        // (measured at C5 with pairs and the bounds in registers: 16: 7.77-7.8 ms, 20: 7.9, 24: 7.8, 28: 7.9-8.2, 32: 8.1-8.2 (15 scratch instructions in
+        // the iteration), 40: 7.8-7.9, 64: 8.4; program order: 10.4; LLVM's own schedule of the round-2 program: 9.7)
+        int window = 24;
+        if (const char *ev = getenv("SPCIES_BSP_WINDOW")) window = std::max(1, atoi(ev));
+        std::vector<int> order = sched::schedule(P, window);
+        if (getenv("SPCIES_BSP_NOREORDER")) std::iota(order.begin(), order.end(), 0);  // (experiments: the generator's program order)
+        // ---- blocks that appear many times in the stream (stage-invariant dynamics) stay in registers: every product's A operand
+        // otherwise comes through the LDS pipe, the busiest unit of the iteration (SPCIES_BSP_KREG: how many; 0 = none)
+        int kreg_max = 0;  // (measured at C5: 8 blocks 7.8 ms like none, 12: 8.0, 16: 8.3 - the registers they take cost more than the reads they save)
+        if (const char *ev = getenv("SPCIES_BSP_KREG")) kreg_max = std::max(0, std::min(64, atoi(ev)));
+        std::map<std::vector<double>, int> kreg_of;
+        {
+            std::map<std::vector<double>, int> freq;
+            for (const sched::Op &o : P.ops)
+                if (o.kind == sched::K_MFMA) freq[std::vector<double>(o.blk, o.blk + 16)]++;
+            std::vector<std::pair<int, std::vector<double>>> byf;
+            for (auto &kv : freq) byf.push_back({kv.second, kv.first});
+            std::stable_sort(byf.begin(), byf.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
+            for (size_t k = 0; k < byf.size() && (int)k < kreg_max && byf[k].first >= 3; k++) {
+                kreg_of[byf[k].second] = (int)k;
+                for (int kk = 0; kk < 4; kk++)
+                    for (int i = 0; i < 4; i++) kreg_blocks.push_back(byf[k].second[i * 4 + kk]);
+            }
+        }
+        // ---- emission: the blocks enter the table in issue order
+        std::string head, light, full;
+        bool after_mark = false;
+        for (int idx : order) {
+            const sched::Op &o = P.ops[idx];
+            std::string l0, l1;
+            if (o.kind == sched::K_MFMA) {
+                const auto kr = kreg_of.find(std::vector<double>(o.blk, o.blk + 16));
+                if (kr != kreg_of.end()) {
+                    l0 = F_("            %s%s = __builtin_amdgcn_mfma_f64_4x4x4f64(kb[%d], %s, %s, 0, 0, 0);\n", o.acc_first ? "double " : "",
+                            o.acc.c_str(), kr->second, o.x.c_str(), o.acc_first ? "0.0" : o.acc.c_str());
+                    n_mfma++;
+                    if (!after_mark) head += l0;
+                    else { light += l0; full += l0; }
+                    continue;
+                }
+                const int t = emit_block(o.blk);
+                if (pairs) {  // ring of block PAIRS (one ds_read_b128 per two products)
+                    const int P2 = t / 2;
+                    l0 = F_("            %s%s = __builtin_amdgcn_mfma_f64_4x4x4f64(a%d.%c, %s, %s, 0, 0, 0);", o.acc_first ? "double " : "",
+                            o.acc.c_str(), P2 % PF, t % 2 ? 'y' : 'x', o.x.c_str(), o.acc_first ? "0.0" : o.acc.c_str());
+                    l0 += (t % 2) ? F_(" @%d@\n", P2) : std::string("\n");
+                } else {
+                    l0 = F_("            %s%s = __builtin_amdgcn_mfma_f64_4x4x4f64(a%d, %s, %s, 0, 0, 0); @%d@\n", o.acc_first ? "double " : "",
+                            o.acc.c_str(), t % PF, o.x.c_str(), o.acc_first ? "0.0" : o.acc.c_str(), t);
+                }
+                n_mfma++;
+            } else if (o.kind == sched::K_MARK) {
+                after_mark = true;
+                continue;
+            } else {
+                l0 = "            " + o.text[0] + "\n";
+                if (!o.text[1].empty()) l1 = "            " + o.text[1] + "\n";
+            }
+            if (!after_mark) head += l1.empty() ? l0 : l1;
+            else { light += l0; full += l1.empty() ? l0 : l1; }
+        }
+        body = head + "            HITUPD;\n            if (all_hit) {\n" + light + "            } else {\n            double rd_ = 0.0, rp_ = 0.0;\n" + full +
+               "            res |= (rd_ > tol_d) | (rp_ > tol_p);\n            }\n";
+        if (getenv("SPCIES_BSP_VERBOSE")) {  // how often the same 4x4 block appears in the stream
+            std::map<std::vector<double>, int> freq;
+            for (const sched::Op &o : P.ops)
+                if (o.kind == sched::K_MFMA) freq[std::vector<double>(o.blk, o.blk + 16)]++;
+            std::vector<int> cnt;
+            for (auto &kv : freq) cnt.push_back(kv.second);
+            std::sort(cnt.rbegin(), cnt.rend());
+            int acc = 0;
+            fprintf(stderr, "[spcies bsp] %zu distinct blocks of %d; cumulative coverage of the most frequent:", cnt.size(), n_mfma);
+            for (size_t k = 0; k < cnt.size() && k < 48; k++) { acc += cnt[k]; if (k % 4 == 3) fprintf(stderr, " %zu:%d", k + 1, acc); }
+            fprintf(stderr, "\n");
+        }
+        if (getenv("SPCIES_BSP_VERBOSE")) {  // live values (two registers each) along the issue order
+            std::vector<int> last_use(P.ids.size(), -1), first_def(P.ids.size(), -1);
+            for (size_t k = 0; k < order.size(); k++) {
+                const sched::Op &o = P.ops[order[k]];
+                for (int v : o.reads) last_use[v] = (int)k;
+                for (int v : o.writes) { if (first_def[v] < 0) first_def[v] = (int)k; last_use[v] = std::max(last_use[v], (int)k); }
+            }
+            int live = 0, peak = 0, peak_at = 0;
+            std::vector<int> delta(order.size() + 1, 0);
+            for (size_t v = 0; v < P.ids.size(); v++)
+                if (first_def[v] >= 0) { delta[first_def[v]]++; delta[last_use[v]]--; }
+            for (size_t k = 0; k < order.size(); k++) { live += delta[k]; if (live > peak) { peak = live; peak_at = (int)k; } }
+            fprintf(stderr, "[spcies bsp] peak of %d temporaries live at operation %d of %zu (state arrays not counted)\n", peak, peak_at, order.size());
+        }
+        if (getenv("SPCIES_BSP_VERBOSE")) {
+            int last = 0;
+            for (const sched::Op &o : P.ops) last = std::max(last, o.issue + o.cost);
+            fprintf(stderr, "[spcies bsp] scheduled %zu operations (%d products): model %d quads per iteration\n", P.ops.size(), n_mfma, last);
+        }
+    }
+    if (!use_sched) {
     // ---- A. rhs = -bh, B. rhs += G q_hat  (column-oriented: q_hat of a slab is formed once, used, and dropped)
     body += "            // rhs = (-Gh Hh^-1) q_hat - bh\n";
-    std::vector<int> bh_slabs;  // slabs of the right-hand side that hold a row of bh: -A x0, r, -PhiP xr (:97-131)
     for (int Ib = 0; Ib < NR; Ib++) {
         bool any = false;
         for (int r = 4 * Ib; r < 4 * Ib + 4; r++) any |= (r < n) || (r == n_eq - 1) || (r > n_eq && r <= n_eq + n);
@@ -185,7 +510,82 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     }
     body += "            SEG;\n            // W mu = rhs: forward substitution by blocks\n";
     std::vector<std::vector<double>> Linv(NR, std::vector<double>(16));
-    for (int Ib = 0; Ib < NR; Ib++) {
+    // Column order ("right-looking", SPCIES_BSP_RL=0 restores the row order): x_J = Linv_JJ rh_J, then rh_I -= L_IJ x_J for the rows I
+    // below.  In row order a block row is ONE chain of MFMAs on one accumulator (22 cycles per link instead of 16) that ends in the
+    // product with the solution slab finished right before it; in column order consecutive products go to different accumulators and
+    // only the chain D_J -> U_{J+1,J} -> D_{J+1} is dependent - its links are spaced by the other updates of the columns
+    // (a queue ordered by the row they go to: every update of rh_I is out before D_I).
+    const bool rl = !(getenv("SPCIES_BSP_RL") && getenv("SPCIES_BSP_RL")[0] == '0');
+    struct Pend { int I, J; };
+    auto run_columns = [&](bool forward) {
+        std::vector<Pend> queue;  // kept sorted by distance of I from the current column
+        auto pop_front = [&]() { Pend q = queue.front(); queue.erase(queue.begin()); return q; };
+        auto emit_update = [&](const Pend &q) {
+            double lj[16], o[16];
+            if (forward) {
+                block_of(L, RR, q.I, q.J, lj);
+                for (int e = 0; e < 16; e++) o[e] = -lj[e];
+            } else {  // rows I < J: -D_I (L_JI)'  (D = 1 / Dinv: the solve runs on x, the scaling sits in the diagonal block)
+                block_of(L, RR, q.J, q.I, lj);
+                for (int i = 0; i < 4; i++)
+                    for (int k = 0; k < 4; k++) o[i * 4 + k] = -lj[k * 4 + i] / Dinv[4 * q.I + i];
+            }
+            snprintf(a1, sizeof(a1), "rh[%d]", q.I);
+            snprintf(a2, sizeof(a2), "rh[%d]", q.J);
+            MF(a1, emit_block(o), a2);
+        };
+        int step = 0;
+        for (int J = forward ? 0 : NR - 1; forward ? J < NR : J >= 0; J += forward ? 1 : -1, step++) {
+            const int nxt = forward ? J + 1 : J - 1;
+            double d[16];
+            if (forward) {
+                for (int e = 0; e < 16; e++) d[e] = Linv[J][e];
+            } else {
+                for (int i = 0; i < 4; i++)
+                    for (int k = 0; k < 4; k++) d[i * 4 + k] = Linv[J][k * 4 + i] * Dinv[4 * J + k];
+            }
+            snprintf(line, sizeof(line), "            { double xx = 0.0; MF(xx, a%d, rh[%d]); @%d@ rh[%d] = xx; }\n", (int)(tab.size() / 16) % PF, J,
+                     (int)(tab.size() / 16), J);
+            emit_block(d);
+            body += line;
+            n_mfma++;
+            // this column's updates: the one into the next slab is the critical link, the others wait in the queue
+            bool crit = false;
+            std::vector<int> rows;
+            if (forward) { for (int I : bL.by_col[J]) if (I > J) rows.push_back(I); }
+            else { for (int I : bL.by_row[J]) if (I < J) rows.push_back(I); }
+            // slot a: what still has to reach rh_next (else one update of an older column) hides the latency D_J -> U_{next,J}
+            bool any = false;
+            while (!queue.empty() && queue.front().I == nxt) { emit_update(pop_front()); any = true; }
+            if (!any && !queue.empty()) emit_update(pop_front());
+            for (int I : rows) {
+                if (I == nxt) crit = true;
+                else queue.push_back(Pend{I, J});
+            }
+            std::stable_sort(queue.begin(), queue.end(), [&](const Pend &x, const Pend &y) { return forward ? x.I < y.I : x.I > y.I; });
+            if (crit) emit_update(Pend{nxt, J});
+            // slot b: between U_{next,J} and D_next
+            bool one = false;
+            while (queue.size() > 1 || (!one && !queue.empty())) {
+                if (queue.front().I == nxt) break;  // (cannot happen: those left in slot a)
+                emit_update(pop_front());
+                one = true;
+            }
+            if (step % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
+        }
+        while (!queue.empty()) emit_update(pop_front());  // (empty by construction)
+    };
+    if (rl) {
+        for (int Ib = 0; Ib < NR; Ib++) {
+            double d[16];
+            block_of(L, RR, Ib, Ib, d);
+            inv_unit_lower(d, Linv[Ib].data());
+        }
+        run_columns(true);
+        body += "            SEG;\n            // D^-1 and the backward substitution by blocks (U = L')\n";
+        run_columns(false);
+    }
+    for (int Ib = 0; Ib < NR && !rl; Ib++) {
         double d[16];
         block_of(L, RR, Ib, Ib, d);
         inv_unit_lower(d, Linv[Ib].data());
@@ -205,8 +605,8 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
         body += line;
         if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
     }
-    body += "            SEG;\n            // D^-1 and the backward substitution by blocks (U = L')\n";
-    for (int Ib = NR - 1; Ib >= 0; Ib--) {
+    if (!rl) body += "            SEG;\n            // D^-1 and the backward substitution by blocks (U = L')\n";
+    for (int Ib = NR - 1; Ib >= 0 && !rl; Ib--) {
         // Uinv_II = (Linv_II)';  Bk_II = Uinv_II diag(Dinv_I);  Bk_IJ = -Uinv_II U_IJ,  U_IJ = (L_JI)'
         double ui[16], d[16];
         for (int i = 0; i < 4; i++)
@@ -236,7 +636,6 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     std::vector<int> last_use(NP, -1);
     for (int Ib = 0; Ib < NP; Ib++)
         for (int J : bH.by_row[Ib]) last_use[J] = std::max(last_use[J], Ib);
-    std::map<int, int> saved;  // slab -> index into sv[]
     for (int J = 0; J < NP; J++)
         if (last_use[J] > J) { const int idx = (int)saved.size(); saved[J] = idx; }
     body += "            // primal_hat = (-Hh^-1) q_hat + (-Hh^-1 Gh') mu; z: box, lambda; s: cone, mu; residuals\n";
@@ -263,7 +662,6 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     // read behind; measured 10.05 -> 9.92 ms at C5.  Also tried: two accumulators per block row of the substitutions, used in turn - a
     // chain of v_mfma_f64_4x4x4 on one accumulator issues every 22 cycles, several chains every 16.8 - with the nearest dependence
     // last: 11.4 ms against 9.9 - slower, and so was the same program with the second accumulator left unused.)
-    const bool early_bounds = !getenv("SPCIES_BSP_LATE_BOUNDS");
     for (int Ib = 0; Ib < ZS; Ib++) {
         if (early_bounds) snprintf(line, sizeof(line), "            { double ph = 0.0; const double lbx = LBR(%d), ubx = UBR(%d);\n", Ib, Ib);
         else snprintf(line, sizeof(line), "            { double ph = 0.0; const double lbx = 0.0, ubx = 0.0; (void)lbx; (void)ubx;\n");
@@ -280,7 +678,6 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
         if (Ib == 0) body += "/*SPLIT*/";  // the rest of the iteration exists twice: with and without residual checks (below)
         if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
     }
-    if (SS > 8) { p.why = "more than 32 cone rows"; return 0; }
     body += "            { double sh[SS_];\n";
     for (int k = 0; k < SS; k++) {
         snprintf(line, sizeof(line), "              sh[%d] = 0.0;\n", k);
@@ -289,8 +686,43 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
         prim_row(ZS + k, a1);
     }
     body += "              SUPD(sh); }\n";
+    }  // (!use_sched)
+    if (pairs) {  // pair p at doubles [32 p, 32 p + 32): element e of block 2 p + h at 32 p + 2 e + h
+        if ((tab.size() / 16) % 2) tab.resize(tab.size() + 16, 0.0);
+        std::vector<double> t2(tab.size());
+        for (size_t b = 0; b < tab.size() / 16; b++)
+            for (int e = 0; e < 16; e++) t2[(b / 2) * 32 + 2 * e + (b % 2)] = tab[b * 16 + e];
+        tab.swap(t2);
+    }
     p.n_blocks = (int)(tab.size() / 16);
     p.n_mfma = n_mfma;
+    if (pairs) {
+        const int np = p.n_blocks / 2, n_pad = (np + PF - 1) / PF * PF;
+        std::string out;
+        auto refill = [&](int t) {
+            const int nx = (t + PF) % n_pad;
+            if (nx >= np) return;
+            snprintf(line, sizeof(line), "a%d = PBLK(blk%d, %d);", t % PF, nx / 256, nx % 256);
+            out += line;
+        };
+        bool last_seen = false;
+        for (size_t i = 0; i < body.size();) {
+            if (body[i] == '@') {
+                const size_t j = body.find('@', i + 1);
+                const int t = atoi(body.substr(i + 1, j - i - 1).c_str());
+                last_seen |= t == np - 1;
+                refill(t);
+                i = j + 1;
+            } else {
+                out.push_back(body[i++]);
+            }
+        }
+        out += "            ";
+        if (!last_seen) refill(np - 1);  // (an odd number of products: the last pair's second half is a pad)
+        for (int t = np; t < n_pad; t++) refill(t);
+        out += "\n";
+        body.swap(out);
+    } else
     {  // resolve the refill markers.  The stream is padded to a multiple of PF positions (the holes past the last block consume
        // nothing), so that position t always sits in ring slot t % PF, also across the wrap into the next iteration: after
        // block t is consumed its slot takes position t + PF; the slots of the holes are refilled at the end of the iteration
@@ -334,9 +766,11 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     }
     // ---- LB / UB rows of the z slabs (rows past dim - n - 1 are free; pads are pinned to 0 by 0 <= z <= 0)
     const int rc_lb = (int)tab.size();
-    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < dim - n - 1 ? F[c.LB + r] : (r < dim ? -1e300 : 0.0));
+    for (int r = 0; r < 4 * ZS; r++) tab.push_back(lb_rows[r]);
     const int rc_ub = (int)tab.size();
-    for (int r = 0; r < 4 * ZS; r++) tab.push_back(r < dim - n - 1 ? F[c.UB + r] : (r < dim ? 1e300 : 0.0));
+    for (int r = 0; r < 4 * ZS; r++) tab.push_back(ub_rows[r]);
+    const int kb_off = (int)tab.size();
+    tab.insert(tab.end(), kreg_blocks.begin(), kreg_blocks.end());
     for (double x : tab)
         if (!std::isfinite(x)) { p.why = "non-finite block"; return 0; }
     const size_t lds_bytes = tab.size() * sizeof(double);
@@ -369,13 +803,23 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     if (early_bounds) s += "#define EARLY_BOUNDS_ 1\n";
     def("TAB_DOUBLES_", (long)tab.size()); def("RC_LB_", rc_lb); def("RC_UB_", rc_ub); def("DIM_", dim); def("NSC_", n_s);
     s += "#define RING_INIT";
-    for (int i = 0; i < PF; i++) { snprintf(line, sizeof(line), " double a%d = BLK(blk%d, %d);", i, (i % p.n_blocks) / 512, (i % p.n_blocks) % 512); s += line; }
+    for (int i = 0; i < PF; i++) {
+        if (pairs) snprintf(line, sizeof(line), " double2 a%d = PBLK(blk%d, %d);", i, (i % (p.n_blocks / 2)) / 256, (i % (p.n_blocks / 2)) % 256);
+        else snprintf(line, sizeof(line), " double a%d = BLK(blk%d, %d);", i, (i % p.n_blocks) / 512, (i % p.n_blocks) % 512);
+        s += line;
+    }
     s += "\n";
     {
         const int nb = p.n_blocks;
         def("NB0_", std::max(1, std::min(nb, 512))); def("NB1_", std::max(1, std::min(nb - 512, 512))); def("NB2_", std::max(1, nb - 1024));
     }
     for (int J = 0; J < ZS; J++) { snprintf(line, sizeof(line), "#define QI_%d %d\n", J, qi[J]); s += line; }
+    def("KREG_", (long)(kreg_blocks.size() / 16)); def("KB_OFF_", kb_off);
+    def("NBND_", bnd_in_regs ? (long)bnd_slab.size() : 1L);
+    def("BND_IN_REGS_", bnd_in_regs ? 1 : 0);
+    s += "static __device__ const int BNDSLAB_[NBND_] = {";
+    for (size_t i = 0; i < (bnd_in_regs ? bnd_slab.size() : (size_t)1); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", bnd_slab[i]); s += line; }
+    s += "};\n";
     def("NBH_", (long)bh_slabs.size());
     s += "static __device__ const int BHSLAB_[NBH_] = {";
     for (size_t i = 0; i < bh_slabs.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", bh_slabs[i]); s += line; }
@@ -413,7 +857,13 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
     const double *cA = cst, *cQ = cA + n * n, *cR = cQ + n * n, *cT = cR + m * m, *cPhiP = cT + n * n;
     int ao = g * 4 + (lane & 3);
     const long n_tiles = (p.B + 15) / 16;
+#if KREG_ > 0
+    double kb[KREG_];  // blocks that repeat along the horizon: A operands in registers for the whole launch
+#pragma unroll
+    for (int u = 0; u < KREG_; u++) kb[u] = table_g[KB_OFF_ + u * 16 + ao];
+#endif
 #define BLK(arr, t) arr[(t) * 16 + ao]
+#define PBLK(arr, pp) (*reinterpret_cast<const double2 *>(&arr[(pp) * 32 + 2 * ao]))
 #define MF(acc, a, x) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((a), (x), (acc), 0, 0, 0)
 #define SEG __builtin_amdgcn_sched_barrier(0)
     for (long tile = (long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long)gridDim.x * 4) {
@@ -470,6 +920,14 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
         int go = g;  // (laundered once per iteration like ao: keeps LICM from hoisting every bound read out of the loop)
 #define LBR(I) ldsr[4 * (I) + go]
 #define UBR(I) ldsr[4 * ZS_ + 4 * (I) + go]
+#if BND_IN_REGS_
+        double lbv[NBND_], ubv[NBND_];  // the distinct (LB, UB) slab patterns
+#pragma unroll
+        for (int u = 0; u < NBND_; u++) {
+            lbv[u] = ldsr[4 * BNDSLAB_[u] + g];
+            ubv[u] = ldsr[4 * ZS_ + 4 * BNDSLAB_[u] + g];
+        }
+#endif
 #ifdef EARLY_BOUNDS_  // the slab's bounds were read at the top of its block (lbx, ubx)
 #define BND_LB(I) lbx
 #define BND_UB(I) ubx
@@ -638,7 +1096,11 @@ inline int compile_program(Plan &p, int *scratch, const char *name0 = "soc_bsp_k
     if (p.module) hipModuleUnload(p.module);
     p.module = nullptr;
     // experiments: SPCIES_BSP_FLAGS holds extra compiler options, blank-separated
-    const std::vector<std::string> extra = rtc::split_flags(getenv("SPCIES_BSP_FLAGS"));
+    std::vector<std::string> extra = rtc::split_flags(getenv("SPCIES_BSP_FLAGS"));
+    if (p.scheduled && !getenv("SPCIES_BSP_KEEP_MISCHED")) {  // the order printed by bsp_sched.hpp is the order issued
+        extra.push_back("-mllvm");
+        extra.push_back("-enable-misched=false");
+    }
     // (cached per process: the handles spcies_hip_create_multi builds for the same controller print the same program)
     int rc = rtc::compile_module(p.src.c_str(), "spcies_soc_bsp.hip", {name0, name1}, extra, &p.module, p.fn, true);
     if (rc) return rc;
@@ -661,9 +1123,11 @@ inline int finish_soc(Plan &p, const SocDev &c, const double *F, const int *I) {
     // a compiler that spills far more than the one this was tuned with (an older comgr loaded first: 1 KB and more, 77-99 ms) gets a
     // shorter ring
     if (!getenv("SPCIES_BSP_PF"))
-        for (int pf : {12, 8, 4}) {
+        for (int pf : {-4, 12, 8, 4}) {  // (-4: the scheduled program with a ring of four pairs; then the round-2 form)
             if (scratch <= 640) break;
-            rc = build_soc(p, c, F, I, pf);
+            if (pf < 0 && !p.scheduled) continue;
+            p.legacy_order = pf > 0;
+            rc = build_soc(p, c, F, I, pf < 0 ? -pf : pf);
             if (rc) return rc;
             if (p.src.empty()) return fail(SPCIES_HIP_ENOSUP, "BSP program: %s", p.why.c_str());
             rc = compile_program(p, &scratch);

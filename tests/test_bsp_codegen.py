@@ -21,7 +21,7 @@ rt = C.CDLL(sys.argv[1])
 src = open(sys.argv[2], "rb").read()
 prog = C.c_void_p()
 assert rt.hiprtcCreateProgram(C.byref(prog), src, b"prog.hip", 0, None, None) == 0
-opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-honor-nans"]
+opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-honor-nans"] + [o.encode() for o in sys.argv[4:]]
 arr = (C.c_char_p * len(opts))(*opts)
 rc = rt.hiprtcCompileProgram(prog, len(opts), arr)
 n = C.c_size_t()
@@ -37,11 +37,11 @@ open(sys.argv[3], "wb").write(code.raw)
 """
 
 
-def _compile(src_path, co_path):
+def _compile(src_path, co_path, extra=()):
     """hiprtc in a process of its own: this one may have loaded another ROCm user-space (PyTorch bundles an older comgr, which
     the loader would then hand to the installed hiprtc as well - mfma4_rtc.hpp opens a private link namespace for that case)."""
     import sys
-    r = subprocess.run([sys.executable, "-c", _COMPILE, HIPRTC, str(src_path), str(co_path)], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", _COMPILE, HIPRTC, str(src_path), str(co_path), *extra], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     notes = subprocess.run([READELF, "--notes", str(co_path)], capture_output=True, text=True).stdout
     kernels = dict(re.findall(r"\.name:\s+(soc_bsp_kernel\w*)\s+\.private_segment_fixed_size:\s+(\d+)", notes))
@@ -62,8 +62,10 @@ def _generate(cfg_name, path, monkeypatch):
 
 @pytest.mark.parametrize("cfg_name,n_blocks", [("C1_soc", 261), ("C5_soc", 1015)])
 def test_bsp_program_is_generated_compiles_and_keeps_state_in_registers(cfg_name, n_blocks, tmp_path, monkeypatch):
+    """The round-2 form (SPCIES_BSP_SCHED=0): the generator's own order, left to LLVM's scheduler."""
     if not (os.path.exists(HIPRTC) and os.path.exists(READELF)):
         pytest.skip("needs the ROCm installation's hiprtc and llvm-readelf")
+    monkeypatch.setenv("SPCIES_BSP_SCHED", "0")
     src = _generate(cfg_name, tmp_path / "prog.hip", monkeypatch)
     assert "soc_bsp_kernel" in src
     # the iteration: a head, then ONE wave-uniform branch `if (all_hit) { tail without residual checks } else { tail }` (soc_bsp.hpp);
@@ -84,9 +86,83 @@ def test_bsp_program_is_generated_compiles_and_keeps_state_in_registers(cfg_name
 def test_bsp_plain_program_has_no_scratch_at_c5(tmp_path, monkeypatch):
     if not (os.path.exists(HIPRTC) and os.path.exists(READELF)):
         pytest.skip("needs the ROCm installation's hiprtc and llvm-readelf")
+    monkeypatch.setenv("SPCIES_BSP_SCHED", "0")
     monkeypatch.setenv("SPCIES_BSP_PF", "12")     # the round-1 program: one copy of the tail, 12-deep ring
     monkeypatch.setenv("SPCIES_BSP_NOSPLIT", "1")
     src = _generate("C5_soc", tmp_path / "prog.hip", monkeypatch)
     assert "if (all_hit) {" not in src and len(re.findall(r"\bMF\(", src)) == 1015 + 1  # + the macro definition
     kernels, _ = _compile(tmp_path / "prog.hip", tmp_path / "prog.co")
     assert int(kernels["soc_bsp_kernel"]) == 0
+
+
+@pytest.mark.parametrize("cfg_name,n_blocks", [("C1_soc", 261), ("C5_soc", 1015)])
+def test_scheduled_bsp_program(cfg_name, n_blocks, tmp_path, monkeypatch):
+    """The default form (round 3): the iteration as micro-operations ordered by bsp_sched.hpp, block pairs through ds_read_b128, the
+    distinct bound patterns in registers.  Every block is consumed by exactly one product on either path through the iteration, every
+    pair of the table is read into the ring exactly once per iteration, each value is defined before it is used (the program is
+    straight-line C: the compiler checks that), and the ITERATION touches no scratch memory."""
+    if not (os.path.exists(HIPRTC) and os.path.exists(READELF)):
+        pytest.skip("needs the ROCm installation's hiprtc and llvm-readelf")
+    src = _generate(cfg_name, tmp_path / "prog.hip", monkeypatch)
+    body = src[src.index("while (true)"):]
+    i_if, i_else = body.index("if (all_hit) {"), body.index("} else {", body.index("if (all_hit) {"))
+    i_end = body.index("res |= (rd_ > tol_d)")
+    head, light, full = body[:i_if], body[i_if:i_else], body[i_else:i_end]
+    n_mf = lambda t: len(re.findall(r"__builtin_amdgcn_mfma_f64_4x4x4f64\(", t))
+    assert n_mf(head) + n_mf(light) == n_blocks and n_mf(light) == n_mf(full)
+    n_pairs = (n_blocks + 1) // 2
+    refills = lambda t: re.findall(r"a\d+ = PBLK\(blk(\d), (\d+)\);", t)
+    tail_refills = refills(body[i_end:body.index("exit test per instance")])
+    for path in (light, full):
+        seen = sorted(int(a) * 256 + int(b) for a, b in refills(head) + refills(path) + tail_refills)
+        assert seen == list(range(n_pairs)), "every pair of the table enters the ring once per iteration"
+    assert "rd_ = fmax(rd_" in full and "rd_ = fmax(rd_" not in light  # the checks live in one branch only
+    assert "lbv[" in src and "LBR(" not in head + light + full  # bounds: register patterns, no LDS read in the iteration
+    kernels, lds = _compile(tmp_path / "prog.hip", tmp_path / "prog.co", ["-mllvm", "-enable-misched=false"])
+    assert set(kernels) == {"soc_bsp_kernel", "soc_bsp_kernel_sol"}
+    assert lds and max(lds) <= 160 * 1024
+    assert int(kernels["soc_bsp_kernel"]) <= 640
+
+
+def test_scheduler_respects_dependences_and_latencies():
+    """bsp_sched.hpp on a toy program (host-only test binary): a chain D -> U -> D with independent fillers; the order must be a
+    topological order of the read / write dependences, and the fillers must sit between the links of the chain."""
+    import subprocess
+    import sys
+    import tempfile
+    src = r'''
+#include "bsp_sched.hpp"
+using namespace spcies::bsp::sched;
+int main() {
+    Program P;
+    double b[16] = {0};
+    P.stmt(K_VALU, "x0", "", {}, {"x0"}, 1);
+    P.mfma("y0", true, b, "x0");       // D0
+    P.mfma("r1", true, b, "y0");       // U10 (critical)
+    P.mfma("y1", true, b, "r1");       // D1
+    P.mfma("f0", true, b, "x0");       // fillers: independent of the chain
+    P.mfma("f1", true, b, "x0");
+    P.mfma("f2", true, b, "x0");
+    P.mfma("f3", true, b, "x0");
+    P.stmt(K_VALU, "w", "", {"y1", "f0", "f1", "f2", "f3"}, {"w"}, 1);
+    std::vector<int> ord = schedule(P, 64);
+    std::vector<int> pos(ord.size());
+    for (size_t i = 0; i < ord.size(); i++) pos[ord[i]] = (int)i;
+    // dependences
+    if (!(pos[0] < pos[1] && pos[1] < pos[2] && pos[2] < pos[3] && pos[3] < pos[8])) return 1;
+    for (int f = 4; f < 8; f++) if (!(pos[0] < pos[f] && pos[f] < pos[8])) return 2;
+    // the fillers hide the chain's latency: D0, U10, D1 are never adjacent
+    if (pos[2] == pos[1] + 1 || pos[3] == pos[2] + 1) return 3;
+    // model time: 7 products on the pipe (28 quads) + the two vector statements, no stall beyond the chain's ends
+    int last = 0;
+    for (const Op &o : P.ops) last = std::max(last, o.issue + o.cost);
+    printf("%d\\n", last);
+    return last <= 40 ? 0 : 4;
+}
+'''
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spcies_amd", "csrc")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        subprocess.run(["g++", "-std=c++17", "-O1", "-I", inc, "-o", os.path.join(d, "t"), os.path.join(d, "t.cpp")], check=True)
+        r = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True)
+        assert r.returncode == 0, (r.returncode, r.stdout)
