@@ -140,10 +140,13 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     const BlockList bG = blocks_of(Gm, RR, PR_), bHG = blocks_of(HG, PR_, RR), bH = blocks_of(H, PR_, PR_), bL = blocks_of(L, RR, RR);
     // ring depth: measured at the C2 shape (ms, scratch B per lane): 8: 10.5 / 0, 12: 9.94 / 116, 16: 9.77 / 148, 20: 9.58 / 156, 24: 9.29 / 280
     // (the laxMPC programs do not care: 12.5 ms and no scratch at any depth)
-    int SEG_EVERY = 4, PF = 24;
+    // round 3: the ring holds block PAIRS read by ds_read_b128 (PF counts pairs; SPCIES_BSP_PAIRS=0: single blocks, PF counts blocks) -
+    // one ds_read_b64 per product kept the LDS pipe busier than the matrix pipe (soc_bsp.hpp)
+    const bool pairs = !(getenv("SPCIES_BSP_PAIRS") && getenv("SPCIES_BSP_PAIRS")[0] == '0');
+    int SEG_EVERY = 4, PF = pairs ? 12 : 24;
     if (const char *ev = getenv("SPCIES_BSP_SEG")) SEG_EVERY = std::max(1, atoi(ev));
     if (const char *ev = getenv("SPCIES_BSP_PF")) PF = std::min(64, std::max(2, atoi(ev)));
-    if (pf_request > 0) PF = pf_request;
+    if (pf_request > 0) PF = pairs ? std::max(2, pf_request / 2) : pf_request;
     std::vector<double> &tab = p.table;
     tab.clear();
     std::string body;
@@ -176,7 +179,12 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
             }
     };
     auto MF = [&](const char *acc, int t, const char *x) {
-        snprintf(line, sizeof(line), "            MF(%s, a%d, %s); @%d@\n", acc, t % PF, x, t);
+        if (pairs) {
+            if (t % 2) snprintf(line, sizeof(line), "            MF(%s, a%d.y, %s); @%d@\n", acc, (t / 2) % PF, x, t / 2);
+            else snprintf(line, sizeof(line), "            MF(%s, a%d.x, %s);\n", acc, (t / 2) % PF, x);
+        } else {
+            snprintf(line, sizeof(line), "            MF(%s, a%d, %s); @%d@\n", acc, t % PF, x, t);
+        }
         body += line;
         n_mfma++;
     };
@@ -345,8 +353,43 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         dense_tail(a.P_half, 1.0, "lamN", "tt");
         body += "              EUPD_B; }\n";
     }
+    if (pairs) {  // pair p at doubles [32 p, 32 p + 32): element e of block 2 p + h at 32 p + 2 e + h
+        if ((tab.size() / 16) % 2) tab.resize(tab.size() + 16, 0.0);
+        std::vector<double> t2(tab.size());
+        for (size_t b = 0; b < tab.size() / 16; b++)
+            for (int e = 0; e < 16; e++) t2[(b / 2) * 32 + 2 * e + (b % 2)] = tab[b * 16 + e];
+        tab.swap(t2);
+    }
     p.n_blocks = (int)(tab.size() / 16);
     p.n_mfma = n_mfma;
+    if (pairs) {
+        const int np = p.n_blocks / 2, n_pad = (np + PF - 1) / PF * PF;
+        std::string out;
+        out.reserve(body.size() + (size_t)np * 40);
+        auto refill = [&](int t) {
+            const int nx = (t + PF) % n_pad;
+            if (nx >= np) return;
+            snprintf(line, sizeof(line), "a%d = PBLK(blk%d, %d);", t % PF, nx / 256, nx % 256);
+            out += line;
+        };
+        bool last_seen = false;
+        for (size_t i = 0; i < body.size();) {
+            if (body[i] == '@') {
+                const size_t j = body.find('@', i + 1);
+                const int t = atoi(body.substr(i + 1, j - i - 1).c_str());
+                last_seen |= t == np - 1;
+                refill(t);
+                i = j + 1;
+            } else {
+                out.push_back(body[i++]);
+            }
+        }
+        out += "            ";
+        if (!last_seen) refill(np - 1);  // (an odd number of products: the last pair's second half is a pad)
+        for (int t = np; t < n_pad; t++) refill(t);
+        out += "\n";
+        body.swap(out);
+    } else
     {
         const int nb = p.n_blocks, n_pad = (nb + PF - 1) / PF * PF;
         std::string out;
@@ -385,7 +428,7 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         if (!std::isfinite(x)) { p.why = "non-finite block"; return 0; }
     }
     if (tab.size() * sizeof(double) > 160 * 1024 - 1024 || p.n_blocks > 1536) { p.why = "block table exceeds the LDS"; return 0; }
-    if (p.n_blocks <= PF) {  // a very small controller: a shorter ring
+    if (p.n_blocks <= (pairs ? 2 * PF : PF)) {  // a very small controller: a shorter ring
         if (p.n_blocks >= 6 && pf_request != p.n_blocks / 2) return build_ellip(p, a, p.n_blocks / 2);
         p.why = "fewer blocks than the prefetch ring";
         return 0;
@@ -417,7 +460,11 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     def("NBT_", std::max(NR - bt_first, 1)); def("BT_ROW0_", equ ? (long)(N - 1) * n : (long)4 * NR); def("BT_FIRST_", bt_first);
     def("TAB_DOUBLES_", (long)tab.size()); def("RC_", rc_lb); def("DIM_", dim); def("DZ_", dz); def("NN_", n);
     s += "#define RING_INIT";
-    for (int i = 0; i < PF; i++) { snprintf(line, sizeof(line), " double a%d = BLK(blk%d, %d);", i, (i % p.n_blocks) / 512, (i % p.n_blocks) % 512); s += line; }
+    for (int i = 0; i < PF; i++) {
+        if (pairs) snprintf(line, sizeof(line), " double2 a%d = PBLK(blk%d, %d);", i, (i % (p.n_blocks / 2)) / 256, (i % (p.n_blocks / 2)) % 256);
+        else snprintf(line, sizeof(line), " double a%d = BLK(blk%d, %d);", i, (i % p.n_blocks) / 512, (i % p.n_blocks) % 512);
+        s += line;
+    }
     s += "\n";
     {
         const int nb = p.n_blocks;
@@ -483,6 +530,7 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
     int ao = g * 4 + (lane & 3);
     const long n_tiles = (p.B + 15) / 16;
 #define BLK(arr, t) arr[(t) * 16 + ao]
+#define PBLK(arr, pp) (*reinterpret_cast<const double2 *>(&arr[(pp) * 32 + 2 * ao]))
 #define MF(acc, a, x) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((a), (x), (acc), 0, 0, 0)
 #define SEG __builtin_amdgcn_sched_barrier(0)
 #define LAUNDER asm volatile("" : "+v"(go))
