@@ -76,6 +76,7 @@ struct Mfma4Layout {
 
 struct Mfma4Plan {
     bool ok = false;
+    bool unit = false;       // unit-box coordinates (admm_mfma4u.hpp): the table holds scaled blocks and Mfma4uRC row constants
     bool needs_rtc = false;  // tables are packed, but no kernel of this shape was instantiated at build time (mfma4_rtc.hpp)
     std::string why = "not built";
     Mfma4Layout lay{};
@@ -90,6 +91,17 @@ inline void mfma4_plan_free(Mfma4Plan &p) {
 }
 
 inline bool mfma4_shape_instantiated(int N, int KX, int KS);
+
+// unit-box coordinates (admm_mfma4u.hpp): row scalings D = ub - lb and shifts lb per kind of stage, when the bounds allow them
+struct Mfma4uScaling {
+    bool ok = false;
+    std::string why;
+    std::vector<double> D_mid, D_0, D_N, lb_mid, lb_0, lb_N;  // 16 entries each; D = 1, lb = 0 on rows that do not exist
+};
+inline Mfma4uScaling mfma4u_scaling(const AdmmHost &a);
+inline void mfma4u_row_constants(const AdmmHost &a, const Mfma4uScaling &sc, const std::vector<double> &hd_mid, const std::vector<double> &hd_0,
+                                 double *rc0);
+inline int mfma4u_rc_count();
 
 inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
     using namespace hostla;
@@ -106,7 +118,9 @@ inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
         for (int j = 0; j < nm; j++)
             if (a.Hi[(size_t)l * nm + j] != a.Hi[j]) { p.why = "Hi differs between stages (vector rho?)"; return 0; }
     p.lay = L;
-    std::vector<double> tab((size_t)L.total_doubles(), 0.0);
+    const Mfma4uScaling sc = mfma4u_scaling(a);
+    { const char *ev = getenv("SPCIES_MFMA4_UNIT"); p.unit = sc.ok && !(ev && ev[0] == '0'); }
+    std::vector<double> tab((size_t)L.n_tiles() * 16 + (size_t)(p.unit ? mfma4u_rc_count() : (int)Mfma4Layout::RC_COUNT) * 16, 0.0);
     int cursor = 0;
     // append the non-zero 4x4 blocks of M in issue order (J outer, I inner); a block that the pattern
     // declares zero must really be zero
@@ -158,16 +172,24 @@ inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) Al[l][i * 16 + j] = a.Alpha[((size_t)l * n + i) * n + j];
     }
+    // unit-box coordinates: the blocks that multiply q_hat = rho D s get their columns scaled by rho D, the blocks that produce z
+    // their rows by 1 / D
+    std::vector<double> cs_mid(16, 1.0), cs_0(16, 1.0), cs_N(16, 1.0), rs_mid(16, 1.0), rs_0(16, 1.0), rs_N(16, 1.0);
+    if (p.unit)
+        for (int j = 0; j < 16; j++) {
+            cs_mid[j] = a.rho * sc.D_mid[j]; cs_0[j] = a.rho * sc.D_0[j]; cs_N[j] = a.rho * sc.D_N[j];
+            rs_mid[j] = 1.0 / sc.D_mid[j]; rs_0[j] = 1.0 / sc.D_0[j]; rs_N[j] = 1.0 / sc.D_N[j];
+        }
     Mat ABt = transpose(AB);
-    const Mat Zmid = neg(scale_rows(ABt, hd_mid));
+    const Mat Zmid = scale_rows(neg(scale_rows(ABt, hd_mid)), rs_mid);
     // ---- forward blocks
     for (int l = 0; l < N; l++) {
         Mat BiT = transpose(Bi[l]);
-        emit(neg(mul(BiT, scale_cols(AB, l == 0 ? hd_0 : hd_mid))), L.F2(l));
+        emit(neg(mul(BiT, scale_cols(scale_cols(AB, l == 0 ? hd_0 : hd_mid), l == 0 ? cs_0 : cs_mid))), L.F2(l));
         if (L.hasF1(l)) {
             Mat Dx = zeros();
-            if (l + 1 == N) Dx = HiN;
-            else for (int j = 0; j < n; j++) Dx[j * 16 + j] = hdx_mid[j];
+            if (l + 1 == N) Dx = scale_cols(HiN, cs_N);
+            else for (int j = 0; j < n; j++) Dx[j * 16 + j] = hdx_mid[j] * cs_mid[j];
             emit(mul(BiT, Dx), L.F1(l));
         }
         if (l >= 1) emit(neg(mul(BiT, transpose(Al[l - 1]))), L.F3());
@@ -178,12 +200,12 @@ inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
         if (l < N - 1) emit(neg(mul(Bi[l], Al[l])), L.B2());
         const int t = l + 2;
         if (L.stage_exists(t)) {
-            if (t == N) emit(neg(HiN), L.ZN());
+            if (t == N) emit(scale_rows(neg(HiN), rs_N), L.ZN());
             else emit(Zmid, L.Zmid());
         }
     }
     emit(Zmid, L.Zmid());                                // stage 1
-    emit(neg(scale_rows(ABt, hd_0)), L.Z0());            // stage 0
+    emit(scale_rows(neg(scale_rows(ABt, hd_0)), rs_0), L.Z0());  // stage 0
     if (cursor != L.stream_tiles()) return fail(SPCIES_HIP_EINVAL, "MFMA4 packer/stream mismatch (%d vs %d)", cursor, L.stream_tiles());
     cursor = L.setup_base();
     emit(mul(transpose(Bi[0]), A), L.S());               // x0 -> c0
@@ -191,24 +213,25 @@ inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
     else emit(neg(transpose(Bi[N - 1])), L.S());         // xr -> cN
     if (!structure_ok) { p.why = "a block expected to be structurally zero is not"; return 0; }
     auto rc = [&](int i) { return tab.data() + L.rc_off(i); };
-    for (int j = 0; j < 16; j++) {
+    if (p.unit) mfma4u_row_constants(a, sc, hd_mid, hd_0, tab.data() + (size_t)L.n_tiles() * 16);
+    for (int j = 0; j < 16 && !p.unit; j++) {
         rc(Mfma4Layout::RC_NEGHD_MID)[j] = -hd_mid[j];
         rc(Mfma4Layout::RC_NEGHD_0)[j] = -hd_0[j];
     }
-    for (int j = 0; j < nm; j++) {
+    for (int j = 0; j < nm && !p.unit; j++) {
         rc(Mfma4Layout::RC_LB_MID)[j] = a.LB[j];
         rc(Mfma4Layout::RC_UB_MID)[j] = a.UB[j];
     }
-    for (int j = 0; j < m; j++) {
+    for (int j = 0; j < m && !p.unit; j++) {
         rc(Mfma4Layout::RC_LB_0)[n + j] = a.LB[n + j];
         rc(Mfma4Layout::RC_UB_0)[n + j] = a.UB[n + j];
     }
-    for (int j = 0; j < n; j++) {
+    for (int j = 0; j < n && !p.unit; j++) {
         rc(Mfma4Layout::RC_LB_N)[j] = a.LB[j];
         rc(Mfma4Layout::RC_UB_N)[j] = a.UB[j];
         rc(Mfma4Layout::RC_QR)[j] = a.Q[j];
     }
-    for (int j = 0; j < m; j++) rc(Mfma4Layout::RC_QR)[n + j] = a.R[j];
+    for (int j = 0; j < m && !p.unit; j++) rc(Mfma4Layout::RC_QR)[n + j] = a.R[j];
     for (double x : tab)
         if (!std::isfinite(x)) { p.why = "non-finite folded constant (singular Beta block?)"; return 0; }
     p.table_bytes = tab.size() * sizeof(double);
@@ -548,6 +571,14 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
 }
 // [rtc-end]
 
+// (admm_mfma4u.hpp: the same kernel in unit-box coordinates; chosen when Mfma4Plan::unit)
+template <int N, int KX, int KS, bool TERMINAL, bool WANT_SOL>
+__global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const double *__restrict__ table_g, const double *__restrict__ x0g,
+                                                             const double *__restrict__ xrg, const double *__restrict__ urg,
+                                                             double *__restrict__ u_out, int *__restrict__ k_out, int *__restrict__ e_out,
+                                                             double *__restrict__ z_out, double *__restrict__ v_out,
+                                                             double *__restrict__ lam_out, double *__restrict__ dump);
+
 #define SPCIES_MFMA4_SHAPES(X) X(10, 2, 2) X(15, 3, 4)
 
 inline bool mfma4_shape_instantiated(int N, int KX, int KS) {
@@ -571,7 +602,7 @@ static int launch_mfma4_shape(Mfma4Plan &pl, const AdmmHost &a, const MfmaArgs &
     dim3 grid((unsigned)wgs), block(256);
 #define SPCIES_LAUNCH(TERM, SOL)                                                                                     \
     do {                                                                                                             \
-        auto kern = admm_mfma4_kernel<N, KX, KS, TERM, SOL>;                                                         \
+        auto kern = pl.unit ? admm_mfma4u_kernel<N, KX, KS, TERM, SOL> : admm_mfma4_kernel<N, KX, KS, TERM, SOL>;    \
         /* per device, so set before every launch (a handle may live on any GPU of the process) */                   \
         SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                                  160 * 1024));                                                      \

@@ -6,7 +6,7 @@
 // controller at create time, 2.0-2.3x faster than MFMA4G on the shapes of tools/bench_rtc.py.  SPCIES_HIP_RTC=0 in
 // the environment turns it off; libhiprtc.so is bound with dlopen on first use.
 #pragma once
-#include "admm_mfma4.hpp"
+#include "admm_mfma4u.hpp"
 #include "rtc_common.hpp"
 
 namespace spcies {
@@ -28,11 +28,12 @@ inline void module_free(Mfma4Module &m) {
 }
 
 // compile admm_mfma4_kernel<N, KX, KS, TERMINAL, false / true> for gfx950
-inline int compile_mfma4(Mfma4Module &out, int N, int KX, int KS, bool terminal) {
+inline int compile_mfma4(Mfma4Module &out, int N, int KX, int KS, bool terminal, bool unit = false) {
     std::vector<std::string> names;
     for (int s = 0; s < 2; s++) {
         char nm[128];
-        snprintf(nm, sizeof(nm), "spcies::admm_mfma4_kernel<%d, %d, %d, %s, %s>", N, KX, KS, terminal ? "true" : "false", s ? "true" : "false");
+        snprintf(nm, sizeof(nm), "spcies::admm_mfma4%s_kernel<%d, %d, %d, %s, %s>", unit ? "u" : "", N, KX, KS, terminal ? "true" : "false",
+                 s ? "true" : "false");
         names.push_back(nm);
     }
     std::vector<std::string> extra = {"-DSPCIES_RTC_STATIC_LDS=1"};

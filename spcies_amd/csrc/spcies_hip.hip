@@ -721,7 +721,7 @@ static int ensure_mfma4_rtc(Solver &s) {
     if (s.mfma4.ok) return 0;
     if (!s.mfma4.needs_rtc) return fail(SPCIES_HIP_ENOSUP, "MFMA4 variant not available for this shape: %s", s.mfma4.why.c_str());
     const Mfma4Layout &L = s.mfma4.lay;
-    int rc = rtc::compile_mfma4(s.mfma4_rtc, L.N, L.KX, L.KS, L.terminal);
+    int rc = rtc::compile_mfma4(s.mfma4_rtc, L.N, L.KX, L.KS, L.terminal, s.mfma4.unit);
     if (rc) return rc;
     s.mfma4.ok = true;
     s.mfma4.why.clear();
@@ -1658,7 +1658,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         // kernel experiments: SPCIES_MFMA4_RTC_FLAGS="-DX=1 ..." re-specialises a built-in shape with extra compiler options
         if (s->mfma4.ok && !s->mfma4_rtc.ok && getenv("SPCIES_MFMA4_RTC_FLAGS")) {
             const Mfma4Layout &L = s->mfma4.lay;
-            rc = rtc::compile_mfma4(s->mfma4_rtc, L.N, L.KX, L.KS, L.terminal);
+            rc = rtc::compile_mfma4(s->mfma4_rtc, L.N, L.KX, L.KS, L.terminal, s->mfma4.unit);
             if (rc) return rc;
         }
     }
