@@ -97,9 +97,10 @@ struct Edge { int to, lat; };
 
 struct Model {
     int lds = 32, mm_c = 4, mm_b = 6, mv = 7, vm = 2, vv = 1, valu_pipe = 1;
+    int sw = 0;  // issue slots lost when a vector instruction follows a product (profiles/r03_microbench_issue.txt: 2)
     Model() {
-        if (const char *ev = getenv("SPCIES_BSP_MODEL"))  // experiments: "lds,mm_c,mm_b,mv,vm,vv,valu_pipe"
-            sscanf(ev, "%d,%d,%d,%d,%d,%d,%d", &lds, &mm_c, &mm_b, &mv, &vm, &vv, &valu_pipe);
+        if (const char *ev = getenv("SPCIES_BSP_MODEL"))  // experiments: "lds,mm_c,mm_b,mv,vm,vv,valu_pipe,sw"
+            sscanf(ev, "%d,%d,%d,%d,%d,%d,%d,%d", &lds, &mm_c, &mm_b, &mv, &vm, &vv, &valu_pipe, &sw);
     }
 };
 inline const Model &model() {
@@ -161,6 +162,7 @@ inline std::vector<int> schedule(Program &p, int window) {
     std::vector<char> done(n, 0);
     order.reserve(n);
     int t = 0, pipe_free = 0, first_waiting = 0;
+    bool last_mfma = false;
     std::vector<int> ready;
     for (int i = 0; i < n; i++)
         if (npred[i] == 0) ready.push_back(i);
@@ -171,8 +173,10 @@ inline std::vector<int> schedule(Program &p, int window) {
             if (c > first_waiting + window) continue;
             const Op &o = p.ops[c];
             int est = std::max(earliest[c], t);
-            if (o.pipe) est = std::max(est, pipe_free);
-            if (best < 0 || est < best_t || (est == best_t && (prio[c] > prio[best] || (prio[c] == prio[best] && c < best)))) {
+            if (o.pipe) est = std::max(est, pipe_free + ((o.kind == K_VALU && last_mfma) ? model().sw : 0));
+            // (a run of vector instructions is continued before the matrix pipe is taken again: every switch costs)
+            const bool cont = model().sw > 0 && !last_mfma && o.kind == K_VALU, bcont = best >= 0 && model().sw > 0 && !last_mfma && p.ops[best].kind == K_VALU;
+            if (best < 0 || est < best_t || (est == best_t && ((cont && !bcont) || (cont == bcont && (prio[c] > prio[best] || (prio[c] == prio[best] && c < best)))))) {
                 best = c;
                 best_t = est;
             }
@@ -185,6 +189,7 @@ inline std::vector<int> schedule(Program &p, int window) {
         o.issue = best_t;
         t = best_t + (o.kind == K_MFMA ? 1 : std::max(1, o.cost));
         if (o.pipe) pipe_free = best_t + (o.kind == K_MFMA ? 4 : o.cost * model().valu_pipe);
+        if (o.pipe) last_mfma = o.kind == K_MFMA;
         done[best] = 1;
         order.push_back(best);
         ready.erase(std::find(ready.begin(), ready.end(), best));
