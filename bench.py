@@ -51,13 +51,13 @@ def traffic_from_profile(variant):
     profiles/rNN_<variant>_pmc_summary.txt: separate FETCH_SIZE / WRITE_SIZE runs of this same command), corrected as
     MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE x 2 on gfx950, values in KB.  Returns (bytes, file) -
     a constant read from the repository, NOT a measurement of the run that prints it (`traffic_source` says so)."""
-    for stem in (f"r02_C2_{variant}", f"r02_{variant}", f"r01_{variant}"):
+    for stem in (f"r03_C2_{variant}", f"r02_C2_{variant}", f"r02_{variant}", f"r01_{variant}"):
         path = os.path.join(ROOT, "profiles", f"{stem}_pmc_summary.txt")
         if not os.path.exists(path):
             continue
         fetch = write = None
         for line in open(path):
-            if f"admm_{variant}_kernel" not in line:
+            if f"admm_{variant}_kernel" not in line and f"admm_{variant}u_kernel" not in line:  # (mfma4u: the unit-box form of MFMA4)
                 continue
             val = float(line.split("mean=")[1].split()[0])
             if line.startswith("FETCH_SIZE"):
