@@ -1263,6 +1263,52 @@ def test_eadmm_mfma4r_state_placements(env, monkeypatch):
     s.close()
 
 
+def test_mfma4_unit_box_form_agrees_with_the_plain_kernel_and_falls_back(monkeypatch):
+    """MFMA4 runs in unit-box coordinates (admm_mfma4u.hpp: rows scaled to their boxes, the clamp as the [0, 1] output modifier) when
+    every real row has finite bounds with ub > lb, and as the plain kernel otherwise.  Same instances through both forms: `k`, `e_flag`
+    equal, iterates equal to rounding; with an unbounded state the switch changes nothing (bit-identical: the plain kernel ran twice)."""
+    import copy
+    from types import SimpleNamespace
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    for cfg_name in ("C2_lax", "C2_equ", "C1_lax"):
+        cfg = benchmarks.config(cfg_name)
+        v = benchmarks.ingredients(cfg, tol=1e-5, k_max=400)
+        x0, xr, ur = benchmarks.sample_batch(cfg, 96)
+        out = {}
+        for unit in ("1", "0"):
+            monkeypatch.setenv("SPCIES_MFMA4_UNIT", unit)
+            s = HipSolver(v)
+            s.set_variant("mfma4")
+            out[unit] = s(x0, xr, ur)
+            s.close()
+        (u1, k1, e1, s1), (u0, k0, e0, s0) = out["1"], out["0"]
+        assert np.array_equal(e1, e0) and np.abs(k1.astype(int) - k0.astype(int)).max() <= 1 and (k1 != k0).mean() <= 0.02
+        same = k1 == k0
+        assert not np.array_equal(s1.z, s0.z), "two different kernels ran"
+        assert np.abs(u1 - u0)[same].max() < 1e-11 and np.abs(s1.z - s0.z)[same].max() < 1e-10 and np.abs(s1.v - s0.v)[same].max() < 1e-10
+        _compare("mfma4", out["1"], oracle.admm_banded_batch(v, x0, xr, ur), v)
+    # one state without an upper bound: no box to scale to
+    cfg = copy.copy(benchmarks.config("C1_lax"))
+    sysd = dict(vars(cfg.sys))
+    ub = np.array(sysd["UBx"], dtype=float).copy()
+    ub[0] = np.inf
+    sysd["UBx"] = ub
+    cfg.sys = SimpleNamespace(**sysd)
+    v = benchmarks.ingredients(cfg)
+    x0, xr, ur = benchmarks.sample_batch(cfg, 64)
+    out = {}
+    for unit in ("1", "0"):
+        monkeypatch.setenv("SPCIES_MFMA4_UNIT", unit)
+        s = HipSolver(v)
+        s.set_variant("mfma4")
+        out[unit] = s(x0, xr, ur)
+        s.close()
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][3].z, out["0"][3].z) and np.isfinite(out["1"][0]).all()
+    _compare("mfma4", out["1"], oracle.admm_banded_batch(v, x0, xr, ur), v)
+
+
 # ----------------------------------------------------------------------------------------------
 # lax/equ MPC ADMM with vector rho and stage-wise bounds (SURVEY section 8f rank 3: no SCALAR_RHO, VAR_BOUNDS)
 # ----------------------------------------------------------------------------------------------
