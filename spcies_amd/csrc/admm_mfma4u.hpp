@@ -137,12 +137,30 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
 
     int ao = g * 4 + (lane & 3), go = g;
     auto BLK = [&](int t) -> double { return lds[(t / 2) * 32 + 2 * ao + (t % 2)]; };
-    auto PAIR = [&](int p) -> double2 { return *reinterpret_cast<const double2 *>(lds + p * 32 + 2 * ao); };
+    // The block stream is longer than the 64 KB an LDS instruction's immediate offset reaches: without two bases kept in registers the compiler
+    // forms `base + 0x...` with a vector add in front of every few reads - an isolated vector instruction between MFMAs costs 12 clocks
+    // (profiles/r03_microbench_issue.txt).  Both bases are laundered once per iteration (like ao) so that they stay registers.
+    unsigned pb0 = (unsigned)(size_t)(lds + 2 * ao), pb1 = pb0 + 65536u;
+    auto PAIR = [&](int p) -> double2 {
+        const unsigned off = (unsigned)p * 256u;
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) const dbl2 *lds_p;
+        const dbl2 v = off < 65536u ? *(lds_p)(size_t)(pb0 + off) : *(lds_p)(size_t)(pb1 + (off - 65536u));
+        double2 r;
+        r.x = v[0];
+        r.y = v[1];
+        return r;
+    };
     auto RC = [&](int i) -> d4 {
         const double *r = lds + RC0 + i * 16;
         return d4{r[go], r[4 + go], r[8 + go], r[12 + go]};
     };
 #define MFMA4(acc, a, b) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (acc), 0, 0, 0)
+#ifdef SPCIES_MFMA4U_NOSPLIT
+#define SPCIES_SEG_SPLIT
+#else
+#define SPCIES_SEG_SPLIT __builtin_amdgcn_sched_barrier(0)
+#endif
     auto clamp01 = [](const d4 &x) -> d4 {
         d4 r;
 #pragma unroll
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
         auto iteration = [&](auto first_tag) -> bool {
             constexpr bool FIRST = decltype(first_tag)::value;
             kk += 1;
-            asm volatile("" : "+v"(ao), "+v"(go));
+            asm volatile("" : "+v"(ao), "+v"(go), "+v"(pb0), "+v"(pb1));
             long il = inst;
             asm volatile("" : "+v"(il));
             double *zp = WANT_SOL ? z_out + il * dim + g : nullptr;
@@ -282,22 +300,30 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
             LAUNDER4(a1m); LAUNDER4(a3m); LAUNDER4(kap_m);
             asm volatile("" : "+v"(kap_0s), "+v"(kap_N[0]), "+v"(kap_N[1]), "+v"(kap_N[2]));
             bool res = false, all_hit = false;
-            auto stage_z = [&](int t, d4 &cwt) -> d4 {
+            // z'_t in two parts: the elementwise seed (vector instructions only) and the products on top of it.  The seed of a stage is
+            // formed BEFORE the products of the loop trip it belongs to, behind the previous stage's update: one run of vector instructions
+            // and one run of MFMAs per trip (every switch from the matrix instruction to a vector instruction costs 8 clocks,
+            // profiles/r03_microbench_issue.txt)
+            auto stage_seed = [&](int t, d4 &cwt, d4 &x) -> d4 {
                 d4 z;
                 const d4 s = qhat(t, cwt);
                 if (t == N) {
-                    const d4 wv = RC(Mfma4uRC::RD_N) * s - mu[N - 1];
+                    x = RC(Mfma4uRC::RD_N) * s - mu[N - 1];
                     z = -A3(N);
-                    prod(z, wv, LL.ZN());
                 } else if (t == 0) {
                     z = RC(Mfma4uRC::A1_0) * s - A3(0);
-                    prod(z, mu[0], LL.Z0());
+                    x = mu[0];
                 } else {
                     z = a1m * s - a3m;
                     z = z - a2m * mu[t - 1];  // (a2 is zero on the u rows; mu has x rows only)
-                    prod(z, mu[t], LL.Zmid());
+                    x = mu[t];
                 }
                 return z;
+            };
+            auto stage_prod = [&](int t, d4 &z, const d4 &x) {
+                if (t == N) prod(z, x, LL.ZN());
+                else if (t == 0) prod(z, x, LL.Z0());
+                else prod(z, x, LL.Zmid());
             };
             auto stage_w = [&](int t, const d4 &z, const d4 &cwt) {
                 d4 wn;
@@ -329,22 +355,28 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
             d4 zc = {0, 0, 0, 0}, cwc = {0, 0, 0, 0};
 #pragma unroll
             for (int l = N - 1; l >= 0; l--) {
-                const int tp = l + 3;
+                const int tp = l + 3, t = l + 2;
                 if (LL.stage_exists(tp)) stage_w(tp, zc, cwc);
+                d4 xz = {0, 0, 0, 0};
+                if (LL.stage_exists(t)) zc = stage_seed(t, cwc, xz);
+                SPCIES_SEG_SPLIT;
                 d4 acc = {0, 0, 0, 0};
                 prod(acc, mu[l], LL.B1());
                 if (l < N - 1) prod(acc, mu[l + 1], LL.B2());
-                const int t = l + 2;
-                if (LL.stage_exists(t)) zc = stage_z(t, cwc);
+                if (LL.stage_exists(t)) stage_prod(t, zc, xz);
                 mu[l] = acc;
                 SPCIES_SEG_BARRIER;
             }
             {
                 asm volatile("" : "+v"(go));
-                d4 cw1, cw0;
-                const d4 z1 = stage_z(1, cw1);
-                const d4 z0 = stage_z(0, cw0);
+                d4 cw1, cw0, x1, x0s;
                 stage_w(2, zc, cwc);
+                d4 z1 = stage_seed(1, cw1, x1);
+                d4 z0 = stage_seed(0, cw0, x0s);
+                SPCIES_SEG_SPLIT;
+                stage_prod(1, z1, x1);
+                stage_prod(0, z0, x0s);
+                SPCIES_SEG_SPLIT;
                 stage_w(1, z1, cw1);
                 stage_w(0, z0, cw0);
                 SPCIES_SEG_BARRIER;
