@@ -156,6 +156,12 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
         return d4{r[go], r[4 + go], r[8 + go], r[12 + go]};
     };
 #define MFMA4(acc, a, b) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (acc), 0, 0, 0)
+// (the seed of an accumulator chain is moved to the accumulator file inside the run of vector instructions that formed it)
+#ifdef SPCIES_MFMA4U_SEED_ACC
+#define SPCIES_SEED_TO_ACC(z) asm volatile("" : "+a"(z[0]), "+a"(z[1]), "+a"(z[2]), "+a"(z[3]))
+#else
+#define SPCIES_SEED_TO_ACC(z)
+#endif
 #ifdef SPCIES_MFMA4U_NOSPLIT
 #define SPCIES_SEG_SPLIT
 #else
@@ -283,9 +289,11 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
                 if constexpr (!TERMINAL) {
                     if (l == N - 1) acc = cN;
                 }
-                prod(acc, qh, LL.F2(l));
+                // (s of stage l + 2 in ONE run of vector instructions in front of the trip's products, not spread between them)
                 d4 qnn = qn;
                 if (LL.stage_exists(l + 2)) qnn = qhat(l + 2, cw);
+                SPCIES_SEG_SPLIT;
+                prod(acc, qh, LL.F2(l));
                 if (LL.hasF1(l)) prod(acc, qn, LL.F1(l));
                 if (l >= 1) prod(acc, mu[l - 1], LL.F3());
                 mu[l] = acc;
@@ -358,7 +366,10 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
                 const int tp = l + 3, t = l + 2;
                 if (LL.stage_exists(tp)) stage_w(tp, zc, cwc);
                 d4 xz = {0, 0, 0, 0};
-                if (LL.stage_exists(t)) zc = stage_seed(t, cwc, xz);
+                if (LL.stage_exists(t)) {
+                    zc = stage_seed(t, cwc, xz);
+                    SPCIES_SEED_TO_ACC(zc);
+                }
                 SPCIES_SEG_SPLIT;
                 d4 acc = {0, 0, 0, 0};
                 prod(acc, mu[l], LL.B1());
