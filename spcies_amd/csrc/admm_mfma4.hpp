@@ -288,7 +288,20 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
     // (laundered once per iteration: keeps LICM from hoisting every LDS read out of the iteration loop)
     int ao = g * 4 + (lane & 3), go = g;  // A operand: element [i = lane%4][k = lane/16] of a 16-double block
     auto BLK = [&](int t) -> double { return lds[(t / 2) * 32 + 2 * ao + (t % 2)]; };                 // single block
-    auto PAIR = [&](int p) -> double2 { return *reinterpret_cast<const double2 *>(lds + p * 32 + 2 * ao); };  // ds_read_b128
+    // ds_read_b128; two bases kept in registers (laundered once per iteration with ao): the stream is longer than the 64 KB an LDS
+    // instruction's immediate offset reaches, and a vector add in front of a read - an isolated vector instruction between MFMAs - costs
+    // 12 clocks (profiles/r03_microbench_issue.txt, admm_mfma4u.hpp)
+    unsigned pb0 = (unsigned)(size_t)(lds + 2 * ao), pb1 = pb0 + 65536u;
+    auto PAIR = [&](int p) -> double2 {
+        const unsigned off = (unsigned)p * 256u;
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) const dbl2 *lds_p;
+        const dbl2 v = off < 65536u ? *(lds_p)(size_t)(pb0 + off) : *(lds_p)(size_t)(pb1 + (off - 65536u));
+        double2 r;
+        r.x = v[0];
+        r.y = v[1];
+        return r;
+    };
     auto RC = [&](int i) -> d4 {
         const double *r = lds + LL.rc_off(i);
         return d4{r[go], r[4 + go], r[8 + go], r[12 + go]};
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
         while (true) {
             kk += 1;
             const double fz = (kk == 1) ? 0.0 : 1.0, rf = rho * fz;  // cold start: v = lambda = 0 in iteration 1
-            asm volatile("" : "+v"(ao), "+v"(go));
+            asm volatile("" : "+v"(ao), "+v"(go), "+v"(pb0), "+v"(pb1));
             long il = inst;
             asm volatile("" : "+v"(il));
             double *zp = WANT_SOL ? z_out + il * dim + g : nullptr;
@@ -441,9 +454,11 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
                 if constexpr (!TERMINAL) {
                     if (l == N - 1) acc = cN;
                 }
-                prod(acc, qh, LL.F2(l));
+                // (q_hat of stage l + 2 in ONE run of vector instructions in front of the trip's products, not spread between them)
                 d4 qnn = qn;
                 if (LL.stage_exists(l + 2)) qnn = qhat(l + 2, cw);
+                SPCIES_SEG_BARRIER;
+                prod(acc, qh, LL.F2(l));
                 if (LL.hasF1(l)) prod(acc, qn, LL.F1(l));
                 if (l >= 1) prod(acc, mu[l - 1], LL.F3());
                 mu[l] = acc;
