@@ -242,8 +242,12 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
 #endif
         constexpr int NP = LL.stream_pairs(), PF = SPCIES_MFMA4_PF;
         static_assert(NP > PF, "ring");
-        static_assert(PF == 8, "the unit-box kernel is written for the ring of eight pairs");
-        double2 r0 = PAIR(0), r1 = PAIR(1), r2 = PAIR(2), r3 = PAIR(3), r4 = PAIR(4), r5 = PAIR(5), r6 = PAIR(6), r7 = PAIR(7), cur = r0;
+#ifndef SPCIES_MFMA4U_PF
+#define SPCIES_MFMA4U_PF 8
+#endif
+        constexpr int PFU = SPCIES_MFMA4U_PF;
+        static_assert(PFU == 4 || PFU == 6 || PFU == 8, "ring depth");
+        double2 r0 = PAIR(0), r1 = PAIR(1), r2 = PAIR(2), r3 = PAIR(3), r4 = PAIR(4 % PFU), r5 = PAIR(5 % PFU), r6 = PAIR(6 % PFU), r7 = PAIR(7 % PFU), cur = r0;
 
         // one iteration; FIRST: the cold start (q_hat = q, w^+ = z' + kappa, v_old = 0).  Returns false when the wavefront is done.
         auto iteration = [&](auto first_tag) -> bool {
@@ -262,8 +266,10 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
                     for (int I = 0; I < 4; I++)
                         if (P.nz(I, J)) {
                             if (tix % 2 == 0) {
-                                const double2 nw = PAIR((tix / 2 + PF) % NP);
-                                cur = r0, r0 = r1, r1 = r2, r2 = r3, r3 = r4, r4 = r5, r5 = r6, r6 = r7, r7 = nw;
+                                const double2 nw = PAIR((tix / 2 + PFU) % NP);
+                                if constexpr (PFU == 8) { cur = r0, r0 = r1, r1 = r2, r2 = r3, r3 = r4, r4 = r5, r5 = r6, r6 = r7, r7 = nw; }
+                                else if constexpr (PFU == 6) { cur = r0, r0 = r1, r1 = r2, r2 = r3, r3 = r4, r4 = r5, r5 = nw; }
+                                else { cur = r0, r0 = r1, r1 = r2, r2 = r3, r3 = nw; }
                             }
                             MFMA4(acc[I], (tix % 2 == 0) ? cur.x : cur.y, x[J]);
                             tix++;
