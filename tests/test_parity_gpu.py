@@ -1309,6 +1309,36 @@ def test_mfma4_unit_box_form_agrees_with_the_plain_kernel_and_falls_back(monkeyp
     _compare("mfma4", out["1"], oracle.admm_banded_batch(v, x0, xr, ur), v)
 
 
+@pytest.mark.parametrize("n,m,N,formulation", [(6, 2, 7, "laxMPC"), (9, 3, 8, "laxMPC"), (5, 3, 6, "equMPC"), (12, 4, 5, "laxMPC"), (8, 1, 10, "equMPC")])
+def test_mfma4_unit_box_with_boxes_that_do_not_contain_zero(n, m, N, formulation):
+    """The unit-box form on run-time specialised shapes whose boxes are asymmetric and, for some rows, do not contain zero: the cold start
+    (v = lambda = 0, not a point of the box) is the peeled first iteration, not a value of the scaled state; tight and loose tolerances."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=700 + n)
+    cfg.formulation = formulation
+    rng = np.random.default_rng(31 * n + m)
+    cfg.sys.LBu = np.where(rng.random(m) < 0.5, 0.05 + 0.1 * rng.random(m), -0.4 - rng.random(m))   # some inputs must stay positive
+    cfg.sys.UBu = cfg.sys.LBu + 0.3 + rng.random(m)
+    cfg.sys.LBx = -0.3 - 2.0 * rng.random(n)
+    cfg.sys.UBx = 0.2 + 3.0 * rng.random(n)
+    if formulation == "laxMPC":
+        k = int(rng.integers(n))
+        cfg.sys.LBx[k], cfg.sys.UBx[k] = 0.02, 1.5   # a state whose box excludes the origin
+    for tol, k_max in ((1e-4, 500), (1e-7, 3000)):
+        cfg.solver_options = dict(rho=6.0, tol=tol, k_max=k_max)
+        v = benchmarks.ingredients(cfg)
+        s = HipSolver(v)
+        s.set_variant("mfma4")
+        B = 80
+        x0 = 0.5 * rng.standard_normal((B, n))
+        xr = 0.2 * rng.standard_normal((B, n)) + 0.1
+        ur = 0.1 * rng.standard_normal((B, m)) + 0.2
+        _compare("mfma4", s(x0, xr, ur), oracle.admm_banded_batch(v, x0, xr, ur), v)
+        s.close()
+
+
 # ----------------------------------------------------------------------------------------------
 # lax/equ MPC ADMM with vector rho and stage-wise bounds (SURVEY section 8f rank 3: no SCALAR_RHO, VAR_BOUNDS)
 # ----------------------------------------------------------------------------------------------
