@@ -233,20 +233,38 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         else snprintf(line, sizeof(line), "            rh[%d] = 0.0;\n", Ib);
         body += line;
     }
-    for (int J = 0; J < NP; J++) {
-        if (bG.by_col[J].empty()) continue;
-        char e[64];
-        qhat_expr(J, e, sizeof(e));
-        snprintf(line, sizeof(line), "            { const double qh = %s;\n", e);
-        body += line;
-        for (int Ib : bG.by_col[J]) {
-            double blk[16];
-            block_of(Gm, PR_, Ib, J, blk);
-            snprintf(a1, sizeof(a1), "rh[%d]", Ib);
-            MF(a1, emit_block(blk), "qh");
+    // (round 3: q_hat of SEG_EVERY slabs in ONE run of vector instructions in front of their products - a fence keeps the compiler from
+    // putting each slab's four instructions right in front of its own MFMAs: a switch from the matrix instruction to a vector instruction costs
+    // 8 clocks, profiles/r03_microbench_issue.txt)
+    const bool group_qhat = !(getenv("SPCIES_BSP_GROUP") && getenv("SPCIES_BSP_GROUP")[0] == '0');
+    for (int J0 = 0; J0 < NP; J0 += SEG_EVERY) {
+        const int J1 = std::min(NP, J0 + SEG_EVERY);
+        body += "            {\n";
+        for (int J = J0; J < J1 && group_qhat; J++) {
+            if (bG.by_col[J].empty()) continue;
+            char e[64];
+            qhat_expr(J, e, sizeof(e));
+            snprintf(line, sizeof(line), "              const double qh_%d = %s;\n", J, e);
+            body += line;
         }
-        body += "            }\n";
-        if (J % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
+        if (group_qhat) body += "              SEG;\n";
+        for (int J = J0; J < J1; J++) {
+            if (bG.by_col[J].empty()) continue;
+            char e[64], qn[32];
+            qhat_expr(J, e, sizeof(e));
+            snprintf(qn, sizeof(qn), "qh_%d", J);
+            if (!group_qhat) {
+                snprintf(line, sizeof(line), "              const double qh_%d = %s;\n", J, e);
+                body += line;
+            }
+            for (int Ib : bG.by_col[J]) {
+                double blk[16];
+                block_of(Gm, PR_, Ib, J, blk);
+                snprintf(a1, sizeof(a1), "rh[%d]", Ib);
+                MF(a1, emit_block(blk), qn);
+            }
+        }
+        body += "            }\n            SEG;\n";
     }
     // (the bound rows are read again in the update phase: laundering their index keeps the compiler from holding all of them
     // in registers across the solve)
@@ -308,7 +326,8 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
             double blk[16];
             block_of(H, PR_, Ib, J, blk);
             char e[64];
-            if (J < ZS) snprintf(e, sizeof(e), "QHZP(%d)", J);
+            if (J < ZS && group_qhat) snprintf(e, sizeof(e), "qp_%d", J);  // (formed with its group's, in front of the group's products)
+            else if (J < ZS) snprintf(e, sizeof(e), "QHZP(%d)", J);
             else qhat_expr(J, e, sizeof(e));
             snprintf(line, sizeof(line), "            { const double qh = %s;\n  ", e);
             body += line;
@@ -322,7 +341,7 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
             MF(acc, emit_block(blk), a2);
         }
     };
-    for (int Ib = 0; Ib < ZS; Ib++) {
+    for (int Ib = 0; Ib < ZS && !group_qhat; Ib++) {
         body += "            { double ph = 0.0;\n";
         prim_row(Ib, "ph");
         // (the index of the bound rows is laundered right before the update: the compiler otherwise issues the bound reads of
@@ -330,6 +349,27 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         snprintf(line, sizeof(line), "              LAUNDER; ZUPD(%d, ph); }\n", Ib);
         body += line;
         if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
+    }
+    // (round 3: by groups of SEG_EVERY rows - the q_hat of the group in one run of vector instructions, the group's products, the group's box
+    // updates in one run)
+    for (int I0 = 0; I0 < ZS && group_qhat; I0 += SEG_EVERY) {
+        const int I1 = std::min(ZS, I0 + SEG_EVERY);
+        body += "            {\n";
+        for (int Ib = I0; Ib < I1; Ib++) {
+            snprintf(line, sizeof(line), "              double ph_%d = 0.0; const double qp_%d = QHZP(%d);\n", Ib, Ib, Ib);
+            body += line;
+        }
+        body += "              SEG;\n";
+        for (int Ib = I0; Ib < I1; Ib++) {
+            snprintf(a1, sizeof(a1), "ph_%d", Ib);
+            prim_row(Ib, std::string(a1).c_str());
+        }
+        body += "              SEG;\n";
+        for (int Ib = I0; Ib < I1; Ib++) {
+            snprintf(line, sizeof(line), "              LAUNDER; ZUPD(%d, ph_%d);\n", Ib, Ib);
+            body += line;
+        }
+        body += "            }\n            SEG;\n";
     }
     // ---- terminal block (:318-386)
     if (!equ) body += "            SEG;\n            { double zN[TS_], vn[TS_], dd[TS_], pv[TS_], tt[TS_];\n";
