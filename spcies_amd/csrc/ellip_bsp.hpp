@@ -270,7 +270,66 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     // in registers across the solve)
     body += "            SEG;\n            LAUNDER;\n            // W mu = rhs: forward substitution by blocks\n";
     std::vector<std::vector<double>> Linv(NR, std::vector<double>(16));
-    for (int Ib = 0; Ib < NR; Ib++) {
+    // round 3: both substitutions in column order (soc_bsp.hpp: x_J = Linv_JJ rh_J, then rh_I -= L_IJ x_J for the rows below; the
+    // dependent chain D_J -> U_{J+1,J} -> D_{J+1} with the other updates between its links) - SPCIES_BSP_RL=0: one accumulator chain per row
+    const bool rl = !(getenv("SPCIES_BSP_RL") && getenv("SPCIES_BSP_RL")[0] == '0');
+    struct Pend { int I, J; };
+    auto run_columns = [&](bool forward) {
+        std::vector<Pend> queue;
+        auto pop_front = [&]() { Pend q = queue.front(); queue.erase(queue.begin()); return q; };
+        auto emit_update = [&](const Pend &q) {
+            double lj[16], o[16];
+            if (forward) {
+                block_of(L, RR, q.I, q.J, lj);
+                for (int e = 0; e < 16; e++) o[e] = -lj[e];
+            } else {
+                block_of(L, RR, q.J, q.I, lj);
+                for (int i = 0; i < 4; i++)
+                    for (int k = 0; k < 4; k++) o[i * 4 + k] = -lj[k * 4 + i] / Dinv[4 * q.I + i];
+            }
+            snprintf(a1, sizeof(a1), "rh[%d]", q.I);
+            snprintf(a2, sizeof(a2), "rh[%d]", q.J);
+            MF(a1, emit_block(o), a2);
+        };
+        int step = 0;
+        for (int J = forward ? 0 : NR - 1; forward ? J < NR : J >= 0; J += forward ? 1 : -1, step++) {
+            const int nxt = forward ? J + 1 : J - 1;
+            double d[16];
+            if (forward) {
+                for (int e = 0; e < 16; e++) d[e] = Linv[J][e];
+            } else {
+                for (int i = 0; i < 4; i++)
+                    for (int k = 0; k < 4; k++) d[i * 4 + k] = Linv[J][k * 4 + i] * Dinv[4 * J + k];
+            }
+            body += "            { double xx = 0.0;\n";
+            snprintf(a2, sizeof(a2), "rh[%d]", J);
+            MF("xx", emit_block(d), a2);
+            snprintf(line, sizeof(line), "              rh[%d] = xx; }\n", J);
+            body += line;
+            bool crit = false, any = false;
+            while (!queue.empty() && queue.front().I == nxt) { emit_update(pop_front()); any = true; }
+            if (!any && !queue.empty()) emit_update(pop_front());
+            if (forward) { for (int I : bL.by_col[J]) if (I > J) { if (I == nxt) crit = true; else queue.push_back(Pend{I, J}); } }
+            else { for (int I : bL.by_row[J]) if (I < J) { if (I == nxt) crit = true; else queue.push_back(Pend{I, J}); } }
+            std::stable_sort(queue.begin(), queue.end(), [&](const Pend &x, const Pend &y) { return forward ? x.I < y.I : x.I > y.I; });
+            if (crit) emit_update(Pend{nxt, J});
+            bool one = false;
+            while ((queue.size() > 1 || (!one && !queue.empty())) && queue.front().I != nxt) { emit_update(pop_front()); one = true; }
+            if (step % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
+        }
+        while (!queue.empty()) emit_update(pop_front());
+    };
+    if (rl) {
+        for (int Ib = 0; Ib < NR; Ib++) {
+            double d[16];
+            block_of(L, RR, Ib, Ib, d);
+            inv_unit_lower(d, Linv[Ib].data());
+        }
+        run_columns(true);
+        body += "            SEG;\n            // D^-1 and the backward substitution by blocks (U = L')\n";
+        run_columns(false);
+    }
+    for (int Ib = 0; Ib < NR && !rl; Ib++) {
         double d[16];
         block_of(L, RR, Ib, Ib, d);
         inv_unit_lower(d, Linv[Ib].data());
@@ -289,8 +348,8 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         body += line;
         if (Ib % SEG_EVERY == SEG_EVERY - 1) body += "            SEG;\n";
     }
-    body += "            SEG;\n            // D^-1 and the backward substitution by blocks (U = L')\n";
-    for (int Ib = NR - 1; Ib >= 0; Ib--) {
+    if (!rl) body += "            SEG;\n            // D^-1 and the backward substitution by blocks (U = L')\n";
+    for (int Ib = NR - 1; Ib >= 0 && !rl; Ib--) {
         double ui[16], d[16];
         for (int i = 0; i < 4; i++)
             for (int k = 0; k < 4; k++) ui[i * 4 + k] = Linv[Ib][k * 4 + i];
