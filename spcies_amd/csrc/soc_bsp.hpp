@@ -252,14 +252,19 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
             if (st) (*st)[idx] = 1;
             P.mfma(acc, first, blk, x);
         };
-        for (int J = 0; J < NP; J++) {
-            if (bG.by_col[J].empty()) continue;
-            qhat_ops(J, "g");
-            for (int Ib : bG.by_col[J]) {
-                double blk[16];
-                block_of(G, PR_, Ib, J, blk);
-                product(R("rh", Ib), &started, Ib, blk, R("qg", J));
-            }
+        // program order by groups of GRP slabs: the q_hat of the group (one run of vector instructions), then the group's products - a vector
+        // instruction alone between two MFMAs costs 12 clocks, in a run 4 (profiles/r03_microbench_issue.txt)
+        int GRP = 6;  // (measured at C5, program order issued as it is: 4: 7.82 ms, 6: 7.76, 8: 7.78)
+        if (const char *ev = getenv("SPCIES_BSP_GRP")) GRP = std::max(1, atoi(ev));
+        for (int J0 = 0; J0 < NP; J0 += GRP) {
+            for (int J = J0; J < std::min(NP, J0 + GRP); J++)
+                if (!bG.by_col[J].empty()) qhat_ops(J, "g");
+            for (int J = J0; J < std::min(NP, J0 + GRP); J++)
+                for (int Ib : bG.by_col[J]) {
+                    double blk[16];
+                    block_of(G, PR_, Ib, J, blk);
+                    product(R("rh", Ib), &started, Ib, blk, R("qg", J));
+                }
         }
         for (int Ib = 0; Ib < NR; Ib++)
             if (!started[Ib]) P.stmt(sched::K_VALU, F_("double rh_%d = 0.0;", Ib), "", {}, {R("rh", Ib)}, 1, false);
@@ -340,11 +345,13 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
             }
             if (first) P.stmt(sched::K_VALU, "double " + acc + " = 0.0;", "", {}, {acc}, 1, false);
         };
-        for (int Ib = 0; Ib < ZS; Ib++) {
+        auto row_pre = [&](int Ib) {
             need_qp(Ib);  // (its clamp, bounds and w - clamp(w) are the update's too)
+            for (int J : bH.by_row[Ib]) need_qp(J);
+            P.stmt(sched::K_VALU, F_("const double dp_%d = wp_%d - cp_%d;", Ib, Ib, Ib), "", {R("wp", Ib), R("cp", Ib)}, {R("dp", Ib)}, 1);
+        };
+        auto row_post = [&](int Ib) {
             const std::string ph = R("ph", Ib), w = R("w", Ib), cc = R("cp", Ib), lb = R("lbp", Ib), ub = R("ubp", Ib), dd = R("dp", Ib);
-            P.stmt(sched::K_VALU, F_("const double dp_%d = wp_%d - cp_%d;", Ib, Ib, Ib), "", {R("wp", Ib), cc}, {dd}, 1);
-            prim_row(Ib, ph);
             const std::string store = F_(" if (WANT_SOL) *((4 * %d + 3 < DIM_ || 4 * %d + g < DIM_) ? zhp + 4 * %d : dump) = ph_%d;", Ib, Ib, Ib, Ib);
             const std::string light = F_("w[%d] = ph_%d + dp_%d;", Ib, Ib, Ib) + store;
             const std::string full0 =
@@ -361,9 +368,15 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
                 // later check of this iteration can change the outcome - the rest of the iteration exists with and without the checks
                 P.mark = P.stmt(sched::K_MARK, "", "", {"res"}, {"branch"}, 2, false);
             } else {
-                sched::Op &o = P.ops[P.stmt(sched::K_VALU, light, full, {ph, dd, cc, lb, ub, "branch"}, {w}, 2)];
-                (void)o;
+                P.stmt(sched::K_VALU, light, full, {ph, dd, cc, lb, ub, "branch"}, {w}, 2);
             }
+        };
+        // (slab 0 alone: the branch follows its check; then groups of GRP rows: their q_hat and w - clamp(w), their products, their updates)
+        for (int I0 = 0; I0 < ZS; I0 = (I0 == 0 ? 1 : I0 + GRP)) {
+            const int I1 = I0 == 0 ? 1 : std::min(ZS, I0 + GRP);
+            for (int Ib = I0; Ib < I1; Ib++) row_pre(Ib);
+            for (int Ib = I0; Ib < I1; Ib++) prim_row(Ib, R("ph", Ib));
+            for (int Ib = I0; Ib < I1; Ib++) row_post(Ib);
         }
         {
             std::string args;
@@ -388,8 +401,11 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
         // the iteration), 40: 7.8-7.9, 64: 8.4; program order: 10.4; LLVM's own schedule of the round-2 program: 9.7)
         int window = 24;
         if (const char *ev = getenv("SPCIES_BSP_WINDOW")) window = std::max(1, atoi(ev));
+        // The program order above - vector instructions in runs per group of slabs, the substitutions' dependent chain spaced by the other
+        // updates - is issued as it is.  SPCIES_BSP_REORDER=1 list-schedules it (bsp_sched.hpp, `window` operations of look-ahead): measured at C5
+        // 7.8 ms either way (grouped order 7.76; scheduled ungrouped order 7.8; grouped AND scheduled with window 24: 9.8, spills in the loop)
         std::vector<int> order = sched::schedule(P, window);
-        if (getenv("SPCIES_BSP_NOREORDER")) std::iota(order.begin(), order.end(), 0);  // (experiments: the generator's program order)
+        if (!(getenv("SPCIES_BSP_REORDER") && getenv("SPCIES_BSP_REORDER")[0] == '1')) std::iota(order.begin(), order.end(), 0);
         // ---- blocks that appear many times in the stream (stage-invariant dynamics) stay in registers: every product's A operand
         // otherwise comes through the LDS pipe, the busiest unit of the iteration (SPCIES_BSP_KREG: how many; 0 = none)
         int kreg_max = 0;  // (measured at C5: 8 blocks 7.8 ms like none, 12: 8.0, 16: 8.3 - the registers they take cost more than the reads they save)
