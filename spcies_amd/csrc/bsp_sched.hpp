@@ -1,20 +1,23 @@
-// Issue-order scheduler of the BSP block programs (soc_bsp.hpp, ellip_bsp.hpp).
+// Micro-operation form and (optional) issue-order scheduler of the BSP block programs (soc_bsp.hpp).
 //
-// One ADMM iteration of a BSP program is ~1 000 v_mfma_f64_4x4x4 block products, ~700 FP64 vector instructions (q_hat, box / cone
-// updates, residuals) and the LDS reads of bounds, in ONE basic block of straight-line code with every operand a literal.  LLVM's
-// machine scheduler orders that block for register pressure, not for the latencies that matter at one wavefront per SIMD: the
-// matrix pipe is busy 56 % of the time, the rest is a result waited for (a product whose B operand left the pipe a moment ago, a
-// clamp / fma chain placed right in front of the product that consumes it, a row's box update right behind the row's last
-// product).  The generators therefore emit the iteration as a list of micro-operations with their dependences, this file orders
-// them with the latencies MEASURED on gfx950 (profiles/r01_microbench_f64_v*.txt, LLVM's hazard table for the 4-pass DGEMM), and the
-// program is compiled with the machine scheduler switched off, so the order printed here is the order issued.
+// One ADMM iteration of a BSP program is ~1 000 v_mfma_f64_4x4x4 block products, ~600 FP64 vector instructions (q_hat, box / cone
+// updates, residuals) and a few LDS reads, in straight-line code with every operand a literal.  The generator emits it as a list of
+// micro-operations - one statement each: a product, one FP64 instruction, an LDS read; every temporary a value of its own - with their
+// read / write sets (`Program`).  That form is what keeps LLVM from mis-optimising the text (an or-chain of residuals sunk to the end of the
+// iteration, the right-hand side's q_hat CSE'd with the primal phase's and kept alive across both solves) and what lets the generator
+// decide the order: the program is compiled with the machine scheduler switched off, so the order printed is the order issued.
 //
-// Machine model, in issue slots of 4 clocks ("quads": one wave64 instruction per quad at one wavefront per SIMD):
+// Which order: the generator's own program order - vector instructions in runs per group of slabs, the substitutions' dependent chain
+// spaced by the other updates of the columns - is the default.  `schedule()` list-schedules the operations on a model of the SIMD
+// (SPCIES_BSP_REORDER=1); measured at C5 it is no faster than the grouped program order (7.8 ms both), because what it models - result
+// latencies hidden behind other work - is not what costs time at one wavefront per SIMD (profiles/r03_microbench_issue.txt: a vector
+// instruction does not overlap with the wavefront's own MFMA; alone between two MFMAs it costs 12 clocks, in a run 4).
+//
+// Machine model of `schedule()`, in issue slots of 4 clocks ("quads"):
 //   v_mfma_f64_4x4x4 occupies the FP64 pipe for 4 quads; its result feeds the next product's accumulator after 4 quads, a
-//   product's B operand after 6, a vector instruction after 7 (accumulator-file read included);
-//   an FP64 vector instruction occupies the same pipe for 1 quad (they do not co-issue with the matrix instruction),
-//   result to a dependent vector instruction after 2, to a product's B operand after 3;
-//   an LDS read returns after ~32 quads.
+//   product's B operand after 6, a vector instruction after 7 (LLVM's hazard table for the 4-pass DGEMM, accumulator-file read included);
+//   an FP64 vector instruction occupies the same pipe for 1 quad, result to a dependent vector instruction after 2, to a product's B
+//   operand after 3; an LDS read returns after ~32 quads; `sw` quads are lost when a vector instruction follows a product.
 #pragma once
 #include <algorithm>
 #include <cstdio>
