@@ -8,6 +8,7 @@
 
 #include "../../include/spcies_hip.h"
 #include "fista_r.hpp"
+#define SPCIES_FR_NFULL 1  // the build-time instantiations serve controllers whose n is a multiple of 4 (plan_build checks)
 #include "fista_r_kernel.inc"
 #include "rtc_common.hpp"
 
@@ -200,7 +201,7 @@ int plan_build(Plan &p, const Host &h) {
         int idx = 0;
 #define X(NN, KKX, KKS, TT, WW, LL)                                                                                         \
     if (h.N == NN && KX == KKX && KS == KKS && h.terminal == TT && p.NW == WW && p.NLDS == LL && !getenv("SPCIES_FR_RTC_FLAGS") && \
-        !getenv("SPCIES_FR_PD"))                                                                                             \
+        !getenv("SPCIES_FR_PD") && h.n % 4 == 0)                                                                             \
         p.builtin = idx;                                                                                                     \
     idx++;
         SPCIES_FR_BUILTIN(X)
@@ -220,7 +221,8 @@ int plan_build(Plan &p, const Host &h) {
     if (const char *ev = getenv("SPCIES_FR_PD")) pd = atoi(ev);
     p.PD = std::min(std::max(pd, 1), h.N);
     // the horizon is unrolled by #pragma unroll: lift the size limit under which clang honours the pragma
-    std::vector<std::string> extra = {"-DSPCIES_FR_PD=" + std::to_string(p.PD), "-mllvm", "-pragma-unroll-threshold=1000000",
+    std::vector<std::string> extra = {"-DSPCIES_FR_PD=" + std::to_string(p.PD), std::string("-DSPCIES_FR_NFULL=") + (h.n % 4 == 0 ? "1" : "0"),
+                                      "-mllvm", "-pragma-unroll-threshold=1000000",
                                       // MFMA results in either register file: without it the y / lambda values that do not fit
                                       // the 256 architectural registers are spilled to scratch memory instead of AGPRs
                                       "-mllvm", "-amdgpu-mfma-vgpr-form"};
