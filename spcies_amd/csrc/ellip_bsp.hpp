@@ -237,17 +237,48 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     // putting each slab's four instructions right in front of its own MFMAs: a switch from the matrix instruction to a vector instruction costs
     // 8 clocks, profiles/r03_microbench_issue.txt)
     const bool group_qhat = !(getenv("SPCIES_BSP_GROUP") && getenv("SPCIES_BSP_GROUP")[0] == '0');
+    // the distinct (LB, UB, rho) slab patterns: up to 24 live in registers; beyond (vector rho / stage-wise bounds) every slab reads its rows
+    // from LDS - and those reads are requested ONE GROUP AHEAD, behind the previous group's products (a read requested in front of the run of
+    // vector instructions that needs it is waited for: nothing hides it at one wavefront per SIMD)
+    bool in_regs_early;
+    {
+        std::map<std::vector<double>, int> pat;
+        for (int J = 0; J < ZS; J++) {
+            std::vector<double> key;
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * J + r;
+                key.push_back(row < dz ? lb_row[row] : 0.0);
+                key.push_back(row < dz ? ub_row[row] : 0.0);
+                key.push_back(row < dz ? rho_row[row] : 1.0);
+            }
+            pat.emplace(key, (int)pat.size());
+        }
+        in_regs_early = pat.size() <= 24;
+        if (const char *ev = getenv("SPCIES_BSP_BND_REGS")) in_regs_early = atoi(ev) != 0 && pat.size() <= 24;
+    }
+    const bool prefetch_bounds = group_qhat && !in_regs_early && !(getenv("SPCIES_BSP_BND_PREFETCH") && getenv("SPCIES_BSP_BND_PREFETCH")[0] == '0');
+    auto bound_loads = [&](int J0, int J1, const char *tag) {  // named copies of the group's bound / rho rows
+        std::string o;
+        for (int J = J0; J < J1; J++) {
+            snprintf(line, sizeof(line), "              const double lb%s_%d = LBL(%d), ub%s_%d = UBL(%d), rh%s_%d = RHOL(%d);\n", tag, J, J, tag, J, J, tag, J, J);
+            o += line;
+        }
+        return o;
+    };
+    if (prefetch_bounds) body += bound_loads(0, std::min(ZS, SEG_EVERY), "g");
     for (int J0 = 0; J0 < NP; J0 += SEG_EVERY) {
         const int J1 = std::min(NP, J0 + SEG_EVERY);
-        body += "            {\n";
+        if (!prefetch_bounds) body += "            {\n";
         for (int J = J0; J < J1 && group_qhat; J++) {
             if (bG.by_col[J].empty()) continue;
-            char e[64];
-            qhat_expr(J, e, sizeof(e));
+            char e[160];
+            if (prefetch_bounds && J < ZS) snprintf(e, sizeof(e), "(qv[QI_%d] + rhg_%d * (w[%d] - 2.0 * fmin(fmax(w[%d], lbg_%d), ubg_%d)))", J, J, J, J, J, J);
+            else qhat_expr(J, e, sizeof(e));
             snprintf(line, sizeof(line), "              const double qh_%d = %s;\n", J, e);
             body += line;
         }
         if (group_qhat) body += "              SEG;\n";
+        if (prefetch_bounds && J1 < ZS) body += bound_loads(J1, std::min(ZS, J1 + SEG_EVERY), "g");
         for (int J = J0; J < J1; J++) {
             if (bG.by_col[J].empty()) continue;
             char e[64], qn[32];
@@ -264,7 +295,7 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
                 MF(a1, emit_block(blk), qn);
             }
         }
-        body += "            }\n            SEG;\n";
+        body += prefetch_bounds ? "            SEG;\n" : "            }\n            SEG;\n";
     }
     // (the bound rows are read again in the update phase: laundering their index keeps the compiler from holding all of them
     // in registers across the solve)
@@ -411,24 +442,30 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
     }
     // (round 3: by groups of SEG_EVERY rows - the q_hat of the group in one run of vector instructions, the group's products, the group's box
     // updates in one run)
+    if (prefetch_bounds && group_qhat) body += bound_loads(0, std::min(ZS, SEG_EVERY), "p");
     for (int I0 = 0; I0 < ZS && group_qhat; I0 += SEG_EVERY) {
         const int I1 = std::min(ZS, I0 + SEG_EVERY);
-        body += "            {\n";
+        if (!prefetch_bounds) body += "            {\n";
         for (int Ib = I0; Ib < I1; Ib++) {
-            snprintf(line, sizeof(line), "              double ph_%d = 0.0; const double qp_%d = QHZP(%d);\n", Ib, Ib, Ib);
+            if (prefetch_bounds)
+                snprintf(line, sizeof(line), "              double ph_%d = 0.0; double wl_%d = w[%d]; asm volatile(\"\" : \"+v\"(wl_%d)); const double qp_%d = qv[QI_%d] + rhp_%d * "
+                         "(wl_%d - 2.0 * fmin(fmax(wl_%d, lbp_%d), ubp_%d));\n", Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib);
+            else snprintf(line, sizeof(line), "              double ph_%d = 0.0; const double qp_%d = QHZP(%d);\n", Ib, Ib, Ib);
             body += line;
         }
         body += "              SEG;\n";
+        if (prefetch_bounds && I1 < ZS) body += bound_loads(I1, std::min(ZS, I1 + SEG_EVERY), "p");
         for (int Ib = I0; Ib < I1; Ib++) {
             snprintf(a1, sizeof(a1), "ph_%d", Ib);
             prim_row(Ib, std::string(a1).c_str());
         }
         body += "              SEG;\n";
         for (int Ib = I0; Ib < I1; Ib++) {
-            snprintf(line, sizeof(line), "              LAUNDER; ZUPD(%d, ph_%d);\n", Ib, Ib);
+            if (prefetch_bounds) snprintf(line, sizeof(line), "              ZUPD2(%d, ph_%d, lbp_%d, ubp_%d);\n", Ib, Ib, Ib, Ib);
+            else snprintf(line, sizeof(line), "              LAUNDER; ZUPD(%d, ph_%d);\n", Ib, Ib);
             body += line;
         }
-        body += "            }\n            SEG;\n";
+        body += prefetch_bounds ? "            SEG;\n" : "            }\n            SEG;\n";
     }
     // ---- terminal block (:318-386)
     if (!equ) body += "            SEG;\n            { double zN[TS_], vn[TS_], dd[TS_], pv[TS_], tt[TS_];\n";
@@ -732,9 +769,10 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
         int kk = 0;
         RING_INIT
         // z slab I: v = clamp(z + lambda / rho), lambda += rho (z - v), residuals (:490-568)
-#define ZUPD(I, zh)                                                                              \
+#define ZUPD(I, zh) ZUPD2(I, zh, LBR(I), UBR(I))
+#define ZUPD2(I, zh, lbx_, ubx_)                                                                 \
     do {                                                                                         \
-        const double lb_ = LBR(I), ub_ = UBR(I);                                                 \
+        const double lb_ = (lbx_), ub_ = (ubx_);                                                 \
         const double wo_ = w[I], vo_ = fmin(fmax(wo_, lb_), ub_);                                \
         const double wn_ = (zh) + (wo_ - vo_), v_ = fmin(fmax(wn_, lb_), ub_);                   \
         w[I] = wn_;                                                                              \
