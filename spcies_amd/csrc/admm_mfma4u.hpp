@@ -227,7 +227,17 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
             }
             return t == N ? kap_N : kap_m;
         };
+#ifdef SPCIES_MFMA4U_RC_REGS
+        // (experiment: the row constants of stages 0 and N in registers too - an LDS read in front of the instruction that needs it is waited for)
+        d4 a3N = RC(Mfma4uRC::A3_N), rdN = RC(Mfma4uRC::RD_N);
+        double a30s = RC(Mfma4uRC::A3_0)[KS - 1], a10s = RC(Mfma4uRC::A1_0)[KS - 1];
+#pragma unroll
+        for (int r = KX; r < 4; r++) { a3N[r] = 0.0; rdN[r] = 0.0; }
+        auto one = [&](double x) -> d4 { d4 k0 = {0, 0, 0, 0}; k0[KS - 1] = x; return k0; };
+        auto A3 = [&](int t) -> d4 { return t == 0 ? one(a30s) : (t == N ? a3N : a3m); };
+#else
         auto A3 = [&](int t) -> d4 { return t == 0 ? RC(Mfma4uRC::A3_0) : (t == N ? RC(Mfma4uRC::A3_N) : a3m); };
+#endif
         auto DD = [&](int t) -> d4 { return RC(t == 0 ? Mfma4uRC::D_0 : (t == N ? Mfma4uRC::D_N : Mfma4uRC::D_MID)); };
         auto LBo = [&](int t) -> d4 { return RC(t == 0 ? Mfma4uRC::LB_0 : (t == N ? Mfma4uRC::LB_N : Mfma4uRC::LB_MID)); };
 
@@ -322,10 +332,18 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
                 d4 z;
                 const d4 s = qhat(t, cwt);
                 if (t == N) {
+#ifdef SPCIES_MFMA4U_RC_REGS
+                    x = rdN * s - mu[N - 1];
+#else
                     x = RC(Mfma4uRC::RD_N) * s - mu[N - 1];
+#endif
                     z = -A3(N);
                 } else if (t == 0) {
+#ifdef SPCIES_MFMA4U_RC_REGS
+                    z = one(a10s) * s - A3(0);
+#else
                     z = RC(Mfma4uRC::A1_0) * s - A3(0);
+#endif
                     x = mu[0];
                 } else {
                     z = a1m * s - a3m;
