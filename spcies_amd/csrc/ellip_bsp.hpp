@@ -642,6 +642,28 @@ struct EArgs {
     double tol, rho, rho_i, r2, r;
     long B;
 };
+// cross-row reductions without the LDS crossbar (gfx950 v_permlane16_swap / v_permlane32_swap: a handful of vector instructions instead of
+// ds_bpermute round trips whose latency nothing hides at one wavefront per SIMD; bit-identical sums, tools/probe_permlane_swap.hip)
+__device__ __forceinline__ double xsum16_(double x) {  // x + x[lane ^ 16]
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double xsum32_(double x) {  // x + x[lane ^ 32]
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double row0_(double x) {  // x[lane % 16]: the first 16-lane row in every row
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const auto c = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(b[0], b[0], false, false);
+    return __hiloint2double(d[0], c[0]);
+}
 template <bool WANT_SOL>
 __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__restrict__ table_g, const double *__restrict__ cst,
                                                const double *__restrict__ x0g, const double *__restrict__ xrg,
@@ -794,8 +816,8 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
     do {                                                                                         \
         double vpv_ = 0.0;                                                                       \
         _Pragma("unroll") for (int k_ = 0; k_ < TS_; k_++) vpv_ += dd[k_] * pv[k_];              \
-        vpv_ += __shfl_xor(vpv_, 16);                                                            \
-        vpv_ += __shfl_xor(vpv_, 32);                                                            \
+        vpv_ = xsum16_(vpv_);                                                                          \
+        vpv_ = xsum32_(vpv_);                                                                          \
         if (vpv_ > p.r2) {                                                                       \
             const double sc_ = p.r / sqrt(vpv_);                                                 \
             _Pragma("unroll") for (int k_ = 0; k_ < TS_; k_++) vn[k_] = sc_ * dd[k_] + CE(k_);   \

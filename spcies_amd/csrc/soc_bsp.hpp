@@ -849,6 +849,28 @@ struct Args {
     double tol_p, tol_d, rho, rho_i, sigma, sigma_i;
     long B;
 };
+// cross-row reductions without the LDS crossbar (gfx950 v_permlane16_swap / v_permlane32_swap: a handful of vector instructions instead of
+// ds_bpermute round trips whose latency nothing hides at one wavefront per SIMD; bit-identical sums, tools/probe_permlane_swap.hip)
+__device__ __forceinline__ double xsum16_(double x) {  // x + x[lane ^ 16]
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double xsum32_(double x) {  // x + x[lane ^ 32]
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double row0_(double x) {  // x[lane % 16]: the first 16-lane row in every row
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const auto c = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(b[0], b[0], false, false);
+    return __hiloint2double(d[0], c[0]);
+}
 template <bool WANT_SOL>
 __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__restrict__ table_g, const double *__restrict__ cst,
                                              const double *__restrict__ x0g, const double *__restrict__ xrg,
@@ -988,9 +1010,9 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
             v_[k_] = (sh)[k_] + rho_i * mu[k_];                                                  \
             nrm_ += (k_ == 0 && g == 0) ? 0.0 : v_[k_] * v_[k_];                                 \
         }                                                                                        \
-        nrm_ += __shfl_xor(nrm_, 16);                                                            \
-        nrm_ += __shfl_xor(nrm_, 32);                                                            \
-        const double s_norm_ = sqrt(nrm_), s0_ = __shfl(v_[0], c);                               \
+        nrm_ = xsum16_(nrm_);                                                                          \
+        nrm_ = xsum32_(nrm_);                                                                          \
+        const double s_norm_ = sqrt(nrm_), s0_ = row0_(v_[0]);                                   \
         _Pragma("unroll") for (int k_ = 0; k_ < SS_; k_++) {                                     \
             double v = v_[k_];                                                                   \
             if (s_norm_ <= s0_) {                                                                \
@@ -1014,9 +1036,9 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
             v_[k_] = (sh)[k_] + rho_i * mu[k_];                                                  \
             nrm_ += (k_ == 0 && g == 0) ? 0.0 : v_[k_] * v_[k_];                                 \
         }                                                                                        \
-        nrm_ += __shfl_xor(nrm_, 16);                                                            \
-        nrm_ += __shfl_xor(nrm_, 32);                                                            \
-        const double s_norm_ = sqrt(nrm_), s0_ = __shfl(v_[0], c);                               \
+        nrm_ = xsum16_(nrm_);                                                                          \
+        nrm_ = xsum32_(nrm_);                                                                          \
+        const double s_norm_ = sqrt(nrm_), s0_ = row0_(v_[0]);                                   \
         _Pragma("unroll") for (int k_ = 0; k_ < SS_; k_++) {                                     \
             double v = v_[k_];                                                                   \
             if (s_norm_ <= s0_) {                                                                \
