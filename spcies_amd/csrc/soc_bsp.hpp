@@ -218,6 +218,17 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
             }
         }
         // q_hat of primal slab J from the current state, as micro-operations; `ph`: "g" (right-hand side) or "p" (primal phase)
+        // the (LB, UB) rows of slab J when they are not register patterns: LDS reads, requested ONE GROUP AHEAD of the run of vector
+        // instructions that needs them (behind the previous group's products: a read requested in front of its use is waited for)
+        std::vector<char> bl_done[2] = {std::vector<char>(ZS, 0), std::vector<char>(ZS, 0)};
+        auto bound_loads = [&](int J, const char *ph) {
+            const int pi = ph[0] == 'p';
+            if (bnd_in_regs || J >= ZS || bl_done[pi][J]) return;
+            bl_done[pi][J] = 1;
+            const std::string lb = F_("lb%s_%d", ph, J), ub = F_("ub%s_%d", ph, J), gov = pi ? "go_p" : "go_g";
+            P.stmt(sched::K_LDS, F_("const double %s = LBR(%d);", lb.c_str(), J), "", {gov}, {lb}, 1);
+            P.stmt(sched::K_LDS, F_("const double %s = UBR(%d);", ub.c_str(), J), "", {gov}, {ub}, 1);
+        };
         auto qhat_ops = [&](int J, const char *ph) {
             if (J < ZS) {
                 const bool prim = ph[0] == 'p';
@@ -234,9 +245,9 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
                 if (bnd_in_regs) {  // (plain aliases: no instruction)
                     P.stmt(sched::K_VALU, F_("const double %s = lbv[%d], %s = ubv[%d];", lb.c_str(), bnd_of[J], ub.c_str(), bnd_of[J]), "", {}, {lb, ub}, 0, false);
                 } else {
-                    P.stmt(sched::K_LDS, F_("const double %s = LBR(%d);", lb.c_str(), J), "", {gov}, {lb}, 1);
-                    P.stmt(sched::K_LDS, F_("const double %s = UBR(%d);", ub.c_str(), J), "", {gov}, {ub}, 1);
+                    bound_loads(J, ph);
                 }
+                (void)gov;
                 P.stmt(sched::K_VALU, F_("const double %s = fmax(%s, %s);", c1.c_str(), wx.c_str(), lb.c_str()), "", {wv, lb}, {c1}, 1);
                 P.stmt(sched::K_VALU, F_("const double %s = fmin(%s, %s);", cc.c_str(), c1.c_str(), ub.c_str()), "", {c1, ub}, {cc}, 1);
                 P.stmt(sched::K_VALU, F_("const double %s = __builtin_fma(-2.0, %s, %s);", tt.c_str(), cc.c_str(), wx.c_str()), "", {cc, wv}, {tt}, 1);
@@ -259,6 +270,8 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
         for (int J0 = 0; J0 < NP; J0 += GRP) {
             for (int J = J0; J < std::min(NP, J0 + GRP); J++)
                 if (!bG.by_col[J].empty()) qhat_ops(J, "g");
+            for (int J = J0 + GRP; J < std::min(ZS, J0 + 2 * GRP); J++)
+                if (!bG.by_col[J].empty()) bound_loads(J, "g");
             for (int J = J0; J < std::min(NP, J0 + GRP); J++)
                 for (int Ib : bG.by_col[J]) {
                     double blk[16];
@@ -375,6 +388,7 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
         for (int I0 = 0; I0 < ZS; I0 = (I0 == 0 ? 1 : I0 + GRP)) {
             const int I1 = I0 == 0 ? 1 : std::min(ZS, I0 + GRP);
             for (int Ib = I0; Ib < I1; Ib++) row_pre(Ib);
+            for (int Ib = I1; Ib < std::min(ZS, I1 + GRP); Ib++) bound_loads(Ib, "p");
             for (int Ib = I0; Ib < I1; Ib++) prim_row(Ib, R("ph", Ib));
             for (int Ib = I0; Ib < I1; Ib++) row_post(Ib);
         }
