@@ -80,27 +80,36 @@ struct RecordWriter {
     RecordWriter(double *b, bool pr) : base(b), pair(pr) {}
     void emit(const DM &M, int KI, int KJ, int pat) {
         auto at = [&](int i, int j) { return (i < M.r && j < M.c) ? M(i, j) : 0.0; };
-        for (int J = 0; J < KJ; J++)
-            for (int R = 0; R < (KI + 1) / 2; R++) {
-                if (!mf_nz(R, J, KI, pat)) {
-                    for (int r = 0; r < 2; r++)
-                        for (int i = 0; i < 4; i++)
-                            for (int k = 0; k < 4; k++)
-                                if (at(4 * (2 * R + r) + i, 4 * J + k) != 0.0) structure_ok = false;
-                    continue;
-                }
-                double *t = pair ? base + (size_t)(cursor / 2) * 64 + (cursor % 2) : base + (size_t)cursor * 32;
-                for (int k = 0; k < 4; k++)
-                    for (int r = 0; r < 2; r++)
-                        for (int i = 0; i < 4; i++) {
-                            // a block outside the pattern that shares its MFMA with one inside must be structurally zero too
-                            const bool inside = 2 * R + r < KI && blk_nz(2 * R + r, J, pat);
-                            const double v = at(4 * (2 * R + r) + i, 4 * J + k);
-                            if (!inside && v != 0.0) structure_ok = false;
-                            t[(pair ? 2 : 1) * (4 * (2 * k + r) + i)] = inside ? v : 0.0;
-                        }
-                cursor++;
+        // one record: block r = 0 carries M[2 R][J0], block r = 1 carries M[2 R + 1][J1] (J < 0: no block)
+        auto put = [&](int R, int J0, int J1, bool issued) {
+            const int Jr[2] = {J0, J1};
+            if (!issued) {
+                for (int r = 0; r < 2; r++)
+                    for (int i = 0; i < 4 && Jr[r] >= 0; i++)
+                        for (int k = 0; k < 4; k++)
+                            if (at(4 * (2 * R + r) + i, 4 * Jr[r] + k) != 0.0) structure_ok = false;
+                return;
             }
+            double *t = pair ? base + (size_t)(cursor / 2) * 64 + (cursor % 2) : base + (size_t)cursor * 32;
+            for (int k = 0; k < 4; k++)
+                for (int r = 0; r < 2; r++)
+                    for (int i = 0; i < 4; i++) {
+                        // a block outside the pattern that shares its MFMA with one inside must be structurally zero too
+                        const bool inside = Jr[r] >= 0 && in_blk(2 * R + r, Jr[r], KI, KJ, pat);
+                        const double v = Jr[r] >= 0 ? at(4 * (2 * R + r) + i, 4 * Jr[r] + k) : 0.0;
+                        if (!inside && v != 0.0) structure_ok = false;
+                        t[(pair ? 2 : 1) * (4 * (2 * k + r) + i)] = inside ? v : 0.0;
+                    }
+            cursor++;
+        };
+        // pair order (eadmm_r_kernel.inc, mf_count): for P, for R: the diagonal record, the cross record; then an odd last k-slab
+        for (int P = 0; P < KJ / 2; P++)
+            for (int R = 0; R < (KI + 1) / 2; R++) {
+                put(R, 2 * P, 2 * P + 1, nz_diag(R, P, KI, KJ, pat));
+                put(R, 2 * P + 1, 2 * P, nz_cross(R, P, KI, KJ, pat));
+            }
+        if (KJ % 2)
+            for (int R = 0; R < (KI + 1) / 2; R++) put(R, KJ - 1, KJ - 1, mf_nz(R, KJ - 1, KI, pat));
     }
 };
 
