@@ -302,9 +302,18 @@ int spcies_hip_get_extra_width(spcies_hip_handle h, long *doubles_per_instance);
 int spcies_hip_host_alloc(size_t bytes, void **ptr);
 int spcies_hip_host_free(void *ptr);
 
-/* Run-time specialised kernels (hiprtc) are compiled once per process and controller: code objects served from /
- * added to the process-wide cache so far (the N handles of spcies_hip_create_multi compile once). */
+/* Run-time specialised kernels (hiprtc) are compiled once per controller and MACHINE: code objects are served from a bounded
+ * in-memory cache (SPCIES_HIP_RTC_CACHE_MB, default 256), then from the on-disk cache $SPCIES_HIP_CACHE_DIR |
+ * $XDG_CACHE_HOME/spcies_hip | $HOME/.cache/spcies_hip (<sha256 of compiler identity, options, source>.hsaco, written
+ * atomically, compiled under flock: the ranks of a multi-GPU job, a later MATLAB session or test process read the file instead
+ * of compiling; SPCIES_HIP_DISK_CACHE=0 switches the disk off).  *hits = served from memory or disk, *misses = compilations. */
 int spcies_hip_rtc_cache_stats(long *hits, long *misses);
+/* out[0..n): memory hits, disk hits, compilations, evictions from memory, files written, failed file writes (n <= 6 used). */
+int spcies_hip_rtc_cache_stats_ex(long *out, int n);
+/* Test hook (no GPU, no hiprtc): runs the cache machinery above with a stand-in compiler that takes work_ms milliseconds
+ * (work_ms < 0: fails) and returns bytes that depend on `text` only.  *source: 0 memory, 1 disk, 2 compiled; *checksum of the
+ * code object handed back; drop_memory != 0 empties the in-memory cache first.  tests/test_rtc_disk_cache.py. */
+int spcies_hip_rtc_cache_selftest(const char *text, int work_ms, int drop_memory, int *source, unsigned long long *checksum);
 
 /* Batch statistics of a solve (the batch counterpart of the dense MATLAB solvers' genHist record,
  * platforms/Matlab/spcies_laxMPC_ADMM_solver.m:253-261): k, e_flag are DEVICE arrays [B] as a device solve left them;

@@ -214,7 +214,7 @@ void plan_free(Plan &p) {
     p.d_table = nullptr;
     if (p.d_yscr) hipFree(p.d_yscr);
     p.d_yscr = nullptr;
-    if (p.module) hipModuleUnload((hipModule_t)p.module);
+    if (p.module) rtc::unload_module((hipModule_t)p.module);
     p.module = nullptr;
     p.ok = false;
 }

@@ -178,7 +178,7 @@ void plan_free(Plan &p) {
     p.d_table = nullptr;
     if (p.d_scr) hipFree(p.d_scr);
     p.d_scr = nullptr;
-    if (p.module) hipModuleUnload((hipModule_t)p.module);
+    if (p.module) rtc::unload_module((hipModule_t)p.module);
     p.module = nullptr;
     p.ok = false;
 }

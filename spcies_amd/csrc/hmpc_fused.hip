@@ -163,7 +163,7 @@ void plan_free(Plan &p) {
     if (p.d_ME) hipFree(p.d_ME);
     if (p.d_PRO) hipFree(p.d_PRO);
     if (p.d_C) hipFree(p.d_C);
-    if (p.module) hipModuleUnload((hipModule_t)p.module);
+    if (p.module) rtc::unload_module((hipModule_t)p.module);
     p.d_ME = p.d_PRO = p.d_C = nullptr;
     p.module = nullptr;
     p.ok = false;

@@ -22,7 +22,7 @@ struct Mfma4Module {
     bool ok = false;
 };
 inline void module_free(Mfma4Module &m) {
-    if (m.module) hipModuleUnload(m.module);
+    if (m.module) rtc::unload_module(m.module);
     m.module = nullptr;
     m.ok = false;
 }

@@ -11,6 +11,9 @@
 #include <memory>
 #include <mutex>
 
+#include <sys/stat.h>
+
+#include "code_cache.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -87,29 +90,61 @@ inline Hiprtc &hiprtc() {  // one binding (and one link namespace) per process
 }
 
 // Everything that touches the binding - open(), the environment sync of the private link namespace, the compiler itself - runs
-// under ONE process-wide lock: handles may be created from several host threads (spcies_hip_create_multi does: one per device).
+// under ONE process-wide lock: handles may be created from several host threads (spcies_hip_create_multi does: one per device), and
+// neither the dlmopen'ed namespace's environment nor comgr's global state is documented as thread-safe.  Cache look-ups, disk hits
+// and the statistics do NOT take it (code_cache.hpp has its own short lock).
 inline std::mutex &rtc_mutex() {
     static std::mutex mu;
     return mu;
 }
 
-// Code objects compiled in this process, keyed by (source, file name, name expressions, options): the N handles of
-// spcies_hip_create_multi - and any later handle for the same controller - compile once (4-10 s for a BSP / MFMA4R program) and
-// load the same code object on their own device.  Entries are immutable once inserted and live as long as the process.
-struct CodeObject {
-    std::vector<char> code;
-    std::vector<std::string> lowered;
-};
-inline std::map<std::string, std::shared_ptr<const CodeObject>> &code_cache() {
-    static std::map<std::string, std::shared_ptr<const CodeObject>> cache;
-    return cache;
-}
-struct CacheStats { long hits = 0, misses = 0; };
-inline CacheStats &cache_stats() {
-    static CacheStats st;
-    return st;
+// Identity of the compiler that would run: hiprtc's version and the installed libraries' path, size and modification time - part
+// of every cache key, so a ROCm update never serves code objects of the previous compiler (code_cache.hpp).
+inline const std::string &compiler_identity() {
+    static std::string id;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        Hiprtc &rt = hiprtc();
+        std::string s = "hiprtc";
+        if (rt.lib) {
+            int (*version)(int *, int *) = (int (*)(int *, int *))dlsym(rt.lib, "hiprtcVersion");
+            int major = 0, minor = 0;
+            if (version && version(&major, &minor) == 0) s += " " + std::to_string(major) + "." + std::to_string(minor);
+            Dl_info info;
+            if (rt.create && dladdr((void *)rt.create, &info) && info.dli_fname) {
+                char real[PATH_MAX];
+                const std::string path = realpath(info.dli_fname, real) ? real : info.dli_fname;
+                const std::string dir = path.substr(0, path.rfind('/') + 1);
+                for (const std::string &f : {path, dir + "libamd_comgr.so"}) {
+                    char r2[PATH_MAX];
+                    const std::string rp = realpath(f.c_str(), r2) ? r2 : f;
+                    struct stat st;
+                    if (stat(rp.c_str(), &st) == 0)
+                        s += " " + rp + ":" + std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtime);
+                }
+            }
+        }
+        id = s;
+    });
+    return id;
 }
 
+// A loaded module pins the code object it was created from (hipModuleLoadData is not documented to copy the image): the pin is
+// dropped by unload_module, which every owner of a run-time compiled module calls instead of hipModuleUnload.
+inline std::map<hipModule_t, std::shared_ptr<const CodeObject>> &module_pins() {
+    static std::map<hipModule_t, std::shared_ptr<const CodeObject>> pins;
+    return pins;
+}
+inline std::mutex &pins_mutex() {
+    static std::mutex mu;
+    return mu;
+}
+inline void unload_module(hipModule_t m) {
+    if (!m) return;
+    (void)hipModuleUnload(m);
+    std::lock_guard<std::mutex> lk(pins_mutex());
+    module_pins().erase(m);
+}
 
 inline std::vector<std::string> split_flags(const char *ev) {  // blank-separated compiler options of an experiment variable
     std::vector<std::string> out;
@@ -127,68 +162,68 @@ inline std::vector<std::string> split_flags(const char *ev) {  // blank-separate
     return out;
 }
 
-// Compile `src` for gfx950 (or take the code object this process compiled before) and load it on the current device: `names`
-// are name expressions (template instantiations) resolved to functions
+// Compile `src` for gfx950 - or take the code object from the process's cache or the on-disk cache (code_cache.hpp) - and load it
+// on the current device: `names` are name expressions (template instantiations) resolved to functions
 inline int compile_module(const char *src, const char *fname, const std::vector<std::string> &names, const std::vector<std::string> &extra_opts,
                           hipModule_t *module, hipFunction_t *fns, bool names_are_symbols = false) {
     // names_are_symbols: `names` are extern "C" kernels of the source (a generated program), taken as they are
-    std::shared_ptr<const CodeObject> co;
-    {
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans"};
+    for (const std::string &e : extra_opts) opts.push_back(e);
+    {   // the binding first: the key carries the identity of the compiler that would run
         std::lock_guard<std::mutex> lk(rtc_mutex());
-        // the key holds the full text: a hash collision must not hand a controller somebody else's program
-        std::string key = std::string(fname) + '\x1f';
-        for (const std::string &nm : names) key += nm + '\x1e';
-        key += '\x1f';
-        for (const std::string &e : extra_opts) key += e + '\x1e';
-        key += '\x1f';
-        key += src;
-        auto it = getenv("SPCIES_HIP_RTC_NOCACHE") ? code_cache().end() : code_cache().find(key);
-        if (it != code_cache().end()) {
-            co = it->second;
-            cache_stats().hits++;
-        } else {
-            Hiprtc &rt = hiprtc();
-            int rc = rt.open();
-            if (rc) return rc;
-            rt.sync_env();
-            void *prog = nullptr;
-            if (rt.create(&prog, src, fname, 0, nullptr, nullptr) != 0) return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");
-            for (const std::string &nm : names)
-                if (!names_are_symbols && rt.add_name(prog, nm.c_str()) != 0) {
-                    rt.destroy(&prog);
-                    return fail(SPCIES_HIP_EHIP, "hiprtcAddNameExpression failed");
-                }
-            std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans"};
-            for (const std::string &e : extra_opts) opts.push_back(e.c_str());
-            if (rt.compile(prog, (int)opts.size(), opts.data()) != 0) {
-                size_t ls = 0;
-                rt.log_size(prog, &ls);
-                std::string lg(ls + 1, '\0');
-                if (ls) rt.log(prog, &lg[0]);
-                rt.destroy(&prog);
-                return fail(SPCIES_HIP_EHIP, "hiprtcCompileProgram failed: %.400s", lg.c_str());
-            }
-            auto fresh = std::make_shared<CodeObject>();
-            size_t cs = 0;
-            rt.code_size(prog, &cs);
-            fresh->code.resize(cs);
-            rt.code(prog, fresh->code.data());
-            for (const std::string &nm : names) {
-                const char *ln = names_are_symbols ? nm.c_str() : nullptr;
-                if (!names_are_symbols && (rt.lowered(prog, nm.c_str(), &ln) != 0 || !ln)) {
-                    rt.destroy(&prog);
-                    return fail(SPCIES_HIP_EHIP, "hiprtcGetLoweredName failed");
-                }
-                fresh->lowered.push_back(ln);
-            }
-            rt.destroy(&prog);
-            cache_stats().misses++;
-            co = fresh;
-            if (!getenv("SPCIES_HIP_RTC_NOCACHE")) code_cache().emplace(std::move(key), co);
-        }
+        int rc = hiprtc().open();
+        if (rc) return rc;
     }
+    std::vector<std::string> key_names = names;
+    key_names.push_back(names_are_symbols ? "#symbols" : "#expressions");
+    const CacheKey key = make_key(compiler_identity(), fname, key_names, opts, src);
+    auto compile = [&](CodeObject &out) -> int {
+        std::lock_guard<std::mutex> lk(rtc_mutex());
+        Hiprtc &rt = hiprtc();
+        rt.sync_env();
+        void *prog = nullptr;
+        if (rt.create(&prog, src, fname, 0, nullptr, nullptr) != 0) return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");
+        for (const std::string &nm : names)
+            if (!names_are_symbols && rt.add_name(prog, nm.c_str()) != 0) {
+                rt.destroy(&prog);
+                return fail(SPCIES_HIP_EHIP, "hiprtcAddNameExpression failed");
+            }
+        std::vector<const char *> copts;
+        for (const std::string &o : opts) copts.push_back(o.c_str());
+        if (rt.compile(prog, (int)copts.size(), copts.data()) != 0) {
+            size_t ls = 0;
+            rt.log_size(prog, &ls);
+            std::string lg(ls + 1, '\0');
+            if (ls) rt.log(prog, &lg[0]);
+            rt.destroy(&prog);
+            return fail(SPCIES_HIP_EHIP, "hiprtcCompileProgram failed: %.400s", lg.c_str());
+        }
+        size_t cs = 0;
+        rt.code_size(prog, &cs);
+        out.code.resize(cs);
+        rt.code(prog, out.code.data());
+        for (const std::string &nm : names) {
+            const char *ln = names_are_symbols ? nm.c_str() : nullptr;
+            if (!names_are_symbols && (rt.lowered(prog, nm.c_str(), &ln) != 0 || !ln)) {
+                rt.destroy(&prog);
+                return fail(SPCIES_HIP_EHIP, "hiprtcGetLoweredName failed");
+            }
+            out.lowered.push_back(ln);
+        }
+        rt.destroy(&prog);
+        return 0;
+    };
+    std::shared_ptr<const CodeObject> co;
+    const int rc = CodeCache::instance().get(key, compile, &co);
+    if (rc) return rc;
+    if (co->lowered.size() != names.size())
+        return fail(SPCIES_HIP_EHIP, "cached code object of %s has %zu kernels, %zu expected", fname, co->lowered.size(), names.size());
     // loading is per device (the caller has made its device current) and needs no lock
     SPCIES_HIP_CHECK(hipModuleLoadData(module, co->code.data()));
+    {
+        std::lock_guard<std::mutex> lk(pins_mutex());
+        module_pins()[*module] = co;
+    }
     for (size_t i = 0; i < co->lowered.size(); i++) SPCIES_HIP_CHECK(hipModuleGetFunction(&fns[i], *module, co->lowered[i].c_str()));
     return 0;
 }

@@ -46,7 +46,7 @@ struct Plan {
     int num_cu = 256;
 };
 inline void plan_free(Plan &p) {
-    if (p.module) hipModuleUnload(p.module);
+    if (p.module) rtc::unload_module(p.module);
     if (p.d_table) hipFree(p.d_table);
     if (p.d_consts) hipFree(p.d_consts);
     p.module = nullptr;
@@ -1145,7 +1145,7 @@ extern "C" __global__ __launch_bounds__(256, 1) void soc_bsp_kernel_sol(Args p, 
 
 // compiles p.src (hiprtc) and loads the module; *scratch = bytes of scratch memory per lane of the no-record kernel
 inline int compile_program(Plan &p, int *scratch, const char *name0 = "soc_bsp_kernel", const char *name1 = "soc_bsp_kernel_sol") {
-    if (p.module) hipModuleUnload(p.module);
+    if (p.module) rtc::unload_module(p.module);
     p.module = nullptr;
     // experiments: SPCIES_BSP_FLAGS holds extra compiler options, blank-separated
     std::vector<std::string> extra = rtc::split_flags(getenv("SPCIES_BSP_FLAGS"));

@@ -1745,9 +1745,41 @@ int spcies_hip_host_free(void *ptr) {
 }
 
 int spcies_hip_rtc_cache_stats(long *hits, long *misses) {
-    std::lock_guard<std::mutex> lk(rtc::rtc_mutex());
-    if (hits) *hits = rtc::cache_stats().hits;
-    if (misses) *misses = rtc::cache_stats().misses;
+    const rtc::CacheStats st = rtc::CodeCache::instance().stats();  // (the cache's own short lock: never waits for a compilation)
+    if (hits) *hits = st.mem_hits + st.disk_hits;
+    if (misses) *misses = st.compiles;
+    return 0;
+}
+
+int spcies_hip_rtc_cache_stats_ex(long *out, int n) {
+    if (!out || n < 0) return fail(SPCIES_HIP_EINVAL, "NULL argument");
+    const rtc::CacheStats st = rtc::CodeCache::instance().stats();
+    const long all[6] = {st.mem_hits, st.disk_hits, st.compiles, st.evictions, st.disk_writes, st.disk_errors};
+    for (int i = 0; i < n && i < 6; i++) out[i] = all[i];
+    for (int i = 6; i < n; i++) out[i] = 0;
+    return 0;
+}
+
+int spcies_hip_rtc_cache_selftest(const char *text, int work_ms, int drop_memory, int *source, unsigned long long *checksum) {
+    if (!text) return fail(SPCIES_HIP_EINVAL, "NULL argument");
+    if (drop_memory) rtc::CodeCache::instance().clear_memory();
+    const rtc::CacheKey key = rtc::make_key("selftest compiler", "selftest.hip", {"kernel"}, {"-O3"}, text);
+    // the stand-in compiler: takes work_ms, returns bytes that depend on the text only
+    auto compile = [&](rtc::CodeObject &out) -> int {
+        if (work_ms < 0) return fail(SPCIES_HIP_EHIP, "selftest: the stand-in compiler was told to fail");
+        usleep((useconds_t)work_ms * 1000);
+        const size_t len = strlen(text);
+        out.code.resize(4096);
+        for (size_t i = 0; i < out.code.size(); i++) out.code[i] = (char)(text[i % (len ? len : 1)] ^ (char)(i * 31));
+        out.lowered = {std::string("lowered_") + std::to_string(len)};
+        return 0;
+    };
+    std::shared_ptr<const rtc::CodeObject> co;
+    int src = -1;
+    const int rc = rtc::CodeCache::instance().get(key, compile, &co, &src);
+    if (rc) return rc;
+    if (source) *source = src;
+    if (checksum) *checksum = rtc::fnv1a64(co->code.data(), co->code.size(), rtc::fnv1a64(co->lowered[0].data(), co->lowered[0].size()));
     return 0;
 }
 
