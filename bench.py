@@ -43,6 +43,11 @@ EXTRA_CONFIGS = {
                    what="configs[4]a: ellipMPC-ADMM-soc, 12-state, N=15, 200 iterations, 1/8 shard (65536) of batch=524288"),
     "C5_hmpc": dict(name="C5_HMPC_SADMM", B=65536, flop=2.0 * 282 * 282 * 200, io=232,
                     what="configs[4]b: HMPC-SADMM split, 12-state, N=15, 200 iterations, 1/8 shard (65536) of batch=524288"),
+    # the time-varying laxMPC-ADMM solver at the C2 shape, ONE MODEL PER INSTANCE (A, B, Q, R, LB, UB arrive with the
+    # call: 232 doubles per instance next to x0, xr, ur) - the on-line factorisation plus 200 iterations.  Sixteen instances no longer
+    # share their matrices, so this path is HBM-bound by design: `flop` as C2 plus the update phase, `io` = inputs + model + outputs.
+    "C2_tv": dict(name="C2_lax", tv=True, B=65536, flop=27498.0 * 200 + 95e3, io=232 + 232 * 8,
+                  what="SURVEY 8f rank 1: time-varying laxMPC-ADMM, C2 shape (n=12, m=2, N=15), one model per instance, 200 iterations, batch=65536"),
 }
 
 
@@ -51,7 +56,7 @@ def traffic_from_profile(variant):
     profiles/rNN_<variant>_pmc_summary.txt: separate FETCH_SIZE / WRITE_SIZE runs of this same command), corrected as
     MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE x 2 on gfx950, values in KB.  Returns (bytes, file) -
     a constant read from the repository, NOT a measurement of the run that prints it (`traffic_source` says so)."""
-    for stem in (f"r03_C2_{variant}", f"r02_C2_{variant}", f"r02_{variant}", f"r01_{variant}"):
+    for stem in (f"r04_C2_{variant}", f"r03_C2_{variant}", f"r02_C2_{variant}", f"r02_{variant}", f"r01_{variant}"):
         path = os.path.join(ROOT, "profiles", f"{stem}_pmc_summary.txt")
         if not os.path.exists(path):
             continue
@@ -69,14 +74,14 @@ def traffic_from_profile(variant):
     return None, None
 
 
-_PROFILE_TAG = {"C3": "C3", "C4": "C4", "C5_soc": "C5soc", "C5_hmpc": "C5hmpc"}
+_PROFILE_TAG = {"C3": "C3", "C4": "C4", "C5_soc": "C5soc", "C5_hmpc": "C5hmpc", "C2_tv": "C2tv"}
 
 
 def design_traffic(key, variant):
     """HBM bytes per launch of a configuration's kernel from its committed rocprofv3 PMC passes (profiles/rNN_<config>_<variant>_pmc_summary.txt,
     newest round first; FETCH_SIZE x 2 + WRITE_SIZE, KB) - the DESIGN traffic, a constant read from the repository like `roofline.traffic`
     above.  Only a profile of the SAME variant counts."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{_PROFILE_TAG.get(key, key)}_{variant}_pmc_summary.txt")
         if not os.path.exists(path):
             continue
@@ -415,12 +420,14 @@ def run_multi(args):
 # ---------------------------------------------------------------------------------------------------------------------
 # the other BASELINE.json configurations (N = 1 only), each with its own roofline and an in-region oracle check
 # ---------------------------------------------------------------------------------------------------------------------
-def _oracle_check(cfg, v, x0, xr, ur, u_gpu, k_gpu, count=32):
+def _oracle_check(cfg, v, x0, xr, ur, u_gpu, k_gpu, count=32, model=None):
     """GPU result of the timed region against the oracle on the first `count` instances."""
     import numpy as np
     from oracle import oracle
     a = (x0[:count], xr[:count], ur[:count])
-    if cfg.formulation == "HMPC":
+    if model is not None:  # time-varying solver: update phase + iteration of the oracle on the same per-instance models
+        o = oracle.admm_tv_batch(v, *a, model[:count], True, want_sol=False)
+    elif cfg.formulation == "HMPC":
         o = oracle.admm_hmpc_batch(v, *a, want_sol=False) if getattr(cfg, "submethod", "") == "split" \
             else oracle.hmpc_dense_batch(v, *a, want_sol=False)
     elif cfg.formulation == "ellipMPC" and getattr(cfg, "submethod", "") == "soc":
@@ -441,7 +448,8 @@ def bench_config(spec, dev, steps, warmup, key=""):
     from spcies_amd.solver import HipSolver
     cfg = benchmarks.config(spec["name"])
     B = spec["B"]
-    v = benchmarks.ingredients(cfg)
+    tv = bool(spec.get("tv"))
+    v = benchmarks.ingredients(cfg, time_varying=True) if tv else benchmarks.ingredients(cfg)
     solver = HipSolver(v, device=dev.index)
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
     t = lambda a: torch.from_numpy(a).to(dev)
@@ -452,11 +460,22 @@ def bench_config(spec, dev, steps, warmup, key=""):
     extra = None
     if cfg.formulation == "ellipMPC" and getattr(cfg, "submethod", "") == "soc":
         extra = torch.full((1,), float(cfg.param.r), dtype=torch.float64, device=dev)
+    extra_stride, model = 0, None
+    if tv:  # one model per instance: the design model jittered by 2 % (A, B, Q, R) / 5 % (bounds), seeded
+        import numpy as np
+        rng = np.random.default_rng(cfg.seed + 7)
+        sysm, prm = cfg.sys, cfg.param
+        LB = np.concatenate([np.ravel(sysm.LBx), np.ravel(sysm.LBu)])
+        UB = np.concatenate([np.ravel(sysm.UBx), np.ravel(sysm.UBu)])
+        jit = lambda a, sc: np.asarray(a, float)[None] * (1.0 + sc * (2 * rng.random((B,) + np.shape(a)) - 1))
+        model, extra_stride = solver._pack_model((jit(sysm.A, 0.02), jit(sysm.B, 0.02), jit(np.diag(prm.Q), 0.02), jit(np.diag(prm.R), 0.02),
+                                                  jit(LB, 0.05), jit(UB, 0.05)), B)
+        extra = t(model)
     solver.reserve(B)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
-        solver.solve_device_ex(tx0, txr, tur, tu, tk, te, extra=extra, extra_stride=0, stream=stream)
+        solver.solve_device_ex(tx0, txr, tur, tu, tk, te, extra=extra, extra_stride=extra_stride, stream=stream)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -475,7 +494,9 @@ def bench_config(spec, dev, steps, warmup, key=""):
            "roofline": {"bound": "hbm" if variant in ("mfma4g", "stream", "tile") else "mfma",  # (what binds the DESIGN; `achieved` is algorithmic flop either way)
                         "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_MFMA_TFLOPS,
                         "flop_per_solve": spec["flop"], "algorithmic_io_gbs": gbs, "hbm_frac_algorithmic": gbs / PEAK_HBM_GBS},
-           "oracle_check": _oracle_check(cfg, v, x0, xr, ur, tu[:32].cpu().numpy(), tk[:32].cpu().numpy())}
+           "oracle_check": _oracle_check(cfg, v, x0, xr, ur, tu[:32].cpu().numpy(), tk[:32].cpu().numpy(), model=model)}
+    if tv:  # what bounds this path is the per-instance factor traffic: report the design bytes against the HBM peak as the fraction
+        out["roofline"]["bound"] = "hbm"
     traffic, src = design_traffic(key, variant)
     if traffic is not None:  # what the kernel really moves through HBM (design bytes, not algorithmic ones) against the 8 TB/s peak
         out["roofline"].update(traffic=traffic, traffic_source=src, hbm_frac_design=traffic / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS)
@@ -681,19 +702,33 @@ def run_rank(args):
                                                   "cores": tmpl["cores"], "note": tmpl["sample"] + "; constants printed by this "
                                                   "repository's generator under the reference's dec_var.m rules, not by MATLAB"}
                 out["cpu_baseline"] = port
-    if solver is not None:
-        solver.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        # Under a launcher (torchrun: the driver's N > 1 contract) rank 0 also reports the one-process leg: the other ranks
-        # are past their last collective and exiting, the leg runs in a FRESH child process (this one keeps its idle context on
-        # GPU 0 and is never replaced), bounded by a timeout; its failure is reported inside `multi_launch`, the line survives.
-        # Self-launched runs do this in the parent instead (launch_ranks).
-        if world > 1 and not dry and not args.no_multi_leg and not os.environ.get("SPCIES_BENCH_SELF_LAUNCHED"):
-            out["multi_launch"] = run_multi_leg_child(args)
-        print(json.dumps(out), flush=True)
+    # From here on nothing may lose the measured line: a peer that died after its last timed step makes the closing barrier
+    # raise or time out, and the one-process leg is a child with its own failure modes - rank 0 prints in a `finally`.
+    try:
+        if solver is not None:
+            solver.close()
+        if world > 1:
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception as ex:  # noqa: BLE001 - reported in the line, never instead of it
+                if rank == 0:
+                    out["teardown_error"] = f"{type(ex).__name__}: {ex}"[:300]
+        if rank == 0:
+            # Under a launcher (torchrun: the driver's N > 1 contract) rank 0 also reports the one-process leg: the other ranks
+            # are past their last collective and exiting (a short pause lets them release their GPUs, so that the leg is not timed
+            # against their teardown), the leg runs in a FRESH child process (this one keeps its idle context on GPU 0 and is
+            # never replaced), bounded by a timeout; its failure is reported inside `multi_launch`, the line survives.
+            # Self-launched runs do this in the parent instead (launch_ranks).
+            if world > 1 and not dry and not args.no_multi_leg and not os.environ.get("SPCIES_BENCH_SELF_LAUNCHED"):
+                time.sleep(2.0)
+                try:
+                    out["multi_launch"] = run_multi_leg_child(args)
+                except Exception as ex:  # noqa: BLE001
+                    out["multi_launch"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    finally:
+        if rank == 0:
+            print(json.dumps(out), flush=True)
 
 
 def main(argv=None):

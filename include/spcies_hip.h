@@ -253,10 +253,12 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
 int spcies_hip_destroy(spcies_hip_handle h);
 int spcies_hip_get_info(spcies_hip_handle h, spcies_hip_info *info);
 int spcies_hip_set_variant(spcies_hip_handle h, int variant);
-/* A failed run-time specialisation (hiprtc missing, compile error, state too large) is not an error: AUTO uses the next
- * variant.  *notes (owned by the handle, "" when nothing was given up) says which faster variants are unavailable and why;
- * SPCIES_HIP_VERBOSE=1 in the environment prints the same line to stderr at create time; SPCIES_HIP_STRICT=1 turns a non-empty
- * note into an error of spcies_hip_create (SPCIES_HIP_ENOSUP) - for deployments that must not run on a slower variant unnoticed. */
+/* A faster variant that AUTO cannot use is not an error: AUTO uses the next one.  *notes (owned by the handle, "" when nothing
+ * was given up) says which faster variants are unavailable and why - both when the variant does not apply to the controller by
+ * design (general Q and R, a shape outside the packer, state beyond registers + LDS, run-time specialisation switched off) and
+ * when it applies but could not be built (hiprtc missing, compile error); SPCIES_HIP_VERBOSE=1 in the environment prints the
+ * same line to stderr at create time.  SPCIES_HIP_STRICT=1 turns a FAILED BUILD - and only that - into an error of
+ * spcies_hip_create (SPCIES_HIP_ENOSUP): for deployments that must not run on a slower variant unnoticed. */
 int spcies_hip_get_notes(spcies_hip_handle h, const char **notes);
 /* Override the blob's exit settings (the reference bakes them in as #defines k_max / tol,
  * cons_laxMPC_ADMM_C.m:76-77).  tol < 0 keeps the current value; k_max <= 0 keeps the current value. */

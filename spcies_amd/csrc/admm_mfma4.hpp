@@ -79,6 +79,7 @@ struct Mfma4Plan {
     bool unit = false;       // unit-box coordinates (admm_mfma4u.hpp): the table holds scaled blocks and Mfma4uRC row constants
     bool needs_rtc = false;  // tables are packed, but no kernel of this shape was instantiated at build time (mfma4_rtc.hpp)
     std::string why = "not built";
+    bool build_failed = false;  // the variant applies to this controller but its run-time specialisation failed (hiprtc missing, compile error): what SPCIES_HIP_STRICT reacts to
     Mfma4Layout lay{};
     double *d_table = nullptr;
     size_t table_bytes = 0;
@@ -120,6 +121,10 @@ inline int mfma4_plan_build(Mfma4Plan &p, const AdmmHost &a) {
     p.lay = L;
     const Mfma4uScaling sc = mfma4u_scaling(a);
     { const char *ev = getenv("SPCIES_MFMA4_UNIT"); p.unit = sc.ok && !(ev && ev[0] == '0'); }
+    // the unit-box table carries 20 rows of constants against 9 (1.4 KB more): a shape whose plain table just fits the LDS keeps MFMA4
+    // in the plain form instead of losing it
+    auto table_bytes_of = [&](bool unit) { return ((size_t)L.n_tiles() * 16 + (size_t)(unit ? mfma4u_rc_count() : (int)Mfma4Layout::RC_COUNT) * 16) * sizeof(double); };
+    if (p.unit && table_bytes_of(true) > 160 * 1024 - 512 && table_bytes_of(false) <= 160 * 1024 - 512) p.unit = false;
     std::vector<double> tab((size_t)L.n_tiles() * 16 + (size_t)(p.unit ? mfma4u_rc_count() : (int)Mfma4Layout::RC_COUNT) * 16, 0.0);
     int cursor = 0;
     // append the non-zero 4x4 blocks of M in issue order (J outer, I inner); a block that the pattern

@@ -241,6 +241,7 @@ int plan_build(Plan &p, const Host &h) {
         hipFunction_t fns[2] = {nullptr, nullptr};
         if (rtc::compile_module(kCsFusedSource, "spcies_cs_fused.hip", names, extra, &mod, fns) != 0) {
             p.why = g_last_error;
+            p.build_failed = true;
             return 0;  // not an error: AUTO falls back, the reason is reported when FUSED is asked for
         }
         p.module = mod;

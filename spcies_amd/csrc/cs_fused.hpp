@@ -22,6 +22,7 @@ struct Host {  // what parse_mpct_cs collected (cons_MPCT_ADMM_cs_C.m:66-112)
 struct Plan {
     bool ok = false;
     std::string why = "not built";
+    bool build_failed = false;  // the variant applies to this controller but its run-time specialisation failed (hiprtc missing, compile error): what SPCIES_HIP_STRICT reacts to
     int n = 0, m = 0, N = 0, NR = 0, NCH = 0, CHB = 0;
     double *d_ME = nullptr, *d_PRO = nullptr, *d_C = nullptr;
     int oLB = 0, oUB = 0, oRho = 0;

@@ -271,7 +271,7 @@ int plan_build(Plan &p, const Host &h) {
         hipModule_t mod = nullptr;
         hipFunction_t fns[2] = {nullptr, nullptr};
         int rc = rtc::compile_module(kSource, "spcies_eadmm_r_rtc.hip", nm, extra, &mod, fns);
-        if (rc) { p.why = std::string("MFMA4R: run-time specialisation failed: ") + spcies_hip_last_error(); return 0; }
+        if (rc) { p.why = std::string("MFMA4R: run-time specialisation failed: ") + spcies_hip_last_error(); p.build_failed = true; return 0; }
         int scratch = 0;
         if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fns[0]) != hipSuccess) scratch = 0;
         if (getenv("SPCIES_ER_VERBOSE"))

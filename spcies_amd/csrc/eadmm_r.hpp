@@ -18,6 +18,7 @@ struct Host {  // what parse_banded collected for the MPCT EADMM solver (cons_MP
 struct Plan {
     bool ok = false;
     std::string why = "not built";
+    bool build_failed = false;  // the variant applies to this controller but its run-time specialisation failed (hiprtc missing, compile error): what SPCIES_HIP_STRICT reacts to
     int n = 0, m = 0, N = 0, KX = 0, KS = 0, RX = 0, NLS = 0;  // NLS: stages whose z3 / lambda live in LDS
     bool midsame = false;                                     // one table of row constants for the stages 1 .. N - 1
     double *d_table = nullptr;

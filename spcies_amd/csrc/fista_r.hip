@@ -242,7 +242,7 @@ int plan_build(Plan &p, const Host &h) {
     hipModule_t mod = nullptr;
     hipFunction_t fns[2] = {nullptr, nullptr};
     int rc = rtc::compile_module(kSource, "spcies_fista_r_rtc.hip", nm, extra, &mod, fns);
-    if (rc) { p.why = std::string("MFMA4R: run-time specialisation failed: ") + spcies_hip_last_error(); return 0; }
+    if (rc) { p.why = std::string("MFMA4R: run-time specialisation failed: ") + spcies_hip_last_error(); p.build_failed = true; return 0; }
     p.module = mod;
     p.fn[0] = fns[0];
     p.fn[1] = fns[1];

@@ -146,6 +146,7 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
         hipFunction_t fns[2] = {nullptr, nullptr};
         if (rtc::compile_module(kFusedSource, "spcies_hmpc_fused.hip", names, extra, &mod, fns) != 0) {
             p.why = g_last_error;
+            p.build_failed = true;
             return 0;  // not an error: AUTO falls back, the reason is reported when FUSED is asked for
         }
         p.module = mod;

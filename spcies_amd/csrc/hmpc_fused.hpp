@@ -31,6 +31,7 @@ struct NosplitHost {  // what parse_hmpc_dense collected (HMPC ADMM / SADMM with
 struct Plan {
     bool ok = false;
     std::string why = "not built";
+    bool build_failed = false;  // the variant applies to this controller but its run-time specialisation failed (hiprtc missing, compile error): what SPCIES_HIP_STRICT reacts to
     int n = 0, m = 0, N = 0, use_soc = 0, symmetric = 0, mode = 0, ny = 0;  // mode 0: split, 1: no splitting; ny > 0: coupled constraints
     int NR = 0, NK = 0, NCH = 0, CHB = 0;
     double *d_ME = nullptr, *d_PRO = nullptr, *d_C = nullptr;  // iteration table, prologue table (inputs | 1), constants

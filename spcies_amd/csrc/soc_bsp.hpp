@@ -34,6 +34,7 @@ struct Args {  // mirrored in the generated source
 struct Plan {
     bool ok = false;
     std::string why = "not built";
+    bool build_failed = false;  // the variant applies to this controller but its run-time specialisation failed (hiprtc missing, compile error): what SPCIES_HIP_STRICT reacts to
     std::string src;             // generated kernel source
     std::vector<double> table;   // blocks in issue order, then LB / UB rows (internal layout)
     int n_blocks = 0, ZS = 0, SS = 0, NR = 0, n_mfma = 0;

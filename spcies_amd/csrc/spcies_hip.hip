@@ -100,6 +100,8 @@ struct Solver {
     rtc::Mfma4Module mfma4_rtc;  // run-time compiled MFMA4 kernel when the shape was not instantiated at build time
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
+    unsigned long long *d_hist = nullptr;  // spcies_hip_k_histogram_device's bins and counters
+    std::string build_failures;    // the subset of `notes` that are failed builds (SPCIES_HIP_STRICT)
     std::string notes;             // which faster (run-time specialised) variants AUTO could not use, and why (spcies_hip_get_notes)
     fr::Plan frplan;               // MFMA4R (FISTA with the iteration state in registers + LDS, run-time specialised)
     er::Plan erplan;               // MFMA4R (MPCT EADMM, diagonal Q, R: the whole iteration state on the chip, run-time specialised)
@@ -1500,7 +1502,9 @@ __global__ void k_histogram_kernel(const int *__restrict__ k, const int *__restr
     __syncthreads();
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < B; i += (long)gridDim.x * blockDim.x) {
         const int kk = k[i], ee = e[i];
-        long b = kk <= 0 ? 0 : ((long)(kk - 1) * n_bins) / (k_max > 0 ? k_max : 1);
+        // bin b holds b k_max / n_bins < k <= (b + 1) k_max / n_bins, also when n_bins does not divide k_max:  b = ceil(k n_bins / k_max) - 1
+        const long km = k_max > 0 ? k_max : 1;
+        long b = kk <= 0 ? 0 : ((long)kk * n_bins + km - 1) / km - 1;
         if (b >= n_bins) b = n_bins - 1;
         atomicAdd(&s_h[b], 1ull);
         atomicAdd(&s_h[n_bins + (ee > 0 ? 0 : (ee == -1 ? 1 : 2))], 1ull);
@@ -1533,6 +1537,7 @@ int spcies_hip_device_count(int *count) {
 static void free_solver(Solver *s) {
     if (!s) return;
     if (s->device_bound) hipSetDevice(s->device);
+    if (s->d_hist) hipFree(s->d_hist);
     if (s->d_consts) hipFree(s->d_consts);
     if (s->d_scratch) hipFree(s->d_scratch);
     if (s->d_io) hipFree(s->d_io);
@@ -1616,7 +1621,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     // failure is not an error: AUTO then runs TILE, and the reason is reported if BSP is asked for.
     if (s->is_soc() && !s->is_hmpc() && !s->bsp.src.empty()) {
         const char *ev = getenv("SPCIES_HIP_BSP");
-        if (!(ev && ev[0] == '0') && bsp::finish_soc(s->bsp, s->sdev, s->soc_f64.data(), s->soc_i32.data()) != 0) s->bsp.why = g_last_error;
+        if (!(ev && ev[0] == '0') && bsp::finish_soc(s->bsp, s->sdev, s->soc_f64.data(), s->soc_i32.data()) != 0) s->bsp.why = g_last_error, s->bsp.build_failed = true;
     }
     // laxMPC ADMM with vector rho / stage-wise bounds: the register-resident MFMA4 kernels do not take them, and the block
     // program is 1.4x faster than MFMA4G there (12.5 against 17.4 ms at the C2 shape)
@@ -1626,12 +1631,12 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         if (!(ev && ev[0] == '0')) {
             rc = bsp::build_ellip(s->bsp, s->host);
             if (rc) return rc;
-            if (!s->bsp.src.empty() && bsp::finish_ellip(s->bsp, s->host) != 0) s->bsp.why = g_last_error;
+            if (!s->bsp.src.empty() && bsp::finish_ellip(s->bsp, s->host) != 0) s->bsp.why = g_last_error, s->bsp.build_failed = true;
         }
     }
     if (s->host.ellip && !s->bsp.src.empty()) {  // ellipMPC ADMM: the same kind of program (ellip_bsp.hpp)
         const char *ev = getenv("SPCIES_HIP_BSP");
-        if (!(ev && ev[0] == '0') && bsp::finish_ellip(s->bsp, s->host) != 0) s->bsp.why = g_last_error;
+        if (!(ev && ev[0] == '0') && bsp::finish_ellip(s->bsp, s->host) != 0) s->bsp.why = g_last_error, s->bsp.build_failed = true;
     }
     if (s->eng) {
         if (s->tv) return fail(SPCIES_HIP_ENOSUP, "in_engineering with time_varying is not built");
@@ -1653,7 +1658,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         // off).  A failure is not an error: AUTO then runs MFMA4G, and the reason is reported if MFMA4 is asked for.
         const char *ev = getenv("SPCIES_HIP_RTC");
         if (s->mfma4.needs_rtc && !(ev && ev[0] == '0')) {
-            if (ensure_mfma4_rtc(*s) != 0) s->mfma4.why = g_last_error;
+            if (ensure_mfma4_rtc(*s) != 0) s->mfma4.why = g_last_error, s->mfma4.build_failed = true;
         }
         // kernel experiments: SPCIES_MFMA4_RTC_FLAGS="-DX=1 ..." re-specialises a built-in shape with extra compiler options
         if (s->mfma4.ok && !s->mfma4_rtc.ok && getenv("SPCIES_MFMA4_RTC_FLAGS")) {
@@ -1698,21 +1703,25 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         }
     }
     // what AUTO had to give up (a failed run-time specialisation is not an error, but the caller can ask)
-    auto note = [&](const char *name, bool wanted, bool ok, const std::string &why) {
-        if (wanted && !ok) s->notes += std::string(s->notes.empty() ? "" : "; ") + name + " unavailable: " + why;
+    // Two kinds of reasons: the variant does not APPLY to this controller (general Q and R, a shape outside the packer, state beyond
+    // registers + LDS, switched off by the caller) - and the variant applies but could not be BUILT (hiprtc missing, compile error).
+    auto note = [&](const char *name, bool wanted, bool ok, const std::string &why, bool build_failed) {
+        if (!wanted || ok) return;
+        s->notes += std::string(s->notes.empty() ? "" : "; ") + name + " unavailable: " + why;
+        if (build_failed) s->build_failures += std::string(s->build_failures.empty() ? "" : "; ") + name + ": " + why;
     };
-    note("MFMA4R", s->method == SPCIES_FISTA && !s->tv, s->frplan.ok, s->frplan.why);
-    note("MFMA4R", s->method == SPCIES_EADMM, s->erplan.ok, s->erplan.why);
-    note("BSP", (s->is_soc() && !s->is_hmpc()) || s->host.ellip, s->bsp.ok, s->bsp.why);
-    note("MFMA4", s->mfma4.needs_rtc, s->mfma4.ok, s->mfma4.why);
-    note("FUSED", s->is_hmpc() || s->is_hdense(), s->hfused.ok, s->hfused.why);
-    note("FUSED", s->is_cs(), s->csf.ok, s->csf.why);
+    note("MFMA4R", s->method == SPCIES_FISTA && !s->tv, s->frplan.ok, s->frplan.why, s->frplan.build_failed);
+    note("MFMA4R", s->method == SPCIES_EADMM, s->erplan.ok, s->erplan.why, s->erplan.build_failed);
+    note("BSP", (s->is_soc() && !s->is_hmpc()) || s->host.ellip, s->bsp.ok, s->bsp.why, s->bsp.build_failed);
+    note("MFMA4", s->mfma4.needs_rtc, s->mfma4.ok, s->mfma4.why, s->mfma4.build_failed);
+    note("FUSED", s->is_hmpc() || s->is_hdense(), s->hfused.ok, s->hfused.why, s->hfused.build_failed);
+    note("FUSED", s->is_cs(), s->csf.ok, s->csf.why, s->csf.build_failed);
     if (!s->notes.empty() && getenv("SPCIES_HIP_VERBOSE")) fprintf(stderr, "[spcies_hip] %s\n", s->notes.c_str());
-    // SPCIES_HIP_STRICT=1: a faster variant that could not be built (hiprtc missing, compile error, state too large) is an error instead
-    // of a silent 2-12x slower default - for deployments that must notice
-    if (!s->notes.empty()) {
+    // SPCIES_HIP_STRICT=1: a faster variant that applies to this controller but could not be built is an error instead of a silent
+    // 2-12x slower default - for deployments that must notice.  A variant that does not apply by design is a note, never an error.
+    if (!s->build_failures.empty()) {
         const char *strict = getenv("SPCIES_HIP_STRICT");
-        if (strict && strict[0] == '1') return fail(SPCIES_HIP_ENOSUP, "SPCIES_HIP_STRICT: %s", s->notes.c_str());
+        if (strict && strict[0] == '1') return fail(SPCIES_HIP_ENOSUP, "SPCIES_HIP_STRICT: %s", s->build_failures.c_str());
     }
     *out = reinterpret_cast<spcies_hip_handle>(s.release());
     return 0;
@@ -1796,8 +1805,9 @@ int spcies_hip_k_histogram_device(spcies_hip_handle h, const int *k, const int *
     std::lock_guard<std::mutex> lk(s->mu);
     SPCIES_HIP_CHECK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
-    unsigned long long *d = nullptr;
-    SPCIES_HIP_CHECK(hipMalloc((void **)&d, (n_bins + 4) * sizeof(unsigned long long)));
+    // a small buffer owned by the handle (1024 bins + 4 counters): no hipMalloc / hipFree - a device synchronisation each - per call
+    if (!s->d_hist) SPCIES_HIP_CHECK(hipMalloc((void **)&s->d_hist, (1024 + 4) * sizeof(unsigned long long)));
+    unsigned long long *d = s->d_hist;
     hipError_t er = hipMemsetAsync(d, 0, (n_bins + 4) * sizeof(unsigned long long), st);
     if (er == hipSuccess) {
         long blocks = (B + 255) / 256;
@@ -1808,7 +1818,6 @@ int spcies_hip_k_histogram_device(spcies_hip_handle h, const int *k, const int *
     std::vector<unsigned long long> hst(n_bins + 4);
     if (er == hipSuccess) er = hipMemcpyAsync(hst.data(), d, (n_bins + 4) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
     if (er == hipSuccess) er = hipStreamSynchronize(st);
-    hipFree(d);
     if (er != hipSuccess) return fail(SPCIES_HIP_EHIP, "k_histogram: %s", hipGetErrorString(er));
     for (int i = 0; i < n_bins; i++) hist[i] = (long)hst[i];
     for (int i = 0; i < 4; i++) counts[i] = (long)hst[n_bins + i];

@@ -1485,6 +1485,47 @@ def test_multi_handle_equals_single_handle(cfg_name, B, devices):
         assert (k3 <= 3).all()
 
 
+@pytest.mark.parametrize("cfg_name", ["C2", "C1_equ_FISTA"])
+def test_multi_handle_on_every_visible_device(cfg_name):
+    """`devices=None`: one handle per VISIBLE device (spcies_hip_create_multi with n_dev <= 0) - on the driver's 8-GPU node that is
+    eight distinct GPUs, one host thread each, the run-time specialised kernel compiled once for all of them; on a one-GPU box it is
+    the single-device case.  The sharded result equals one handle's result for the whole batch bit for bit, every per-device handle
+    sits on its own device, and a ragged batch (B not a multiple of the device count, B < device count) is split without loss."""
+    import ctypes as C
+    from spcies_amd import _lib, benchmarks
+    from spcies_amd.solver import HipSolver, MultiHipSolver
+    lib = _lib.load()
+    nvis = C.c_int(0)
+    _lib.check(lib.spcies_hip_device_count(C.byref(nvis)))
+    cfg = benchmarks.config(cfg_name)
+    v = benchmarks.ingredients(cfg)
+
+    def cache_stats():
+        out = (C.c_long * 6)()
+        _lib.check(lib.spcies_hip_rtc_cache_stats_ex(out, 6))
+        return list(out)
+    st0 = cache_stats()
+    with HipSolver(v) as s1, MultiHipSolver(v, devices=None) as sm:
+        st1 = cache_stats()
+        if s1.variant == "mfma4r":  # a run-time specialised kernel: 1 + n_dev handles cost at most ONE compilation, the rest are cache hits
+            assert st1[2] - st0[2] <= 1 and (st1[0] - st0[0]) + (st1[1] - st0[1]) >= nvis.value
+        assert sm.n_dev == nvis.value >= 1
+        seen = []
+        for i in range(sm.n_dev):
+            info = _lib.Info()
+            _lib.check(lib.spcies_hip_get_info(sm.single(i), C.byref(info)))
+            seen.append(info.device)
+            assert info.variant == _lib.VARIANTS[s1.variant]  # every device runs the variant the single handle runs
+        assert seen == list(range(nvis.value))
+        for B in (64 * sm.n_dev + 5, max(1, sm.n_dev - 1), 1):
+            x0, xr, ur = benchmarks.sample_batch(cfg, B)
+            u1, k1, e1, sol1 = s1(x0, xr, ur)
+            um, km, em, solm = sm(x0, xr, ur)
+            assert np.array_equal(u1, um) and np.array_equal(k1, km) and np.array_equal(e1, em), B
+            for name, _ in s1.sol_fields:
+                f = name if name != "lambda" else "lam"
+                assert np.array_equal(getattr(sol1, f), getattr(solm, f)), (B, name)
+
 @pytest.mark.gpu
 def test_notes_report_what_auto_gave_up(monkeypatch):
     """A failed / disabled run-time specialisation is not an error, but it is not silent either: spcies_hip_get_notes."""
@@ -1519,19 +1560,38 @@ def test_k_histogram_of_a_device_solve():
     assert np.array_equal(h.hist, want) and h.hist.sum() == B
     assert h.converged == int((e > 0).sum()) and h.k_max_reached == int((e == -1).sum()) and h.other == 0
     assert abs(h.mean_k - k.mean()) < 1e-9 and 0 < h.converged < B  # both outcomes occur on this batch
+    # a bin count that does not divide k_max: bin b still holds b k_max / n_bins < k <= (b + 1) k_max / n_bins
+    for nb in (7, 3, 1):
+        h = s.k_histogram(tk, te, n_bins=nb)
+        want = np.bincount(np.minimum(-(-np.maximum(k, 1).astype(np.int64) * nb // 800) - 1, nb - 1), minlength=nb)
+        edges = np.arange(nb + 1) * 800 / nb
+        assert np.array_equal(want, [np.sum((k > edges[b]) & (k <= edges[b + 1])) for b in range(nb)])
+        assert np.array_equal(h.hist, want), nb
     s.close()
 
 
-def test_strict_mode_turns_a_missing_fast_variant_into_an_error(monkeypatch):
-    """SPCIES_HIP_STRICT=1: AUTO silently landing on a slower variant (here: run-time specialisation switched off, so FISTA would fall from
-    MFMA4R to MFMA4G) is an error of create; without it the handle exists and `notes` says what is missing."""
+def test_strict_mode_turns_a_failed_build_into_an_error(monkeypatch):
+    """SPCIES_HIP_STRICT=1: a faster variant that APPLIES to the controller but could not be built (here: a compiler option hiprtc
+    rejects, so FISTA would fall from MFMA4R to MFMA4G) is an error of create; without STRICT the handle exists and `notes` says what
+    is missing.  A variant that does not apply by design - run-time specialisation switched off by the caller, MPCT EADMM with general
+    Q and R (MFMA4R carries the diagonal branch only) - is a note and never an error."""
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
     v = benchmarks.ingredients(benchmarks.config("C1_equ_FISTA"))
-    monkeypatch.setenv("SPCIES_HIP_RTC", "0")
+    monkeypatch.setenv("SPCIES_FR_RTC_FLAGS", "--spcies-no-such-compiler-option")
     s = HipSolver(v)
     assert s.variant == "mfma4g" and "MFMA4R unavailable" in s.notes
     s.close()
     monkeypatch.setenv("SPCIES_HIP_STRICT", "1")
-    with pytest.raises(Exception, match="SPCIES_HIP_STRICT: MFMA4R unavailable"):
+    with pytest.raises(Exception, match="SPCIES_HIP_STRICT: MFMA4R"):
         HipSolver(v)
+    monkeypatch.delenv("SPCIES_FR_RTC_FLAGS")
+    # not applicable by design: notes, no error
+    monkeypatch.setenv("SPCIES_HIP_RTC", "0")
+    s = HipSolver(v)
+    assert s.variant == "mfma4g" and "MFMA4R unavailable" in s.notes and "SPCIES_HIP_RTC=0" in s.notes
+    s.close()
+    monkeypatch.delenv("SPCIES_HIP_RTC")
+    s = HipSolver(benchmarks.ingredients(benchmarks.config("C1_MPCT_nd")))
+    assert s.variant == "mfma4g" and "general Q, R" in s.notes
+    s.close()
