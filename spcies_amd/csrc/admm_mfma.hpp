@@ -601,6 +601,7 @@ inline bool mfma_shape_instantiated(int N, int KX, int KS) {
     return false;
 }
 
+#ifndef SPCIES_NO_BUILTIN_LAUNCHERS  // (admm_mfma4u.hip includes these headers for the host-side declarations only: no second copy of the kernels there)
 template <int N, int KX, int KS>
 static int launch_mfma_shape(MfmaPlan &pl, const AdmmHost &a, const MfmaArgs &args, const double *x0, const double *xr,
                              const double *ur, double *u, int *k, int *e, double *z, double *v, double *lam,
@@ -643,5 +644,7 @@ inline int launch_mfma(MfmaPlan &pl, const AdmmHost &a, const double *x0, const 
 #undef X
     return fail(SPCIES_HIP_ENOSUP, "MFMA kernel not instantiated for N=%d KX=%d KS=%d", pl.lay.N, pl.lay.KX, pl.lay.KS);
 }
+
+#endif  // SPCIES_NO_BUILTIN_LAUNCHERS
 
 }  // namespace spcies

@@ -591,13 +591,11 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4_kernel(MfmaArgs p, const do
 }
 // [rtc-end]
 
-// (admm_mfma4u.hpp: the same kernel in unit-box coordinates; chosen when Mfma4Plan::unit)
-template <int N, int KX, int KS, bool TERMINAL, bool WANT_SOL>
-__global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const double *__restrict__ table_g, const double *__restrict__ x0g,
-                                                             const double *__restrict__ xrg, const double *__restrict__ urg,
-                                                             double *__restrict__ u_out, int *__restrict__ k_out, int *__restrict__ e_out,
-                                                             double *__restrict__ z_out, double *__restrict__ v_out,
-                                                             double *__restrict__ lam_out, double *__restrict__ dump);
+// (admm_mfma4u.hpp: the same kernel in unit-box coordinates, chosen when Mfma4Plan::unit; its build-time instantiations live in
+// admm_mfma4u.hip - compiled with -amdgpu-mfma-vgpr-form - behind this launcher)
+int mfma4u_launch_builtin(int N, int KX, int KS, bool terminal, bool want_sol, dim3 grid, dim3 block, size_t shmem, hipStream_t st,
+                          const MfmaArgs &args, const double *table, const double *x0, const double *xr, const double *ur, double *u, int *k,
+                          int *e, double *z, double *v, double *lam, double *dump);
 
 #define SPCIES_MFMA4_SHAPES(X) X(10, 2, 2) X(15, 3, 4)
 
@@ -609,6 +607,7 @@ inline bool mfma4_shape_instantiated(int N, int KX, int KS) {
     return false;
 }
 
+#ifndef SPCIES_NO_BUILTIN_LAUNCHERS  // (admm_mfma4u.hip includes these headers for the host-side declarations only: no second copy of the kernels there)
 template <int N, int KX, int KS>
 static int launch_mfma4_shape(Mfma4Plan &pl, const AdmmHost &a, const MfmaArgs &args, const double *x0, const double *xr,
                               const double *ur, double *u, int *k, int *e, double *z, double *v, double *lam,
@@ -620,9 +619,16 @@ static int launch_mfma4_shape(Mfma4Plan &pl, const AdmmHost &a, const MfmaArgs &
     if (wgs > pl.num_cu) wgs = pl.num_cu;
     const size_t shmem = pl.table_bytes;
     dim3 grid((unsigned)wgs), block(256);
+    if (pl.unit) {
+        int rc = mfma4u_launch_builtin(N, KX, KS, a.terminal, want_sol, grid, block, shmem, st, args, pl.d_table, x0, xr, ur, u, k, e, z, v, lam,
+                                       pl.d_table + pl.table_bytes / sizeof(double));
+        if (rc) return rc;
+        SPCIES_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
 #define SPCIES_LAUNCH(TERM, SOL)                                                                                     \
     do {                                                                                                             \
-        auto kern = pl.unit ? admm_mfma4u_kernel<N, KX, KS, TERM, SOL> : admm_mfma4_kernel<N, KX, KS, TERM, SOL>;    \
+        auto kern = admm_mfma4_kernel<N, KX, KS, TERM, SOL>;                                                         \
         /* per device, so set before every launch (a handle may live on any GPU of the process) */                   \
         SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                                  160 * 1024));                                                      \
@@ -651,5 +657,7 @@ inline int launch_mfma4(Mfma4Plan &pl, const AdmmHost &a, const double *x0, cons
 #undef X
     return fail(SPCIES_HIP_ENOSUP, "MFMA4 kernel not instantiated for N=%d KX=%d KS=%d", pl.lay.N, pl.lay.KX, pl.lay.KS);
 }
+
+#endif  // SPCIES_NO_BUILTIN_LAUNCHERS
 
 }  // namespace spcies

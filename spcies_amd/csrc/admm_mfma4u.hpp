@@ -212,6 +212,10 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
         }
         // kappa = q / (rho D) - lb / D per kind of stage; the middle stages' row constants stay in registers
         d4 a1m = RC(Mfma4uRC::A1_MID), a2m = RC(Mfma4uRC::A2_MID), a3m = RC(Mfma4uRC::A3_MID);
+        // merged backward seed (round 4; -DSPCIES_MFMA4U_PLAIN_SEED keeps the round-3 form for A/B timing): with d = w^ - c' the next state is  w^+ = z' + d = (a1 + 1) o d - a1 o c' - a3 - a2 o mu + Z mu:
+        // the products accumulate ON TOP of d and deliver w^+ itself - five vector instructions per register and stage where
+        // "s, seed, seed, then d, then z' + d" took six, and no value of the stage but the accumulator stays alive across its products
+        d4 a1p = a1m + 1.0;
         d4 kap_m = qraw * RC(Mfma4uRC::IRD_MID) - a3m;
         // (stage 0 has its real rows - the inputs - inside the last slab, stage N in the first KX slabs: the other components are zero,
         // and the compiler is told so: registers)
@@ -268,6 +272,9 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
             asm volatile("" : "+v"(il));
             double *zp = WANT_SOL ? z_out + il * dim + g : nullptr;
             LAUNDER4(a1m); LAUNDER4(a3m);
+#ifndef SPCIES_MFMA4U_PLAIN_SEED
+            LAUNDER4(a1p);
+#endif
             int tix = 0;
             auto prod = [&](d4 &acc, const d4 &x, const Prod4 P) {
 #pragma unroll
@@ -322,14 +329,50 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
             // difference of every stage alive to the end of the backward sweep - 25 spilled values per iteration)
             asm volatile("" : "+v"(go));
             LAUNDER4(a1m); LAUNDER4(a3m); LAUNDER4(kap_m);
+#ifndef SPCIES_MFMA4U_PLAIN_SEED
+            LAUNDER4(a1p);
+#endif
             asm volatile("" : "+v"(kap_0s), "+v"(kap_N[0]), "+v"(kap_N[1]), "+v"(kap_N[2]));
             bool res = false, all_hit = false;
+#ifndef SPCIES_MFMA4U_PLAIN_SEED
+            constexpr bool MERGED = !FIRST;  // (the cold start keeps the plain form: it runs once)
+#else
+            constexpr bool MERGED = false;
+#endif
             // z'_t in two parts: the elementwise seed (vector instructions only) and the products on top of it.  The seed of a stage is
             // formed BEFORE the products of the loop trip it belongs to, behind the previous stage's update: one run of vector instructions
             // and one run of MFMAs per trip (every switch from the matrix instruction to a vector instruction costs 8 clocks,
             // profiles/r03_microbench_issue.txt)
             auto stage_seed = [&](int t, d4 &cwt, d4 &x) -> d4 {
                 d4 z;
+                if constexpr (MERGED) {
+                    // returns the seed of w^+ (not of z'): d + a1 o (d - c') - a3 [- a2 o mu]
+                    const d4 cw0 = clamp01(w[t] - KAP(t));
+                    const d4 dd = w[t] - cw0;
+                    cwt = cw0;
+                    if (t == N) {
+                        const d4 s = dd - cw0;
+#ifdef SPCIES_MFMA4U_RC_REGS
+                        x = rdN * s - mu[N - 1];
+#else
+                        x = RC(Mfma4uRC::RD_N) * s - mu[N - 1];
+#endif
+                        return dd - A3(N);
+                    } else if (t == 0) {
+#ifdef SPCIES_MFMA4U_RC_REGS
+                        const d4 a10 = one(a10s);
+#else
+                        const d4 a10 = RC(Mfma4uRC::A1_0);
+#endif
+                        x = mu[0];
+                        return (a10 + 1.0) * dd - a10 * cw0 - A3(0);
+                    }
+                    z = a1p * dd - a3m;
+                    z = z - a1m * cw0;
+                    z = z - a2m * mu[t - 1];
+                    x = mu[t];
+                    return z;
+                }
                 const d4 s = qhat(t, cwt);
                 if (t == N) {
 #ifdef SPCIES_MFMA4U_RC_REGS
@@ -357,10 +400,18 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
                 else if (t == 0) prod(z, x, LL.Z0());
                 else prod(z, x, LL.Zmid());
             };
-            auto stage_w = [&](int t, const d4 &z, const d4 &cwt) {
-                d4 wn;
+            auto stage_w = [&](int t, const d4 &zin, const d4 &cwin) {
+                d4 wn, z = zin, cwt = cwin;
                 if constexpr (FIRST) wn = z + KAP(t);
+                else if constexpr (MERGED) wn = zin;  // the products ran on top of d: this IS w^+
                 else wn = z + (w[t] - cwt);
+                if constexpr (MERGED) {
+                    // z' and the old clamp are needed by the residual checks and the record only: rebuilt from the old state (cold path)
+                    if (WANT_SOL || !all_hit) {
+                        cwt = clamp01(w[t] - KAP(t));
+                        z = wn - (w[t] - cwt);
+                    }
+                }
                 if (!all_hit) {
                     const d4 vn = clamp01(wn - KAP(t));
                     const d4 told = tol * RC(t == 0 ? Mfma4uRC::ID_0 : (t == N ? Mfma4uRC::ID_N : Mfma4uRC::ID_MID));

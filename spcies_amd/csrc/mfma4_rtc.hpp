@@ -37,6 +37,10 @@ inline int compile_mfma4(Mfma4Module &out, int N, int KX, int KS, bool terminal,
         names.push_back(nm);
     }
     std::vector<std::string> extra = {"-DSPCIES_RTC_STATIC_LDS=1"};
+    if (unit) {  // as the build-time instantiations (admm_mfma4u.hip): accumulators seeded and consumed by vector instructions belong in VGPRs
+        extra.push_back("-mllvm");
+        extra.push_back("-amdgpu-mfma-vgpr-form");
+    }
     // experiments: SPCIES_MFMA4_RTC_FLAGS holds extra options, blank-separated
     for (const std::string &e : split_flags(getenv("SPCIES_MFMA4_RTC_FLAGS"))) extra.push_back(e);
     int rc = compile_module(kMfma4Source, "spcies_mfma4_rtc.hip", names, extra, &out.module, out.fn);  // cached per process

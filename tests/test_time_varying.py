@@ -51,7 +51,8 @@ def test_oracle_time_varying_matches_offline(name, test_name, golden_dir):
     assert np.abs(out[6] - v["Alpha"]).max() <= 1e-12
     assert np.abs(np.triu(out[7]) - np.triu(v["Beta"])).max() <= 1e-11
     assert np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2])
-    lscale = np.maximum(1.0, np.abs(ref[5]).max(axis=1, keepdims=True) / 100.0)
+    from _cases import TOL_SPCIES, scaled_bar  # (the measured |lambda| allowance: tests/test_oracle_conditioning.py)
+    lscale = scaled_bar(np.abs(ref[5]).max(axis=1, keepdims=True)) / TOL_SPCIES
     assert (np.abs(out[0] - ref[0]) / lscale).max() <= 1e-10 and (np.abs(out[3] - ref[3]) / lscale).max() <= 1e-9
     if test_name:
         with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
