@@ -1322,7 +1322,8 @@ def test_mfma4_unit_box_form_agrees_with_the_plain_kernel_and_falls_back(monkeyp
         assert np.array_equal(e1, e0) and np.abs(k1.astype(int) - k0.astype(int)).max() <= 1 and (k1 != k0).mean() <= 0.02
         same = k1 == k0
         assert not np.array_equal(s1.z, s0.z), "two different kernels ran"
-        assert np.abs(u1 - u0)[same].max() < 1e-11 and np.abs(s1.z - s0.z)[same].max() < 1e-10 and np.abs(s1.v - s0.v)[same].max() < 1e-10
+        bar = scaled_bar(np.abs(s0.lam).max(axis=1, keepdims=True))  # (C2_equ holds instances with an unreachable terminal equality: _cases)
+        assert (np.abs(u1 - u0) / bar)[same].max() < 0.1 and (np.abs(s1.z - s0.z) / bar)[same].max() < 1.0 and (np.abs(s1.v - s0.v) / bar)[same].max() < 1.0
         _compare("mfma4", out["1"], oracle.admm_banded_batch(v, x0, xr, ur), v, rerun=_rerun_admm(v, x0, xr, ur))
     # one state without an upper bound: no box to scale to
     cfg = copy.copy(benchmarks.config("C1_lax"))
