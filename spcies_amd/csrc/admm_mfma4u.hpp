@@ -231,8 +231,12 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
             }
             return t == N ? kap_N : kap_m;
         };
-#ifdef SPCIES_MFMA4U_RC_REGS
-        // (experiment: the row constants of stages 0 and N in registers too - an LDS read in front of the instruction that needs it is waited for)
+#ifndef SPCIES_MFMA4U_RC_REGS
+#define SPCIES_MFMA4U_RC_REGS 1
+#endif
+#if SPCIES_MFMA4U_RC_REGS
+        // (round 4, default: the row constants of stages 0 and N in registers too - an LDS read in front of the instruction that needs it is
+        // waited for: 5.86 -> 5.77 ms at configs[1]; -DSPCIES_MFMA4U_RC_REGS=0 reads them from LDS)
         d4 a3N = RC(Mfma4uRC::A3_N), rdN = RC(Mfma4uRC::RD_N);
         double a30s = RC(Mfma4uRC::A3_0)[KS - 1], a10s = RC(Mfma4uRC::A1_0)[KS - 1];
 #pragma unroll
@@ -352,14 +356,14 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
                     cwt = cw0;
                     if (t == N) {
                         const d4 s = dd - cw0;
-#ifdef SPCIES_MFMA4U_RC_REGS
+#if SPCIES_MFMA4U_RC_REGS
                         x = rdN * s - mu[N - 1];
 #else
                         x = RC(Mfma4uRC::RD_N) * s - mu[N - 1];
 #endif
                         return dd - A3(N);
                     } else if (t == 0) {
-#ifdef SPCIES_MFMA4U_RC_REGS
+#if SPCIES_MFMA4U_RC_REGS
                         const d4 a10 = one(a10s);
 #else
                         const d4 a10 = RC(Mfma4uRC::A1_0);
@@ -375,14 +379,14 @@ __global__ __launch_bounds__(256, 1) void admm_mfma4u_kernel(MfmaArgs p, const d
                 }
                 const d4 s = qhat(t, cwt);
                 if (t == N) {
-#ifdef SPCIES_MFMA4U_RC_REGS
+#if SPCIES_MFMA4U_RC_REGS
                     x = rdN * s - mu[N - 1];
 #else
                     x = RC(Mfma4uRC::RD_N) * s - mu[N - 1];
 #endif
                     z = -A3(N);
                 } else if (t == 0) {
-#ifdef SPCIES_MFMA4U_RC_REGS
+#if SPCIES_MFMA4U_RC_REGS
                     z = one(a10s) * s - A3(0);
 #else
                     z = RC(Mfma4uRC::A1_0) * s - A3(0);

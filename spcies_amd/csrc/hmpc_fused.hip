@@ -161,6 +161,10 @@ int finish_plan(Plan &p, const Dims &D, int n, int m, int N, int use_soc, int sy
 }  // namespace
 
 void plan_free(Plan &p) {
+    if (p.d_ZR) hipFree(p.d_ZR);
+    if (p.d_T) hipFree(p.d_T);
+    p.d_ZR = p.d_T = nullptr;
+    p.cap_T = 0;
     if (p.d_ME) hipFree(p.d_ME);
     if (p.d_PRO) hipFree(p.d_PRO);
     if (p.d_C) hipFree(p.d_C);
@@ -368,7 +372,50 @@ int plan_build_nosplit(Plan &p, const NosplitHost &h) {
     p.oZcol = put(flat, zcol);
     p.oZcoef = put(flat, zcoef);
     p.oZd = put(flat, zd);
+    if (ny) {  // the z record of the coupled form: z = L [x0; xr; ur] + G1 (rho s + lambda) - rho G1 d, one row of d_ZR per decision variable
+        const int w = nin + n_s + 1;
+        std::vector<double> ZR((size_t)dim * w, 0.0);
+        for (int i = 0; i < dim; i++) {
+            double cst = 0.0;
+            for (int q = 0; q < nin; q++) ZR[(size_t)i * w + q] = L[(size_t)i * nin + q];
+            for (int r = 0; r < n_s; r++) {
+                ZR[(size_t)i * w + nin + r] = G1[(size_t)i * n_s + r];
+                cst -= h.rho * G1[(size_t)i * n_s + r] * dv[r];
+            }
+            ZR[(size_t)i * w + nin + n_s] = cst;
+        }
+        for (double x : ZR)
+            if (!std::isfinite(x)) { p.why = "non-finite M1 / M2"; return 0; }
+        if (p.d_ZR) hipFree(p.d_ZR);
+        SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_ZR, ZR.size() * sizeof(double)));
+        SPCIES_HIP_CHECK(hipMemcpy(p.d_ZR, ZR.data(), ZR.size() * sizeof(double), hipMemcpyHostToDevice));
+        p.z_dim = dim; p.z_ns = n_s; p.z_rho = h.rho;
+    }
     return finish_plan(p, D, n, m, N, h.use_soc, h.symmetric, 1, Mx, flat, ny);
+}
+
+// z of the iteration every instance stopped at, HMPC without the splitting and with coupled constraints (code_HMPC_ADMM_C.c:123-157):
+// z = (M2 b + M1 q) + (M1 C') (rho (s - d) + lambda) with the s, lambda the last product consumed - the operand T = rho s + lambda the FUSED
+// kernel left in `T` at the exit.  One workgroup per instance (grid-stride), the inputs and T staged in LDS, one row of z per thread and
+// pass; once per solve, off the iteration: 2 dim (2 n + m + n_s) flop per instance.
+__global__ __launch_bounds__(128) void z_from_operand_kernel(const double *__restrict__ ZR, int dim, int n_s, int n, int m, const double *__restrict__ x0g,
+                                                             const double *__restrict__ xrg, const double *__restrict__ urg, int ref_stride, long B,
+                                                             const double *__restrict__ T, double *__restrict__ z_out) {
+    extern __shared__ double sh[];  // [x0; xr; ur] (2 n + m) | T (n_s)
+    const int nin = 2 * n + m, w = nin + n_s + 1;
+    for (long inst = blockIdx.x; inst < B; inst += gridDim.x) {
+        const double *xr = ref_stride ? xrg + inst * n : xrg, *ur = ref_stride ? urg + inst * m : urg;
+        for (int i = threadIdx.x; i < nin + n_s; i += blockDim.x)
+            sh[i] = i < n ? x0g[inst * n + i] : (i < 2 * n ? xr[i - n] : (i < nin ? ur[i - 2 * n] : T[inst * (long)n_s + (i - nin)]));
+        __syncthreads();
+        for (int j = threadIdx.x; j < dim; j += blockDim.x) {
+            const double *row = ZR + (size_t)j * w;
+            double a = row[nin + n_s];
+            for (int i = 0; i < nin + n_s; i++) a += row[i] * sh[i];
+            z_out[inst * (long)dim + j] = a;
+        }
+        __syncthreads();
+    }
 }
 
 int launch(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rho_i, double sigma, double sigma_i, double alpha,
@@ -384,12 +431,27 @@ int launch(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rh
     double *ff[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool want_sol = false;
     for (int i = 0; i < nf; i++) { ff[i] = f[i]; want_sol |= f[i] != nullptr; }
-    if (p.mode == 1 && p.ny > 0 && f[0])
-        return fail(SPCIES_HIP_ENOSUP, "FUSED, HMPC without the splitting and with coupled constraints: the z record comes from the GEMM variant");
+    double *z_want = nullptr;
+    if (p.mode == 1 && p.ny > 0 && f[0]) {
+        // coupled constraints: no slack row carries a decision variable, so the kernel cannot read z off its accumulators.  It leaves the
+        // operand of every instance's last product in d_T (field slot 3, unused by this solver's record) and z_from_operand_kernel forms z
+        if (!p.d_ZR) return fail(SPCIES_HIP_ENOSUP, "FUSED, HMPC without the splitting and with coupled constraints: no z-record table");
+        if (rho != p.z_rho) return fail(SPCIES_HIP_ENOSUP, "FUSED: rho changed after the z-record table was folded");
+        if (B > p.cap_T) {  // grown on demand (a device synchronisation: make one record call before capturing into a hipGraph)
+            if (p.d_T) hipFree(p.d_T);
+            p.d_T = nullptr;
+            p.cap_T = 0;
+            SPCIES_HIP_CHECK(hipMalloc((void **)&p.d_T, (size_t)B * p.z_ns * sizeof(double)));
+            p.cap_T = B;
+        }
+        z_want = f[0];
+        ff[0] = nullptr;
+        ff[3] = p.d_T;
+    }
     const long groups = (B + 31) / 32;
     const unsigned grid = (unsigned)std::min<long>(groups, p.num_cu);
     const double *ME = p.d_ME, *PRO = p.d_PRO, *C = p.d_C;
-    if (p.builtin >= 0) {
+    if (p.builtin >= 0) {  // (the build-time shapes have box constraints: no z_want here)
         int idx = 0;
 #define X(nn, mm, NN, SS, UU, MM)                                                                                              \
     if (p.builtin == idx) return launch_builtin<nn, mm, NN, SS, UU, MM>(a, ME, PRO, C, x0, xr, ur, u, k, e, ff, want_sol, grid, st); \
@@ -401,6 +463,13 @@ int launch(Plan &p, int k_max, double tol_p, double tol_d, double rho, double rh
     double *f0 = ff[0], *f1 = ff[1], *f2 = ff[2], *f3 = ff[3], *f4 = ff[4], *f5 = ff[5];
     void *params[] = {&a, &ME, &PRO, &C, &x0, &xr, &ur, &u, &k, &e, &f0, &f1, &f2, &f3, &f4, &f5};
     SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 1 : 0], grid, 1, 1, kNWV * 64, 1, 1, 0, st, params, nullptr));
+    if (z_want) {
+        const int nin = 2 * p.n + p.m;
+        const unsigned zgrid = (unsigned)std::min<long>(B, 8L * p.num_cu);
+        hipLaunchKernelGGL(z_from_operand_kernel, dim3(zgrid), dim3(128), (size_t)(nin + p.z_ns) * sizeof(double), st, p.d_ZR, p.z_dim, p.z_ns, p.n, p.m, x0,
+                           xr, ur, ref_stride, B, p.d_T, z_want);
+        SPCIES_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 

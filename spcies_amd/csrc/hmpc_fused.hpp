@@ -40,6 +40,12 @@ struct Plan {
     void *module = nullptr;        // hipModule_t of a run-time specialised kernel (shapes not instantiated at build time)
     void *fn[2] = {nullptr, nullptr};  // WANT_SOL = false, true
     int builtin = -1;              // index into the build-time instantiations, or -1
+    // HMPC without the splitting and WITH coupled constraints: the z record.  d_ZR [dim][nin + n_s + 1] = (M2 b + M1 q as a map of
+    // [x0; xr; ur] | M1 C' | -rho M1 C' d), d_T [cap_T][n_s] the operand rho s + lambda of every instance's last product
+    double *d_ZR = nullptr, *d_T = nullptr;
+    long cap_T = 0;
+    int z_dim = 0, z_ns = 0;
+    double z_rho = 0;              // (the rho the constant column was folded with)
 };
 
 int plan_build_split(Plan &p, const SplitHost &h);

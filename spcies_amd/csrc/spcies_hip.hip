@@ -1315,8 +1315,9 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         return launch_cs_stream(s, x0, xr, ur, ref_stride, B, u, k, e, f, st);
     }
     if (s.is_hdense()) {
-        // (coupled constraints: the FUSED kernel carries u only; a call that asks for the z record runs on GEMM unless FUSED was asked for by name)
-        if (resolve_variant(s) == SPCIES_VARIANT_FUSED && !(s.variant == SPCIES_VARIANT_AUTO && s.hfused.mode == 1 && s.hfused.ny > 0 && f[0])) {
+        // (coupled constraints: the FUSED kernel carries u and the operand of its last product; the z record follows from that operand in a
+        // small kernel of hmpc_fused.hip - since round 4 no call of this solver is handed to the library GEMM unless GEMM is asked for by name)
+        if (resolve_variant(s) == SPCIES_VARIANT_FUSED) {
             const hdense::Host &hh = s.hd_host;  // k_max / tolerances: set_exit overrides land here
             return hfused::launch(s.hfused, hh.k_max, hh.tol_p, hh.tol_d, hh.rho, hh.rho_i, 0.0, 0.0, hh.alpha, x0, xr, ur, ref_stride, B, u, k,
                                   e, f, st);

@@ -766,9 +766,10 @@ def test_hmpc_coupled_nosplit_vs_oracle(variant, cfg_name, B, golden_dir):
 
 @pytest.mark.parametrize("cfg_name,B", [("C1_HMPCcc_nosplit", 40), ("C1_HMPCcc_SADMM_nosplit", 70), ("C1_HMPCcc_soc_nosplit", 33)])
 def test_hmpc_coupled_nosplit_fused(cfg_name, B):
-    """HMPC without the splitting and WITH coupled output constraints on the hand-written FUSED kernel (round 3; rocBLAS before): no
-    decision variable has a slack row of its own there, so u rides in one more row register of the slack-space product.  AUTO is
-    FUSED for the control action and GEMM for a call that asks for the z record; FUSED by name refuses the record."""
+    """HMPC without the splitting and WITH coupled output constraints on the hand-written FUSED kernel: no decision variable has a slack
+    row of its own there, so u rides in one more row register of the slack-space product, and - round 4 - the z record is formed from
+    the operand of every instance's last product by a small kernel of the library (code_HMPC_ADMM_C.c:123-157): AUTO is FUSED for
+    EVERY call of this solver, the library GEMM runs only when asked for by name."""
     from oracle import oracle
     from spcies_amd import benchmarks
     cfg, v, s = _fista_solver(cfg_name, None)
@@ -777,20 +778,27 @@ def test_hmpc_coupled_nosplit_fused(cfg_name, B):
     st = benchmarks.tester_status(cfg.sys)
     x0[0], xr[0], ur[0] = st.x, st.xr, st.ur
     O = oracle.hmpc_dense_batch(v, x0, xr, ur)
-    u, k, e, sol = s(x0, xr, ur, want_sol=False)  # the FUSED kernel
+    rerun = _rerun_with(oracle.hmpc_dense_batch, v, x0, xr, ur, keys=("tol_p", "tol_d"))
+    u, k, e, sol = s(x0, xr, ur, want_sol=False)  # the FUSED kernel, no record
     assert sol.z is None
-    same = assert_k(k, O[1], _rerun_with(oracle.hmpc_dense_batch, v, x0, xr, ur, keys=("tol_p", "tol_d")), max_share=0.03, what="coupled no-split FUSED")
+    same = assert_k(k, O[1], rerun, max_share=0.03, what="coupled no-split FUSED")
     dk = (~same).astype(int)
     assert np.array_equal(e[same], O[2][same])
     assert np.abs(u - O[0])[dk == 0].max() <= TOL_SPCIES
     _margins.record("hmpc_coupled_nosplit_fused", "fused", du=np.abs(u - O[0])[dk == 0].max(), k_differs=(dk > 0).sum(), bar=TOL_SPCIES,
                     frac_of_bar=np.abs(u - O[0])[dk == 0].max() / TOL_SPCIES)
-    _compare_hmpc_nosplit(s(x0, xr, ur), O, "gemm")  # the record: AUTO hands this call to GEMM
-    s.set_variant("fused")
-    with pytest.raises(Exception, match="z record"):
-        s(x0, xr, ur)
-    u2, k2, _, _ = s(x0, xr, ur, want_sol=False)
-    assert np.array_equal(u2, u) and np.array_equal(k2, k)
+    full = s(x0, xr, ur)  # the record (z, s, lambda): still AUTO, still FUSED
+    assert s.variant == "fused" and full[3].z is not None and np.array_equal(full[0], u) and np.array_equal(full[1], k)
+    _compare_hmpc_nosplit(full, O, "fused", rerun=rerun)
+    s.set_variant("fused")  # by name: the same kernels
+    byname = s(x0, xr, ur)
+    assert np.array_equal(byname[3].z, full[3].z) and np.array_equal(byname[0], u)
+    # a ragged second batch through the same handle (the operand scratch grows / is reused), shared reference
+    part = s(x0[:7], xr[0], ur[0])
+    Op = oracle.hmpc_dense_batch(v, x0[:7], xr[0], ur[0])
+    _compare_hmpc_nosplit(part, Op, "fused")
+    s.set_variant("gemm")  # the library GEMM: by name only, same record to 1e-10
+    _compare_hmpc_nosplit(s(x0, xr, ur), O, "gemm", rerun=rerun)
     s.close()
 
 
