@@ -76,6 +76,7 @@ struct KArr<true> {
 // Row offsets of the per-instance constants of the time-varying solvers inside their scratch (tv_layout()).
 struct TvLayout {
     int AB, Alpha, Beta, Hi, Hi_0, Q, R, LB, UB, AQiAt, BRiBt, rows;
+    int Bi, rows_all;  // the explicit inverses Beta^-1 of the MFMA4R variant (admm_tvr.hpp), behind everything the other variants use
 };
 __host__ __device__ inline TvLayout tv_layout(int n, int m, int N) {
     TvLayout L;
@@ -93,6 +94,8 @@ __host__ __device__ inline TvLayout tv_layout(int n, int m, int N) {
     L.AQiAt = r; r += n * n;
     L.BRiBt = r; r += n * n;
     L.rows = r;
+    L.Bi = r; r += N * n * n;
+    L.rows_all = r;
     return L;
 }
 
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(64) void admm_tv_update_kernel(int N, double rho, c
 
 // [rows][Bp] structure-of-arrays scratch -> [B][rows] instance-contiguous output (the layout the
 // reference's DEBUG copy-out produces per instance, code_laxMPC_ADMM_C.c:657-686).
-__global__ __launch_bounds__(256) void soa_to_aos_kernel(const double *__restrict__ S, long Bp, long B, int rows,
+static __global__ __launch_bounds__(256) void soa_to_aos_kernel(const double *__restrict__ S, long Bp, long B, int rows,
                                                           double *__restrict__ out) {
     __shared__ double tile[64][65];
     const long b0 = (long)blockIdx.x * 64;

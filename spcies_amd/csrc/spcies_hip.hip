@@ -8,6 +8,7 @@
 #include "mfma4_rtc.hpp"
 #include "admm_stream.hpp"
 #include "admm_tvw.hpp"
+#include "admm_tvr.hpp"
 #include "fista_stream.hpp"
 #include "fista_mfma4g.hpp"
 #include "admm_mfma4g.hpp"
@@ -742,12 +743,21 @@ static int tvw_waves(const Solver &s) {
     return (int)std::min<long>(4, (160 * 1024) / per);
 }
 
+// Time-varying lax/equ ADMM, variant MFMA4R (admm_tvr.hpp: one wavefront per instance, the instance's factors in its registers):
+// built for the shapes instantiated at build time; SPCIES_HIP_TVR=0 switches it off
+static bool tvr_ok(const Solver &s) {
+    if (!s.tv || s.method != SPCIES_ADMM) return false;
+    if (const char *ev = getenv("SPCIES_HIP_TVR"))
+        if (ev[0] == '0') return false;
+    return tvr::shape_built(s.host.n, s.host.m, s.host.N);
+}
+
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
     if (s.host.ellip) return s.bsp.ok ? SPCIES_VARIANT_BSP : SPCIES_VARIANT_STREAM;
-    // (time-varying ADMM also has TILE - one wavefront per instance, admm_tvw.hpp - on request: measured 0.157 M solves/s against
-    // STREAM's 0.279 M at the configs[1] shape, so AUTO stays on STREAM)
-    if (s.tv) return (s.variant == SPCIES_VARIANT_TILE && tvw_waves(s) > 0) ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
+    // (time-varying ADMM: MFMA4R - one wavefront per instance, factors in registers, admm_tvr.hpp - where its kernel is built; TILE - the
+    // same with the factors in LDS and the reference's recurrences, admm_tvw.hpp - on request only: 0.157 M solves/s against STREAM's 0.28 M)
+    if (s.tv) return tvr_ok(s) ? SPCIES_VARIANT_MFMA4R : SPCIES_VARIANT_STREAM;
     if (s.is_hdense()) return s.hfused.ok ? SPCIES_VARIANT_FUSED : SPCIES_VARIANT_GEMM;
     if (s.is_cs()) return s.csf.ok ? SPCIES_VARIANT_FUSED : (s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM);
     if (s.is_hmpc() && s.hfused.ok) return SPCIES_VARIANT_FUSED;
@@ -976,11 +986,19 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
     const bool want_sol = (z || v || lam);
     const size_t dim = (size_t)s.host.dim();
     const int nw = resolve_variant(s) == SPCIES_VARIANT_TILE ? tvw_waves(s) : 0;  // TILE: one wavefront per instance (admm_tvw.hpp)
-    const size_t rows_stream = nw ? 0 : 2 * dim + (size_t)N * n + (want_sol ? dim : 0);
-    long chunk = (long)((3900ull << 20) / ((size_t)tl.rows * 8)) / 64 * 64;
+    const bool regs = resolve_variant(s) == SPCIES_VARIANT_MFMA4R;               // MFMA4R: one wavefront per instance, factors in registers (admm_tvr.hpp)
+    const size_t rows_stream = (nw || regs) ? 0 : 2 * dim + (size_t)N * n + (want_sol ? dim : 0);
+    const size_t rows_tv = regs ? (size_t)tl.rows_all : (size_t)tl.rows;  // (MFMA4R: the explicit inverses behind the factors)
+    long chunk = (long)((3900ull << 20) / (rows_tv * 8)) / 64 * 64;
     if (chunk > B) chunk = (B + 63) / 64 * 64;
-    int rc = ensure_scratch(s, (rows_stream + (size_t)tl.rows) * (size_t)chunk * sizeof(double));
+    int rc = ensure_scratch(s, (rows_stream + rows_tv) * (size_t)chunk * sizeof(double));
     if (rc) return rc;
+    int num_cu = 256;
+    if (regs) {
+        hipDeviceProp_t prop;
+        SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, s.device));
+        if (prop.multiProcessorCount > 0) num_cu = prop.multiProcessorCount;
+    }
     for (long b0 = 0; b0 < B; b0 += chunk) {
         const long Bc = std::min(chunk, B - b0), Bp = (Bc + 63) / 64 * 64;
         double *V = s.d_scratch, *LAM = V + dim * Bp, *Y = LAM + dim * Bp;
@@ -989,6 +1007,20 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
         const double *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
         const double *mc = model_stride ? model + b0 * (long)model_stride : model;
         dim3 grid((unsigned)(Bp / 64)), block(64);
+        if (regs) {  // update phase as before (the reference's factorisation, one lane per instance), then the inverses and one wavefront per instance
+            if (s.host.terminal)
+                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
+                                   (long)model_stride, Bc, Bp, TVS);
+            else
+                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, false>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
+                                   (long)model_stride, Bc, Bp, TVS);
+            SPCIES_HIP_CHECK(hipGetLastError());
+            tvr::Args ta{s.host.k_max, ref_stride, s.host.rho, s.host.tol, Bc, Bp};
+            rc = tvr::launch(n, m, N, s.host.terminal, want_sol, ta, s.d_consts + s.dev.Hi_N, s.d_consts + s.dev.T, TVS, x0 + b0 * n, xrc, urc, u + b0 * m,
+                             k + b0, e + b0, z ? z + b0 * dim : nullptr, v ? v + b0 * dim : nullptr, lam ? lam + b0 * dim : nullptr, num_cu, st);
+            if (rc) return rc;
+            continue;
+        }
         if (nw) {  // update phase as before (the reference's operation order, one lane per instance), then one wavefront per instance
             if (s.host.terminal)
                 hipLaunchKernelGGL((admm_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
@@ -1427,8 +1459,10 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (!extra) return fail(SPCIES_HIP_EINVAL, "time-varying solvers take A, B, Q, R, LB, UB with every call (extra): Spcies:laxMPC:nrhs:number");
         if (extra_stride != 0 && extra_stride != s.tv_model_size())
             return fail(SPCIES_HIP_EINVAL, "time-varying: extra_stride must be 0 (shared model) or %d", s.tv_model_size());
-        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM && !(s.variant == SPCIES_VARIANT_TILE && tvw_waves(s) > 0))
-            return fail(SPCIES_HIP_ENOSUP, "time-varying ADMM: variants STREAM and TILE (one wavefront per instance, when the factors fit the LDS) are built");
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM && !(s.variant == SPCIES_VARIANT_TILE && tvw_waves(s) > 0) &&
+            !(s.variant == SPCIES_VARIANT_MFMA4R && tvr_ok(s)))
+            return fail(SPCIES_HIP_ENOSUP, "time-varying ADMM: variants STREAM, MFMA4R (factors in registers: the shapes built in admm_tvr.hpp) and TILE "
+                                          "(one wavefront per instance, when the factors fit the LDS) are built");
         if (s.host.n == 6 && s.host.m == 2) return launch_tv_nm<6, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         if (s.host.n == 12 && s.host.m == 2) return launch_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
@@ -1893,6 +1927,11 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
         return 0;
     }
     if (variant == SPCIES_VARIANT_TILE && s->tv && tvw_waves(*s) > 0) {  // time-varying ADMM: one wavefront per instance (admm_tvw.hpp)
+        s->variant = variant;
+        return 0;
+    }
+    if (variant == SPCIES_VARIANT_MFMA4R && s->tv) {  // time-varying ADMM: factors in registers (admm_tvr.hpp)
+        if (!tvr_ok(*s)) return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying ADMM): no kernel built for n = %d, m = %d, N = %d", s->host.n, s->host.m, s->host.N);
         s->variant = variant;
         return 0;
     }

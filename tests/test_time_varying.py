@@ -69,8 +69,38 @@ def test_blob_roundtrip_time_varying():
     assert not blob.unpack(blob.pack(v))["time_varying"]
 
 
+def _compare_tv(variant, got, O, vt, x0, xr, ur, model, per):
+    """STREAM and TILE run the reference's operation order: bit for bit.  MFMA4R (factors in registers, explicit Beta^-1, w-form) re-associates
+    sums: 1e-10 on u, z, v (the measured |lambda| allowance of tests/_cases.py for instances whose multipliers blow up), k equal unless the
+    oracle itself flips when its tolerance moves by 1e-12."""
+    from oracle import oracle
+    from _cases import TOL_SPCIES, assert_k, scaled_bar
+    u, k, e, sol = got
+    if variant != "mfma4r":
+        assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+        if sol.z is not None:
+            assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.v, O[4]) and np.array_equal(sol.lam, O[5])
+        return
+
+    def rerun(idx, dtol):
+        v2 = dict(vt)
+        v2["tol"] = float(vt["tol"]) + dtol
+        pr = np.ndim(xr) == 2
+        return oracle.admm_tv_batch(v2, x0[idx], xr[idx] if pr else xr, ur[idx] if pr else ur, model[idx] if per else model, per, want_sol=False)[1]
+    lscale = np.abs(O[5]).max(axis=1, keepdims=True)
+    bar = scaled_bar(lscale)
+    same = assert_k(k, O[1], rerun, scale=bar / TOL_SPCIES, what="time-varying MFMA4R")
+    assert np.array_equal(e[same], O[2][same])
+    assert (np.abs(u - O[0]) / bar)[same].max() <= 1.0
+    if sol.z is not None:
+        assert (np.abs(sol.z - O[3]) / bar)[same].max() <= 1.0 and (np.abs(sol.v - O[4]) / bar)[same].max() <= 1.0
+        assert (np.abs(sol.lam - O[5]) / (bar * (1.0 + lscale)))[same].max() <= 1.0
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["stream", "tile"])  # tile: one wavefront per instance, the factors in LDS (admm_tvw.hpp) - bit-exact too
+# tile: one wavefront per instance, the factors in LDS, the reference's recurrences (admm_tvw.hpp) - bit-exact too; mfma4r: one wavefront per
+# instance, the factors in REGISTERS, explicit inverses on the matrix pipe (admm_tvr.hpp) - 1e-10, AUTO's choice where its kernel is built
+@pytest.mark.parametrize("variant", ["stream", "tile", "mfma4r"])
 @pytest.mark.parametrize("name,B,overrides", [("C1_lax", 70, {}), ("C1_equ", 40, {}), ("C2_lax", 130, {}),
                                               ("C2_lax", 50, dict(tol=1e-6, k_max=3000)), ("C2_equ", 45, {})])
 def test_hip_time_varying_vs_oracle(name, B, overrides, variant):
@@ -80,7 +110,7 @@ def test_hip_time_varying_vs_oracle(name, B, overrides, variant):
     cfg, v, vt, design = _setup(name)
     vt = benchmarks.ingredients(cfg, time_varying=True, **overrides)
     s = HipSolver(vt)
-    assert s.time_varying and s.variant == "stream"  # AUTO (TILE is the slower of the two: DESIGN.md 4.2f)
+    assert s.time_varying and s.variant == "mfma4r"  # AUTO (TILE is the slowest of the three: DESIGN.md 4.2f)
     s.set_variant(variant)
     assert s.variant == variant
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
@@ -89,19 +119,33 @@ def test_hip_time_varying_vs_oracle(name, B, overrides, variant):
     # one shared model (the design model)
     model, per = oracle.pack_tv_model(*design)
     O = oracle.admm_tv_batch(vt, x0, xr, ur, model, per)
-    u, k, e, sol = s(x0, xr, ur, *design)
-    assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
-    assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.v, O[4]) and np.array_equal(sol.lam, O[5])
+    _compare_tv(variant, s(x0, xr, ur, *design), O, vt, x0, xr, ur, model, per)
     # one model per instance
     models = _perturbed_models(design, B)
     model, per = oracle.pack_tv_model(*models)
     O = oracle.admm_tv_batch(vt, x0, xr, ur, model, per)
-    u, k, e, sol = s(x0, xr, ur, *models)
-    assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
-    assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.v, O[4]) and np.array_equal(sol.lam, O[5])
-    nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)
-    assert np.array_equal(nosol[0], O[0][:9]) and np.array_equal(nosol[1], O[1][:9])
+    full = s(x0, xr, ur, *models)
+    _compare_tv(variant, full, O, vt, x0, xr, ur, model, per)
+    nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)  # the no-record kernel: the same bits
+    assert np.array_equal(nosol[0], full[0][:9]) and np.array_equal(nosol[1], full[1][:9])
+    # ragged batch sizes around the four instances of a workgroup, and one reference for the whole batch
+    for Bs in (1, 3, 5):
+        part = s(x0[:Bs], xr[0], ur[0], *[a[:Bs] for a in models])
+        Os = oracle.admm_tv_batch(vt, x0[:Bs], xr[0], ur[0], model[:Bs], per)
+        _compare_tv(variant, part, Os, vt, x0[:Bs], xr[0], ur[0], model[:Bs], per)
     s.close()
+
+
+@pytest.mark.gpu
+def test_time_varying_mfma4r_is_switched_off_by_the_environment(monkeypatch):
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg, v, vt, design = _setup("C1_lax")
+    monkeypatch.setenv("SPCIES_HIP_TVR", "0")
+    with HipSolver(vt) as s:
+        assert s.variant == "stream"
+        with pytest.raises(Exception, match="MFMA4R"):
+            s.set_variant("mfma4r")
 
 
 # ----------------------------------------------------------------------------------------------
