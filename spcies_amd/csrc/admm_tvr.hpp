@@ -71,6 +71,17 @@ __global__ __launch_bounds__(64) void admm_tv_bi_kernel(int N, long B, long Bp, 
 
 #define SPCIES_TVR_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (acc), 0, 0, 0)
 
+// every lane of a 16-lane row <- lane I of that row (v_mov_b32_dpp row_newbcast:I, every lane written: no previous value to keep)
+template <int I>
+__device__ __forceinline__ double bcast(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + I, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + I, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast_i(double v, int i) {  // i = 0, 4, 8, 12: a constant at every call once the loops are unrolled
+    return i == 0 ? bcast<0>(v) : (i == 4 ? bcast<4>(v) : (i == 8 ? bcast<8>(v) : bcast<12>(v)));
+}
+
 template <int n, int m, int N, bool TERMINAL, bool WANT_SOL>
 __global__ __launch_bounds__(256, 1) void admm_tvr_kernel(Args p, const double *__restrict__ TRIg, const double *__restrict__ Tg,
                                                           const double *__restrict__ TVS, const double *__restrict__ x0g,
@@ -195,13 +206,25 @@ __global__ __launch_bounds__(256, 1) void admm_tvr_kernel(Args p, const double *
         auto Qt = [&](int t) { return t == 0 ? q0 : (t == N ? qTv : qv); };
         auto clampv = [](double x, double lo, double hi) { return fmin(fmax(x, lo), hi); };
         // acc += M x: one MFMA per four columns; the B operand is the vector's register with lane 4 J of every row broadcast
-        auto mv = [&](double &acc, const double *A, const int KJ, const double x) __attribute__((always_inline)) {
+        // (the B operands of a product are formed in ONE run of DPP moves in front of its MFMAs: a vector instruction alone between two
+        // MFMAs costs 12 clocks, in a run 4 - profiles/r03_microbench_issue.txt)
+        auto bops = [&](double (&b)[4], const int KJ, const double x) __attribute__((always_inline)) {
 #pragma unroll
-            for (int J = 0; J < KJ; J++) SPCIES_TVR_MFMA(acc, A[J], tvw::row_bcast_i(x, 4 * J));
+            for (int J = 0; J < 4; J++) b[J] = J < KJ ? bcast_i(x, 4 * J) : 0.0;
         };
-        auto mv_al = [&](double &acc, const int kind, const int l, const double x) __attribute__((always_inline)) {
+        auto mvb = [&](double &acc, const double *A, const int KJ, const double (&b)[4]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int J = 0; J < KX; J++) SPCIES_TVR_MFMA(acc, AL(kind, l, J), tvw::row_bcast_i(x, 4 * J));
+            for (int J = 0; J < KJ; J++) SPCIES_TVR_MFMA(acc, A[J], b[J]);
+        };
+        auto mv = [&](double &acc, const double *A, const int KJ, const double x) __attribute__((always_inline)) {
+            double b[4];
+            bops(b, KJ, x);
+            __builtin_amdgcn_sched_barrier(0);  // (the moves stay one run: the scheduler would sink each pair next to its MFMA)
+            mvb(acc, A, KJ, b);
+        };
+        auto al_load = [&](double (&a)[4], const int kind, const int l) __attribute__((always_inline)) {  // this stage's LDS images, requested early
+#pragma unroll
+            for (int J = 0; J < 4; J++) a[J] = J < KX ? AL(kind, l, J) : 0.0;
         };
         int kk = 0;
         while (true) {
@@ -230,8 +253,13 @@ __global__ __launch_bounds__(256, 1) void admm_tvr_kernel(Args p, const double *
                     acc = -xrv;  // equMPC: x_N = xr in the last block row (code_equMPC_ADMM_C.c:337-352)
                 }
                 if (l == 0) acc += c0v;      // - b = A x0
-                mv(acc, ABHA, KS, qh);       // - AB (Hi o q_hat_l)
-                if (l >= 1) mv_al(acc, 1, l >= 1 ? l - 1 : 0, mu[l >= 1 ? l - 1 : 0]);  // - Alpha_{l-1}' y_{l-1}
+                double bq[4], by[4], alt[4];
+                if (l >= 1) al_load(alt, 1, l >= 1 ? l - 1 : 0);
+                bops(bq, KS, qh);
+                if (l >= 1) bops(by, KX, mu[l >= 1 ? l - 1 : 0]);
+                __builtin_amdgcn_sched_barrier(0);
+                mvb(acc, ABHA, KS, bq);      // - AB (Hi o q_hat_l)
+                if (l >= 1) mvb(acc, alt, KX, by);  // - Alpha_{l-1}' y_{l-1}
                 double y = 0.0;
                 mv(y, BiTA[l], KX, acc);     // Bi_l' ( . )
                 mu[l] = y;
@@ -255,7 +283,13 @@ __global__ __launch_bounds__(256, 1) void admm_tvr_kernel(Args p, const double *
             for (int l = N - 1; l >= 0; l--) {
                 asm volatile("" : "+v"(ldsa));
                 double acc = mu[l];
-                if (l < N - 1) mv_al(acc, 0, l < N - 1 ? l : 0, mu[l < N - 1 ? l + 1 : 0]);  // y_l - Alpha_l mu_{l+1}
+                double bm[4], al[4];  // B operands of mu_{l+1}: for Alpha_l here and for AB' of stage l + 1 below
+                if (l < N - 1) {
+                    al_load(al, 0, l < N - 1 ? l : 0);
+                    bops(bm, KX, mu[l < N - 1 ? l + 1 : 0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mvb(acc, al, KX, bm);  // y_l - Alpha_l mu_{l+1}
+                }
                 double mn = 0.0;
                 mv(mn, BiA[l], KX, acc);
                 const int t = l + 1;
@@ -269,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void admm_tvr_kernel(Args p, const double *
                 } else {
                     const double qq = qhat(t, cw);
                     double z = nhd * (qq - mn);  // (mu has x rows only: its u rows are zero)
-                    mv(z, ZTA, KX, mu[t]);        // - Hi o (AB' mu_t)
+                    mvb(z, ZTA, KX, bm);          // - Hi o (AB' mu_t): t = l + 1 <= N - 1, the operands formed above
                     finish(t, z, cw);
                 }
                 mu[l] = mn;
