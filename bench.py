@@ -495,8 +495,10 @@ def bench_config(spec, dev, steps, warmup, key=""):
                         "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_MFMA_TFLOPS,
                         "flop_per_solve": spec["flop"], "algorithmic_io_gbs": gbs, "hbm_frac_algorithmic": gbs / PEAK_HBM_GBS},
            "oracle_check": _oracle_check(cfg, v, x0, xr, ur, tu[:32].cpu().numpy(), tk[:32].cpu().numpy(), model=model)}
-    if tv:  # what bounds this path is the per-instance factor traffic: report the design bytes against the HBM peak as the fraction
+    if tv and variant == "stream":  # STREAM re-reads the instance's factors in every iteration: bound by that design traffic (hbm_frac_design)
         out["roofline"]["bound"] = "hbm"
+    # (MFMA4R for the time-varying solver keeps the factors in registers: no traffic inside the iteration; one instance per wavefront, the
+    # dependent chain of 2 N block solves - issue / latency bound far below the matrix peak, which `frac` shows)
     traffic, src = design_traffic(key, variant)
     if traffic is not None:  # what the kernel really moves through HBM (design bytes, not algorithmic ones) against the 8 TB/s peak
         out["roofline"].update(traffic=traffic, traffic_source=src, hbm_frac_design=traffic / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS)

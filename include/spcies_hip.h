@@ -324,6 +324,14 @@ int spcies_hip_rtc_cache_selftest(const char *text, int work_ms, int drop_memory
 int spcies_hip_k_histogram_device(spcies_hip_handle h, const int *k, const int *e_flag, long B, int n_bins, long *hist, long *counts,
                                   void *stream);
 
+/* Residual history of a solve (what the dense MATLAB solvers record with genHist > 0: hRp(k) = ||z - v||_inf, hRd(k) =
+ * ||v - v_prev||_inf, platforms/Matlab/spcies_laxMPC_ADMM_solver.m:253-261, 311-319) for the lax / equ MPC ADMM solvers: host
+ * buffers; r_p, r_d are [B][K], entry [i][j-1] = the residuals of iteration j of instance i, zero behind the iteration the instance
+ * leaves at under the handle's own exit settings (returned in k_exit [B], may be NULL).  A diagnostic: iteration j is read off a
+ * solve stopped at k_max = j on the handle's current variant (K (K + 1) / 2 iterations in all); the handle's settings are restored. */
+int spcies_hip_residual_trace(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride, long B, int K,
+                              double *r_p, double *r_d, int *k_exit);
+
 /* Time `reps` back-to-back device solves with hipEvents recorded on `stream` (the stream the
  * kernel is launched on); returns the mean milliseconds per launch in *ms_per_launch. */
 int spcies_hip_time_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur,

@@ -2113,6 +2113,51 @@ int spcies_hip_solve_batch(spcies_hip_handle h, const double *x0, const double *
                                      (z || v || lambda) ? f : nullptr, s->n_fields(), timing);
 }
 
+// the per-instance residual history the dense MATLAB solvers record with genHist > 0 (hRp(k) = ||z - v||_inf, hRd(k) =
+// ||v - v_prev||_inf, platforms/Matlab/spcies_laxMPC_ADMM_solver.m:253-261, 311-319).  A diagnostic, not a hot path: the trace is read
+// off the SAME kernels a solve runs - iteration j of every instance is the record (z, v) of a solve stopped at k_max = j with the exit
+// test off - so what is plotted is what the selected variant computes, and no kernel carries trace code.  K (K + 1) / 2 iterations.
+int spcies_hip_residual_trace(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride, long B, int K,
+                              double *r_p, double *r_d, int *k_exit) {
+    if (!h || !r_p || !r_d) return fail(SPCIES_HIP_EINVAL, "NULL argument");
+    if (K < 1 || B < 0) return fail(SPCIES_HIP_EINVAL, "residual trace: K >= 1, B >= 0");
+    Solver *s = reinterpret_cast<Solver *>(h);
+    const bool lax = (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC) && s->method == SPCIES_ADMM && !s->tv && !s->host.ellip;
+    if (!lax) return fail(SPCIES_HIP_ENOSUP, "residual trace: built for the lax / equ MPC ADMM solvers (record z, v, lambda)");
+    if (B == 0) return 0;
+    const size_t dim = (size_t)s->host.dim(), m = (size_t)s->host.m;
+    const int k_max0 = s->host.k_max;
+    const double tol0 = s->host.tol;
+    std::vector<double> u((size_t)B * m), z((size_t)B * dim), v((size_t)B * dim), lam((size_t)B * dim), vprev((size_t)B * dim, 0.0);
+    std::vector<int> k((size_t)B), e((size_t)B), kx((size_t)B);
+    // the exit iteration under the handle's own settings: entries behind it stay zero, as in the MATLAB record
+    int rc = spcies_hip_solve_batch(h, x0, xr, ur, ref_stride, B, u.data(), kx.data(), e.data(), nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    for (long i = 0; i < B * (long)K; i++) r_p[i] = r_d[i] = 0.0;
+    for (int j = 1; j <= K && rc == 0; j++) {
+        spcies_hip_set_exit(h, j, 0.0);  // exactly j iterations (tol = 0: the reference tests' fixed-iteration setting)
+        rc = spcies_hip_solve_batch(h, x0, xr, ur, ref_stride, B, u.data(), k.data(), e.data(), z.data(), v.data(), lam.data(), nullptr);
+        if (rc) break;
+        for (long i = 0; i < B; i++) {
+            if (j <= kx[i]) {
+                double rp = 0.0, rd = 0.0;
+                for (size_t c = 0; c < dim; c++) {
+                    rp = std::max(rp, std::fabs(z[i * dim + c] - v[i * dim + c]));
+                    rd = std::max(rd, std::fabs(v[i * dim + c] - vprev[i * dim + c]));
+                }
+                r_p[i * (long)K + (j - 1)] = rp;
+                r_d[i * (long)K + (j - 1)] = rd;
+            }
+        }
+        vprev = v;
+    }
+    spcies_hip_set_exit(h, k_max0, tol0);
+    if (rc) return rc;
+    if (k_exit)
+        for (long i = 0; i < B; i++) k_exit[i] = kx[i];
+    return 0;
+}
+
 int spcies_hip_time_device(spcies_hip_handle h, const double *x0, const double *xr, const double *ur, int ref_stride,
                            long B, double *u, int *k, int *e_flag, void *stream, int reps, double *ms_per_launch) {
     if (!h || !ms_per_launch || reps <= 0) return fail(SPCIES_HIP_EINVAL, "bad argument");

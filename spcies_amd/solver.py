@@ -249,6 +249,19 @@ class HipSolver:
         return SimpleNamespace(hist=np.array(hist[:], dtype=np.int64), converged=int(counts[0]), k_max_reached=int(counts[1]),
                                other=int(counts[2]), mean_k=(counts[3] / B if B else 0.0))
 
+    def residual_trace(self, x0, xr, ur, K):
+        """Residual history of the lax / equ MPC ADMM solvers (the dense MATLAB solvers' ``hRp`` / ``hRd`` record,
+        ``spcies_laxMPC_ADMM_solver.m:253-261, 311-319``): returns ``SimpleNamespace(r_p, r_d, k)`` with ``r_p[i, j-1] = ||z - v||_inf`` and
+        ``r_d[i, j-1] = ||v - v_prev||_inf`` of iteration ``j`` of instance ``i`` (zero behind the iteration it leaves at, ``k[i]``)."""
+        x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=np.float64)))
+        B = x0.shape[0]
+        xr = np.ascontiguousarray(np.asarray(xr, dtype=np.float64))
+        ur = np.ascontiguousarray(np.asarray(ur, dtype=np.float64))
+        per = 1 if xr.ndim == 2 else 0
+        rp, rd, kx = np.zeros((B, int(K))), np.zeros((B, int(K))), np.zeros(B, dtype=np.int32)
+        _lib.check(self._lib.spcies_hip_residual_trace(self._h, _dp(x0), _dp(xr), _dp(ur), C.c_int(per), C.c_long(B), int(K), _dp(rp), _dp(rd), _ip(kx)))
+        return SimpleNamespace(r_p=rp, r_d=rd, k=kx)
+
     def time_device(self, x0, xr, ur, u, k, e_flag, stream=0, reps=1):
         """Mean ms per launch over ``reps`` back-to-back solves, hipEvents on ``stream``."""
         ptr = lambda a: C.c_void_p(a.data_ptr())

@@ -1583,6 +1583,37 @@ def test_notes_report_what_auto_gave_up(monkeypatch):
         assert s.variant == "mfma4g" and "MFMA4R unavailable" in s.notes and "SPCIES_HIP_RTC" in s.notes
 
 
+@pytest.mark.parametrize("variant", ["stream", "mfma4"])
+def test_residual_trace_matches_the_dense_matlab_record(variant):
+    """hRp / hRd of the dense MATLAB solver (spcies_laxMPC_ADMM_solver.m:253-261, 311-319) - here from the numpy restatement of
+    that solver (oracle/dense_admm.py, which shares nothing with the banded path) and from the oracle stopped at every iteration."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _solver("C1_lax", variant, tol=1e-5, k_max=3000)
+    x0, xr, ur = benchmarks.sample_batch(cfg, 6)
+    K = 40
+    tr = s.residual_trace(x0, xr, ur, K)
+    assert tr.r_p.shape == (6, K) and (tr.k > K).all()  # (none of these instances converges within 40 iterations)
+    vprev = np.zeros((6, v["N"] * (v["n"] + v["m"])))
+    for j in (1, 2, 3, 17, K):
+        O = oracle.admm_banded_batch(dict(v, tol=0.0, k_max=j), x0, xr, ur)
+        Op = oracle.admm_banded_batch(dict(v, tol=0.0, k_max=j - 1), x0, xr, ur) if j > 1 else None
+        rp = np.abs(O[3] - O[4]).max(axis=1)
+        rd = np.abs(O[4] - (Op[4] if Op is not None else 0.0)).max(axis=1)
+        assert np.abs(tr.r_p[:, j - 1] - rp).max() <= (0.0 if variant == "stream" else 1e-10)
+        assert np.abs(tr.r_d[:, j - 1] - rd).max() <= (0.0 if variant == "stream" else 1e-10)
+    # an instance that converges early: its trace is zero behind its exit iteration, and the handle's settings are restored
+    s.set_exit(k_max=3000, tol=1e-2)
+    tr2 = s.residual_trace(x0[:2], xr[:2], ur[:2], 60)
+    assert (tr2.k < 60).all()
+    for i in range(2):
+        assert (tr2.r_p[i, tr2.k[i]:] == 0).all() and (tr2.r_d[i, tr2.k[i]:] == 0).all()
+        assert max(tr2.r_p[i, tr2.k[i] - 1], tr2.r_d[i, tr2.k[i] - 1]) <= 1e-2 < max(tr2.r_p[i, tr2.k[i] - 2], tr2.r_d[i, tr2.k[i] - 2])
+    u, k, e, _ = s(x0[:2], xr[:2], ur[:2], want_sol=False)
+    assert np.array_equal(k, tr2.k)
+    s.close()
+
+
 def test_k_histogram_of_a_device_solve():
     """the batch histogram of k and the exit-flag counts, computed on the device from the arrays a device solve wrote."""
     import torch
