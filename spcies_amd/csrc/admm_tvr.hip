@@ -1,17 +1,69 @@
 // Host side of the MFMA4R variant of the time-varying lax/equ ADMM solvers (admm_tvr.hpp): the explicit inverses after the update phase,
 // then one wavefront per instance.  A translation unit of its own: the horizon is unrolled by #pragma unroll (register arrays), which
-// needs clang's size limit lifted, and the kernels are large.
+// needs clang's size limit lifted; accumulators in VGPR form (they are seeded and consumed by vector instructions).
 #include "admm_tvr.hpp"
+#include "admm_stream.hpp"  // tv_layout: the rows the update phase writes
+#include "admm_tvr_kernel.inc"
+#include "rtc_common.hpp"
 
 namespace spcies {
 namespace tvr {
 
+static const char *const kSource =
+#include "admm_tvr_src.inc"
+    ;
+
+void plan_free(Plan &p) {
+    if (p.module) rtc::unload_module((hipModule_t)p.module);
+    p.module = nullptr;
+    p.ok = false;
+}
+
+int plan_build(Plan &p, int n, int m, int N, bool terminal) {
+    p.ok = false;
+    p.n = n; p.m = m; p.N = N; p.terminal = terminal;
+    if (!((n == 6 && m == 2) || (n == 12 && m == 2))) { p.why = "time-varying solvers are instantiated for (n, m) = (6, 2) and (12, 2)"; return 0; }
+    if (N < 2) { p.why = "N < 2"; return 0; }
+    {   // the kernel's restatement of the update phase's row layout must be the layout
+        const TvLayout a = tv_layout(n, m, N);
+        const Rows b = rows_of(n, m, N);
+        if (a.AB != b.AB || a.Alpha != b.Alpha || a.Beta != b.Beta || a.Hi != b.Hi || a.Q != b.Q || a.R != b.R || a.LB != b.LB || a.UB != b.UB || a.Bi != b.Bi)
+            return fail(SPCIES_HIP_EINVAL, "MFMA4R (time-varying): row layout mismatch between admm_stream.hpp and admm_tvr_kernel.inc");
+    }
+    // registers: Bi and Bi' (2 N KX doubles per lane), the Alpha blocks the LDS does not hold, the state (2 N + 1), constants and temporaries
+    const int KX = (n + 3) / 4, NL = std::min(N - 1, 80 / (2 * KX));
+    const int doubles = 2 * N * KX + 2 * (N - 1 - NL) * KX + 16 + (2 * N + 1) + 40;
+    if (2 * doubles > 500) { p.why = "MFMA4R (time-varying): the instance's factors do not fit the wavefront's registers (use STREAM)"; return 0; }
+    p.builtin = shape_built(n, m, N);
+    if (!p.builtin) {
+        const char *ev = getenv("SPCIES_HIP_RTC");
+        if (ev && ev[0] == '0') { p.why = "horizon not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
+        std::vector<std::string> nm;
+        char name[160];
+        snprintf(name, sizeof(name), "spcies::tvr::admm_tv_bi_kernel<%d, %d>", n, m);
+        nm.push_back(name);
+        for (int s = 0; s < 2; s++) {
+            snprintf(name, sizeof(name), "spcies::tvr::admm_tvr_kernel<%d, %d, %d, %s, %s>", n, m, N, terminal ? "true" : "false", s ? "true" : "false");
+            nm.push_back(name);
+        }
+        std::vector<std::string> extra = {"-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form"};
+        for (const std::string &e : rtc::split_flags(getenv("SPCIES_TVR_RTC_FLAGS"))) extra.push_back(e);
+        hipModule_t mod = nullptr;
+        hipFunction_t fns[3] = {nullptr, nullptr, nullptr};
+        int rc = rtc::compile_module(kSource, "spcies_admm_tvr_rtc.hip", nm, extra, &mod, fns);
+        if (rc) { p.why = std::string("MFMA4R (time-varying): run-time specialisation failed: ") + spcies_hip_last_error(); p.build_failed = true; return 0; }
+        p.module = mod;
+        p.fn[0] = fns[0]; p.fn[1] = fns[1]; p.fn[2] = fns[2];
+    }
+    p.ok = true;
+    p.why.clear();
+    return 0;
+}
+
 template <int n, int m, int N>
 static int launch_shape(bool terminal, bool want_sol, const Args &a, const double *TRI, const double *T, double *TVS, const double *x0, const double *xr,
-                        const double *ur, double *u, int *k, int *e, double *z, double *v, double *lam, int num_cu, hipStream_t st) {
+                        const double *ur, double *u, int *k, int *e, double *z, double *v, double *lam, unsigned grid, hipStream_t st) {
     hipLaunchKernelGGL((admm_tv_bi_kernel<n, m>), dim3((unsigned)(a.Bp / 64)), dim3(64), 0, st, N, a.B, a.Bp, TVS);
-    const long groups = (a.B + 3) / 4;
-    const unsigned grid = (unsigned)std::min<long>(groups, (long)num_cu);
 #define SPCIES_TVR_GO(TT, SS) \
     hipLaunchKernelGGL((admm_tvr_kernel<n, m, N, TT, SS>), dim3(grid), dim3(256), 0, st, a, TRI, T, TVS, x0, xr, ur, u, k, e, z, v, lam)
     if (terminal) {
@@ -24,14 +76,29 @@ static int launch_shape(bool terminal, bool want_sol, const Args &a, const doubl
     return 0;
 }
 
-int launch(int n, int m, int N, bool terminal, bool want_sol, const Args &a, const double *TRI, const double *T, double *TVS, const double *x0,
-           const double *xr, const double *ur, double *u, int *k, int *e, double *z, double *v, double *lam, int num_cu, hipStream_t st) {
+int launch(const Plan &p, bool want_sol, const Args &a, const double *TRI, const double *T, double *TVS, const double *x0, const double *xr,
+           const double *ur, double *u, int *k, int *e, double *z, double *v, double *lam, int num_cu, hipStream_t st) {
+    if (!p.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying) unavailable: %s", p.why.c_str());
     if (want_sol && !(z && v && lam)) return fail(SPCIES_HIP_EINVAL, "MFMA4R (time-varying): pass all of z, v, lambda or none");
+    const long groups = (a.B + 3) / 4;
+    const unsigned grid = (unsigned)std::min<long>(groups, (long)num_cu);
+    if (p.builtin) {
 #define X(nn, mm, NN) \
-    if (n == nn && m == mm && N == NN) return launch_shape<nn, mm, NN>(terminal, want_sol, a, TRI, T, TVS, x0, xr, ur, u, k, e, z, v, lam, num_cu, st);
-    SPCIES_TVR_SHAPES(X)
+    if (p.n == nn && p.m == mm && p.N == NN) return launch_shape<nn, mm, NN>(p.terminal, want_sol, a, TRI, T, TVS, x0, xr, ur, u, k, e, z, v, lam, grid, st);
+        SPCIES_TVR_SHAPES(X)
 #undef X
-    return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying): no kernel for n = %d, m = %d, N = %d", n, m, N);
+        return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying): bad build-time shape");
+    }
+    {
+        int N = p.N;
+        long B = a.B, Bp = a.Bp;
+        void *params[] = {&N, &B, &Bp, &TVS};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[0], (unsigned)(a.Bp / 64), 1, 1, 64, 1, 1, 0, st, params, nullptr));
+    }
+    Args aa = a;
+    void *params[] = {&aa, &TRI, &T, &TVS, &x0, &xr, &ur, &u, &k, &e, &z, &v, &lam};
+    SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 2 : 1], grid, 1, 1, 256, 1, 1, 0, st, params, nullptr));
+    return 0;
 }
 
 }  // namespace tvr

@@ -102,6 +102,7 @@ struct Solver {
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
     unsigned long long *d_hist = nullptr;  // spcies_hip_k_histogram_device's bins and counters
+    tvr::Plan tvrp;                        // time-varying ADMM, MFMA4R: one wavefront per instance, factors in registers (admm_tvr.hpp)
     std::string build_failures;    // the subset of `notes` that are failed builds (SPCIES_HIP_STRICT)
     std::string notes;             // which faster (run-time specialised) variants AUTO could not use, and why (spcies_hip_get_notes)
     fr::Plan frplan;               // MFMA4R (FISTA with the iteration state in registers + LDS, run-time specialised)
@@ -743,14 +744,9 @@ static int tvw_waves(const Solver &s) {
     return (int)std::min<long>(4, (160 * 1024) / per);
 }
 
-// Time-varying lax/equ ADMM, variant MFMA4R (admm_tvr.hpp: one wavefront per instance, the instance's factors in its registers):
-// built for the shapes instantiated at build time; SPCIES_HIP_TVR=0 switches it off
-static bool tvr_ok(const Solver &s) {
-    if (!s.tv || s.method != SPCIES_ADMM) return false;
-    if (const char *ev = getenv("SPCIES_HIP_TVR"))
-        if (ev[0] == '0') return false;
-    return tvr::shape_built(s.host.n, s.host.m, s.host.N);
-}
+// Time-varying lax/equ ADMM, variant MFMA4R (admm_tvr.hpp: one wavefront per instance, the instance's factors in its registers): the
+// plan is built at create time (hiprtc for horizons without a build-time kernel); SPCIES_HIP_TVR=0 switches the variant off
+static bool tvr_ok(const Solver &s) { return s.tv && s.method == SPCIES_ADMM && s.tvrp.ok; }
 
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
@@ -1016,7 +1012,7 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
                                    (long)model_stride, Bc, Bp, TVS);
             SPCIES_HIP_CHECK(hipGetLastError());
             tvr::Args ta{s.host.k_max, ref_stride, s.host.rho, s.host.tol, Bc, Bp};
-            rc = tvr::launch(n, m, N, s.host.terminal, want_sol, ta, s.d_consts + s.dev.Hi_N, s.d_consts + s.dev.T, TVS, x0 + b0 * n, xrc, urc, u + b0 * m,
+            rc = tvr::launch(s.tvrp, want_sol, ta, s.d_consts + s.dev.Hi_N, s.d_consts + s.dev.T, TVS, x0 + b0 * n, xrc, urc, u + b0 * m,
                              k + b0, e + b0, z ? z + b0 * dim : nullptr, v ? v + b0 * dim : nullptr, lam ? lam + b0 * dim : nullptr, num_cu, st);
             if (rc) return rc;
             continue;
@@ -1573,6 +1569,7 @@ static void free_solver(Solver *s) {
     if (!s) return;
     if (s->device_bound) hipSetDevice(s->device);
     if (s->d_hist) hipFree(s->d_hist);
+    tvr::plan_free(s->tvrp);
     if (s->d_consts) hipFree(s->d_consts);
     if (s->d_scratch) hipFree(s->d_scratch);
     if (s->d_io) hipFree(s->d_io);
@@ -1738,6 +1735,14 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         }
     }
     // what AUTO had to give up (a failed run-time specialisation is not an error, but the caller can ask)
+    if (s->tv && s->method == SPCIES_ADMM) {  // time-varying ADMM: the register-resident variant (hiprtc for a horizon without a build-time kernel)
+        const char *ev = getenv("SPCIES_HIP_TVR");
+        if (ev && ev[0] == '0') s->tvrp.why = "SPCIES_HIP_TVR=0";
+        else {
+            rc = tvr::plan_build(s->tvrp, s->host.n, s->host.m, s->host.N, s->host.terminal);
+            if (rc) return rc;
+        }
+    }
     // Two kinds of reasons: the variant does not APPLY to this controller (general Q and R, a shape outside the packer, state beyond
     // registers + LDS, switched off by the caller) - and the variant applies but could not be BUILT (hiprtc missing, compile error).
     auto note = [&](const char *name, bool wanted, bool ok, const std::string &why, bool build_failed) {
@@ -1747,6 +1752,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     };
     note("MFMA4R", s->method == SPCIES_FISTA && !s->tv, s->frplan.ok, s->frplan.why, s->frplan.build_failed);
     note("MFMA4R", s->method == SPCIES_EADMM, s->erplan.ok, s->erplan.why, s->erplan.build_failed);
+    note("MFMA4R", s->tv && s->method == SPCIES_ADMM, s->tvrp.ok, s->tvrp.why, s->tvrp.build_failed);
     note("BSP", (s->is_soc() && !s->is_hmpc()) || s->host.ellip, s->bsp.ok, s->bsp.why, s->bsp.build_failed);
     note("MFMA4", s->mfma4.needs_rtc, s->mfma4.ok, s->mfma4.why, s->mfma4.build_failed);
     note("FUSED", s->is_hmpc() || s->is_hdense(), s->hfused.ok, s->hfused.why, s->hfused.build_failed);
@@ -1931,7 +1937,7 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
         return 0;
     }
     if (variant == SPCIES_VARIANT_MFMA4R && s->tv) {  // time-varying ADMM: factors in registers (admm_tvr.hpp)
-        if (!tvr_ok(*s)) return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying ADMM): no kernel built for n = %d, m = %d, N = %d", s->host.n, s->host.m, s->host.N);
+        if (!tvr_ok(*s)) return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying ADMM) unavailable: %s", s->tvrp.why.c_str());
         s->variant = variant;
         return 0;
     }

@@ -137,6 +137,35 @@ def test_hip_time_varying_vs_oracle(name, B, overrides, variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,N", [("C1_lax", 4), ("C1_equ", 13), ("C1_lax", 23), ("C2_lax", 8), ("C2_equ", 9)])  # (equMPC needs N m >= n: with fewer inputs than states the terminal equality makes W singular - the oracle itself returns NaN)
+def test_time_varying_mfma4r_other_horizons(name, N):
+    """MFMA4R for a horizon without a build-time kernel: specialised with hiprtc at create time (the register arrays are indexed by the
+    unrolled horizon), AUTO's choice; 1e-10 against the oracle with one model per instance."""
+    import copy
+    from types import SimpleNamespace
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = copy.copy(benchmarks.config(name))
+    cfg.param = SimpleNamespace(**dict(vars(cfg.param), N=N))
+    vt = benchmarks.ingredients(cfg, time_varying=True, tol=1e-6, k_max=600)
+    sysm, prm = cfg.sys, cfg.param
+    LB = np.concatenate([np.ravel(sysm.LBx), np.ravel(sysm.LBu)])
+    UB = np.concatenate([np.ravel(sysm.UBx), np.ravel(sysm.UBu)])
+    design = (np.asarray(sysm.A, float), np.asarray(sysm.B, float), np.diag(prm.Q).copy(), np.diag(prm.R).copy(), LB, UB)
+    with HipSolver(vt) as s:
+        assert s.variant == "mfma4r", s.notes
+        B = 21
+        x0, xr, ur = benchmarks.sample_batch(cfg, B)
+        models = _perturbed_models(design, B)
+        model, per = oracle.pack_tv_model(*models)
+        O = oracle.admm_tv_batch(vt, x0, xr, ur, model, per)
+        _compare_tv("mfma4r", s(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
+        s.set_variant("stream")  # the bit-exact variant on the same handle
+        _compare_tv("stream", s(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
+
+
+@pytest.mark.gpu
 def test_time_varying_mfma4r_is_switched_off_by_the_environment(monkeypatch):
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
