@@ -2,7 +2,8 @@
 // then one wavefront per instance.  A translation unit of its own: the horizon is unrolled by #pragma unroll (register arrays), which
 // needs clang's size limit lifted; accumulators in VGPR form (they are seeded and consumed by vector instructions).
 #include "admm_tvr.hpp"
-#include "admm_stream.hpp"  // tv_layout: the rows the update phase writes
+#include "admm_stream.hpp"   // tv_layout: the rows the update phase writes
+#include "fista_stream.hpp"  // fista_tv_layout
 #include "admm_tvr_kernel.inc"
 #include "rtc_common.hpp"
 
@@ -19,20 +20,25 @@ void plan_free(Plan &p) {
     p.ok = false;
 }
 
-int plan_build(Plan &p, int n, int m, int N, bool terminal) {
+int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
     p.ok = false;
-    p.n = n; p.m = m; p.N = N; p.terminal = terminal;
+    p.n = n; p.m = m; p.N = N; p.terminal = terminal; p.fista = fista;
     if (!((n == 6 && m == 2) || (n == 12 && m == 2))) { p.why = "time-varying solvers are instantiated for (n, m) = (6, 2) and (12, 2)"; return 0; }
     if (N < 2) { p.why = "N < 2"; return 0; }
-    {   // the kernel's restatement of the update phase's row layout must be the layout
+    if (fista) {   // the kernel's restatement of the update phase's row layout must be the layout
+        const FistaTvLayout a = fista_tv_layout(n, m, N);
+        const FRows b = frows_of(n, m, N);
+        if (a.AB != b.AB || a.Alpha != b.Alpha || a.Beta != b.Beta || a.Q != b.Q || a.R != b.R || a.QRi != b.QRi || a.LB != b.LB || a.UB != b.UB || a.rows != b.Bi)
+            return fail(SPCIES_HIP_EINVAL, "MFMA4R (time-varying FISTA): row layout mismatch between fista_stream.hpp and admm_tvr_kernel.inc");
+    } else {
         const TvLayout a = tv_layout(n, m, N);
         const Rows b = rows_of(n, m, N);
         if (a.AB != b.AB || a.Alpha != b.Alpha || a.Beta != b.Beta || a.Hi != b.Hi || a.Q != b.Q || a.R != b.R || a.LB != b.LB || a.UB != b.UB || a.Bi != b.Bi)
             return fail(SPCIES_HIP_EINVAL, "MFMA4R (time-varying): row layout mismatch between admm_stream.hpp and admm_tvr_kernel.inc");
     }
-    // registers: Bi and Bi' (2 N KX doubles per lane), the Alpha blocks the LDS does not hold, the state (2 N + 1), constants and temporaries
+    // registers: Bi and Bi' (2 N KX doubles per lane), the Alpha blocks the LDS does not hold, the state (2 N + 1; FISTA: 3 N), constants and temporaries
     const int KX = (n + 3) / 4, NL = std::min(N - 1, 80 / (2 * KX));
-    const int doubles = 2 * N * KX + 2 * (N - 1 - NL) * KX + 16 + (2 * N + 1) + 40;
+    const int doubles = 2 * N * KX + 2 * (N - 1 - NL) * KX + 16 + (fista ? 3 * N : 2 * N + 1) + 40;
     if (2 * doubles > 500) { p.why = "MFMA4R (time-varying): the instance's factors do not fit the wavefront's registers (use STREAM)"; return 0; }
     p.builtin = shape_built(n, m, N);
     if (!p.builtin) {
@@ -40,10 +46,10 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal) {
         if (ev && ev[0] == '0') { p.why = "horizon not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
         std::vector<std::string> nm;
         char name[160];
-        snprintf(name, sizeof(name), "spcies::tvr::admm_tv_bi_kernel<%d, %d>", n, m);
+        snprintf(name, sizeof(name), "spcies::tvr::%s_tv_bi_kernel<%d, %d>", fista ? "fista" : "admm", n, m);
         nm.push_back(name);
         for (int s = 0; s < 2; s++) {
-            snprintf(name, sizeof(name), "spcies::tvr::admm_tvr_kernel<%d, %d, %d, %s, %s>", n, m, N, terminal ? "true" : "false", s ? "true" : "false");
+            snprintf(name, sizeof(name), "spcies::tvr::%s_tvr_kernel<%d, %d, %d, %s, %s>", fista ? "fista" : "admm", n, m, N, terminal ? "true" : "false", s ? "true" : "false");
             nm.push_back(name);
         }
         std::vector<std::string> extra = {"-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form"};
@@ -97,6 +103,47 @@ int launch(const Plan &p, bool want_sol, const Args &a, const double *TRI, const
     }
     Args aa = a;
     void *params[] = {&aa, &TRI, &T, &TVS, &x0, &xr, &ur, &u, &k, &e, &z, &v, &lam};
+    SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 2 : 1], grid, 1, 1, 256, 1, 1, 0, st, params, nullptr));
+    return 0;
+}
+
+template <int n, int m, int N>
+static int launch_fista_shape(bool terminal, bool want_sol, const Args &a, const double *T, const double *Ti, double *TVS, const double *x0, const double *xr,
+                              const double *ur, double *u, int *k, int *e, double *z, double *lam, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((fista_tv_bi_kernel<n, m>), dim3((unsigned)(a.Bp / 64)), dim3(64), 0, st, N, a.B, a.Bp, TVS);
+#define SPCIES_TVR_GO(TT, SS) \
+    hipLaunchKernelGGL((fista_tvr_kernel<n, m, N, TT, SS>), dim3(grid), dim3(256), 0, st, a, T, Ti, TVS, x0, xr, ur, u, k, e, z, lam)
+    if (terminal) {
+        if (want_sol) SPCIES_TVR_GO(true, true); else SPCIES_TVR_GO(true, false);
+    } else {
+        if (want_sol) SPCIES_TVR_GO(false, true); else SPCIES_TVR_GO(false, false);
+    }
+#undef SPCIES_TVR_GO
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_fista(const Plan &p, bool want_sol, const Args &a, const double *T, const double *Ti, double *TVS, const double *x0, const double *xr,
+                 const double *ur, double *u, int *k, int *e, double *z, double *lam, int num_cu, hipStream_t st) {
+    if (!p.ok || !p.fista) return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying FISTA) unavailable: %s", p.why.c_str());
+    if (want_sol && !(z && lam)) return fail(SPCIES_HIP_EINVAL, "MFMA4R (time-varying FISTA): pass both z and lambda or neither");
+    const long groups = (a.B + 3) / 4;
+    const unsigned grid = (unsigned)std::min<long>(groups, (long)num_cu);
+    if (p.builtin) {
+#define X(nn, mm, NN) \
+    if (p.n == nn && p.m == mm && p.N == NN) return launch_fista_shape<nn, mm, NN>(p.terminal, want_sol, a, T, Ti, TVS, x0, xr, ur, u, k, e, z, lam, grid, st);
+        SPCIES_TVR_SHAPES(X)
+#undef X
+        return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying FISTA): bad build-time shape");
+    }
+    {
+        int N = p.N;
+        long B = a.B, Bp = a.Bp;
+        void *params[] = {&N, &B, &Bp, &TVS};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[0], (unsigned)(a.Bp / 64), 1, 1, 64, 1, 1, 0, st, params, nullptr));
+    }
+    Args aa = a;
+    void *params[] = {&aa, &T, &Ti, &TVS, &x0, &xr, &ur, &u, &k, &e, &z, &lam};
     SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 2 : 1], grid, 1, 1, 256, 1, 1, 0, st, params, nullptr));
     return 0;
 }

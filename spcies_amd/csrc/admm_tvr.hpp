@@ -50,17 +50,21 @@ struct Plan {
     std::string why = "not built";
     bool build_failed = false;  // the variant applies to this controller but its run-time specialisation failed: what SPCIES_HIP_STRICT reacts to
     int n = 0, m = 0, N = 0;
-    bool terminal = true, builtin = false;
+    bool terminal = true, builtin = false, fista = false;
     void *module = nullptr;            // hipModule_t of a run-time specialised kernel
     void *fn[3] = {nullptr, nullptr, nullptr};  // Bi kernel, iteration without / with the record
 };
 // decides whether the variant applies (n + m <= 16, the (n, m) of the update phase's instantiations, the state within the register file) and,
 // for a horizon without a build-time kernel, compiles one (hiprtc; code-object cache)
-int plan_build(Plan &p, int n, int m, int N, bool terminal);
+int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista = false);
 void plan_free(Plan &p);
 // update-phase follow-up (the explicit inverses) + the solve of one chunk; pointers are device memory, TVS as admm_tv_update_kernel left it
 int launch(const Plan &p, bool want_sol, const Args &a, const double *TRI, const double *T, double *TVS, const double *x0, const double *xr,
            const double *ur, double *u, int *k, int *e, double *z, double *v, double *lam, int num_cu, hipStream_t st);
+// the FISTA twin (code_laxMPC_FISTA_C.c, TIME_VARYING == 1): T, Ti = the negated diagonal terminal weight and -1 / it (controller constants);
+// TVS as fista_tv_update_kernel left it; record z, lambda (= y)
+int launch_fista(const Plan &p, bool want_sol, const Args &a, const double *T, const double *Ti, double *TVS, const double *x0, const double *xr,
+                 const double *ur, double *u, int *k, int *e, double *z, double *lam, int num_cu, hipStream_t st);
 
 }  // namespace tvr
 }  // namespace spcies

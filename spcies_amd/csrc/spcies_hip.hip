@@ -746,7 +746,7 @@ static int tvw_waves(const Solver &s) {
 
 // Time-varying lax/equ ADMM, variant MFMA4R (admm_tvr.hpp: one wavefront per instance, the instance's factors in its registers): the
 // plan is built at create time (hiprtc for horizons without a build-time kernel); SPCIES_HIP_TVR=0 switches the variant off
-static bool tvr_ok(const Solver &s) { return s.tv && s.method == SPCIES_ADMM && s.tvrp.ok; }
+static bool tvr_ok(const Solver &s) { return s.tv && (s.method == SPCIES_ADMM || s.method == SPCIES_FISTA) && s.tvrp.ok; }
 
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
@@ -880,11 +880,19 @@ static int launch_fista_tv_nm(Solver &s, const double *x0, const double *xr, con
     const FistaTvLayout tl = fista_tv_layout(n, m, N);
     const bool want_sol = (z || lam);
     const size_t Nn = (size_t)N * n, dim = (size_t)s.host.dim();
-    const size_t rows_stream = 3 * Nn + (want_sol ? dim : 0);
-    long chunk = (long)((3900ull << 20) / ((size_t)tl.rows * 8)) / 64 * 64;
+    const bool regs = resolve_variant(s) == SPCIES_VARIANT_MFMA4R;  // one wavefront per instance, factors in registers (admm_tvr_kernel.inc)
+    const size_t rows_stream = regs ? 0 : 3 * Nn + (want_sol ? dim : 0);
+    const size_t rows_tv = (size_t)tl.rows + (regs ? (size_t)N * n * n : 0);  // (MFMA4R: the explicit inverses behind the factors)
+    long chunk = (long)((3900ull << 20) / (rows_tv * 8)) / 64 * 64;
     if (chunk > B) chunk = (B + 63) / 64 * 64;
-    int rc = ensure_scratch(s, (rows_stream + (size_t)tl.rows) * (size_t)chunk * sizeof(double));
+    int rc = ensure_scratch(s, (rows_stream + rows_tv) * (size_t)chunk * sizeof(double));
     if (rc) return rc;
+    int num_cu = 256;
+    if (regs) {
+        hipDeviceProp_t prop;
+        SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, s.device));
+        if (prop.multiProcessorCount > 0) num_cu = prop.multiProcessorCount;
+    }
     for (long b0 = 0; b0 < B; b0 += chunk) {
         const long Bc = std::min(chunk, B - b0), Bp = (Bc + 63) / 64 * 64;
         double *Y = s.d_scratch, *LAM = Y + Nn * Bp, *DL = LAM + Nn * Bp;
@@ -893,6 +901,18 @@ static int launch_fista_tv_nm(Solver &s, const double *x0, const double *xr, con
         const double *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
         const double *mc = model_stride ? model + b0 * (long)model_stride : model;
         dim3 grid((unsigned)(Bp / 64)), block(64);
+        if (regs) {
+            if (s.host.terminal)
+                hipLaunchKernelGGL((fista_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride, Bc, Bp, TVS);
+            else
+                hipLaunchKernelGGL((fista_tv_update_kernel<n, m, false>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride, Bc, Bp, TVS);
+            SPCIES_HIP_CHECK(hipGetLastError());
+            tvr::Args ta{s.host.k_max, ref_stride, 0.0, s.host.tol, Bc, Bp};
+            rc = tvr::launch_fista(s.tvrp, want_sol, ta, s.d_consts + s.fdev.T, s.d_consts + s.fdev.Ti, TVS, x0 + b0 * n, xrc, urc, u + b0 * m, k + b0, e + b0,
+                                   z ? z + b0 * dim : nullptr, lam ? lam + b0 * Nn : nullptr, num_cu, st);
+            if (rc) return rc;
+            continue;
+        }
         if (s.host.terminal) {
             hipLaunchKernelGGL((fista_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride,
                                Bc, Bp, TVS);
@@ -1420,8 +1440,8 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (!extra) return fail(SPCIES_HIP_EINVAL, "time-varying solvers take A, B, Q, R, LB, UB with every call (extra): Spcies:laxMPC:nrhs:number");
         if (extra_stride != 0 && extra_stride != s.tv_model_size())
             return fail(SPCIES_HIP_EINVAL, "time-varying: extra_stride must be 0 (shared model) or %d", s.tv_model_size());
-        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM)
-            return fail(SPCIES_HIP_ENOSUP, "time-varying: only the STREAM variant is built");
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM && !(s.variant == SPCIES_VARIANT_MFMA4R && tvr_ok(s)))
+            return fail(SPCIES_HIP_ENOSUP, "time-varying FISTA: variants STREAM and MFMA4R (factors in registers, admm_tvr_kernel.inc) are built");
         if (s.host.n == 6 && s.host.m == 2) return launch_fista_tv_nm<6, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, lam, st);
         if (s.host.n == 12 && s.host.m == 2) return launch_fista_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, lam, st);
         return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
@@ -1735,11 +1755,11 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         }
     }
     // what AUTO had to give up (a failed run-time specialisation is not an error, but the caller can ask)
-    if (s->tv && s->method == SPCIES_ADMM) {  // time-varying ADMM: the register-resident variant (hiprtc for a horizon without a build-time kernel)
+    if (s->tv && (s->method == SPCIES_ADMM || s->method == SPCIES_FISTA)) {  // time-varying ADMM / FISTA: the register-resident variant (hiprtc for a horizon without a build-time kernel)
         const char *ev = getenv("SPCIES_HIP_TVR");
         if (ev && ev[0] == '0') s->tvrp.why = "SPCIES_HIP_TVR=0";
         else {
-            rc = tvr::plan_build(s->tvrp, s->host.n, s->host.m, s->host.N, s->host.terminal);
+            rc = tvr::plan_build(s->tvrp, s->host.n, s->host.m, s->host.N, s->host.terminal, s->method == SPCIES_FISTA);
             if (rc) return rc;
         }
     }
@@ -1752,7 +1772,7 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     };
     note("MFMA4R", s->method == SPCIES_FISTA && !s->tv, s->frplan.ok, s->frplan.why, s->frplan.build_failed);
     note("MFMA4R", s->method == SPCIES_EADMM, s->erplan.ok, s->erplan.why, s->erplan.build_failed);
-    note("MFMA4R", s->tv && s->method == SPCIES_ADMM, s->tvrp.ok, s->tvrp.why, s->tvrp.build_failed);
+    note("MFMA4R", s->tv && (s->method == SPCIES_ADMM || s->method == SPCIES_FISTA), s->tvrp.ok, s->tvrp.why, s->tvrp.build_failed);
     note("BSP", (s->is_soc() && !s->is_hmpc()) || s->host.ellip, s->bsp.ok, s->bsp.why, s->bsp.build_failed);
     note("MFMA4", s->mfma4.needs_rtc, s->mfma4.ok, s->mfma4.why, s->mfma4.build_failed);
     note("FUSED", s->is_hmpc() || s->is_hdense(), s->hfused.ok, s->hfused.why, s->hfused.build_failed);

@@ -1,5 +1,5 @@
 """Time-varying laxMPC-ADMM at the C2 shape (one model per instance): device buffers, kernel time by HIP events around the whole
-solve (update phase + inverses + iteration).  usage: python tools/bench_tv.py [B] [variant] [k_max]"""
+solve (update phase + inverses + iteration).  usage: python tools/bench_tv.py [B] [variant] [k_max|0] [config: C2_lax | C2_lax_FISTA | ...]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,12 +9,12 @@ from spcies_amd.solver import HipSolver
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 variant = sys.argv[2] if len(sys.argv) > 2 else "auto"
-cfg = benchmarks.config("C2_lax")
+cfg = benchmarks.config(sys.argv[4] if len(sys.argv) > 4 else "C2_lax")
 vt = benchmarks.ingredients(cfg, time_varying=True)
 s = HipSolver(vt)
 if variant != "auto":
     s.set_variant(variant)
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and int(sys.argv[3]) > 0:
     s.set_exit(k_max=int(sys.argv[3]))
 sysm, prm = cfg.sys, cfg.param
 LB = np.concatenate([np.ravel(sysm.LBx), np.ravel(sysm.LBu)]); UB = np.concatenate([np.ravel(sysm.UBx), np.ravel(sysm.UBu)])
@@ -36,5 +36,5 @@ for _ in range(4):
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
     times.append(e0.elapsed_time(e1))
 ms = min(times)
-print(json.dumps(dict(config="C2_lax time-varying, one model per instance", B=B, variant=s.variant, ms=round(ms, 2), solves_per_s=round(B / ms * 1e3),
+print(json.dumps(dict(config=cfg.name + " time-varying, one model per instance", B=B, variant=s.variant, ms=round(ms, 2), solves_per_s=round(B / ms * 1e3),
                       k_unique=np.unique(tk.cpu().numpy()).tolist()[:3])))
