@@ -48,6 +48,9 @@ EXTRA_CONFIGS = {
     # share their matrices, so this path is HBM-bound by design: `flop` as C2 plus the update phase, `io` = inputs + model + outputs.
     "C2_tv": dict(name="C2_lax", tv=True, B=65536, flop=27498.0 * 200 + 95e3, io=232 + 232 * 8,
                   what="SURVEY 8f rank 1: time-varying laxMPC-ADMM, C2 shape (n=12, m=2, N=15), one model per instance, 200 iterations, batch=65536"),
+    # ... and its FISTA twin (code_laxMPC_FISTA_C.c with TIME_VARYING == 1): 100 iterations
+    "C2_tv_fista": dict(name="C2_lax_FISTA", tv=True, B=65536, flop=23.8e3 * 100 + 95e3, io=232 + 232 * 8,
+                        what="SURVEY 8f rank 1: time-varying laxMPC-FISTA, C2 shape (n=12, m=2, N=15), one model per instance, 100 iterations, batch=65536"),
 }
 
 
@@ -74,7 +77,7 @@ def traffic_from_profile(variant):
     return None, None
 
 
-_PROFILE_TAG = {"C3": "C3", "C4": "C4", "C5_soc": "C5soc", "C5_hmpc": "C5hmpc", "C2_tv": "C2tv"}
+_PROFILE_TAG = {"C3": "C3", "C4": "C4", "C5_soc": "C5soc", "C5_hmpc": "C5hmpc", "C2_tv": "C2tv", "C2_tv_fista": "C2tvfista"}
 
 
 def design_traffic(key, variant):
@@ -426,7 +429,7 @@ def _oracle_check(cfg, v, x0, xr, ur, u_gpu, k_gpu, count=32, model=None):
     from oracle import oracle
     a = (x0[:count], xr[:count], ur[:count])
     if model is not None:  # time-varying solver: update phase + iteration of the oracle on the same per-instance models
-        o = oracle.admm_tv_batch(v, *a, model[:count], True, want_sol=False)
+        o = (oracle.fista_tv_batch if cfg.method == "FISTA" else oracle.admm_tv_batch)(v, *a, model[:count], True, want_sol=False)
     elif cfg.formulation == "HMPC":
         o = oracle.admm_hmpc_batch(v, *a, want_sol=False) if getattr(cfg, "submethod", "") == "split" \
             else oracle.hmpc_dense_batch(v, *a, want_sol=False)
