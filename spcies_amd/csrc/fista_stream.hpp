@@ -266,8 +266,6 @@ __global__ __launch_bounds__(64) void fista_tv_update_kernel(int N, const double
 #define TBETA(h, i, j) ROW(tl.Beta, ((h) * n + (i)) * n + (j))
 #define TALPHA(h, i, j) ROW(tl.Alpha, ((h) * n + (i)) * n + (j))
     double Q_i[n], R_i[m];
-    for (int i = 0; i < (N - 1) * n * n; i++) ROW(tl.Alpha, i) = 0.0;
-    for (int i = 0; i < N * n * n; i++) ROW(tl.Beta, i) = 0.0;
 #pragma unroll
     for (int i = 0; i < n; i++) {
         Q_i[i] = 1 / Q_in[i];
@@ -282,64 +280,37 @@ __global__ __launch_bounds__(64) void fista_tv_update_kernel(int N, const double
         ROW(tl.LB, j) = LB_in[j];
         ROW(tl.UB, j) = UB_in[j];
     }
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) {
-            double a = 0.0, b = 0.0;
+    {  // A, B once into registers (the model is instance-contiguous: every load of it touches 64 cache lines), then the two products
+        double Ar[n][n], Br[n][m];
+        static_for<0, n>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
 #pragma unroll
-            for (int k = 0; k < n; k++) a += A_in[i + k * n] * Q_i[k] * A_in[j + k * n];
+            for (int k = 0; k < n; k++) Ar[i][k] = A_in[i + k * n];
 #pragma unroll
-            for (int k = 0; k < m; k++) b += B_in[i + k * n] * R_i[k] * B_in[j + k * n];
-            ROW(tl.AQiAt, i * n + j) = a;
-            ROW(tl.BRiBt, i * n + j) = b;
-        }
-    for (int i = 0; i < n; i++)  // Beta{0}
-        for (int j = i; j < n; j++) {
-            double v = ROW(tl.BRiBt, i * n + j);
-            for (int l = 1; l <= i; l++) v -= TBETA(0, l - 1, i) * TBETA(0, l - 1, j);
-            if (i == j) {
-                v += Q_i[i];
-                v = 1 / sqrt(v);
-            } else {
-                v = v * TBETA(0, i, i);
-            }
-            TBETA(0, i, j) = v;
-        }
-    for (int h = 0; h < N - 1; h++) {
-        if (h >= 1) {
-            for (int i = 0; i < n; i++)
-                for (int j = i; j < n; j++) {
-                    double v = ROW(tl.AQiAt, i * n + j) + ROW(tl.BRiBt, i * n + j);
-                    for (int k = 0; k < n; k++) v -= TALPHA(h - 1, k, i) * TALPHA(h - 1, k, j);
-                    for (int l = 1; l <= i; l++) v -= TBETA(h, l - 1, i) * TBETA(h, l - 1, j);
-                    if (i == j) {
-                        v += Q_i[i];
-                        v = 1 / sqrt(v);
-                    } else {
-                        v = v * TBETA(h, i, i);
-                    }
-                    TBETA(h, i, j) = v;
-                }
-        }
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) {
-                double v = -Q_i[i] * ROW(tl.AB, j * nm + i);
-                for (int l = 1; l <= i; l++) v -= TBETA(h, l - 1, i) * TALPHA(h, l - 1, j);
-                TALPHA(h, i, j) = v * TBETA(h, i, i);
-            }
+            for (int k = 0; k < m; k++) Br[i][k] = B_in[i + k * n];
+        });
+        typedef double __attribute__((address_space(1))) * gp;
+        gp pq = (gp)(TVS + (long)tl.AQiAt * Bp), pr = (gp)(TVS + (long)tl.BRiBt * Bp);
+        static_for<0, n>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<0, n>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int k = 0; k < n; k++) a += Ar[i][k] * Q_i[k] * Ar[j][k];
+#pragma unroll
+                for (int k = 0; k < m; k++) b += Br[i][k] * R_i[k] * Br[j][k];
+                pq[t] = a;
+                pr[t] = b;
+                pq += Bp, pr += Bp;
+                asm volatile("" : "+s"(pq), "+s"(pr));  // (running row pointers, out of the optimiser's sight: see tv_band_factor)
+            });
+        });
     }
-    for (int i = 0; i < n; i++)  // Beta{N-1}
-        for (int j = i; j < n; j++) {
-            double v = ROW(tl.AQiAt, i * n + j) + ROW(tl.BRiBt, i * n + j);
-            for (int k = 0; k < n; k++) v -= TALPHA(N - 2, k, i) * TALPHA(N - 2, k, j);
-            for (int l = 1; l <= i; l++) v -= TBETA(N - 1, l - 1, i) * TBETA(N - 1, l - 1, j);
-            if (i == j) {
-                if constexpr (TERMINAL) v -= Ti[i];
-                v = 1 / sqrt(v);
-            } else {
-                v = v * TBETA(N - 1, i, i);
-            }
-            TBETA(N - 1, i, j) = v;
-        }
+    tv_band_factor<n, nm>(N, TVS, (unsigned)t, Bp, tl.Beta, tl.Alpha, tl.AB, tl.AQiAt, tl.BRiBt, Q_i, [&](int i, int j, double &v) {
+        if constexpr (TERMINAL)
+            if (i == j) v -= Ti[i];
+    });
 #pragma unroll
     for (int i = 0; i < n; i++) ROW(tl.Q, i) = -Q_in[i];
 #pragma unroll
