@@ -113,9 +113,9 @@ struct RecordWriter {
     }
 };
 
-template <int KX, int KS, bool MIDSAME>
+template <int KX, int KS, bool MIDSAME, bool GEN>
 int pack(Plan &p, const Host &h, std::vector<double> &tab) {
-    using LY = Layout<KX, KS, MIDSAME>;
+    using LY = Layout<KX, KS, MIDSAME, GEN>;
     const int n = h.n, m = h.m, N = h.N, nm = n + m;
     tab.assign((size_t)LY::table_doubles(N), 0.0);
     DM AB(n, nm), W2(nm, nm), TS(nm, nm);
@@ -132,7 +132,7 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
         for (int j = 0; j < nm; j++) {
             tab[LY::k_off(l, N, LY::K_RHO) + j] = h.rho[(size_t)l * nm + j];  // (MIDSAME: the middle stages write the same table)
             tab[LY::k_off(l, N, LY::K_H1I) + j] = h.H1i[(size_t)l * nm + j];
-            tab[LY::k_off(l, N, LY::K_NH3I) + j] = -h.H3i[(size_t)l * nm + j];
+            tab[LY::k_off(l, N, LY::K_NH3I) + j] = GEN ? 0.0 : -h.H3i[(size_t)l * nm + j];
             tab[LY::k_off(l, N, LY::K_LB) + j] = lb[j];
             tab[LY::k_off(l, N, LY::K_UB) + j] = ub[j];
         }
@@ -143,11 +143,26 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
     }
     bool ok = true;
     const DM ABt = tr(AB);
+    // GEN: G_l = -blkdiag(Q_i, R_i) of stage 0 (Q_mi, R_bi), the middle stages (Q_bi, R_bi), stage N (Q_mi, R_mi) (:321-366)
+    auto Gm = [&](int l) {
+        DM G(nm, nm);
+        if (!GEN) return G;
+        const double *Qi = (l == 0 || l == N) ? h.Q_mi : h.Q_bi, *Ri = (l == N) ? h.R_mi : h.R_bi;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) G(i, j) = -Qi[(size_t)i * n + j];
+        for (int i = 0; i < m; i++)
+            for (int j = 0; j < m; j++) G(n + i, n + j) = -Ri[(size_t)i * m + j];
+        return G;
+    };
     {
         RecordWriter w(tab.data() + LY::inv_off(N), false);
         w.emit(W2, KS, KS, DENSE);
         w.emit(ABt, KS, KX, DENSE);  // stage 0 reads AB' from the header
         ok = ok && w.structure_ok && w.cursor == LY::M_W2 + LY::MG;
+        if (GEN) {
+            w.emit(Gm(0), KS, KS, DENSE);
+            ok = ok && w.structure_ok && w.cursor == 2 * LY::M_W2 + LY::MG;
+        }
         RecordWriter w2(tab.data() + LY::ts_off(N), false);  // setup only: read from L2, not kept in LDS
         w2.emit(TS, KS, KS, DENSE);
         ok = ok && w2.structure_ok && w2.cursor == LY::M_W2;
@@ -165,15 +180,28 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
         if (s < N) {  // forward chunk of block l: y_l = F1 q3_{l+1}[x] + F2 q3_l + F3 y_{l-1}
             const int l = s;
             const DM BiT = tr(Bi[l]);
-            w.emit(neg(mul(BiT, scale_cols(AB, h.H3i + (size_t)l * nm))), KX, KS, DENSE);  // F2, F3 first: they do not wait for q3_{l+1}
-            w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
-            w.emit(scale_cols(BiT, h.H3i + (size_t)(l + 1) * nm), KX, KX, LOWER);
+            if (GEN) {  // (:184-217) the reference's folded AB_mi (stage 0) / AB_bi and Q_mi (stage N) / Q_bi
+                DM ABh(n, nm), Qh(n, n);
+                const double *abh = (l == 0) ? h.AB_mi : h.AB_bi, *qh = (l + 1 == N) ? h.Q_mi : h.Q_bi;
+                for (int i = 0; i < n; i++) {
+                    for (int j = 0; j < nm; j++) ABh(i, j) = abh[(size_t)i * nm + j];
+                    for (int j = 0; j < n; j++) Qh(i, j) = qh[(size_t)i * n + j];
+                }
+                w.emit(neg(mul(BiT, ABh)), KX, KS, DENSE);
+                w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
+                w.emit(mul(BiT, Qh), KX, KX, DENSE);
+            } else {
+                w.emit(neg(mul(BiT, scale_cols(AB, h.H3i + (size_t)l * nm))), KX, KS, DENSE);  // F2, F3 first: they do not wait for q3_{l+1}
+                w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
+                w.emit(scale_cols(BiT, h.H3i + (size_t)(l + 1) * nm), KX, KX, LOWER);
+            }
             ok = ok && w.structure_ok && w.cursor == LY::MF;
         } else {  // backward chunk of block l = 2N-1-s: mu_l = B1 y_l + B2 mu_{l+1}; AB' for stage l + 1
             const int l = 2 * N - 1 - s;
             w.emit(Bi[l], KX, KX, UPPER);
             w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : Zero, KX, KX, DENSE);
             w.emit(ABt, KS, KX, DENSE);
+            if (GEN) w.emit(Gm(l + 1), KS, KS, DENSE);
             ok = ok && w.structure_ok && w.cursor == LY::MB;
         }
     }
@@ -193,16 +221,20 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
     const int nls_max = (int)std::min<long>(N + 1, lds_free / (8L * 2 * RS * 256));
     int nls = std::max(0, ((N + 1) * 2 * RS - max_reg + 2 * RS - 1) / (2 * RS));
     if (const char *ev = getenv("SPCIES_ER_NLS")) nls = atoi(ev);
+    // (the LDS is short of the preferred split - general Q, R at configs[3]: a larger header and ring - : up to 104 doubles of state go to
+    // the registers; the allocator then spills a few row constants of the set-up, measured harmless: 118.0 ms with 364 B, 118.4 ms with none)
+    if (nls > nls_max && ((N + 1) - nls_max) * 2 * RS <= 104 && !getenv("SPCIES_ER_NLS")) nls = nls_max;
     if (nls > nls_max || nls < 0) { p.why = "MFMA4R: the iteration state does not fit registers + LDS (use MFMA4G)"; return 0; }
     p.NLS = nls;
     p.midsame = MIDSAME;
+    p.general = GEN;
     p.RX = RX;
     return 1;
 }
 
 // build-time instantiations (N, KX, KS, NLS, MIDSAME): BASELINE configs[3], MPCT-EADMM n = 20, m = 2, N = 20
 #ifndef SPCIES_ER_BUILTIN
-#define SPCIES_ER_BUILTIN(X) X(20, 5, 6, 6, true)
+#define SPCIES_ER_BUILTIN(X) X(20, 5, 6, 6, true, false)
 #endif
 
 #define SPCIES_ER_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 3) X(3, 4) X(4, 4) X(4, 5) X(5, 5) X(5, 6) X(6, 6)
@@ -233,14 +265,16 @@ int plan_build(Plan &p, const Host &h) {
         for (int l = 2; l < h.N && midsame; l++)
             for (int j = 0; j < nm; j++)
                 if (h.rho[(size_t)l * nm + j] != h.rho[(size_t)nm + j] || h.H1i[(size_t)l * nm + j] != h.H1i[(size_t)nm + j] ||
-                    h.H3i[(size_t)l * nm + j] != h.H3i[(size_t)nm + j])
+                    (!h.general && h.H3i[(size_t)l * nm + j] != h.H3i[(size_t)nm + j]))
                     midsame = false;
         if (getenv("SPCIES_ER_NO_MIDSAME")) midsame = false;
     }
     std::vector<double> tab;
     int got = -1;
-#define X(KKX, KKS) \
-    if (KX == KKX && KS == KKS) got = midsame ? pack<KKX, KKS, true>(p, h, tab) : pack<KKX, KKS, false>(p, h, tab);
+#define X(KKX, KKS)                                                                                                              \
+    if (KX == KKX && KS == KKS)                                                                                                  \
+        got = h.general ? (midsame ? pack<KKX, KKS, true, true>(p, h, tab) : pack<KKX, KKS, false, true>(p, h, tab))             \
+                        : (midsame ? pack<KKX, KKS, true, false>(p, h, tab) : pack<KKX, KKS, false, false>(p, h, tab));
     SPCIES_ER_SHAPES(X)
 #undef X
     if (got < 0) { p.why = "MFMA4R: (ceil(n/4), ceil((n+m)/4)) outside the packer's shapes"; return 0; }
@@ -248,8 +282,8 @@ int plan_build(Plan &p, const Host &h) {
     p.builtin = -1;
     {
         int idx = 0;
-#define X(NN, KKX, KKS, LL, MM)                                                                                                  \
-    if (h.N == NN && KX == KKX && KS == KKS && p.NLS == LL && p.midsame == MM && !getenv("SPCIES_ER_RTC_FLAGS")) p.builtin = idx; \
+#define X(NN, KKX, KKS, LL, MM, GG)                                                                                                                  \
+    if (h.N == NN && KX == KKX && KS == KKS && p.NLS == LL && p.midsame == MM && p.general == GG && !getenv("SPCIES_ER_RTC_FLAGS")) p.builtin = idx; \
     idx++;
         SPCIES_ER_BUILTIN(X)
 #undef X
@@ -260,8 +294,8 @@ int plan_build(Plan &p, const Host &h) {
         std::vector<std::string> nm;
         for (int s = 0; s < 2; s++) {
             char name[160];
-            snprintf(name, sizeof(name), "spcies::er::eadmm_r_kernel<%d, %d, %d, %s, %d, %s>", h.N, KX, KS, s ? "true" : "false", p.NLS,
-                     p.midsame ? "true" : "false");
+            snprintf(name, sizeof(name), "spcies::er::eadmm_r_kernel<%d, %d, %d, %s, %d, %s, %s>", h.N, KX, KS, s ? "true" : "false", p.NLS,
+                     p.midsame ? "true" : "false", p.general ? "true" : "false");
             nm.push_back(name);
         }
         // the horizon is unrolled by #pragma unroll: lift the size limit under which clang honours the pragma; MFMA results in
@@ -275,7 +309,7 @@ int plan_build(Plan &p, const Host &h) {
         int scratch = 0;
         if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fns[0]) != hipSuccess) scratch = 0;
         if (getenv("SPCIES_ER_VERBOSE"))
-            fprintf(stderr, "[spcies eadmm_r] N=%d KX=%d KS=%d NLS=%d midsame=%d scratch=%d B per lane\n", h.N, KX, KS, p.NLS, (int)p.midsame, scratch);
+            fprintf(stderr, "[spcies eadmm_r] N=%d KX=%d KS=%d NLS=%d midsame=%d general=%d scratch=%d B per lane\n", h.N, KX, KS, p.NLS, (int)p.midsame, (int)p.general, scratch);
         p.module = mod;
         p.fn[0] = fns[0];
         p.fn[1] = fns[1];
@@ -314,13 +348,13 @@ int launch(Plan &p, int k_max, double tol, const double *x0, const double *xr, c
     double *yscr = p.d_yscr;
     if (p.builtin >= 0) {
         int idx = 0;
-#define X(NN, KKX, KKS, LL, MM)                                                                                                          \
+#define X(NN, KKX, KKS, LL, MM, GG)                                                                                                      \
     if (p.builtin == idx) {                                                                                                              \
         if (want_sol)                                                                                                                    \
-            hipLaunchKernelGGL((eadmm_r_kernel<NN, KKX, KKS, true, LL, MM>), dim3((unsigned)wgs), dim3(256), 0, st, args, table, x0, xr, ur, u, k, e, \
+            hipLaunchKernelGGL((eadmm_r_kernel<NN, KKX, KKS, true, LL, MM, GG>), dim3((unsigned)wgs), dim3(256), 0, st, args, table, x0, xr, ur, u, k, e, \
                                z1, z2, z3, lam, yscr);                                                                                   \
         else                                                                                                                             \
-            hipLaunchKernelGGL((eadmm_r_kernel<NN, KKX, KKS, false, LL, MM>), dim3((unsigned)wgs), dim3(256), 0, st, args, table, x0, xr, ur, u, k, e, \
+            hipLaunchKernelGGL((eadmm_r_kernel<NN, KKX, KKS, false, LL, MM, GG>), dim3((unsigned)wgs), dim3(256), 0, st, args, table, x0, xr, ur, u, k, e, \
                                z1, z2, z3, lam, yscr);                                                                                   \
     }                                                                                                                                    \
     idx++;

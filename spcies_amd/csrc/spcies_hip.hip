@@ -106,7 +106,7 @@ struct Solver {
     std::string build_failures;    // the subset of `notes` that are failed builds (SPCIES_HIP_STRICT)
     std::string notes;             // which faster (run-time specialised) variants AUTO could not use, and why (spcies_hip_get_notes)
     fr::Plan frplan;               // MFMA4R (FISTA with the iteration state in registers + LDS, run-time specialised)
-    er::Plan erplan;               // MFMA4R (MPCT EADMM, diagonal Q, R: the whole iteration state on the chip, run-time specialised)
+    er::Plan erplan;               // MFMA4R (MPCT EADMM, diagonal or general Q, R: the whole iteration state on the chip, run-time specialised)
     hfused::Plan hfused;           // FUSED (HMPC split NON_SPARSE path: product + projections in one MFMA kernel)
     std::vector<double> h_M1, h_M2, h_bh_nat;
     bsp::Plan bsp;                 // BSP (ellipMPC soc): block-sparse MFMA program, generated per controller
@@ -1428,7 +1428,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
             return g4::launch_eadmm_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f[0], f[1], f[2], f[3], st);
         }
         if (ev != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "EADMM: variants STREAM, MFMA4G and MFMA4R are built");
-        if (s.e_general) return fail(SPCIES_HIP_ENOSUP, "EADMM with general Q, R: the MFMA4G variant is built (STREAM covers the diagonal path)");
+        if (s.e_general) return fail(SPCIES_HIP_ENOSUP, "EADMM with general Q, R: the MFMA4G and MFMA4R variants are built (STREAM covers the diagonal path)");
         if (!eadmm_stream_shape_built(s.host.n, s.host.m))
             return fail(SPCIES_HIP_ENOSUP, "EADMM STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
@@ -1727,12 +1727,15 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         if (rc) return rc;
         // MFMA4R: the whole iteration state on the chip, the kernel specialised for this controller (hiprtc unless the shape was
         // instantiated at build time).  A failure is not an error: AUTO then runs MFMA4G.
-        if (s->e_general) {
-            s->erplan.why = "general Q, R (IS_DIAG == 0): MFMA4G carries that path";
-        } else {
+        {
             er::Host eh2{s->host.n, s->host.m, s->host.N, s->host.k_max, s->host.tol, s->host.AB.data(), s->host.Alpha.data(), s->host.Beta.data(),
                          s->host.T.data(), s->e_S.data(), s->e_rho.data(), s->e_rho0.data(), s->e_rhos.data(), s->host.LB.data(), s->host.UB.data(),
                          s->e_LB0.data(), s->e_UB0.data(), s->e_LBs.data(), s->e_UBs.data(), s->e_H1i.data(), s->e_W2.data(), s->e_H3i.data()};
+            if (s->e_general) {  // IS_DIAG == 0: the dense inverses of the blocks of H3 instead of the vector H3i
+                eh2.general = true;
+                eh2.Q_bi = s->e_Qbi.data(); eh2.Q_mi = s->e_Qmi.data(); eh2.R_bi = s->e_Rbi.data(); eh2.R_mi = s->e_Rmi.data();
+                eh2.AB_bi = s->e_ABbi.data(); eh2.AB_mi = s->e_ABmi.data();
+            }
             rc = er::plan_build(s->erplan, eh2);
             if (rc) return rc;
         }

@@ -409,28 +409,31 @@ def test_mpct_general_qr_reference_test_instance(golden_dir):
     from oracle import oracle
     from spcies_amd import benchmarks
     cfg, v, s = _fista_solver("C1_MPCT_nd0")
-    assert s.variant == "mfma4g" and not v["is_diag"]
+    assert s.variant == "mfma4r" and not v["is_diag"]  # (round 4: the register-resident variant carries IS_DIAG == 0 too)
     st = benchmarks.tester_status(cfg.sys)
-    u, k, e, sol = s(st.x, st.xr, st.ur)
     with open(os.path.join(golden_dir, "reference_z_opt.json")) as f:
         z_opt = np.array(json.load(f)["test_MPCT_EADMM"])
-    assert e == 1 and np.abs(sol.z1 - z_opt).max() <= TOL_OPT
     O = oracle.eadmm_mpct_batch(v, st.x[None], st.xr, st.ur)
-    _compare_mpct("mfma4g", (u[None], np.array([k]), np.array([e]),
-                             type(sol)(z1=sol.z1[None], z2=sol.z2[None], z3=sol.z3[None], lam=sol.lam[None])), O)
+    for variant in ("mfma4r", "mfma4g"):
+        s.set_variant(variant)
+        u, k, e, sol = s(st.x, st.xr, st.ur)
+        assert e == 1 and np.abs(sol.z1 - z_opt).max() <= TOL_OPT
+        _compare_mpct(variant, (u[None], np.array([k]), np.array([e]),
+                                type(sol)(z1=sol.z1[None], z2=sol.z2[None], z3=sol.z3[None], lam=sol.lam[None])), O)
     with pytest.raises(Exception, match="general Q, R"):
         s.set_variant("stream")
         s(st.x, st.xr, st.ur)
 
 
+@pytest.mark.parametrize("variant", ["mfma4g", "mfma4r"])
 @pytest.mark.parametrize("cfg_name,B,overrides", [("C1_MPCT_nd", 100, {}), ("C4_nd", 90, {}), ("C4_nd", 40, dict(tol=1e-5, k_max=4000))])
-def test_mpct_general_qr_seeded_batch_vs_oracle(cfg_name, B, overrides, golden_dir):
+def test_mpct_general_qr_seeded_batch_vs_oracle(cfg_name, B, overrides, variant, golden_dir):
     from oracle import oracle
     from spcies_amd import benchmarks
-    cfg, v, s = _fista_solver(cfg_name, "mfma4g", **overrides)
+    cfg, v, s = _fista_solver(cfg_name, variant, **overrides)
     x0, xr, ur = benchmarks.sample_batch(cfg, B)
     got = s(x0, xr, ur)
-    _compare_mpct("mfma4g", got, oracle.eadmm_mpct_batch(v, x0, xr, ur), rerun=_rerun_with(oracle.eadmm_mpct_batch, v, x0, xr, ur))
+    _compare_mpct(variant, got, oracle.eadmm_mpct_batch(v, x0, xr, ur), rerun=_rerun_with(oracle.eadmm_mpct_batch, v, x0, xr, ur))
     nosol = s(x0[:33], xr[:33], ur[:33], want_sol=False)
     assert np.array_equal(nosol[0], got[0][:33]) and np.array_equal(nosol[1], got[1][:33])
     if not overrides:  # and the compiled reference template's outputs on its fixture
@@ -1648,8 +1651,8 @@ def test_k_histogram_of_a_device_solve():
 def test_strict_mode_turns_a_failed_build_into_an_error(monkeypatch):
     """SPCIES_HIP_STRICT=1: a faster variant that APPLIES to the controller but could not be built (here: a compiler option hiprtc
     rejects, so FISTA would fall from MFMA4R to MFMA4G) is an error of create; without STRICT the handle exists and `notes` says what
-    is missing.  A variant that does not apply by design - run-time specialisation switched off by the caller, MPCT EADMM with general
-    Q and R (MFMA4R carries the diagonal branch only) - is a note and never an error."""
+    is missing.  A variant that does not apply by design - run-time specialisation switched off by the caller - is a note and never an
+    error."""
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
     v = benchmarks.ingredients(benchmarks.config("C1_equ_FISTA"))
@@ -1667,6 +1670,3 @@ def test_strict_mode_turns_a_failed_build_into_an_error(monkeypatch):
     assert s.variant == "mfma4g" and "MFMA4R unavailable" in s.notes and "SPCIES_HIP_RTC=0" in s.notes
     s.close()
     monkeypatch.delenv("SPCIES_HIP_RTC")
-    s = HipSolver(benchmarks.ingredients(benchmarks.config("C1_MPCT_nd")))
-    assert s.variant == "mfma4g" and "general Q, R" in s.notes
-    s.close()
