@@ -39,6 +39,10 @@ EXTRA_CONFIGS = {
                what="configs[2]: equMPC-FISTA, 12-state, N=30, 100 iterations, batch=262144"),
     "C4": dict(name="C4", B=131072, flop=101e3 * 200, io=360,
                what="configs[3]: MPCT-EADMM, 20-state, N=20, 200 iterations, 1/8 shard (131072) of batch=1048576"),
+    # the general-Q/R branch of the same solver (IS_DIAG == 0, code_MPCT_EADMM_C.c:184-217, 321-366): dense n x n / m x m inverse blocks instead of the
+    # vector H3i - 2 N n^2 + 2 (N + 1)(n^2 + m^2) more flop per iteration than the diagonal branch
+    "C4_nd": dict(name="C4_nd", B=131072, flop=133.5e3 * 200, io=360,
+                  what="configs[3] shape with general (non-diagonal) Q, R: MPCT-EADMM IS_DIAG == 0, 20-state, N=20, 200 iterations, batch=131072"),
     "C5_soc": dict(name="C5_soc", B=65536, flop=23.4e3 * 200, io=240,
                    what="configs[4]a: ellipMPC-ADMM-soc, 12-state, N=15, 200 iterations, 1/8 shard (65536) of batch=524288"),
     "C5_hmpc": dict(name="C5_HMPC_SADMM", B=65536, flop=2.0 * 282 * 282 * 200, io=232,

@@ -5,6 +5,9 @@
 // Built on the single-device entry points only: one spcies_hip_handle per device, created from the same blob.
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -12,9 +15,68 @@
 #include "../../include/spcies_hip.h"
 #include "common.hpp"
 
+// One resident host thread per device beyond the first (the caller's thread drives device 0): a closed-loop caller solves a small batch
+// every sample time, and starting G - 1 threads per call (rounds 1-3) cost more than the 50 us such a solve takes on the device.
+// A job is posted under the mutex as a generation number; worker g runs job(g) and reports back.  Calls on ONE multi handle are
+// serialised (call_mu): the single-device handles underneath own one stream and one scratch allocation each.
 struct spcies_hip_multi_s {
     std::vector<spcies_hip_handle> h;
     std::vector<int> dev;
+    std::vector<std::thread> workers;
+    std::mutex mu, call_mu;
+    std::condition_variable cv_job, cv_done;
+    std::function<void(int)> job;
+    unsigned long generation = 0;
+    int pending = 0;
+    bool stop = false;
+
+    void start_workers() {
+        for (int g = 1; g < (int)h.size(); g++)
+            workers.emplace_back([this, g] {
+                unsigned long seen = 0;
+                for (;;) {
+                    std::function<void(int)> fn;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_job.wait(lk, [&] { return stop || generation != seen; });
+                        if (stop) return;
+                        seen = generation;
+                        fn = job;
+                    }
+                    fn(g);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    // runs fn(0) on the calling thread and fn(g) on worker g, returns when all are done
+    void run_all(const std::function<void(int)> &fn) {
+        if (workers.empty()) {
+            fn(0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = fn;
+            pending = (int)workers.size();
+            generation++;
+        }
+        cv_job.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void stop_workers() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_job.notify_all();
+        for (std::thread &t : workers) t.join();
+        workers.clear();
+    }
 };
 
 extern "C" {
@@ -68,12 +130,14 @@ int spcies_hip_create_multi(const void *blob, size_t bytes, const int *device_id
             delete m;
             return spcies::fail(rc, "device %d (handle %d of %d): %s", d, i, n_dev, why.c_str());
         }
+    m->start_workers();
     *out = m;
     return 0;
 }
 
 int spcies_hip_multi_destroy(spcies_hip_multi_handle m) {
     if (!m) return 0;
+    m->stop_workers();
     int rc = 0;
     for (spcies_hip_handle x : m->h) {
         int r = spcies_hip_destroy(x);
@@ -137,6 +201,7 @@ int spcies_hip_multi_solve_batch_ex(spcies_hip_multi_handle m, const double *x0,
         if (extra_width <= 0) extra_width = w;
         if (extra_width != w) return spcies::fail(SPCIES_HIP_EINVAL, "extra_width = %ld, this solver's per-instance extra input is %ld doubles", extra_width, w);
     }
+    std::lock_guard<std::mutex> one_call(m->call_mu);
     const int G = (int)m->h.size();
     std::vector<int> rcs(G, 0);
     std::vector<std::string> errs(G);
@@ -155,10 +220,7 @@ int spcies_hip_multi_solve_batch_ex(spcies_hip_multi_handle m, const double *x0,
                                            u + (size_t)lo * mm, k + lo, e_flag + lo, fields ? f : nullptr, nf, &tms[g]);
         if (rcs[g]) errs[g] = spcies_hip_last_error();  // thread-local: carried to the caller below
     };
-    std::vector<std::thread> th;
-    for (int g = 1; g < G; g++) th.emplace_back(work, g);
-    work(0);  // the calling thread drives device 0
-    for (std::thread &t : th) t.join();
+    m->run_all(work);  // the calling thread drives device 0, the resident workers the others
     for (int g = 0; g < G; g++)
         if (rcs[g]) return spcies::fail(rcs[g], "device %d (shard %d of %d): %s", m->dev[g], g, G, errs[g].c_str());
     if (timing) {  // the shards run side by side: the slowest device sets each phase

@@ -1532,6 +1532,30 @@ def test_multi_handle_equals_single_handle(cfg_name, B, devices):
         assert (k3 <= 3).all()
 
 
+def test_multi_handle_resident_workers_over_many_calls():
+    """A closed-loop caller solves a small batch every sample time: the per-device host threads of a multi handle are created once
+    (multi.cpp) and reused by every call - forty calls in a row, two multi handles alive and used alternately, each result equal
+    to the single handle's; destroying one handle leaves the other's workers running."""
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver, MultiHipSolver
+    cfg = benchmarks.config("C1")
+    v = benchmarks.ingredients(cfg)
+    rng = np.random.default_rng(31)
+    with HipSolver(v) as s1, MultiHipSolver(v, devices=[0, 0, 0]) as sa:
+        sb = MultiHipSolver(v, devices=[0, 0])
+        for it in range(40):
+            B = int(rng.integers(1, 9))
+            x0, xr, ur = benchmarks.sample_batch(cfg, B)
+            x0 = x0 * (1.0 + 0.01 * it)
+            u1, k1, e1, _ = s1(x0, xr, ur, want_sol=False)
+            sm = sa if (it % 2 == 0 or sb is None) else sb
+            um, km, em, _ = sm(x0, xr, ur, want_sol=False)
+            assert np.array_equal(u1, um) and np.array_equal(k1, km) and np.array_equal(e1, em), it
+            if it == 25:
+                sb.close()
+                sb = None
+
+
 @pytest.mark.parametrize("cfg_name", ["C2", "C1_equ_FISTA"])
 def test_multi_handle_on_every_visible_device(cfg_name):
     """`devices=None`: one handle per VISIBLE device (spcies_hip_create_multi with n_dev <= 0) - on the driver's 8-GPU node that is
