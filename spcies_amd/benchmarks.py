@@ -54,6 +54,19 @@ def config(name):
         c = config("C2")
         c.name, c.formulation = name, "equMPC"
         return c
+    if name in ("C2_lax_N30", "C2_equ_N30", "C4_lax_ADMM", "C4_equ_ADMM"):
+        # lax / equ ADMM past the register-resident MFMA4 kernel (more than 112 slab registers; n + m > 16): the 12-state plant at the
+        # configs[2] horizon N = 30 and the 20-state plant of configs[3] at N = 20 - the shapes admm_r.hpp (MFMA4R) is for
+        if name.startswith("C2"):
+            c = config("C2" if "lax" in name else "C2_equ")
+            c.param.N = 30
+        else:
+            sys = sp_utils.oscillating_masses_sys(10)
+            Q, R, T = _weights(sys, "dlqr")
+            c = SimpleNamespace(sys=sys, param=SimpleNamespace(Q=Q, R=R, T=T, N=20), formulation="laxMPC" if "lax" in name else "equMPC",
+                                method="ADMM", solver_options=dict(rho=15, k_max=200, tol=0.0), B=65536, seed=1206)
+        c.name = name
+        return c
     if name.endswith("_gen"):  # C1_lax_gen, C1_equ_gen, C2_lax_gen: vector rho + one bound column per prediction step
         c = config(name[:-4])
         c.name = name

@@ -26,6 +26,7 @@
 #include "cs_fused.hpp"
 #include "fista_r.hpp"
 #include "eadmm_r.hpp"
+#include "admm_r.hpp"
 #include "common.hpp"
 
 namespace spcies {
@@ -107,6 +108,7 @@ struct Solver {
     std::string notes;             // which faster (run-time specialised) variants AUTO could not use, and why (spcies_hip_get_notes)
     fr::Plan frplan;               // MFMA4R (FISTA with the iteration state in registers + LDS, run-time specialised)
     er::Plan erplan;               // MFMA4R (MPCT EADMM, diagonal or general Q, R: the whole iteration state on the chip, run-time specialised)
+    ar::Plan arplan;               // MFMA4R (lax / equ ADMM past MFMA4's register file / LDS: w on the chip, blocks streamed, run-time specialised)
     hfused::Plan hfused;           // FUSED (HMPC split NON_SPARSE path: product + projections in one MFMA kernel)
     std::vector<double> h_M1, h_M2, h_bh_nat;
     bsp::Plan bsp;                 // BSP (ellipMPC soc): block-sparse MFMA program, generated per controller
@@ -766,6 +768,7 @@ static int resolve_variant(const Solver &s) {
     if (s.host.gen && s.bsp.ok && (s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC)) return SPCIES_VARIANT_BSP;
     if (s.mfma4.ok) return SPCIES_VARIANT_MFMA4;
     if (s.mfma.ok) return SPCIES_VARIANT_MFMA;
+    if (s.arplan.ok) return SPCIES_VARIANT_MFMA4R;  // (shapes MFMA4 cannot hold: admm_r.hpp)
     if (s.g4plan.ok) return SPCIES_VARIANT_MFMA4G;
     return SPCIES_VARIANT_STREAM;
 }
@@ -1500,6 +1503,18 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (s.mfma4_rtc.ok) return rtc::launch_mfma4(s.mfma4_rtc, s.mfma4, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
         return launch_mfma4(s.mfma4, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
     }
+    if (variant == SPCIES_VARIANT_MFMA4R) {
+        if (!s.arplan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant not available: %s", s.arplan.why.c_str());
+        if ((z || v || lam) && !(z && v && lam)) {  // the kernel writes all three record fields or none: the missing ones go to handle-owned scratch
+            const size_t one = (size_t)B * (size_t)s.host.dim();
+            int rc = ensure_scratch(s, 3 * one * sizeof(double));
+            if (rc) return rc;
+            if (!z) z = s.d_scratch;
+            if (!v) v = s.d_scratch + one;
+            if (!lam) lam = s.d_scratch + 2 * one;
+        }
+        return ar::launch(s.arplan, s.host.k_max, s.host.tol, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
+    }
     if (variant == SPCIES_VARIANT_MFMA4G) {
         if (!s.g4plan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4G variant not available: %s", s.g4plan.why.c_str());
         int rc = ensure_scratch(s, g4::admm_state_bytes(s.g4plan, s.host, B));
@@ -1601,6 +1616,7 @@ static void free_solver(Solver *s) {
     csfused::plan_free(s->csf);
     fr::plan_free(s->frplan);
     er::plan_free(s->erplan);
+    ar::plan_free(s->arplan);
     hdense::plan_free(s->hd_plan);
     bsp::plan_free(s->bsp);
     if (s->d_eng) hipFree(s->d_eng);
@@ -1712,6 +1728,14 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         if (s->mfma4.needs_rtc && !(ev && ev[0] == '0')) {
             if (ensure_mfma4_rtc(*s) != 0) s->mfma4.why = g_last_error, s->mfma4.build_failed = true;
         }
+        // MFMA4R: where neither MFMA4 nor MFMA holds the controller (more than 112 slab registers, n + m > 16, blocks past the LDS) - or on
+        // request (SPCIES_AR_ALWAYS=1: tests and comparisons at shapes MFMA4 serves).  A failure is not an error: AUTO then runs MFMA4G.
+        if (!s->tv && !s->host.gen && !s->host.ellip && ((!s->mfma4.ok && !s->mfma.ok) || getenv("SPCIES_AR_ALWAYS"))) {
+            rc = ar::plan_build(s->arplan, s->host);
+            if (rc) return rc;
+        } else {
+            s->arplan.why = "MFMA4 holds this controller in registers (MFMA4R is built for the shapes past it; SPCIES_AR_ALWAYS=1 builds it anyway)";
+        }
         // kernel experiments: SPCIES_MFMA4_RTC_FLAGS="-DX=1 ..." re-specialises a built-in shape with extra compiler options
         if (s->mfma4.ok && !s->mfma4_rtc.ok && getenv("SPCIES_MFMA4_RTC_FLAGS")) {
             const Mfma4Layout &L = s->mfma4.lay;
@@ -1775,6 +1799,8 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     };
     note("MFMA4R", s->method == SPCIES_FISTA && !s->tv, s->frplan.ok, s->frplan.why, s->frplan.build_failed);
     note("MFMA4R", s->method == SPCIES_EADMM, s->erplan.ok, s->erplan.why, s->erplan.build_failed);
+    note("MFMA4R", s->method == SPCIES_ADMM && !s->tv && !s->host.gen && !s->host.ellip && !s->mfma4.ok && !s->mfma.ok &&
+                       (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC), s->arplan.ok, s->arplan.why, s->arplan.build_failed);
     note("MFMA4R", s->tv && (s->method == SPCIES_ADMM || s->method == SPCIES_FISTA), s->tvrp.ok, s->tvrp.why, s->tvrp.build_failed);
     note("BSP", (s->is_soc() && !s->is_hmpc()) || s->host.ellip, s->bsp.ok, s->bsp.why, s->bsp.build_failed);
     note("MFMA4", s->mfma4.needs_rtc, s->mfma4.ok, s->mfma4.why, s->mfma4.build_failed);
@@ -1968,6 +1994,16 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
         return fail(SPCIES_HIP_ENOSUP, "TILE variant: built for the sparse-KKT solvers (ellipMPC soc, HMPC) whose LDL right-hand side fits the LDS");
     if (variant == SPCIES_VARIANT_MFMA4R && s->method == SPCIES_EADMM && !s->erplan.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant not available for this solver: %s", s->erplan.why.c_str());
+    if (variant == SPCIES_VARIANT_MFMA4R && s->method == SPCIES_ADMM) {  // lax / equ ADMM: built on request where MFMA4 serves the controller (admm_r.hpp)
+        if (!s->arplan.ok && !s->host.gen && !s->host.ellip && (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC)) {
+            SPCIES_HIP_CHECK(hipSetDevice(s->device));
+            int rc = ar::plan_build(s->arplan, s->host);
+            if (rc) return rc;
+        }
+        if (!s->arplan.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant not available for this solver: %s", s->arplan.why.c_str());
+        s->variant = variant;
+        return 0;
+    }
     if (variant == SPCIES_VARIANT_MFMA4R && s->method != SPCIES_EADMM && !s->frplan.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant not available for this solver: %s", s->frplan.why.c_str());
     if (variant == SPCIES_VARIANT_MFMA4G && !s->g4plan.ok)

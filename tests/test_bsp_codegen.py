@@ -166,3 +166,28 @@ int main() {
         subprocess.run(["g++", "-std=c++17", "-O1", "-I", inc, "-o", os.path.join(d, "t"), os.path.join(d, "t.cpp")], check=True)
         r = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True)
         assert r.returncode == 0, (r.returncode, r.stdout)
+
+
+def test_admm_r_kernels_compile_with_the_flags_the_library_uses(tmp_path):
+    """admm_r_kernel.inc (lax / equ ADMM past MFMA4's register file) is specialised with hiprtc INSIDE the caller's process, so a
+    compiler crash there takes the caller down: ROCm 7.2's "Rewrite AGPR-Copy-MFMA" pass does crash on these kernels under
+    -amdgpu-mfma-vgpr-form when the allocator spills (admm_r.hip says why the switch is not used).  The instantiations that showed it -
+    the record kernel at n = 12, N = 30 and the equMPC solve kernel at n = 20, N = 20 - compile here, in a process of their own, with the
+    library's options, and stay within the CU's LDS."""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(here, "spcies_amd", "csrc", "admm_r_kernel.inc")).read()
+    sig = "(Args, const double *, const double *, const double *, const double *, double *, int *, int *, double *, double *, double *, double *, double *)"
+    src += "\nnamespace spcies { namespace ar {\n"
+    for targs in ("30, 3, 4, false, true, 4, 70", "20, 5, 6, false, false, 4, 56"):
+        src += f"template __global__ void admm_r_kernel<{targs}>{sig};\n"
+    src += "}}\n"
+    p = tmp_path / "admm_r_check.hip"
+    p.write_text(src)
+    import sys
+    co = tmp_path / "admm_r_check.co"
+    r = subprocess.run([sys.executable, "-c", _COMPILE, HIPRTC, str(p), str(co), "-DSPCIES_AR_PD=3", "-DSPCIES_AR_KREG=0", "-mllvm",
+                        "-pragma-unroll-threshold=1000000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    notes = subprocess.run([READELF, "--notes", str(co)], capture_output=True, text=True).stdout
+    lds = [int(x) for x in re.findall(r"\.group_segment_fixed_size:\s+(\d+)", notes)]
+    assert len(lds) == 2 and max(lds) <= 160 * 1024

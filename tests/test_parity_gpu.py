@@ -83,7 +83,7 @@ def _rerun_admm(v, x0, xr, ur):
     return rerun
 
 
-VARIANTS = ["stream", "mfma", "mfma4", "mfma4g"]
+VARIANTS = ["stream", "mfma", "mfma4", "mfma4g", "mfma4r"]  # mfma4r (admm_r.hpp): built on request at these shapes, AUTO past MFMA4's register file
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -125,6 +125,29 @@ def test_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
     if not overrides and cfg_name.startswith("C2"):
         assert (got[1] == 200).all() and (got[2] == -1).all()
     _compare(variant, got, ref, v, rerun=_rerun_admm(v, x0, xr, ur))
+
+
+@pytest.mark.parametrize("cfg_name,B,overrides", [
+    ("C2_lax_N30", 70, {}), ("C2_equ_N30", 40, dict(tol=1e-6, k_max=2000, around_xr=0.02)), ("C2_lax_N30", 50, dict(tol=1e-6, k_max=3000)),
+    ("C4_lax_ADMM", 48, {}), ("C4_equ_ADMM", 33, dict(k_max=40, around_xr=0.002)),  # (20 states, 2 inputs: the terminal equality is out of reach, |lambda| grows with k) ("C4_lax_ADMM", 40, dict(tol=1e-6, k_max=3000)),
+])
+def test_admm_past_the_register_file_vs_oracle(cfg_name, B, overrides):
+    """lax / equ ADMM at shapes MFMA4 cannot hold (n = 12 at N = 30: 214 slab registers; n + m = 22): AUTO is MFMA4R (admm_r.hpp: w on the
+    chip, blocks streamed), MFMA4G stays selectable; both against the oracle, and the run without the record returns the same (u, k)."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    overrides = dict(overrides)
+    around = overrides.pop("around_xr", None)
+    cfg, v, s = _solver(cfg_name, "auto", **overrides)
+    assert s.variant == "mfma4r", s.notes
+    x0, xr, ur = benchmarks.sample_batch(cfg, B, around_xr=around)
+    ref = oracle.admm_banded_batch(v, x0, xr, ur)
+    for variant in ("mfma4r", "mfma4g"):
+        s.set_variant(variant)
+        got = s(x0, xr, ur)
+        _compare(variant, got, ref, v, rerun=_rerun_admm(v, x0, xr, ur))
+        nosol = s(x0[:21], xr[:21], ur[:21], want_sol=False)
+        assert np.array_equal(nosol[0], got[0][:21]) and np.array_equal(nosol[1], got[1][:21])
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
