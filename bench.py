@@ -43,6 +43,10 @@ EXTRA_CONFIGS = {
     # vector H3i - 2 N n^2 + 2 (N + 1)(n^2 + m^2) more flop per iteration than the diagonal branch
     "C4_nd": dict(name="C4_nd", B=131072, flop=133.5e3 * 200, io=360,
                   what="configs[3] shape with general (non-diagonal) Q, R: MPCT-EADMM IS_DIAG == 0, 20-state, N=20, 200 iterations, batch=131072"),
+    # laxMPC-ADMM past the register-resident headline kernel: the C2 plant at the configs[2] horizon N = 30 (214 slab registers against MFMA4's
+    # 112) - the MFMA4R variant of admm_r.hpp (w on the chip, blocks streamed); flop per iteration scales with the horizon (2 x C2's 27 498)
+    "C2_N30": dict(name="C2_lax_N30", B=65536, flop=2 * 27498.0 * 200, io=232,
+                   what="laxMPC-ADMM, C2 plant (n=12, m=2) at N=30, 200 iterations, batch=65536: past MFMA4's register file"),
     "C5_soc": dict(name="C5_soc", B=65536, flop=23.4e3 * 200, io=240,
                    what="configs[4]a: ellipMPC-ADMM-soc, 12-state, N=15, 200 iterations, 1/8 shard (65536) of batch=524288"),
     "C5_hmpc": dict(name="C5_HMPC_SADMM", B=65536, flop=2.0 * 282 * 282 * 200, io=232,

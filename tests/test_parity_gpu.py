@@ -129,7 +129,7 @@ def test_seeded_batch_vs_oracle(variant, cfg_name, B, overrides):
 
 @pytest.mark.parametrize("cfg_name,B,overrides", [
     ("C2_lax_N30", 70, {}), ("C2_equ_N30", 40, dict(tol=1e-6, k_max=2000, around_xr=0.02)), ("C2_lax_N30", 50, dict(tol=1e-6, k_max=3000)),
-    ("C4_lax_ADMM", 48, {}), ("C4_equ_ADMM", 33, dict(k_max=40, around_xr=0.002)),  # (20 states, 2 inputs: the terminal equality is out of reach, |lambda| grows with k) ("C4_lax_ADMM", 40, dict(tol=1e-6, k_max=3000)),
+    ("C4_lax_ADMM", 48, {}), ("C4_lax_ADMM", 40, dict(tol=1e-6, k_max=3000)),
 ])
 def test_admm_past_the_register_file_vs_oracle(cfg_name, B, overrides):
     """lax / equ ADMM at shapes MFMA4 cannot hold (n = 12 at N = 30: 214 slab registers; n + m = 22): AUTO is MFMA4R (admm_r.hpp: w on the
@@ -148,6 +148,34 @@ def test_admm_past_the_register_file_vs_oracle(cfg_name, B, overrides):
         _compare(variant, got, ref, v, rerun=_rerun_admm(v, x0, xr, ur))
         nosol = s(x0[:21], xr[:21], ur[:21], want_sol=False)
         assert np.array_equal(nosol[0], got[0][:21]) and np.array_equal(nosol[1], got[1][:21])
+
+
+@pytest.mark.parametrize("n,m,N,formulation", [(5, 3, 6, "laxMPC"), (9, 2, 8, "laxMPC"), (13, 2, 17, "laxMPC"), (16, 4, 12, "laxMPC"),
+                                               (18, 3, 9, "laxMPC"), (21, 3, 7, "laxMPC"), (5, 3, 6, "equMPC"), (16, 4, 12, "equMPC")])
+def test_admm_r_arbitrary_shapes(n, m, N, formulation):
+    """admm_r specialises a kernel per controller: random stable plants whose state / input counts leave 1, 2 or 3 rows in the last
+    slab, n + m past 16 (KS = 5, 6: the row constants read from LDS), a dense terminal weight (laxMPC: Hi_N rides in B2's place of
+    the last block), initial states at the edge of the box (active bounds on some instances, multipliers of order 1-100), equMPC where the plant has the inputs to
+    reach the terminal equality on most instances - against the oracle, (u, k) of the run without the record equal to the run with it."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=900 + n)
+    cfg.formulation = formulation
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    s.set_variant("mfma4r")
+    rng = np.random.default_rng(11 * n + m)
+    B = 37
+    x0 = (0.5 if formulation == "laxMPC" else 0.3) * rng.standard_normal((B, n))
+    xr = 0.1 * rng.standard_normal((B, n))
+    ur = 0.05 * rng.standard_normal((B, m))
+    ref = oracle.admm_banded_batch(v, x0, xr, ur)
+    got = s(x0, xr, ur)
+    _compare("mfma4r", got, ref, v, rerun=_rerun_admm(v, x0, xr, ur))
+    nosol = s(x0[:19], xr[:19], ur[:19], want_sol=False)
+    assert np.array_equal(nosol[0], got[0][:19]) and np.array_equal(nosol[1], got[1][:19])
+    s.close()
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
