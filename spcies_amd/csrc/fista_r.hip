@@ -85,9 +85,9 @@ struct BlockWriter {
     }
 };
 
-template <int KX, int KS, int SPB>
+template <int KX, int KS>
 int pack(Plan &p, const Host &h, std::vector<double> &tab) {
-    using LY = Layout<KX, KS, SPB>;
+    using LY = Layout<KX, KS>;
     const int n = h.n, m = h.m, N = h.N, nm = n + m;
     tab.assign((size_t)LY::table_doubles(N), 0.0);
     DM AB(n, nm);
@@ -124,31 +124,28 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
     }
     const DM Zero(n, n), nABt = neg(tr(AB)), nAB = neg(AB);
     bool ok = true;
-    for (int c = 0; c < LY::nch(N); c++) {  // a chunk: SPB blocks as one continuous stream of pair records
-        BlockWriter w(tab.data() + LY::chunk_off(c, N));
-        const int nb = LY::blocks_in(c, N);
-        for (int b = 0; b < nb; b++) {
-            if (c < LY::nfc(N)) {  // forward block l: one linear stream per stage
-                const int l = c * SPB + b;
-                const DM BiT = tr(Bi[l]);
-                w.emit(nABt, KS, KX, DENSE);
-                w.emit(nAB, KX, KS, DENSE);
-                w.emit(BiT, KX, KX, LOWER);
-                w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
-            } else {  // backward block l = N - 1 - position
-                const int l = N - 1 - ((c - LY::nfc(N)) * SPB + b);
-                w.emit(Bi[l], KX, KX, UPPER);
-                w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : Zero, KX, KX, DENSE);
-            }
+    for (int s = 0; s < 2 * N; s++) {
+        BlockWriter w(tab.data() + LY::chunk_off(s, N));
+        if (s < N) {  // forward chunk of block l = s: one linear stream per stage
+            const int l = s;
+            const DM BiT = tr(Bi[l]);
+            w.emit(nABt, KS, KX, DENSE);
+            w.emit(nAB, KX, KS, DENSE);
+            w.emit(BiT, KX, KX, LOWER);
+            w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
+            ok = ok && w.structure_ok && w.cursor == LY::NTF;
+        } else {  // backward chunk of block l = 2N-1-s
+            const int l = 2 * N - 1 - s;
+            w.emit(Bi[l], KX, KX, UPPER);
+            w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : Zero, KX, KX, DENSE);
+            ok = ok && w.structure_ok && w.cursor == LY::NTB;
         }
-        ok = ok && w.structure_ok && w.cursor == nb * (c < LY::nfc(N) ? LY::NTF : LY::NTB);
     }
     if (!ok) { p.why = "MFMA4R packer: block structure mismatch"; return 0; }
     for (double x : tab)
         if (!std::isfinite(x)) { p.why = "non-finite folded constant (singular Beta block?)"; return 0; }
     p.KX = KX;
     p.KS = KS;
-    p.SPB = SPB;
     // LDS: header + four chunk slots + NLDS state vectors per wavefront; the rest of the 2 N KX state vectors in registers
     const int lds_d = 163840 / 8 - LY::HDR_D - 4 * LY::CF - 128, NV = 2 * N * KX;  // y and lambda on the chip
     int max_reg_vecs = 150;  // 300 of the 512 registers for state (what the register allocator places without spilling)
@@ -193,10 +190,8 @@ int plan_build(Plan &p, const Host &h) {
     const int KX = (h.n + 3) / 4, KS = (h.n + h.m + 3) / 4;
     std::vector<double> tab;
     int got = -1;
-    int spb = 1;
-    if (const char *ev = getenv("SPCIES_FR_SPB")) spb = atoi(ev) == 2 ? 2 : 1;
 #define X(KKX, KKS) \
-    if (KX == KKX && KS == KKS) got = spb == 2 ? pack<KKX, KKS, 2>(p, h, tab) : pack<KKX, KKS, 1>(p, h, tab);
+    if (KX == KKX && KS == KKS) got = pack<KKX, KKS>(p, h, tab);
     SPCIES_FR_SHAPES(X)
 #undef X
     if (got < 0) { p.why = "MFMA4R: (ceil(n/4), ceil((n+m)/4)) outside the packer's shapes"; return 0; }
@@ -205,7 +200,7 @@ int plan_build(Plan &p, const Host &h) {
     {
         int idx = 0;
 #define X(NN, KKX, KKS, TT, WW, LL)                                                                                         \
-    if (h.N == NN && KX == KKX && KS == KKS && h.terminal == TT && p.NW == WW && p.NLDS == LL && p.SPB == 1 && !getenv("SPCIES_FR_RTC_FLAGS") && \
+    if (h.N == NN && KX == KKX && KS == KKS && h.terminal == TT && p.NW == WW && p.NLDS == LL && !getenv("SPCIES_FR_RTC_FLAGS") && \
         !getenv("SPCIES_FR_PD") && h.n % 4 == 0)                                                                             \
         p.builtin = idx;                                                                                                     \
     idx++;
@@ -218,8 +213,8 @@ int plan_build(Plan &p, const Host &h) {
     char names[2][160];
     std::vector<std::string> nm;
     for (int s = 0; s < 2; s++) {
-        snprintf(names[s], sizeof(names[s]), "spcies::fr::fista_r_kernel<%d, %d, %d, %s, %s, %d, %d, %d>", h.N, KX, KS,
-                 h.terminal ? "true" : "false", s ? "true" : "false", p.NW, p.NLDS, p.SPB);
+        snprintf(names[s], sizeof(names[s]), "spcies::fr::fista_r_kernel<%d, %d, %d, %s, %s, %d, %d>", h.N, KX, KS,
+                 h.terminal ? "true" : "false", s ? "true" : "false", p.NW, p.NLDS);
         nm.push_back(names[s]);
     }
     int pd = 3;

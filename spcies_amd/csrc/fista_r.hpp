@@ -19,7 +19,7 @@ struct Plan {
     bool ok = false;
     std::string why = "not built";
     bool build_failed = false;  // the variant applies to this controller but its run-time specialisation failed (hiprtc missing, compile error): what SPCIES_HIP_STRICT reacts to
-    int n = 0, m = 0, N = 0, KX = 0, KS = 0, NW = 0, NLDS = 0, SPB = 1;  // SPB: blocks per chunk = per barrier (fista_r_kernel.inc)
+    int n = 0, m = 0, N = 0, KX = 0, KS = 0, NW = 0, NLDS = 0;
     bool terminal = false;
     double *d_table = nullptr;  // + a dump word for masked-off stores
     double *d_scr = nullptr;    // per-wavefront scratch slots of the forward-substituted d
