@@ -150,11 +150,11 @@ def test_admm_past_the_register_file_vs_oracle(cfg_name, B, overrides):
         assert np.array_equal(nosol[0], got[0][:21]) and np.array_equal(nosol[1], got[1][:21])
 
 
-@pytest.mark.parametrize("n,m,N,formulation", [(5, 3, 6, "laxMPC"), (9, 2, 8, "laxMPC"), (13, 2, 17, "laxMPC"), (16, 4, 12, "laxMPC"),
+@pytest.mark.parametrize("n,m,N,formulation", [(4, 2, 2, "laxMPC"), (7, 3, 3, "laxMPC"), (4, 2, 2, "equMPC"), (5, 3, 6, "laxMPC"), (9, 2, 8, "laxMPC"), (13, 2, 17, "laxMPC"), (16, 4, 12, "laxMPC"),
                                                (18, 3, 9, "laxMPC"), (21, 3, 7, "laxMPC"), (5, 3, 6, "equMPC"), (16, 4, 12, "equMPC")])
 def test_admm_r_arbitrary_shapes(n, m, N, formulation):
-    """admm_r specialises a kernel per controller: random stable plants whose state / input counts leave 1, 2 or 3 rows in the last
-    slab, n + m past 16 (KS = 5, 6: the row constants read from LDS), a dense terminal weight (laxMPC: Hi_N rides in B2's place of
+    """admm_r specialises a kernel per controller: the shortest horizons (N = 2, 3: every y block stays in registers, the ring never
+    fills), random stable plants whose state / input counts leave 1, 2 or 3 rows in the last slab, n + m past 16 (KS = 5, 6: the row constants read from LDS), a dense terminal weight (laxMPC: Hi_N rides in B2's place of
     the last block), initial states at the edge of the box (active bounds on some instances, multipliers of order 1-100), equMPC where the plant has the inputs to
     reach the terminal equality on most instances - against the oracle, (u, k) of the run without the record equal to the run with it."""
     from oracle import oracle
