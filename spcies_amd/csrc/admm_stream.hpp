@@ -16,6 +16,7 @@
 // = (4*420 + 2*180) * 8 B = 16.3 KB  ->  HBM-bound kernel.
 #pragma once
 #include "common.hpp"
+#include "tv_update_kernel.inc"  // time-varying solvers: row layouts of their scratch (TvLayout, FistaTvLayout) and the update-phase kernels
 
 namespace spcies {
 
@@ -73,31 +74,6 @@ struct KArr<true> {
     __device__ __forceinline__ KArr operator+(long off) const { return KArr{r, row + (unsigned)off, bp8, voff}; }
 };
 
-// Row offsets of the per-instance constants of the time-varying solvers inside their scratch (tv_layout()).
-struct TvLayout {
-    int AB, Alpha, Beta, Hi, Hi_0, Q, R, LB, UB, AQiAt, BRiBt, rows;
-    int Bi, rows_all;  // the explicit inverses Beta^-1 of the MFMA4R variant (admm_tvr.hpp), behind everything the other variants use
-};
-__host__ __device__ inline TvLayout tv_layout(int n, int m, int N) {
-    TvLayout L;
-    const int nm = n + m;
-    int r = 0;
-    L.AB = r; r += n * nm;
-    L.Alpha = r; r += (N - 1) * n * n;
-    L.Beta = r; r += N * n * n;
-    L.Hi = r; r += (N - 1) * nm;
-    L.Hi_0 = r; r += m;
-    L.Q = r; r += n;
-    L.R = r; r += m;
-    L.LB = r; r += nm;
-    L.UB = r; r += nm;
-    L.AQiAt = r; r += n * n;
-    L.BRiBt = r; r += n * n;
-    L.rows = r;
-    L.Bi = r; r += N * n * n;
-    L.rows_all = r;
-    return L;
-}
 
 // Scratch: V, LAM are [dim][Bp], Y is [N*n][Bp], ZS (optional, only when the caller wants
 // z / v / lambda back) is [dim][Bp].  Element order inside dim = the reference's flattened order
@@ -541,191 +517,7 @@ __global__ __launch_bounds__(64) void admm_stream_kernel(AdmmDev c, const double
     e_out[t] = flag;
 }
 
-// The banded Cholesky of the update phase (code_laxMPC_ADMM_C.c:172-262; the FISTA generator's is the same recurrence with its own
-// diagonal, code_laxMPC_FISTA_C.c TIME_VARYING block) with THE CURRENT BLOCK IN REGISTERS: Beta{h}'s upper triangle (n (n + 1) / 2) and
-// Alpha{h} (n n) are built in fully unrolled register arrays and stored once; the recurrences read their earlier entries from the
-// registers instead of from the rows just written (round 3 read every one back: 4.4 k row loads per block, 30 GB per 65 536 instances,
-// 8.2 ms of a 55 ms launch).  Operation for operation the sums of the reference, in its order (contraction off): the rows are bit-equal.
-// Qd = the diagonal added to Beta{h < N-1} and scaling Alpha; term(i, j, v) = the last block's terminal contribution.
-// language-level full unrolling (the register arrays below need every index a constant; `#pragma unroll` gives up past a size threshold)
-template <int I0, int I1, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I0 < I1) {
-        f(std::integral_constant<int, I0>{});
-        static_for<I0 + 1, I1>(f);
-    }
-}
-template <int n, int nm, class Term>
-__device__ __forceinline__ void tv_band_factor(int N, double *__restrict__ TVS, unsigned t, long Bp, int rBeta, int rAlpha, int rAB, int rAQ,
-                                               int rBR, const double (&Qd)[n], Term term) {
-    // Rows are walked with running wavefront-uniform pointers (one s_add per row) that the optimiser is not shown through: left to itself it
-    // turns the 288 row addresses of a block into as many 64-bit induction variables and spills the factors to make room for them.
-    // (pointers in the global address space: a pointer that went through the asm statement as a generic one is accessed with flat_*)
-    typedef double __attribute__((address_space(1))) * gp;
-    typedef const double __attribute__((address_space(1))) * cgp;
-    auto hide = [](auto &q) { asm volatile("" : "+s"(q)); };
-    double be[n][n], al[n][n];  // be: j >= i only
-    const cgp pAQ0 = (cgp)(TVS + (long)rAQ * Bp), pBR0 = (cgp)(TVS + (long)rBR * Bp), pAB0 = (cgp)(TVS + (long)rAB * Bp);
-    const long nmBp = (long)nm * Bp;
-    auto beta_block = [&](int h, auto first_c, auto last_c) {
-        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
-        gp po = (gp)(TVS + (long)(rBeta + h * n * n) * Bp);
-        cgp pa = pAQ0, pb = pBR0;
-        hide(po), hide(pa), hide(pb);
-        static_for<0, n>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            double in[n];  // the row's inputs first, all in flight together: one exposed memory latency per row, not per entry
-            static_for<0, n>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (j >= i) in[j] = FIRST ? pb[t] : pa[t] + pb[t];
-                pa += Bp, pb += Bp;
-                hide(pa), hide(pb);
-            });
-            static_for<0, n>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (j < i) {
-                    po[t] = 0.0;  // the reference's array is zero below the diagonal
-                } else {
-                    double v = in[j];
-                    if constexpr (!FIRST) {
-#pragma unroll
-                        for (int k = 0; k < n; k++) v -= al[k][i] * al[k][j];
-                    }
-#pragma unroll
-                    for (int l = 1; l <= i; l++) v -= be[l - 1][i] * be[l - 1][j];
-                    if constexpr (LAST) term(i, j, v);
-                    if (i == j) {
-                        if constexpr (!LAST) v += Qd[i];
-                        v = 1 / sqrt(v);
-                    } else {
-                        v = v * be[i][i];
-                    }
-                    be[i][j] = v;
-                    po[t] = v;
-                }
-                po += Bp;
-                hide(po);
-            });
-        });
-    };
-    auto alpha_block = [&](int h) {
-        gp po = (gp)(TVS + (long)(rAlpha + h * n * n) * Bp);
-        cgp pr = pAB0;  // AB[j][i]: row j nm + i
-        hide(po), hide(pr);
-        static_for<0, n>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            cgp pab = pr;
-            double in[n];
-            static_for<0, n>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                in[j] = pab[t];
-                pab += nmBp;
-                hide(pab);
-            });
-            static_for<0, n>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                double v = -Qd[i] * in[j];
-#pragma unroll
-                for (int l = 1; l <= i; l++) v -= be[l - 1][i] * al[l - 1][j];
-                v = v * be[i][i];
-                al[i][j] = v;
-                po[t] = v;
-                po += Bp;
-                hide(po);
-            });
-            pr += Bp;
-            hide(pr);
-        });
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    beta_block(0, T_{}, F_{});
-    alpha_block(0);
-    for (int h = 1; h < N - 1; h++) {
-        beta_block(h, F_{}, F_{});
-        alpha_block(h);
-    }
-    beta_block(N - 1, F_{}, T_{});
-}
 
-// Update phase of the time-varying solvers (TIME_VARYING == 1, code_laxMPC_ADMM_C.c:117-279, equMPC:
-// code_equMPC_ADMM_C.c:117-265): from the model handed in with the call - A [n][n], B [n][m] column-major, Q, R
-// diagonals, LB, UB, packed per instance in `model` (one shared model when model_stride == 0) - to AB, Hi, Hi_0,
-// the banded Cholesky factors Alpha / Beta, and the negated Q, R, in the instance's rows of the scratch.
-// One lane per instance, the reference's operation order.
-template <int n, int m, bool TERMINAL>
-__global__ __launch_bounds__(64) void admm_tv_update_kernel(int N, double rho, const double *__restrict__ T_rho_i,
-                                                            const double *__restrict__ model, long model_stride, long B,
-                                                            long Bp, double *__restrict__ TVS) {
-    constexpr int nm = n + m;
-    const long t = (long)blockIdx.x * 64 + threadIdx.x;
-    if (t >= B) return;
-    const TvLayout tl = tv_layout(n, m, N);
-    const double *A_in = model + t * model_stride, *B_in = A_in + n * n, *Q_in = B_in + n * m, *R_in = Q_in + n,
-                 *LB_in = R_in + m, *UB_in = LB_in + nm;
-    double *S = TVS + t;
-#define ROW(base, i) S[(long)((base) + (i)) * Bp]
-#define TBETA(h, i, j) ROW(tl.Beta, ((h) * n + (i)) * n + (j))
-#define TALPHA(h, i, j) ROW(tl.Alpha, ((h) * n + (i)) * n + (j))
-    double Q_rho_i[n], R_rho_i[m];
-#pragma unroll
-    for (int i = 0; i < n; i++) {
-        Q_rho_i[i] = 1 / (Q_in[i] + rho);
-        for (int j = 0; j < n; j++) ROW(tl.AB, i * nm + j) = A_in[i + j * n];
-        for (int j = 0; j < m; j++) ROW(tl.AB, i * nm + n + j) = B_in[i + j * n];
-    }
-#pragma unroll
-    for (int j = 0; j < m; j++) {
-        R_rho_i[j] = 1 / (R_in[j] + rho);
-        ROW(tl.Hi_0, j) = R_rho_i[j];
-    }
-    for (int i = 0; i < N - 1; i++) {
-#pragma unroll
-        for (int j = 0; j < nm; j++) ROW(tl.Hi, i * nm + j) = (j < n) ? Q_rho_i[j < n ? j : 0] : R_rho_i[j >= n ? j - n : 0];
-    }
-#pragma unroll
-    for (int j = 0; j < nm; j++) {
-        ROW(tl.LB, j) = LB_in[j];
-        ROW(tl.UB, j) = UB_in[j];
-    }
-    {  // A, B once into registers (the model is instance-contiguous: every load of it touches 64 cache lines), then the two products
-        double Ar[n][n], Br[n][m];
-        static_for<0, n>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-#pragma unroll
-            for (int k = 0; k < n; k++) Ar[i][k] = A_in[i + k * n];
-#pragma unroll
-            for (int k = 0; k < m; k++) Br[i][k] = B_in[i + k * n];
-        });
-        typedef double __attribute__((address_space(1))) * gp;
-        gp pq = (gp)(TVS + (long)tl.AQiAt * Bp), pr = (gp)(TVS + (long)tl.BRiBt * Bp);
-        static_for<0, n>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            static_for<0, n>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                double a = 0.0, b = 0.0;
-#pragma unroll
-                for (int k = 0; k < n; k++) a += Ar[i][k] * Q_rho_i[k] * Ar[j][k];
-#pragma unroll
-                for (int k = 0; k < m; k++) b += Br[i][k] * R_rho_i[k] * Br[j][k];
-                pq[t] = a;
-                pr[t] = b;
-                pq += Bp, pr += Bp;
-                asm volatile("" : "+s"(pq), "+s"(pr));  // (running row pointers, out of the optimiser's sight: see tv_band_factor)
-            });
-        });
-    }
-    tv_band_factor<n, nm>(N, TVS, (unsigned)t, Bp, tl.Beta, tl.Alpha, tl.AB, tl.AQiAt, tl.BRiBt, Q_rho_i, [&](int i, int j, double &v) {
-        if constexpr (TERMINAL) v += T_rho_i[i * n + j];
-    });
-#pragma unroll
-    for (int i = 0; i < n; i++) ROW(tl.Q, i) = -Q_in[i];
-#pragma unroll
-    for (int i = 0; i < m; i++) ROW(tl.R, i) = -R_in[i];
-#undef ROW
-#undef TBETA
-#undef TALPHA
-}
 
 // [rows][Bp] structure-of-arrays scratch -> [B][rows] instance-contiguous output (the layout the
 // reference's DEBUG copy-out produces per instance, code_laxMPC_ADMM_C.c:657-686).

@@ -10,8 +10,11 @@
 namespace spcies {
 namespace tvr {
 
-static const char *const kSource =
+static const char *const kSourceSolve =
 #include "admm_tvr_src.inc"
+    ;
+static const char *const kSourceUpdate =
+#include "tv_update_src.inc"
     ;
 
 void plan_free(Plan &p) {
@@ -23,7 +26,8 @@ void plan_free(Plan &p) {
 int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
     p.ok = false;
     p.n = n; p.m = m; p.N = N; p.terminal = terminal; p.fista = fista;
-    if (!((n == 6 && m == 2) || (n == 12 && m == 2))) { p.why = "time-varying solvers are instantiated for (n, m) = (6, 2) and (12, 2)"; return 0; }
+    p.update_builtin = (n == 6 && m == 2) || (n == 12 && m == 2);  // admm_stream.hpp / fista_stream.hpp instantiate the update phase for these
+    if (n + m > 16 || n < 1 || m < 1) { p.why = "MFMA4R (time-varying): n + m <= 16 (a vector is one register in the D layout)"; return 0; }
     if (N < 2) { p.why = "N < 2"; return 0; }
     if (fista) {   // the kernel's restatement of the update phase's row layout must be the layout
         const FistaTvLayout a = fista_tv_layout(n, m, N);
@@ -41,7 +45,7 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
     const int doubles = 2 * N * KX + 2 * (N - 1 - NL) * KX + 16 + (fista ? 3 * N : 2 * N + 1) + 40;
     if (2 * doubles > 500) { p.why = "MFMA4R (time-varying): the instance's factors do not fit the wavefront's registers (use STREAM)"; return 0; }
     p.builtin = shape_built(n, m, N);
-    if (!p.builtin) {
+    if (!p.builtin || !p.update_builtin) {
         const char *ev = getenv("SPCIES_HIP_RTC");
         if (ev && ev[0] == '0') { p.why = "horizon not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
         std::vector<std::string> nm;
@@ -52,14 +56,21 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
             snprintf(name, sizeof(name), "spcies::tvr::%s_tvr_kernel<%d, %d, %d, %s, %s>", fista ? "fista" : "admm", n, m, N, terminal ? "true" : "false", s ? "true" : "false");
             nm.push_back(name);
         }
+        if (!p.update_builtin) {  // an (n, m) without a build-time update phase: the same text as admm_stream.hpp compiles, specialised here
+            snprintf(name, sizeof(name), "spcies::%s_tv_update_kernel<%d, %d, %s>", fista ? "fista" : "admm", n, m, terminal ? "true" : "false");
+            nm.push_back(name);
+        }
+        const std::string source = std::string(kSourceUpdate) + "\n" + kSourceSolve;
         std::vector<std::string> extra = {"-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form"};
         for (const std::string &e : rtc::split_flags(getenv("SPCIES_TVR_RTC_FLAGS"))) extra.push_back(e);
         hipModule_t mod = nullptr;
-        hipFunction_t fns[3] = {nullptr, nullptr, nullptr};
-        int rc = rtc::compile_module(kSource, "spcies_admm_tvr_rtc.hip", nm, extra, &mod, fns);
+        hipFunction_t fns[4] = {nullptr, nullptr, nullptr, nullptr};
+        int rc = rtc::compile_module(source.c_str(), "spcies_admm_tvr_rtc.hip", nm, extra, &mod, fns);
         if (rc) { p.why = std::string("MFMA4R (time-varying): run-time specialisation failed: ") + spcies_hip_last_error(); p.build_failed = true; return 0; }
         p.module = mod;
         p.fn[0] = fns[0]; p.fn[1] = fns[1]; p.fn[2] = fns[2];
+        p.fn_update = p.update_builtin ? nullptr : (void *)fns[3];
+        p.builtin = false;  // (a build-time horizon of an (n, m) whose update phase is not: everything from the module)
     }
     p.ok = true;
     p.why.clear();
@@ -145,6 +156,19 @@ int launch_fista(const Plan &p, bool want_sol, const Args &a, const double *T, c
     Args aa = a;
     void *params[] = {&aa, &T, &Ti, &TVS, &x0, &xr, &ur, &u, &k, &e, &z, &lam};
     SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 2 : 1], grid, 1, 1, 256, 1, 1, 0, st, params, nullptr));
+    return 0;
+}
+
+int launch_update(const Plan &p, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp, double *TVS, hipStream_t st) {
+    if (!p.ok || !p.fn_update) return fail(SPCIES_HIP_ENOSUP, "time-varying update phase: no run-time specialised kernel for n=%d m=%d", p.n, p.m);
+    int N = p.N;
+    if (p.fista) {
+        void *params[] = {&N, &Tc, &model, &model_stride, &B, &Bp, &TVS};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_update, (unsigned)(Bp / 64), 1, 1, 64, 1, 1, 0, st, params, nullptr));
+    } else {
+        void *params[] = {&N, &c0, &Tc, &model, &model_stride, &B, &Bp, &TVS};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_update, (unsigned)(Bp / 64), 1, 1, 64, 1, 1, 0, st, params, nullptr));
+    }
     return 0;
 }
 

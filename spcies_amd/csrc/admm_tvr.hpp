@@ -53,9 +53,11 @@ struct Plan {
     bool terminal = true, builtin = false, fista = false;
     void *module = nullptr;            // hipModule_t of a run-time specialised kernel
     void *fn[3] = {nullptr, nullptr, nullptr};  // Bi kernel, iteration without / with the record
+    void *fn_update = nullptr;                  // the update-phase kernel of an (n, m) without a build-time instantiation (tv_update_kernel.inc)
+    bool update_builtin = false;                // (n, m) = (6, 2), (12, 2): admm_stream.hpp's instantiations, launched by the caller
 };
-// decides whether the variant applies (n + m <= 16, the (n, m) of the update phase's instantiations, the state within the register file) and,
-// for a horizon without a build-time kernel, compiles one (hiprtc; code-object cache)
+// decides whether the variant applies (n + m <= 16, the state within the register file) and, for a shape without build-time kernels, compiles
+// them (hiprtc; code-object cache) - the update phase included, so that ANY plant size within those limits has a time-varying path
 int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista = false);
 void plan_free(Plan &p);
 // update-phase follow-up (the explicit inverses) + the solve of one chunk; pointers are device memory, TVS as admm_tv_update_kernel left it
@@ -65,6 +67,10 @@ int launch(const Plan &p, bool want_sol, const Args &a, const double *TRI, const
 // TVS as fista_tv_update_kernel left it; record z, lambda (= y)
 int launch_fista(const Plan &p, bool want_sol, const Args &a, const double *T, const double *Ti, double *TVS, const double *x0, const double *xr,
                  const double *ur, double *u, int *k, int *e, double *z, double *lam, int num_cu, hipStream_t st);
+
+// the update phase of a run-time specialised (n, m): what admm_tv_update_kernel<n, m, TERMINAL> / fista_tv_update_kernel<...> do for the build-time ones
+// (ADMM: c0 = rho, Tc = T_rho_i; FISTA: Tc = Ti, c0 unused)
+int launch_update(const Plan &p, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp, double *TVS, hipStream_t st);
 
 }  // namespace tvr
 }  // namespace spcies

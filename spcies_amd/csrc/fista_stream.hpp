@@ -22,27 +22,6 @@ struct FistaDev {
 
 #pragma clang fp contract(off)
 
-// Row offsets of the per-instance constants of the time-varying FISTA solvers inside their scratch [row][Bp]
-struct FistaTvLayout {
-    int AB, Alpha, Beta, Q, R, QRi, LB, UB, AQiAt, BRiBt, rows;
-};
-__host__ __device__ inline FistaTvLayout fista_tv_layout(int n, int m, int N) {
-    FistaTvLayout L;
-    const int nm = n + m;
-    int r = 0;
-    L.AB = r; r += n * nm;
-    L.Alpha = r; r += (N - 1) * n * n;
-    L.Beta = r; r += N * n * n;
-    L.Q = r; r += n;
-    L.R = r; r += m;
-    L.QRi = r; r += nm;
-    L.LB = r; r += nm;
-    L.UB = r; r += nm;
-    L.AQiAt = r; r += n * n;
-    L.BRiBt = r; r += n * n;
-    L.rows = r;
-    return L;
-}
 
 // TV: TIME_VARYING == 1 (code_laxMPC_FISTA_C.c:18, 42-56, 83-262): AB, Alpha, Beta, Q, R, QRi, LB, UB are this instance's own rows
 // of the scratch TVS (written by fista_tv_update_kernel), read through a buffer resource; T, Ti stay controller constants.
@@ -248,76 +227,5 @@ __global__ __launch_bounds__(64) void fista_stream_kernel(FistaDev c, const doub
     e_out[t] = flag;
 }
 
-// Update phase of the time-varying FISTA solvers (code_laxMPC_FISTA_C.c:107-271, code_equMPC_FISTA_C.c:105-255): from the model
-// handed in with the call - A [n][n], B [n][m] column-major, Q, R diagonals, LB, UB, packed per instance in `model` (one
-// shared model when model_stride == 0) - to AB, QRi, the banded Cholesky factors Alpha / Beta of W = G H^-1 G' (no rho here) and
-// the negated Q, R, in the instance's rows of the scratch.  One lane per instance, the reference's operation order.
-template <int n, int m, bool TERMINAL>
-__global__ __launch_bounds__(64) void fista_tv_update_kernel(int N, const double *__restrict__ Ti, const double *__restrict__ model,
-                                                             long model_stride, long B, long Bp, double *__restrict__ TVS) {
-    constexpr int nm = n + m;
-    const long t = (long)blockIdx.x * 64 + threadIdx.x;
-    if (t >= B) return;
-    const FistaTvLayout tl = fista_tv_layout(n, m, N);
-    const double *A_in = model + t * model_stride, *B_in = A_in + n * n, *Q_in = B_in + n * m, *R_in = Q_in + n,
-                 *LB_in = R_in + m, *UB_in = LB_in + nm;
-    double *S = TVS + t;
-#define ROW(base, i) S[(long)((base) + (i)) * Bp]
-#define TBETA(h, i, j) ROW(tl.Beta, ((h) * n + (i)) * n + (j))
-#define TALPHA(h, i, j) ROW(tl.Alpha, ((h) * n + (i)) * n + (j))
-    double Q_i[n], R_i[m];
-#pragma unroll
-    for (int i = 0; i < n; i++) {
-        Q_i[i] = 1 / Q_in[i];
-        for (int j = 0; j < n; j++) ROW(tl.AB, i * nm + j) = A_in[i + j * n];
-        for (int j = 0; j < m; j++) ROW(tl.AB, i * nm + n + j) = B_in[i + j * n];
-    }
-#pragma unroll
-    for (int j = 0; j < m; j++) R_i[j] = 1 / R_in[j];
-#pragma unroll
-    for (int j = 0; j < nm; j++) {
-        ROW(tl.QRi, j) = (j < n) ? -Q_i[j < n ? j : 0] : -R_i[j >= n ? j - n : 0];
-        ROW(tl.LB, j) = LB_in[j];
-        ROW(tl.UB, j) = UB_in[j];
-    }
-    {  // A, B once into registers (the model is instance-contiguous: every load of it touches 64 cache lines), then the two products
-        double Ar[n][n], Br[n][m];
-        static_for<0, n>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-#pragma unroll
-            for (int k = 0; k < n; k++) Ar[i][k] = A_in[i + k * n];
-#pragma unroll
-            for (int k = 0; k < m; k++) Br[i][k] = B_in[i + k * n];
-        });
-        typedef double __attribute__((address_space(1))) * gp;
-        gp pq = (gp)(TVS + (long)tl.AQiAt * Bp), pr = (gp)(TVS + (long)tl.BRiBt * Bp);
-        static_for<0, n>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            static_for<0, n>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                double a = 0.0, b = 0.0;
-#pragma unroll
-                for (int k = 0; k < n; k++) a += Ar[i][k] * Q_i[k] * Ar[j][k];
-#pragma unroll
-                for (int k = 0; k < m; k++) b += Br[i][k] * R_i[k] * Br[j][k];
-                pq[t] = a;
-                pr[t] = b;
-                pq += Bp, pr += Bp;
-                asm volatile("" : "+s"(pq), "+s"(pr));  // (running row pointers, out of the optimiser's sight: see tv_band_factor)
-            });
-        });
-    }
-    tv_band_factor<n, nm>(N, TVS, (unsigned)t, Bp, tl.Beta, tl.Alpha, tl.AB, tl.AQiAt, tl.BRiBt, Q_i, [&](int i, int j, double &v) {
-        if constexpr (TERMINAL)
-            if (i == j) v -= Ti[i];
-    });
-#pragma unroll
-    for (int i = 0; i < n; i++) ROW(tl.Q, i) = -Q_in[i];
-#pragma unroll
-    for (int i = 0; i < m; i++) ROW(tl.R, i) = -R_in[i];
-#undef ROW
-#undef TBETA
-#undef TALPHA
-}
 
 }  // namespace spcies

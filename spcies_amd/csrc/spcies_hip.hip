@@ -1115,6 +1115,46 @@ static int launch_stream(Solver &s, const double *x0, const double *xr, const do
     return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", n, m);
 }
 
+// Time-varying lax / equ ADMM and FISTA at an (n, m) without build-time kernels (STREAM and the update phase are instantiated for (6, 2) and
+// (12, 2)): the MFMA4R path with EVERYTHING run-time specialised - update phase, inverses, solve (admm_tvr.hpp; tv_update_kernel.inc is
+// the same text the build-time instantiations compile).  z, v, lam: ADMM's record; FISTA passes z and lam (v = NULL).
+static int launch_tv_rtc(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, const double *model, int model_stride,
+                         long B, double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
+    const int n = s.host.n, m = s.host.m, N = s.host.N;
+    const bool fista = s.method == SPCIES_FISTA;
+    const bool want_sol = (z || v || lam);
+    const size_t dim = (size_t)s.host.dim(), Nn = (size_t)N * n;
+    const size_t rows_tv = fista ? (size_t)fista_tv_layout(n, m, N).rows + (size_t)N * n * n : (size_t)tv_layout(n, m, N).rows_all;
+    long chunk = (long)((3900ull << 20) / (rows_tv * 8)) / 64 * 64;  // one launch's rows stay below the 4 GB a buffer resource addresses
+    if (chunk > B) chunk = (B + 63) / 64 * 64;
+    int rc = ensure_scratch(s, rows_tv * (size_t)chunk * sizeof(double));
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, s.device));
+    const int num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (long b0 = 0; b0 < B; b0 += chunk) {
+        const long Bc = std::min(chunk, B - b0), Bp = (Bc + 63) / 64 * 64;
+        double *TVS = s.d_scratch;
+        const double *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
+        const double *mc = model_stride ? model + b0 * (long)model_stride : model;
+        if (fista) {
+            rc = tvr::launch_update(s.tvrp, 0.0, s.d_consts + s.fdev.Ti, mc, (long)model_stride, Bc, Bp, TVS, st);
+            if (rc) return rc;
+            tvr::Args ta{s.host.k_max, ref_stride, 0.0, s.host.tol, Bc, Bp};
+            rc = tvr::launch_fista(s.tvrp, want_sol, ta, s.d_consts + s.fdev.T, s.d_consts + s.fdev.Ti, TVS, x0 + b0 * n, xrc, urc, u + b0 * m, k + b0, e + b0,
+                                   z ? z + b0 * dim : nullptr, lam ? lam + b0 * Nn : nullptr, num_cu, st);
+        } else {
+            rc = tvr::launch_update(s.tvrp, s.host.rho, s.d_consts + s.dev.Hi_N, mc, (long)model_stride, Bc, Bp, TVS, st);
+            if (rc) return rc;
+            tvr::Args ta{s.host.k_max, ref_stride, s.host.rho, s.host.tol, Bc, Bp};
+            rc = tvr::launch(s.tvrp, want_sol, ta, s.d_consts + s.dev.Hi_N, s.d_consts + s.dev.T, TVS, x0 + b0 * n, xrc, urc, u + b0 * m, k + b0, e + b0,
+                             z ? z + b0 * dim : nullptr, v ? v + b0 * dim : nullptr, lam ? lam + b0 * dim : nullptr, num_cu, st);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // f[] = the solver's record fields in reference order (Solver::field_name), NULL entries are not produced
 static int launch_soc(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, const double *r,
                       int r_stride, long B, double *u, int *k, int *e, double *const *f, hipStream_t st) {
@@ -1445,9 +1485,11 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
             return fail(SPCIES_HIP_EINVAL, "time-varying: extra_stride must be 0 (shared model) or %d", s.tv_model_size());
         if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM && !(s.variant == SPCIES_VARIANT_MFMA4R && tvr_ok(s)))
             return fail(SPCIES_HIP_ENOSUP, "time-varying FISTA: variants STREAM and MFMA4R (factors in registers, admm_tvr_kernel.inc) are built");
+        if (!s.tvrp.update_builtin && tvr_ok(s) && resolve_variant(s) == SPCIES_VARIANT_MFMA4R)  // any other (n, m): everything run-time specialised
+            return launch_tv_rtc(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, nullptr, lam, st);
         if (s.host.n == 6 && s.host.m == 2) return launch_fista_tv_nm<6, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, lam, st);
         if (s.host.n == 12 && s.host.m == 2) return launch_fista_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, lam, st);
-        return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
+        return fail(SPCIES_HIP_ENOSUP, "time-varying solvers: STREAM is instantiated for (n, m) = (6, 2), (12, 2); MFMA4R for any n + m <= 16 within the register file (n=%d m=%d: %s)", s.host.n, s.host.m, s.tvrp.ok ? "ask for MFMA4R or AUTO" : s.tvrp.why.c_str());
     }
     if (s.method == SPCIES_FISTA) {
         const int fv = resolve_variant(s);
@@ -1482,9 +1524,11 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
             !(s.variant == SPCIES_VARIANT_MFMA4R && tvr_ok(s)))
             return fail(SPCIES_HIP_ENOSUP, "time-varying ADMM: variants STREAM, MFMA4R (factors in registers: the shapes built in admm_tvr.hpp) and TILE "
                                           "(one wavefront per instance, when the factors fit the LDS) are built");
+        if (!s.tvrp.update_builtin && tvr_ok(s) && resolve_variant(s) == SPCIES_VARIANT_MFMA4R)  // any other (n, m): everything run-time specialised
+            return launch_tv_rtc(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         if (s.host.n == 6 && s.host.m == 2) return launch_tv_nm<6, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         if (s.host.n == 12 && s.host.m == 2) return launch_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
-        return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
+        return fail(SPCIES_HIP_ENOSUP, "time-varying solvers: STREAM is instantiated for (n, m) = (6, 2), (12, 2); MFMA4R for any n + m <= 16 within the register file (n=%d m=%d: %s)", s.host.n, s.host.m, s.tvrp.ok ? "ask for MFMA4R or AUTO" : s.tvrp.why.c_str());
     }
     if (!s.is_soc() && s.bsp.ok && resolve_variant(s) == SPCIES_VARIANT_BSP)
         return bsp::launch_ellip(s.bsp, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);

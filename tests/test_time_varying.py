@@ -166,6 +166,49 @@ def test_time_varying_mfma4r_other_horizons(name, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,m,N,formulation,method", [(5, 3, 6, "laxMPC", "ADMM"), (9, 2, 8, "laxMPC", "ADMM"), (10, 4, 7, "equMPC", "ADMM"),
+                                                      (13, 3, 5, "laxMPC", "ADMM"), (4, 2, 9, "laxMPC", "FISTA"), (10, 4, 7, "laxMPC", "FISTA"),
+                                                      (8, 3, 6, "equMPC", "FISTA")])
+def test_time_varying_any_plant_size(n, m, N, formulation, method):
+    """The 9-input solvers of a plant whose (n, m) has no build-time kernel: the whole MFMA4R path - update phase (tv_update_kernel.inc,
+    the text the build-time instantiations compile), inverses, solve - is specialised with hiprtc at create time; one model per
+    instance against the oracle; STREAM (build-time kernels for (6, 2) and (12, 2) only) refuses by name."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    from _cases import random_cfg
+    cfg = random_cfg(n, m, N, seed=1300 + n)
+    cfg.formulation, cfg.method = formulation, method
+    cfg.param.T = np.diag(np.diag(cfg.param.T))  # (FISTA takes a diagonal terminal weight)
+    if method == "FISTA":
+        cfg.solver_options = dict(tol=1e-6, k_max=400)
+    vt = benchmarks.ingredients(cfg, time_varying=True)
+    sysm, prm = cfg.sys, cfg.param
+    LB = np.concatenate([np.ravel(sysm.LBx), np.ravel(sysm.LBu)])
+    UB = np.concatenate([np.ravel(sysm.UBx), np.ravel(sysm.UBu)])
+    design = (np.asarray(sysm.A, float), np.asarray(sysm.B, float), np.diag(prm.Q).copy(), np.diag(prm.R).copy(), LB, UB)
+    rng = np.random.default_rng(17 * n + m)
+    B = 23
+    x0 = (0.6 if method == "FISTA" else 0.4) * rng.standard_normal((B, n))
+    xr = 0.1 * rng.standard_normal((B, n))
+    ur = 0.05 * rng.standard_normal((B, m))
+    models = _perturbed_models(design, B)
+    model, per = oracle.pack_tv_model(*models)
+    with HipSolver(vt) as s:
+        assert s.time_varying and s.variant == "mfma4r", s.notes
+        if method == "FISTA":
+            O = oracle.fista_tv_batch(vt, x0, xr, ur, model, per)
+            _compare_tv_fista("mfma4r", s(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
+        else:
+            O = oracle.admm_tv_batch(vt, x0, xr, ur, model, per)
+            _compare_tv("mfma4r", s(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
+        nosol = s(x0[:7], xr[:7], ur[:7], *[a[:7] for a in models], want_sol=False)
+        assert np.abs(nosol[0] - O[0][:7]).max() <= 1e-9 and np.abs(nosol[1].astype(int) - O[1][:7].astype(int)).max() <= 1
+        with pytest.raises(Exception, match="STREAM variant not instantiated"):
+            s.set_variant("stream")
+
+
+@pytest.mark.gpu
 def test_time_varying_mfma4r_is_switched_off_by_the_environment(monkeypatch):
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
