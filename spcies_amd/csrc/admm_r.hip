@@ -211,7 +211,9 @@ int pack(Plan &p, const AdmmHost &a, std::vector<double> &tab) {
     return 1;
 }
 
-#define SPCIES_AR_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 3) X(3, 4) X(4, 4) X(4, 5) X(5, 5) X(5, 6) X(6, 6)
+// (KX, KS) = (ceil(n / 4), ceil((n + m) / 4)): up to 32 rows, up to three more slabs of inputs than of states (the packers are host code;
+// the kernels are specialised by name)
+#define SPCIES_AR_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(1, 3) X(2, 3) X(3, 3) X(1, 4) X(2, 4) X(3, 4) X(4, 4) X(2, 5) X(3, 5) X(4, 5) X(5, 5) X(3, 6) X(4, 6) X(5, 6) X(6, 6) X(4, 7) X(5, 7) X(6, 7) X(7, 7) X(5, 8) X(6, 8) X(7, 8) X(8, 8)
 
 }  // namespace
 

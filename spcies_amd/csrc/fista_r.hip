@@ -169,7 +169,9 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
 // build-time instantiations (N, KX, KS, TERMINAL, NW, NLDS; SPCIES_FR_PD = 3): BASELINE configs[2], equMPC-FISTA n = 12, m = 2, N = 30
 #define SPCIES_FR_BUILTIN(X) X(30, 3, 4, false, 4, 68)
 
-#define SPCIES_FR_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(2, 3) X(3, 3) X(3, 4) X(4, 4) X(4, 5) X(5, 5) X(5, 6) X(6, 6)
+// (KX, KS) = (ceil(n / 4), ceil((n + m) / 4)): up to 32 rows, up to three more slabs of inputs than of states (the packers are host code;
+// the kernels are specialised by name)
+#define SPCIES_FR_SHAPES(X) X(1, 1) X(1, 2) X(2, 2) X(1, 3) X(2, 3) X(3, 3) X(1, 4) X(2, 4) X(3, 4) X(4, 4) X(2, 5) X(3, 5) X(4, 5) X(5, 5) X(3, 6) X(4, 6) X(5, 6) X(6, 6) X(4, 7) X(5, 7) X(6, 7) X(7, 7) X(5, 8) X(6, 8) X(7, 8) X(8, 8)
 
 }  // namespace
 

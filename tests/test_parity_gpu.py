@@ -1312,6 +1312,42 @@ def test_mfma4g_fista_arbitrary_shapes(n, m, N, formulation, variant):
     s.close()
 
 
+@pytest.mark.parametrize("family", ["admm", "fista", "eadmm"])
+@pytest.mark.parametrize("n,m,N", [(8, 5, 6), (4, 9, 5), (20, 6, 6), (26, 3, 5)])
+def test_mfma4r_plants_with_many_inputs_or_up_to_32_rows(n, m, N, family):
+    """The packers of the three streamed-block kernels (admm_r, fista_r, eadmm_r) take (ceil(n / 4), ceil((n + m) / 4)) with up to three
+    more slabs of inputs than of states and up to 32 rows since round 4 (MFMA4G's build-time kernels stop at n + m = 24 and one slab
+    of inputs): plants with more inputs than a slab, more inputs than states, 26 and 29 rows - AUTO lands on MFMA4R, against the oracle."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=1500 + n)
+    rng = np.random.default_rng(3 * n + m)
+    B = 29
+    x0, xr, ur = 0.4 * rng.standard_normal((B, n)), 0.1 * rng.standard_normal((B, n)), 0.05 * rng.standard_normal((B, m))
+    if family == "fista":
+        cfg.method = "FISTA"
+        cfg.param.T = np.diag(3.0 * np.diag(cfg.param.Q))
+        cfg.solver_options = dict(tol=1e-6, k_max=300)
+    elif family == "eadmm":
+        cfg.formulation, cfg.method = "MPCT", "EADMM"
+        cfg.param.T, cfg.param.S = 10 * cfg.param.Q, cfg.param.R.copy()
+        cfg.solver_options = dict(rho_base=2, rho_mult=20, k_max=300, tol=1e-6)
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    if family == "admm" and n + m <= 16:
+        s.set_variant("mfma4r")  # (MFMA4 holds these in registers and stays AUTO)
+    assert s.variant == "mfma4r", s.notes
+    got = s(x0, xr, ur)
+    if family == "admm":
+        _compare("mfma4r", got, oracle.admm_banded_batch(v, x0, xr, ur), v, rerun=_rerun_admm(v, x0, xr, ur))
+    elif family == "fista":
+        _compare_fista("mfma4r", got, oracle.fista_banded_batch(v, x0, xr, ur), rerun=_rerun_with(oracle.fista_banded_batch, v, x0, xr, ur))
+    else:
+        _compare_mpct("mfma4r", got, oracle.eadmm_mpct_batch(v, x0, xr, ur), rerun=_rerun_with(oracle.eadmm_mpct_batch, v, x0, xr, ur))
+    s.close()
+
+
 @pytest.mark.parametrize("variant", ["mfma4g", "mfma4r"])
 @pytest.mark.parametrize("n,m,N", [(10, 3, 9), (16, 4, 6), (5, 1, 14), (7, 2, 11), (12, 1, 5), (6, 2, 2), (8, 4, 3)])  # odd / even slab counts, n % 4 != 0, the shortest horizons
 def test_mfma4g_eadmm_arbitrary_shapes(n, m, N, variant):
