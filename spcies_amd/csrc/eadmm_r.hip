@@ -155,14 +155,13 @@ int pack(Plan &p, const Host &h, std::vector<double> &tab) {
         return G;
     };
     {
-        RecordWriter w(tab.data() + LY::inv_off(N), false);
+        RecordWriter w(tab.data() + LY::inv_off(N), true);  // HW: W2 (pair records: the header's products are part of the record stream)
         w.emit(W2, KS, KS, DENSE);
-        w.emit(ABt, KS, KX, DENSE);  // stage 0 reads AB' from the header
-        ok = ok && w.structure_ok && w.cursor == LY::M_W2 + LY::MG;
-        if (GEN) {
-            w.emit(Gm(0), KS, KS, DENSE);
-            ok = ok && w.structure_ok && w.cursor == 2 * LY::M_W2 + LY::MG;
-        }
+        ok = ok && w.structure_ok && w.cursor == LY::HW_M;
+        RecordWriter wb(tab.data() + LY::hb_off(N), true);  // HB: AB' for stage 0, then (general Q, R) G_0
+        wb.emit(ABt, KS, KX, DENSE);
+        if (GEN) wb.emit(Gm(0), KS, KS, DENSE);
+        ok = ok && wb.structure_ok && wb.cursor == LY::HB_M;
         RecordWriter w2(tab.data() + LY::ts_off(N), false);  // setup only: read from L2, not kept in LDS
         w2.emit(TS, KS, KS, DENSE);
         ok = ok && w2.structure_ok && w2.cursor == LY::M_W2;
