@@ -50,14 +50,12 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
         if (ev && ev[0] == '0') { p.why = "horizon not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
         std::vector<std::string> nm;
         char name[160];
-        snprintf(name, sizeof(name), "spcies::tvr::%s_tv_bi_kernel<%d, %d>", fista ? "fista" : "admm", n, m);
-        nm.push_back(name);
         for (int s = 0; s < 2; s++) {
             snprintf(name, sizeof(name), "spcies::tvr::%s_tvr_kernel<%d, %d, %d, %s, %s>", fista ? "fista" : "admm", n, m, N, terminal ? "true" : "false", s ? "true" : "false");
             nm.push_back(name);
         }
         if (!p.update_builtin) {  // an (n, m) without a build-time update phase: the same text as admm_stream.hpp compiles, specialised here
-            snprintf(name, sizeof(name), "spcies::%s_tv_update_kernel<%d, %d, %s>", fista ? "fista" : "admm", n, m, terminal ? "true" : "false");
+            snprintf(name, sizeof(name), "spcies::%s_tv_update_kernel<%d, %d, %s, true>", fista ? "fista" : "admm", n, m, terminal ? "true" : "false");
             nm.push_back(name);
         }
         const std::string source = std::string(kSourceUpdate) + "\n" + kSourceSolve;
@@ -68,8 +66,8 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
         int rc = rtc::compile_module(source.c_str(), "spcies_admm_tvr_rtc.hip", nm, extra, &mod, fns);
         if (rc) { p.why = std::string("MFMA4R (time-varying): run-time specialisation failed: ") + spcies_hip_last_error(); p.build_failed = true; return 0; }
         p.module = mod;
-        p.fn[0] = fns[0]; p.fn[1] = fns[1]; p.fn[2] = fns[2];
-        p.fn_update = p.update_builtin ? nullptr : (void *)fns[3];
+        p.fn[0] = nullptr; p.fn[1] = fns[0]; p.fn[2] = fns[1];  // (fn[0]: the inverses' kernel of rounds 3-4; the update phase writes them now)
+        p.fn_update = p.update_builtin ? nullptr : (void *)fns[2];
         p.builtin = false;  // (a build-time horizon of an (n, m) whose update phase is not: everything from the module)
     }
     p.ok = true;
@@ -80,7 +78,6 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
 template <int n, int m, int N>
 static int launch_shape(bool terminal, bool want_sol, const Args &a, const double *TRI, const double *T, double *TVS, const double *x0, const double *xr,
                         const double *ur, double *u, int *k, int *e, double *z, double *v, double *lam, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((admm_tv_bi_kernel<n, m>), dim3((unsigned)(a.Bp / 64)), dim3(64), 0, st, N, a.B, a.Bp, TVS);
 #define SPCIES_TVR_GO(TT, SS) \
     hipLaunchKernelGGL((admm_tvr_kernel<n, m, N, TT, SS>), dim3(grid), dim3(256), 0, st, a, TRI, T, TVS, x0, xr, ur, u, k, e, z, v, lam)
     if (terminal) {
@@ -106,12 +103,6 @@ int launch(const Plan &p, bool want_sol, const Args &a, const double *TRI, const
 #undef X
         return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying): bad build-time shape");
     }
-    {
-        int N = p.N;
-        long B = a.B, Bp = a.Bp;
-        void *params[] = {&N, &B, &Bp, &TVS};
-        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[0], (unsigned)(a.Bp / 64), 1, 1, 64, 1, 1, 0, st, params, nullptr));
-    }
     Args aa = a;
     void *params[] = {&aa, &TRI, &T, &TVS, &x0, &xr, &ur, &u, &k, &e, &z, &v, &lam};
     SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 2 : 1], grid, 1, 1, 256, 1, 1, 0, st, params, nullptr));
@@ -121,7 +112,6 @@ int launch(const Plan &p, bool want_sol, const Args &a, const double *TRI, const
 template <int n, int m, int N>
 static int launch_fista_shape(bool terminal, bool want_sol, const Args &a, const double *T, const double *Ti, double *TVS, const double *x0, const double *xr,
                               const double *ur, double *u, int *k, int *e, double *z, double *lam, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((fista_tv_bi_kernel<n, m>), dim3((unsigned)(a.Bp / 64)), dim3(64), 0, st, N, a.B, a.Bp, TVS);
 #define SPCIES_TVR_GO(TT, SS) \
     hipLaunchKernelGGL((fista_tvr_kernel<n, m, N, TT, SS>), dim3(grid), dim3(256), 0, st, a, T, Ti, TVS, x0, xr, ur, u, k, e, z, lam)
     if (terminal) {
@@ -146,12 +136,6 @@ int launch_fista(const Plan &p, bool want_sol, const Args &a, const double *T, c
         SPCIES_TVR_SHAPES(X)
 #undef X
         return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying FISTA): bad build-time shape");
-    }
-    {
-        int N = p.N;
-        long B = a.B, Bp = a.Bp;
-        void *params[] = {&N, &B, &Bp, &TVS};
-        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[0], (unsigned)(a.Bp / 64), 1, 1, 64, 1, 1, 0, st, params, nullptr));
     }
     Args aa = a;
     void *params[] = {&aa, &T, &Ti, &TVS, &x0, &xr, &ur, &u, &k, &e, &z, &lam};

@@ -52,7 +52,7 @@ struct Plan {
     int n = 0, m = 0, N = 0;
     bool terminal = true, builtin = false, fista = false;
     void *module = nullptr;            // hipModule_t of a run-time specialised kernel
-    void *fn[3] = {nullptr, nullptr, nullptr};  // Bi kernel, iteration without / with the record
+    void *fn[3] = {nullptr, nullptr, nullptr};  // (unused), iteration without / with the record
     void *fn_update = nullptr;                  // the update-phase kernel of an (n, m) without a build-time instantiation (tv_update_kernel.inc)
     bool update_builtin = false;                // (n, m) = (6, 2), (12, 2): admm_stream.hpp's instantiations, launched by the caller
 };
@@ -60,7 +60,8 @@ struct Plan {
 // them (hiprtc; code-object cache) - the update phase included, so that ANY plant size within those limits has a time-varying path
 int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista = false);
 void plan_free(Plan &p);
-// update-phase follow-up (the explicit inverses) + the solve of one chunk; pointers are device memory, TVS as admm_tv_update_kernel left it
+// the solve of one chunk; pointers are device memory, TVS as admm_tv_update_kernel<n, m, TERMINAL, BI = true> left it (factors AND the explicit
+// inverses Bi: tv_update_kernel.inc)
 int launch(const Plan &p, bool want_sol, const Args &a, const double *TRI, const double *T, double *TVS, const double *x0, const double *xr,
            const double *ur, double *u, int *k, int *e, double *z, double *v, double *lam, int num_cu, hipStream_t st);
 // the FISTA twin (code_laxMPC_FISTA_C.c, TIME_VARYING == 1): T, Ti = the negated diagonal terminal weight and -1 / it (controller constants);

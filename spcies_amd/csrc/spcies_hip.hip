@@ -904,11 +904,11 @@ static int launch_fista_tv_nm(Solver &s, const double *x0, const double *xr, con
         const double *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
         const double *mc = model_stride ? model + b0 * (long)model_stride : model;
         dim3 grid((unsigned)(Bp / 64)), block(64);
-        if (regs) {
+        if (regs) {  // (BI: the update phase writes the explicit inverses too)
             if (s.host.terminal)
-                hipLaunchKernelGGL((fista_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride, Bc, Bp, TVS);
+                hipLaunchKernelGGL((fista_tv_update_kernel<n, m, true, true>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride, Bc, Bp, TVS);
             else
-                hipLaunchKernelGGL((fista_tv_update_kernel<n, m, false>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride, Bc, Bp, TVS);
+                hipLaunchKernelGGL((fista_tv_update_kernel<n, m, false, true>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride, Bc, Bp, TVS);
             SPCIES_HIP_CHECK(hipGetLastError());
             tvr::Args ta{s.host.k_max, ref_stride, 0.0, s.host.tol, Bc, Bp};
             rc = tvr::launch_fista(s.tvrp, want_sol, ta, s.d_consts + s.fdev.T, s.d_consts + s.fdev.Ti, TVS, x0 + b0 * n, xrc, urc, u + b0 * m, k + b0, e + b0,
@@ -1026,12 +1026,12 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
         const double *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
         const double *mc = model_stride ? model + b0 * (long)model_stride : model;
         dim3 grid((unsigned)(Bp / 64)), block(64);
-        if (regs) {  // update phase as before (the reference's factorisation, one lane per instance), then the inverses and one wavefront per instance
+        if (regs) {  // update phase (the reference's factorisation, one lane per instance; BI: and the explicit inverses), then one wavefront per instance
             if (s.host.terminal)
-                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
+                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, true, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
                                    (long)model_stride, Bc, Bp, TVS);
             else
-                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, false>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
+                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, false, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
                                    (long)model_stride, Bc, Bp, TVS);
             SPCIES_HIP_CHECK(hipGetLastError());
             tvr::Args ta{s.host.k_max, ref_stride, s.host.rho, s.host.tol, Bc, Bp};
