@@ -50,16 +50,8 @@ struct AdmmHost {
     int dim() const { return N * (n + m) - (terminal ? 0 : n); }
 };
 
-// Offsets (in doubles) of the same arrays inside ONE device allocation.  Kernels take the base as a
-// `const double *__restrict__` kernel argument: that is what lets hipcc prove the constants are
-// never written by the kernel and fetch them with scalar loads (s_load) into SGPRs.
-struct AdmmDev {
-    int AB, Alpha, Beta, Hi, Hi_0, Hi_N, Q, R, T, LB, UB;
-    int N, k_max;
-    double tol, rho, rho_i;
-    int P = 0, P_half = 0, Pinv_half = 0, c_ell = 0, LBz = 0, UBz = 0, LBu0 = 0, UBu0 = 0;  // ellipMPC ADMM / gen
-    double r_ell = 0;
-    int rho_0 = 0, rho_v = 0, rho_N = 0, rho_i_0 = 0, rho_i_v = 0, rho_i_N = 0, LBN = 0, UBN = 0;  // gen only
-};
+}  // namespace spcies
+#include "admm_dev.inc"  // struct AdmmDev: the STREAM kernels' argument (also part of their run-time specialised source)
+namespace spcies {
 
 }  // namespace spcies

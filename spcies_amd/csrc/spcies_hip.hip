@@ -29,6 +29,17 @@
 #include "admm_r.hpp"
 #include "common.hpp"
 
+// Sources of the run-time specialised STREAM kernel (any plant size: ensure_stream_rtc below)
+static const char *const kAdmmDevSrc =
+#include "admm_dev_src.inc"
+    ;
+static const char *const kTvUpdateSrc =
+#include "tv_update_src.inc"
+    ;
+static const char *const kAdmmStreamSrc =
+#include "admm_stream_src.inc"
+    ;
+
 namespace spcies {
 
 thread_local std::string g_last_error;
@@ -109,6 +120,12 @@ struct Solver {
     fr::Plan frplan;               // MFMA4R (FISTA with the iteration state in registers + LDS, run-time specialised)
     er::Plan erplan;               // MFMA4R (MPCT EADMM, diagonal or general Q, R: the whole iteration state on the chip, run-time specialised)
     ar::Plan arplan;               // MFMA4R (lax / equ ADMM past MFMA4's register file / LDS: w on the chip, blocks streamed, run-time specialised)
+    struct StreamRtc {             // STREAM for an (n, m) without a build-time kernel: the same text, specialised with hiprtc on first use
+        bool ok = false, tried = false;
+        std::string why;
+        hipModule_t mod = nullptr;
+        hipFunction_t fn = nullptr;
+    } srtc;
     hfused::Plan hfused;           // FUSED (HMPC split NON_SPARSE path: product + projections in one MFMA kernel)
     std::vector<double> h_M1, h_M2, h_bh_nat;
     bsp::Plan bsp;                 // BSP (ellipMPC soc): block-sparse MFMA program, generated per controller
@@ -1100,6 +1117,59 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
     return 0;
 }
 
+// The plain lax / equ ADMM solvers (scalar rho, constant bounds, not time-varying): their STREAM kernel - the bit-exact variant - exists for
+// EVERY plant size: the build-time instantiations for the benchmark shapes, hiprtc for any other (admm_stream_kernel.inc is the text of both).
+static bool stream_rtc_applies(const Solver &s) {
+    return s.method == SPCIES_ADMM && (s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC) && !s.tv && !s.host.gen && !s.host.ellip &&
+           !s.is_soc() && !s.is_cs() && !s.is_hmpc() && !s.is_hdense();
+}
+static int ensure_stream_rtc(Solver &s) {
+    if (s.srtc.ok) return 0;
+    if (s.srtc.tried) return fail(SPCIES_HIP_ENOSUP, "STREAM variant (run-time specialised for n=%d m=%d) unavailable: %s", s.host.n, s.host.m, s.srtc.why.c_str());
+    s.srtc.tried = true;
+    if (const char *ev = getenv("SPCIES_HIP_RTC"))
+        if (ev[0] == '0') {
+            s.srtc.why = "no build-time kernel for this (n, m) and SPCIES_HIP_RTC=0";
+            return fail(SPCIES_HIP_ENOSUP, "STREAM variant unavailable: %s", s.srtc.why.c_str());
+        }
+    char name[160];
+    snprintf(name, sizeof(name), "spcies::admm_stream_kernel<%d, %d, %s, true>", s.host.n, s.host.m, s.host.terminal ? "true" : "false");
+    const std::string src = std::string(kAdmmDevSrc) + "\n" + kTvUpdateSrc + "\n" + kAdmmStreamSrc;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    int rc = rtc::compile_module(src.c_str(), "spcies_admm_stream_rtc.hip", {std::string(name)}, {}, &mod, &fn);
+    if (rc) {
+        s.srtc.why = spcies_hip_last_error();
+        return rc;
+    }
+    s.srtc.mod = mod;
+    s.srtc.fn = fn;
+    s.srtc.ok = true;
+    return 0;
+}
+static int launch_stream_rtc(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u, int *k, int *e,
+                             double *z, double *v, double *lam, hipStream_t st) {
+    int rc = ensure_stream_rtc(s);
+    if (rc) return rc;
+    const bool want_sol = (z || v || lam);
+    long Bp = (B + 63) / 64 * 64;
+    const size_t dim = (size_t)s.host.dim();
+    double *V = s.d_scratch, *LAM = V + dim * Bp, *Y = LAM + dim * Bp;
+    double *ZS = want_sol ? Y + (size_t)s.host.N * s.host.n * Bp : nullptr;
+    const double *C = s.d_consts, *TVS = nullptr;
+    AdmmDev dev = s.dev;
+    void *params[] = {&dev, &C, &x0, &xr, &ur, &ref_stride, &B, &Bp, &V, &LAM, &Y, &ZS, &u, &k, &e, &TVS};
+    SPCIES_HIP_CHECK(hipModuleLaunchKernel(s.srtc.fn, (unsigned)(Bp / 64), 1, 1, 64, 1, 1, 0, st, params, nullptr));
+    if (want_sol) {
+        dim3 tg((unsigned)(Bp / 64), (unsigned)((dim + 63) / 64));
+        if (z) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, ZS, Bp, B, (int)dim, z);
+        if (v) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, V, Bp, B, (int)dim, v);
+        if (lam) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, LAM, Bp, B, (int)dim, lam);
+        SPCIES_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
 static int launch_stream(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                          double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
     const int n = s.host.n, m = s.host.m;
@@ -1112,6 +1182,7 @@ static int launch_stream(Solver &s, const double *x0, const double *xr, const do
     SPCIES_CASE(4, 1)
     SPCIES_CASE(2, 1)
 #undef SPCIES_CASE
+    if (stream_rtc_applies(s)) return launch_stream_rtc(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
     return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", n, m);
 }
 
@@ -1576,7 +1647,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (s.host.n == 12 && s.host.m == 2) return launch_stream_nm<12, 2, false, true>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
         return fail(SPCIES_HIP_ENOSUP, "STREAM variant with vector rho / stage-wise bounds not instantiated for n=%d m=%d", s.host.n, s.host.m);
     }
-    if (!stream_shape_built(s.host.n, s.host.m))
+    if (!stream_shape_built(s.host.n, s.host.m) && !stream_rtc_applies(s))
         return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
     int rc = ensure_scratch(s, stream_scratch_bytes(s, B, z || v || lam));
     if (rc) return rc;
@@ -1661,6 +1732,7 @@ static void free_solver(Solver *s) {
     fr::plan_free(s->frplan);
     er::plan_free(s->erplan);
     ar::plan_free(s->arplan);
+    if (s->srtc.mod) rtc::unload_module(s->srtc.mod);
     hdense::plan_free(s->hd_plan);
     bsp::plan_free(s->bsp);
     if (s->d_eng) hipFree(s->d_eng);
@@ -2059,8 +2131,12 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     }
     if (variant == SPCIES_VARIANT_MFMA && !s->mfma.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA variant not available for this shape: %s", s->mfma.why.c_str());
-    if (variant == SPCIES_VARIANT_STREAM && !stream_shape_built(s->host.n, s->host.m))
-        return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s->host.n, s->host.m);
+    if (variant == SPCIES_VARIANT_STREAM && !stream_shape_built(s->host.n, s->host.m)) {
+        if (!stream_rtc_applies(*s)) return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s->host.n, s->host.m);
+        SPCIES_HIP_CHECK(hipSetDevice(s->device));
+        int rc = ensure_stream_rtc(*s);  // (the plain lax / equ ADMM solvers: specialised now, for any plant size)
+        if (rc) return rc;
+    }
     s->variant = variant;
     return 0;
 }

@@ -150,6 +150,33 @@ def test_admm_past_the_register_file_vs_oracle(cfg_name, B, overrides):
         assert np.array_equal(nosol[0], got[0][:21]) and np.array_equal(nosol[1], got[1][:21])
 
 
+@pytest.mark.parametrize("n,m,N,formulation", [(7, 3, 6, "laxMPC"), (3, 5, 4, "equMPC"), (36, 4, 5, "laxMPC"), (29, 6, 6, "equMPC")])  # (equMPC needs N m >= n)
+def test_stream_is_bit_exact_for_any_plant_size(n, m, N, formulation):
+    """The bit-exact variant of the plain lax / equ ADMM solvers exists for EVERY plant size: build-time kernels for the benchmark shapes,
+    the same text (admm_stream_kernel.inc) specialised with hiprtc for any other - here plants with no build-time kernel of any variant,
+    two of them past the 32 rows the matrix-pipe packers take (AUTO lands on STREAM there): u, k, e_flag and the record equal the
+    oracle's bit for bit."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=1700 + n)
+    cfg.formulation = formulation
+    v = benchmarks.ingredients(cfg)
+    rng = np.random.default_rng(5 * n + m)
+    B = 70
+    x0, xr, ur = 0.5 * rng.standard_normal((B, n)), 0.1 * rng.standard_normal((B, n)), 0.05 * rng.standard_normal((B, m))
+    with HipSolver(v) as s:
+        if n + m > 32:
+            assert s.variant == "stream", (s.variant, s.notes)
+        s.set_variant("stream")
+        u, k, e, sol = s(x0, xr, ur)
+        O = oracle.admm_banded_batch(v, x0, xr, ur)
+        assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+        assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.v, O[4]) and np.array_equal(sol.lam, O[5])
+        u2, k2, _, _ = s(x0[:33], xr[:33], ur[:33], want_sol=False)
+        assert np.array_equal(u2, u[:33]) and np.array_equal(k2, k[:33])
+
+
 @pytest.mark.parametrize("n,m,N,formulation", [(4, 2, 2, "laxMPC"), (7, 3, 3, "laxMPC"), (4, 2, 2, "equMPC"), (5, 3, 6, "laxMPC"), (9, 2, 8, "laxMPC"), (13, 2, 17, "laxMPC"), (16, 4, 12, "laxMPC"),
                                                (18, 3, 9, "laxMPC"), (21, 3, 7, "laxMPC"), (5, 3, 6, "equMPC"), (16, 4, 12, "equMPC")])
 def test_admm_r_arbitrary_shapes(n, m, N, formulation):
