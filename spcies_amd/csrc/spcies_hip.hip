@@ -39,6 +39,12 @@ static const char *const kTvUpdateSrc =
 static const char *const kAdmmStreamSrc =
 #include "admm_stream_src.inc"
     ;
+static const char *const kFistaStreamSrc =
+#include "fista_stream_src.inc"
+    ;
+static const char *const kEadmmStreamSrc =
+#include "eadmm_stream_src.inc"
+    ;
 
 namespace spcies {
 
@@ -1117,11 +1123,15 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
     return 0;
 }
 
-// The plain lax / equ ADMM solvers (scalar rho, constant bounds, not time-varying): their STREAM kernel - the bit-exact variant - exists for
-// EVERY plant size: the build-time instantiations for the benchmark shapes, hiprtc for any other (admm_stream_kernel.inc is the text of both).
+// The plain banded solvers (lax / equ ADMM with scalar rho and constant bounds, lax / equ FISTA, MPCT EADMM with diagonal Q, R; not time-varying):
+// their STREAM kernel - the bit-exact variant - exists for EVERY plant size: the build-time instantiations for the benchmark shapes, hiprtc for
+// any other (admm_stream_kernel.inc / fista_stream_kernel.inc / eadmm_stream_kernel.inc are the text of both).
 static bool stream_rtc_applies(const Solver &s) {
-    return s.method == SPCIES_ADMM && (s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC) && !s.tv && !s.host.gen && !s.host.ellip &&
-           !s.is_soc() && !s.is_cs() && !s.is_hmpc() && !s.is_hdense();
+    if (s.tv || s.host.gen || s.host.ellip || s.is_soc() || s.is_cs() || s.is_hmpc() || s.is_hdense()) return false;
+    if (s.method == SPCIES_ADMM) return s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC;
+    if (s.method == SPCIES_FISTA) return s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC;
+    if (s.method == SPCIES_EADMM) return !s.e_general;
+    return false;
 }
 static int ensure_stream_rtc(Solver &s) {
     if (s.srtc.ok) return 0;
@@ -1133,11 +1143,22 @@ static int ensure_stream_rtc(Solver &s) {
             return fail(SPCIES_HIP_ENOSUP, "STREAM variant unavailable: %s", s.srtc.why.c_str());
         }
     char name[160];
-    snprintf(name, sizeof(name), "spcies::admm_stream_kernel<%d, %d, %s, true>", s.host.n, s.host.m, s.host.terminal ? "true" : "false");
-    const std::string src = std::string(kAdmmDevSrc) + "\n" + kTvUpdateSrc + "\n" + kAdmmStreamSrc;
+    std::string src = std::string(kAdmmDevSrc) + "\n" + kTvUpdateSrc + "\n" + kAdmmStreamSrc;
+    const char *fname = "spcies_admm_stream_rtc.hip";
+    if (s.method == SPCIES_FISTA) {
+        snprintf(name, sizeof(name), "spcies::fista_stream_kernel<%d, %d, %s, true>", s.host.n, s.host.m, s.host.terminal ? "true" : "false");
+        src += std::string("\n") + kFistaStreamSrc;
+        fname = "spcies_fista_stream_rtc.hip";
+    } else if (s.method == SPCIES_EADMM) {
+        snprintf(name, sizeof(name), "spcies::eadmm_stream_kernel<%d, %d>", s.host.n, s.host.m);
+        src += std::string("\n") + kEadmmStreamSrc;
+        fname = "spcies_eadmm_stream_rtc.hip";
+    } else {
+        snprintf(name, sizeof(name), "spcies::admm_stream_kernel<%d, %d, %s, true>", s.host.n, s.host.m, s.host.terminal ? "true" : "false");
+    }
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
-    int rc = rtc::compile_module(src.c_str(), "spcies_admm_stream_rtc.hip", {std::string(name)}, {}, &mod, &fn);
+    int rc = rtc::compile_module(src.c_str(), fname, {std::string(name)}, {}, &mod, &fn);
     if (rc) {
         s.srtc.why = spcies_hip_last_error();
         return rc;
@@ -1145,6 +1166,53 @@ static int ensure_stream_rtc(Solver &s) {
     s.srtc.mod = mod;
     s.srtc.fn = fn;
     s.srtc.ok = true;
+    return 0;
+}
+// ... FISTA (launch_fista_nm's buffers) and EADMM (launch_eadmm_nm's) through the run-time specialised kernel
+static int launch_fista_rtc(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u, int *k, int *e,
+                            double *z, double *lam, hipStream_t st) {
+    int rc = ensure_stream_rtc(s);
+    if (rc) return rc;
+    const bool want_sol = (z || lam);
+    long Bp = (B + 63) / 64 * 64;
+    const size_t Nn = (size_t)s.host.N * s.host.n, dim = (size_t)s.host.dim();
+    double *Y = s.d_scratch, *LAM = Y + Nn * Bp, *DL = LAM + Nn * Bp;
+    double *ZS = want_sol ? DL + Nn * Bp : nullptr;
+    const double *C = s.d_consts, *TVS = nullptr;
+    FistaDev dev = s.fdev;
+    void *params[] = {&dev, &C, &x0, &xr, &ur, &ref_stride, &B, &Bp, &Y, &LAM, &DL, &ZS, &u, &k, &e, &TVS};
+    SPCIES_HIP_CHECK(hipModuleLaunchKernel(s.srtc.fn, (unsigned)(Bp / 64), 1, 1, 64, 1, 1, 0, st, params, nullptr));
+    if (z) {
+        dim3 tg((unsigned)(Bp / 64), (unsigned)((dim + 63) / 64));
+        hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, ZS, Bp, B, (int)dim, z);
+    }
+    if (lam) {  // the reference returns y as sol.lambda (code_laxMPC_FISTA_C.c:439-445)
+        dim3 tg((unsigned)(Bp / 64), (unsigned)((Nn + 63) / 64));
+        hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, Y, Bp, B, (int)Nn, lam);
+    }
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+static int launch_eadmm_rtc(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u, int *k, int *e,
+                            double *z1, double *z2, double *z3, double *lam, hipStream_t st) {
+    int rc = ensure_stream_rtc(s);
+    if (rc) return rc;
+    long Bp = (B + 63) / 64 * 64;
+    const int n = s.host.n, nm = s.host.n + s.host.m, N = s.host.N;
+    const size_t dz = (size_t)(N + 1) * nm;
+    double *Z1 = s.d_scratch, *Z3 = Z1 + dz * Bp, *LAM = Z3 + dz * Bp, *MU = LAM + (size_t)(N + 3) * nm * Bp;
+    const double *C = s.d_consts;
+    EadmmDev dev = s.edev;
+    void *params[] = {&dev, &C, &x0, &xr, &ur, &ref_stride, &B, &Bp, &Z1, &Z3, &LAM, &MU, &z2, &u, &k, &e};
+    SPCIES_HIP_CHECK(hipModuleLaunchKernel(s.srtc.fn, (unsigned)(Bp / 64), 1, 1, 64, 1, 1, 0, st, params, nullptr));
+    dim3 tg((unsigned)(Bp / 64), (unsigned)((dz + 63) / 64));
+    if (z1) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, Z1, Bp, B, (int)dz, z1);
+    if (z3) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, Z3, Bp, B, (int)dz, z3);
+    if (lam) {
+        const long tot = B * (long)(N + 3) * nm;
+        hipLaunchKernelGGL(eadmm_pack_lambda_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, LAM, Bp, B, N, n, nm, lam);
+    }
+    SPCIES_HIP_CHECK(hipGetLastError());
     return 0;
 }
 static int launch_stream_rtc(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B, double *u, int *k, int *e,
@@ -1543,10 +1611,11 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         }
         if (ev != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "EADMM: variants STREAM, MFMA4G and MFMA4R are built");
         if (s.e_general) return fail(SPCIES_HIP_ENOSUP, "EADMM with general Q, R: the MFMA4G and MFMA4R variants are built (STREAM covers the diagonal path)");
-        if (!eadmm_stream_shape_built(s.host.n, s.host.m))
+        if (!eadmm_stream_shape_built(s.host.n, s.host.m) && !stream_rtc_applies(s))
             return fail(SPCIES_HIP_ENOSUP, "EADMM STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
         if (rc) return rc;
+        if (!eadmm_stream_shape_built(s.host.n, s.host.m)) return launch_eadmm_rtc(s, x0, xr, ur, ref_stride, B, u, k, e, f[0], f[1], f[2], f[3], st);  // any plant size
         return launch_eadmm(s, x0, xr, ur, ref_stride, B, u, k, e, f[0], f[1], f[2], f[3], st);
     }
     double *z = f[0], *v = (s.method == SPCIES_FISTA) ? nullptr : f[1], *lam = (s.method == SPCIES_FISTA) ? f[1] : f[2];
@@ -1581,10 +1650,11 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
             return g4::launch_fista_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, z, lam, st);
         }
         if (fv != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "FISTA: variants STREAM, MFMA4G and MFMA4R are built");
-        if (!stream_shape_built(s.host.n, s.host.m))
+        if (!stream_shape_built(s.host.n, s.host.m) && !stream_rtc_applies(s))
             return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, z || lam));
         if (rc) return rc;
+        if (!stream_shape_built(s.host.n, s.host.m)) return launch_fista_rtc(s, x0, xr, ur, ref_stride, B, u, k, e, z, lam, st);  // any plant size
         return launch_fista(s, x0, xr, ur, ref_stride, B, u, k, e, z, lam, st);
     }
     if (s.tv) {
@@ -2131,7 +2201,7 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     }
     if (variant == SPCIES_VARIANT_MFMA && !s->mfma.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA variant not available for this shape: %s", s->mfma.why.c_str());
-    if (variant == SPCIES_VARIANT_STREAM && !stream_shape_built(s->host.n, s->host.m)) {
+    if (variant == SPCIES_VARIANT_STREAM && !(s->method == SPCIES_EADMM ? eadmm_stream_shape_built(s->host.n, s->host.m) : stream_shape_built(s->host.n, s->host.m))) {
         if (!stream_rtc_applies(*s)) return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s->host.n, s->host.m);
         SPCIES_HIP_CHECK(hipSetDevice(s->device));
         int rc = ensure_stream_rtc(*s);  // (the plain lax / equ ADMM solvers: specialised now, for any plant size)

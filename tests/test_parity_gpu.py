@@ -150,17 +150,28 @@ def test_admm_past_the_register_file_vs_oracle(cfg_name, B, overrides):
         assert np.array_equal(nosol[0], got[0][:21]) and np.array_equal(nosol[1], got[1][:21])
 
 
+@pytest.mark.parametrize("family", ["admm", "fista", "eadmm"])
 @pytest.mark.parametrize("n,m,N,formulation", [(7, 3, 6, "laxMPC"), (3, 5, 4, "equMPC"), (36, 4, 5, "laxMPC"), (29, 6, 6, "equMPC")])  # (equMPC needs N m >= n)
-def test_stream_is_bit_exact_for_any_plant_size(n, m, N, formulation):
-    """The bit-exact variant of the plain lax / equ ADMM solvers exists for EVERY plant size: build-time kernels for the benchmark shapes,
-    the same text (admm_stream_kernel.inc) specialised with hiprtc for any other - here plants with no build-time kernel of any variant,
-    two of them past the 32 rows the matrix-pipe packers take (AUTO lands on STREAM there): u, k, e_flag and the record equal the
-    oracle's bit for bit."""
+def test_stream_is_bit_exact_for_any_plant_size(n, m, N, formulation, family):
+    """The bit-exact variant of the plain banded solvers (lax / equ ADMM and FISTA, MPCT EADMM) exists for EVERY plant size: build-time
+    kernels for the benchmark shapes, the same text (admm_ / fista_ / eadmm_stream_kernel.inc) specialised with hiprtc for any other -
+    here plants with no build-time kernel of any variant, two of them past the 32 rows the matrix-pipe packers take (AUTO lands on
+    STREAM there): u, k, e_flag and the record equal the oracle's bit for bit."""
     from oracle import oracle
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
     cfg = _random_cfg(n, m, N, seed=1700 + n)
     cfg.formulation = formulation
+    if family == "fista":
+        cfg.method = "FISTA"
+        cfg.param.T = np.diag(3.0 * np.diag(cfg.param.Q))
+        cfg.solver_options = dict(tol=1e-6, k_max=300)
+    elif family == "eadmm":
+        if formulation == "equMPC":
+            pytest.skip("MPCT has one formulation")
+        cfg.formulation, cfg.method = "MPCT", "EADMM"
+        cfg.param.T, cfg.param.S = 10 * cfg.param.Q, cfg.param.R.copy()
+        cfg.solver_options = dict(rho_base=2, rho_mult=20, k_max=300, tol=1e-6)
     v = benchmarks.ingredients(cfg)
     rng = np.random.default_rng(5 * n + m)
     B = 70
@@ -169,12 +180,18 @@ def test_stream_is_bit_exact_for_any_plant_size(n, m, N, formulation):
         if n + m > 32:
             assert s.variant == "stream", (s.variant, s.notes)
         s.set_variant("stream")
-        u, k, e, sol = s(x0, xr, ur)
-        O = oracle.admm_banded_batch(v, x0, xr, ur)
-        assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
-        assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.v, O[4]) and np.array_equal(sol.lam, O[5])
+        got = s(x0, xr, ur)
+        if family == "admm":
+            u, k, e, sol = got
+            O = oracle.admm_banded_batch(v, x0, xr, ur)
+            assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+            assert np.array_equal(sol.z, O[3]) and np.array_equal(sol.v, O[4]) and np.array_equal(sol.lam, O[5])
+        elif family == "fista":
+            _compare_fista("stream", got, oracle.fista_banded_batch(v, x0, xr, ur))
+        else:
+            _compare_mpct("stream", got, oracle.eadmm_mpct_batch(v, x0, xr, ur))
         u2, k2, _, _ = s(x0[:33], xr[:33], ur[:33], want_sol=False)
-        assert np.array_equal(u2, u[:33]) and np.array_equal(k2, k[:33])
+        assert np.array_equal(u2, got[0][:33]) and np.array_equal(k2, got[1][:33])
 
 
 @pytest.mark.parametrize("n,m,N,formulation", [(4, 2, 2, "laxMPC"), (7, 3, 3, "laxMPC"), (4, 2, 2, "equMPC"), (5, 3, 6, "laxMPC"), (9, 2, 8, "laxMPC"), (13, 2, 17, "laxMPC"), (16, 4, 12, "laxMPC"),
