@@ -701,7 +701,8 @@ static int upload_consts(Solver &s) {
     if (s.method == SPCIES_FISTA) arrs = {&a.AB, &a.Alpha, &a.Beta, &a.Q, &a.R, &s.QRi, &s.Td, &s.Ti, &a.LB, &a.UB};
     if (s.method == SPCIES_EADMM)
         arrs = {&s.e_rho, &s.e_rho0, &s.e_rhos, &a.LB,    &a.UB,   &s.e_LB0, &s.e_UB0, &s.e_LBs, &s.e_UBs,
-                &a.AB,    &a.T,      &s.e_S,    &a.Alpha, &a.Beta, &s.e_H1i, &s.e_W2,  &s.e_H3i};
+                &a.AB,    &a.T,      &s.e_S,    &a.Alpha, &a.Beta, &s.e_H1i, &s.e_W2,  &s.e_H3i,
+                &s.e_Qbi, &s.e_Qmi,  &s.e_Rbi,  &s.e_Rmi, &s.e_ABbi, &s.e_ABmi};  // (general Q, R: the last six; empty otherwise)
     std::vector<double> flat;
     std::vector<size_t> offs;
     for (auto *v : arrs) {
@@ -715,6 +716,8 @@ static int upload_consts(Solver &s) {
         s.edev = EadmmDev{(int)offs[0],  (int)offs[1],  (int)offs[2],  (int)offs[3],  (int)offs[4],  (int)offs[5],
                           (int)offs[6],  (int)offs[7],  (int)offs[8],  (int)offs[9],  (int)offs[10], (int)offs[11],
                           (int)offs[12], (int)offs[13], (int)offs[14], (int)offs[15], (int)offs[16], a.N, a.k_max, a.tol};
+        s.edev.Q_bi = (int)offs[17]; s.edev.Q_mi = (int)offs[18]; s.edev.R_bi = (int)offs[19]; s.edev.R_mi = (int)offs[20];
+        s.edev.AB_bi = (int)offs[21]; s.edev.AB_mi = (int)offs[22];
         return 0;
     }
     if (s.method == SPCIES_FISTA) {
@@ -1130,7 +1133,7 @@ static bool stream_rtc_applies(const Solver &s) {
     if (s.tv || s.host.gen || s.host.ellip || s.is_soc() || s.is_cs() || s.is_hmpc() || s.is_hdense()) return false;
     if (s.method == SPCIES_ADMM) return s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC;
     if (s.method == SPCIES_FISTA) return s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC;
-    if (s.method == SPCIES_EADMM) return !s.e_general;
+    if (s.method == SPCIES_EADMM) return true;  // (general Q, R: that branch's STREAM kernel is always the run-time specialised one)
     return false;
 }
 static int ensure_stream_rtc(Solver &s) {
@@ -1150,7 +1153,7 @@ static int ensure_stream_rtc(Solver &s) {
         src += std::string("\n") + kFistaStreamSrc;
         fname = "spcies_fista_stream_rtc.hip";
     } else if (s.method == SPCIES_EADMM) {
-        snprintf(name, sizeof(name), "spcies::eadmm_stream_kernel<%d, %d>", s.host.n, s.host.m);
+        snprintf(name, sizeof(name), "spcies::eadmm_stream_kernel<%d, %d, %s>", s.host.n, s.host.m, s.e_general ? "true" : "false");
         src += std::string("\n") + kEadmmStreamSrc;
         fname = "spcies_eadmm_stream_rtc.hip";
     } else {
@@ -1610,12 +1613,11 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
             return g4::launch_eadmm_g(s.g4plan, s.host, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f[0], f[1], f[2], f[3], st);
         }
         if (ev != SPCIES_VARIANT_STREAM) return fail(SPCIES_HIP_ENOSUP, "EADMM: variants STREAM, MFMA4G and MFMA4R are built");
-        if (s.e_general) return fail(SPCIES_HIP_ENOSUP, "EADMM with general Q, R: the MFMA4G and MFMA4R variants are built (STREAM covers the diagonal path)");
         if (!eadmm_stream_shape_built(s.host.n, s.host.m) && !stream_rtc_applies(s))
             return fail(SPCIES_HIP_ENOSUP, "EADMM STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
         int rc = ensure_scratch(s, stream_scratch_bytes(s, B, true));
         if (rc) return rc;
-        if (!eadmm_stream_shape_built(s.host.n, s.host.m)) return launch_eadmm_rtc(s, x0, xr, ur, ref_stride, B, u, k, e, f[0], f[1], f[2], f[3], st);  // any plant size
+        if (s.e_general || !eadmm_stream_shape_built(s.host.n, s.host.m)) return launch_eadmm_rtc(s, x0, xr, ur, ref_stride, B, u, k, e, f[0], f[1], f[2], f[3], st);  // any plant size
         return launch_eadmm(s, x0, xr, ur, ref_stride, B, u, k, e, f[0], f[1], f[2], f[3], st);
     }
     double *z = f[0], *v = (s.method == SPCIES_FISTA) ? nullptr : f[1], *lam = (s.method == SPCIES_FISTA) ? f[1] : f[2];
@@ -2201,7 +2203,7 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     }
     if (variant == SPCIES_VARIANT_MFMA && !s->mfma.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA variant not available for this shape: %s", s->mfma.why.c_str());
-    if (variant == SPCIES_VARIANT_STREAM && !(s->method == SPCIES_EADMM ? eadmm_stream_shape_built(s->host.n, s->host.m) : stream_shape_built(s->host.n, s->host.m))) {
+    if (variant == SPCIES_VARIANT_STREAM && !(s->method == SPCIES_EADMM ? (eadmm_stream_shape_built(s->host.n, s->host.m) && !s->e_general) : stream_shape_built(s->host.n, s->host.m))) {
         if (!stream_rtc_applies(*s)) return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s->host.n, s->host.m);
         SPCIES_HIP_CHECK(hipSetDevice(s->device));
         int rc = ensure_stream_rtc(*s);  // (the plain lax / equ ADMM solvers: specialised now, for any plant size)
