@@ -9,6 +9,9 @@
 #include "../../include/spcies_hip.h"
 #include "fista_r.hpp"
 #define SPCIES_FR_NFULL 1  // the build-time instantiations serve controllers whose n is a multiple of 4 (plan_build checks)
+#define SPCIES_FR_PD 7     // ... and keep the d of the last SEVEN blocks in registers: at configs[2] 33.1 ms against 34.1 with three (round 4 sweep:
+                           // 2: 34.5, 3: 34.1, 4: 33.9, 5: 33.6, 6: 35.0, 7: 33.1, 8: 35.3, 10: 34.9 - the allocator's luck as much as the traffic);
+                           // run-time specialised shapes keep three (SPCIES_FR_PD in the environment changes it)
 #include "fista_r_kernel.inc"
 #include "rtc_common.hpp"
 
@@ -209,7 +212,7 @@ int plan_build(Plan &p, const Host &h) {
         SPCIES_FR_BUILTIN(X)
 #undef X
     }
-    p.PD = 3;
+    p.PD = SPCIES_FR_PD;  // (the build-time kernel's)
     if (p.builtin < 0) {
     // ---- specialise the kernel for this controller (about ten seconds at N = 30)
     char names[2][160];
