@@ -143,7 +143,28 @@ int launch_fista(const Plan &p, bool want_sol, const Args &a, const double *T, c
     return 0;
 }
 
+// the build-time shapes of the update phase WITH the inverses (BI): instantiated here, in this translation unit, next to the kernels that consume them
+template <int n, int m>
+static void launch_update_builtin(const Plan &p, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp, double *TVS,
+                                  hipStream_t st) {
+    const dim3 grid((unsigned)(Bp / 64)), block(64);
+    const int N = p.N;
+    if (p.fista) {
+        if (p.terminal) hipLaunchKernelGGL((fista_tv_update_kernel<n, m, true, true>), grid, block, 0, st, N, Tc, model, model_stride, B, Bp, TVS);
+        else hipLaunchKernelGGL((fista_tv_update_kernel<n, m, false, true>), grid, block, 0, st, N, Tc, model, model_stride, B, Bp, TVS);
+    } else {
+        if (p.terminal) hipLaunchKernelGGL((admm_tv_update_kernel<n, m, true, true>), grid, block, 0, st, N, c0, Tc, model, model_stride, B, Bp, TVS);
+        else hipLaunchKernelGGL((admm_tv_update_kernel<n, m, false, true>), grid, block, 0, st, N, c0, Tc, model, model_stride, B, Bp, TVS);
+    }
+}
+
 int launch_update(const Plan &p, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp, double *TVS, hipStream_t st) {
+    if (p.ok && p.update_builtin) {
+        if (p.n == 6 && p.m == 2) launch_update_builtin<6, 2>(p, c0, Tc, model, model_stride, B, Bp, TVS, st);
+        else launch_update_builtin<12, 2>(p, c0, Tc, model, model_stride, B, Bp, TVS, st);
+        SPCIES_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (!p.ok || !p.fn_update) return fail(SPCIES_HIP_ENOSUP, "time-varying update phase: no run-time specialised kernel for n=%d m=%d", p.n, p.m);
     int N = p.N;
     if (p.fista) {

@@ -69,7 +69,8 @@ int launch(const Plan &p, bool want_sol, const Args &a, const double *TRI, const
 int launch_fista(const Plan &p, bool want_sol, const Args &a, const double *T, const double *Ti, double *TVS, const double *x0, const double *xr,
                  const double *ur, double *u, int *k, int *e, double *z, double *lam, int num_cu, hipStream_t st);
 
-// the update phase of a run-time specialised (n, m): what admm_tv_update_kernel<n, m, TERMINAL> / fista_tv_update_kernel<...> do for the build-time ones
+// the update phase WITH the explicit inverses (admm_tv_update_kernel<n, m, TERMINAL, BI = true> / fista_tv_update_kernel<...>): the build-time shapes
+// (instantiated in admm_tvr.hip) or the run-time specialised kernel of any other (n, m)
 // (ADMM: c0 = rho, Tc = T_rho_i; FISTA: Tc = Ti, c0 unused)
 int launch_update(const Plan &p, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp, double *TVS, hipStream_t st);
 

@@ -930,12 +930,9 @@ static int launch_fista_tv_nm(Solver &s, const double *x0, const double *xr, con
         const double *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
         const double *mc = model_stride ? model + b0 * (long)model_stride : model;
         dim3 grid((unsigned)(Bp / 64)), block(64);
-        if (regs) {  // (BI: the update phase writes the explicit inverses too)
-            if (s.host.terminal)
-                hipLaunchKernelGGL((fista_tv_update_kernel<n, m, true, true>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride, Bc, Bp, TVS);
-            else
-                hipLaunchKernelGGL((fista_tv_update_kernel<n, m, false, true>), grid, block, 0, st, N, s.d_consts + s.fdev.Ti, mc, (long)model_stride, Bc, Bp, TVS);
-            SPCIES_HIP_CHECK(hipGetLastError());
+        if (regs) {  // (the update phase that writes the explicit inverses too: instantiated in admm_tvr.hip)
+            rc = tvr::launch_update(s.tvrp, 0.0, s.d_consts + s.fdev.Ti, mc, (long)model_stride, Bc, Bp, TVS, st);
+            if (rc) return rc;
             tvr::Args ta{s.host.k_max, ref_stride, 0.0, s.host.tol, Bc, Bp};
             rc = tvr::launch_fista(s.tvrp, want_sol, ta, s.d_consts + s.fdev.T, s.d_consts + s.fdev.Ti, TVS, x0 + b0 * n, xrc, urc, u + b0 * m, k + b0, e + b0,
                                    z ? z + b0 * dim : nullptr, lam ? lam + b0 * Nn : nullptr, num_cu, st);
@@ -1052,14 +1049,9 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
         const double *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
         const double *mc = model_stride ? model + b0 * (long)model_stride : model;
         dim3 grid((unsigned)(Bp / 64)), block(64);
-        if (regs) {  // update phase (the reference's factorisation, one lane per instance; BI: and the explicit inverses), then one wavefront per instance
-            if (s.host.terminal)
-                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, true, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
-                                   (long)model_stride, Bc, Bp, TVS);
-            else
-                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, false, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
-                                   (long)model_stride, Bc, Bp, TVS);
-            SPCIES_HIP_CHECK(hipGetLastError());
+        if (regs) {  // update phase (the reference's factorisation, one lane per instance, and the explicit inverses: admm_tvr.hip), then one wavefront per instance
+            rc = tvr::launch_update(s.tvrp, s.host.rho, s.d_consts + s.dev.Hi_N, mc, (long)model_stride, Bc, Bp, TVS, st);
+            if (rc) return rc;
             tvr::Args ta{s.host.k_max, ref_stride, s.host.rho, s.host.tol, Bc, Bp};
             rc = tvr::launch(s.tvrp, want_sol, ta, s.d_consts + s.dev.Hi_N, s.d_consts + s.dev.T, TVS, x0 + b0 * n, xrc, urc, u + b0 * m,
                              k + b0, e + b0, z ? z + b0 * dim : nullptr, v ? v + b0 * dim : nullptr, lam ? lam + b0 * dim : nullptr, num_cu, st);
