@@ -556,9 +556,17 @@ def run_rank(args):
     if args.fail_rank == -2 and rank == 0:  # ... and a rank that hangs before the rendezvous
         time.sleep(3600)
     dry = args.dry_run
+    # --force-dist: the torch.distributed leg (RCCL rendezvous, blob broadcast, all_reduce, barriers, all_gather, teardown) also at
+    # world size 1 - the code an 8-GPU run executes, on the one GPU a builder's box has
+    use_dist = world > 1 or args.force_dist
+    if use_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if dry:  # CPU rehearsal of the launch / rendezvous / timing plumbing (tests/test_bench_contract.py): no solver, no GPU
         dev = torch.device("cpu")
-        if world > 1:
+        if use_dist:
             dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=args.init_timeout))
     else:
         if not torch.cuda.is_available():
@@ -567,9 +575,9 @@ def run_rank(args):
             raise SystemExit(f"rank {rank}: local GPU {local_rank} does not exist ({torch.cuda.device_count()} visible)")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        if world > 1:
+        if use_dist:
             # a finite rendezvous / collective timeout: a rank that died at start-up must not leave the others waiting for minutes
-            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=args.init_timeout))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timedelta(seconds=args.init_timeout))
 
     def sync():
         if not dry:
@@ -581,7 +589,7 @@ def run_rank(args):
     blob = blobmod.pack(v) if rank == 0 else None
     blob = spdist.broadcast_blob(blob, None if dry else dev)
     ranks_seen = 1
-    if world > 1:  # every rank adds one on its device: the sum is the number of ranks RCCL actually connected
+    if use_dist:  # every rank adds one on its device: the sum is the number of ranks RCCL actually connected
         ones = torch.ones(1, dtype=torch.int32, device=dev)
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
@@ -616,7 +624,7 @@ def run_rank(args):
 
     def fence():
         sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             sync()
 
@@ -636,7 +644,7 @@ def run_rank(args):
     kernel_ms = 0.0 if dry else ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream, over the timed region
     per_rank_ms = [dt_local / args.steps * 1e3]
     dt = dt_local
-    if world > 1:
+    if use_dist:
         tdt = torch.tensor([dt_local], dtype=torch.float64, device=dev)
         gathered = [torch.zeros_like(tdt) for _ in range(world)]
         dist.all_gather(gathered, tdt)
@@ -659,7 +667,9 @@ def run_rank(args):
             "config": {"workload": "configs[1]: laxMPC-ADMM, 12-state osc-masses (n=12, m=2), N=15, rho=15, tol=0, "
                                    "k_max=200, batch=65536 random x0 / per-instance (xr, ur) per GPU",
                        "batch_per_gpu": B, "variant": variant, "all_k_200_eflag_-1": k_ok,
-                       "launch": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else ("self" if world > 1 else "single")},
+                       "launch": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else
+                                 ("self" if os.environ.get("SPCIES_BENCH_SELF_LAUNCHED") else "single"),
+                       "process_group": (dist.get_backend() if use_dist else None)},
             "rccl_ranks_seen": ranks_seen, "per_rank_ms_per_step": per_rank_ms,
         }
         if dry:
@@ -720,7 +730,7 @@ def run_rank(args):
     try:
         if solver is not None:
             solver.close()
-        if world > 1:
+        if use_dist:
             try:
                 dist.barrier()
                 dist.destroy_process_group()
@@ -766,6 +776,9 @@ def main(argv=None):
     ap.add_argument("--no-multi-leg", action="store_true", help="N > 1: skip the one-process create_multi leg reported as `multi_launch`")
     ap.add_argument("--launch-timeout", type=float, default=540.0, help="self-launched ranks: overall limit in seconds before the parent stops them")
     ap.add_argument("--init-timeout", type=float, default=120.0, help="torch.distributed rendezvous / collective timeout in seconds")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl = RCCL; gloo with --dry-run) and run every "
+                    "collective of the N > 1 path also at --gpus 1")
+    ap.add_argument("--self-launch", action="store_true", help="go through the self-launcher (fresh rank processes, watchdog) also at --gpus 1; implies --force-dist")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: this rank exits 3 before the rendezvous
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -774,7 +787,11 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         run_multi(args)
         return
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.self_launch:
+        args.force_dist = True
+        if "--force-dist" not in argv:
+            argv = argv + ["--force-dist"]
+    if (args.gpus > 1 or args.self_launch) and "WORLD_SIZE" not in os.environ:
         # must be set before any rank touches the GPU (ROCr reads it at initialisation): the children inherit it
         os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         raise SystemExit(launch_ranks(args, argv))

@@ -33,11 +33,14 @@ def broadcast_blob(blob, device=None, src=0):
     """Broadcast the problem blob (bytes on ``src``, ``None`` elsewhere) to every rank.
 
     Two small collectives at handle-creation time: the length (int64) and the payload (uint8),
-    on ``device`` when given (RCCL) or on CPU tensors (gloo).  Single-process runs return ``blob``.
+    on ``device`` when given (RCCL) or on CPU tensors (gloo).  Without an initialised process group
+    ``blob`` is returned as it is; with one the collectives RUN, also at world size 1 (the same code
+    path as at 8 ranks: ``bench.py --force-dist`` and ``tests/test_rccl_world1.py`` execute it on the
+    one GPU a builder's box has).
     """
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return blob
     dev = device if device is not None else torch.device("cpu")
     n = torch.tensor([len(blob) if dist.get_rank() == src else 0], dtype=torch.int64, device=dev)
@@ -54,7 +57,7 @@ def gather_results(u_local, total=None):
     """Optional: all-gather the sharded ``u`` (results normally stay sharded).  Tensors in, tensor out."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return u_local
     sizes = [torch.zeros(1, dtype=torch.int64, device=u_local.device) for _ in range(dist.get_world_size())]
     dist.all_gather(sizes, torch.tensor([u_local.shape[0]], dtype=torch.int64, device=u_local.device))
