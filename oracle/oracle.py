@@ -12,6 +12,8 @@ _LIB = None
 
 
 def build(force=False):
+    if os.environ.get("SPCIES_ORACLE_LIB"):  # a diagnostic build of the same sources (tools/sanitize.sh oracle)
+        return os.environ["SPCIES_ORACLE_LIB"]
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("admm_banded_oracle.c", "fista_banded_oracle.c", "eadmm_mpct_oracle.c", "admm_soc_oracle.c", "admm_hmpc_oracle.c", "admm_hmpc_dense_oracle.c", "admm_mpct_cs_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):

@@ -12,11 +12,14 @@
 //  * disk   = <dir>/<digest>.hsaco, dir = $SPCIES_HIP_CACHE_DIR | $XDG_CACHE_HOME/spcies_hip | $HOME/.cache/spcies_hip
 //             (SPCIES_HIP_DISK_CACHE=0 switches it off; an unusable directory does too, silently).  A file is written under a
 //             temporary name and rename()d into place; look-up, compilation and write of one digest run under flock() on
-//             <digest>.lock, so N processes that need the same program compile it once and the others read the file.
+//             <digest>.lock, so N processes that need the same program compile it once and the others read the file; the writer
+//             unlinks the lock file (waiters re-check the inode).  Capped in bytes (SPCIES_HIP_DISK_CACHE_MB, default 4096, 0 = no
+//             cap): after a write the least recently used files go until 80 % of the cap is left (prune_disk).
 //  * the compiler runs outside the cache's own lock: look-ups and statistics never wait for a compilation; two threads that ask
 //             for the same digest share one compilation (the second waits for the first one's result).
 // Nothing here touches HIP or hiprtc: the compilation is a callback (tests/test_rtc_disk_cache.py drives it with a fake one).
 #pragma once
+#include <dirent.h>
 #include <fcntl.h>
 #include <sys/file.h>
 #include <sys/stat.h>
@@ -30,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <functional>
 #include <list>
 #include <map>
@@ -382,6 +386,50 @@ class CodeCache {
         if (fsync(fd) != 0 || close(fd) != 0 || rename(tmpl, path.c_str()) != 0) { unlink(tmpl); return false; }
         return true;
     }
+    // Size cap of the disk cache: SPCIES_HIP_DISK_CACHE_MB (default 4096; 0 = no cap).  Called after a write: when the *.hsaco files
+    // of the directory exceed the cap, the least recently used (mtime: set at write and at every hit) are deleted until 80 % of it is
+    // left; stale temporaries and lock files (older than an hour) go too.  One pruner at a time (a directory lock, not waited for);
+    // a reader that loses its file to the pruner recompiles - a code object is never read half.
+    static void prune_disk(const std::string &dir) {
+        long cap_mb = 4096;
+        if (const char *ev = getenv("SPCIES_HIP_DISK_CACHE_MB")) cap_mb = atol(ev);
+        if (cap_mb <= 0) return;
+        const std::string plock = dir + "/.prune.lock";
+        const int fd = open(plock.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        if (fd < 0) return;
+        if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); return; }
+        struct Item { std::string path; off_t size; time_t mtime; };
+        std::vector<Item> files;
+        unsigned long long total = 0;
+        const time_t now = time(nullptr);
+        if (DIR *d = opendir(dir.c_str())) {
+            while (struct dirent *de = readdir(d)) {
+                const std::string name = de->d_name;
+                if (name == "." || name == ".." || name == ".prune.lock") continue;
+                const std::string path = dir + "/" + name;
+                struct stat st;
+                if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
+                const bool code = name.size() > 6 && name.compare(name.size() - 6, 6, ".hsaco") == 0;
+                if (code) {
+                    files.push_back({path, st.st_size, st.st_mtime});
+                    total += (unsigned long long)st.st_size;
+                } else if (now - st.st_mtime > 3600 && (name.compare(0, 5, ".tmp-") == 0 || (name.size() > 5 && name.compare(name.size() - 5, 5, ".lock") == 0))) {
+                    unlink(path.c_str());  // a writer that died, or a lock nobody holds (a holder's inode check re-opens the name)
+                }
+            }
+            closedir(d);
+        }
+        const unsigned long long cap = (unsigned long long)cap_mb << 20;
+        if (total > cap) {
+            std::sort(files.begin(), files.end(), [](const Item &a, const Item &b) { return a.mtime < b.mtime; });
+            for (const Item &it : files) {
+                if (total <= cap / 5 * 4) break;
+                if (unlink(it.path.c_str()) == 0) total -= (unsigned long long)it.size;
+            }
+        }
+        flock(fd, LOCK_UN);
+        close(fd);
+    }
     // memory missed: disk, else compile (under the digest's file lock when the disk cache is on)
     int produce(const CacheKey &key, const Compile &compile, std::shared_ptr<const CodeObject> *out, int *source) {
         const std::string dir = disk_dir();
@@ -396,24 +444,35 @@ class CodeCache {
         }
         const std::string path = dir + "/" + key.digest + ".hsaco", lock_path = dir + "/" + key.digest + ".lock";
         if (read_file(path, key, *fresh)) {  // the common warm case takes no lock: a file is complete once it has its name
+            (void)utimensat(AT_FDCWD, path.c_str(), nullptr, 0);  // "used now": prune_disk deletes the least recently used first
             std::lock_guard<std::mutex> lk(mu_);
             stats_.disk_hits++;
             *out = fresh, *source = 1;
             return 0;
         }
-        const int lock_fd = open(lock_path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
-        if (lock_fd >= 0) {
+        // The digest's lock file.  It is unlinked by the holder that wrote the code object (so the directory does not collect one
+        // lock per controller ever compiled); a waiter that gets the lock on an inode that has lost its name opens the name again.
+        int lock_fd = -1;
+        for (int tries = 0; tries < 16; tries++) {
+            lock_fd = open(lock_path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+            if (lock_fd < 0) break;
             while (flock(lock_fd, LOCK_EX) != 0 && errno == EINTR) {}
+            struct stat a, b;
+            if (fstat(lock_fd, &a) == 0 && stat(lock_path.c_str(), &b) == 0 && a.st_ino == b.st_ino && a.st_dev == b.st_dev) break;
+            close(lock_fd);  // unlinked (or replaced) while we waited
+            lock_fd = -1;
         }
         int rc = 0;
+        bool wrote = false;
         if (lock_fd >= 0 && read_file(path, key, *fresh)) {  // somebody compiled it while we waited for the lock
             std::lock_guard<std::mutex> lk(mu_);
             stats_.disk_hits++;
             *source = 1;
         } else {
+            *fresh = CodeObject();  // (a failed read may have filled part of it)
             rc = compile(*fresh);
             if (rc == 0) {
-                const bool wrote = write_file(dir, path, key, *fresh);
+                wrote = write_file(dir, path, key, *fresh);
                 std::lock_guard<std::mutex> lk(mu_);
                 stats_.compiles++;
                 (wrote ? stats_.disk_writes : stats_.disk_errors)++;
@@ -421,9 +480,11 @@ class CodeCache {
             }
         }
         if (lock_fd >= 0) {
+            if (wrote) unlink(lock_path.c_str());  // still holding it: the next waiter re-opens the name and finds the file
             flock(lock_fd, LOCK_UN);
             close(lock_fd);
         }
+        if (wrote) prune_disk(dir);
         if (rc) return rc;
         *out = fresh;
         return 0;

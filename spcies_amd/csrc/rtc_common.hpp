@@ -141,9 +141,17 @@ inline std::mutex &pins_mutex() {
 }
 inline void unload_module(hipModule_t m) {
     if (!m) return;
-    (void)hipModuleUnload(m);
+    // Unload and un-pin under ONE lock, the lock compile_module loads and pins under: the runtime may hand the handle value of an
+    // unloaded module to the next hipModuleLoadData at once (create_multi builds handles on parallel threads while another handle is
+    // destroyed), and a late erase would then drop the NEW module's pin.  The code object outlives the unload (released last).
+    std::shared_ptr<const CodeObject> keep;
     std::lock_guard<std::mutex> lk(pins_mutex());
-    module_pins().erase(m);
+    auto it = module_pins().find(m);
+    if (it != module_pins().end()) {
+        keep = std::move(it->second);
+        module_pins().erase(it);
+    }
+    (void)hipModuleUnload(m);
 }
 
 inline std::vector<std::string> split_flags(const char *ev) {  // blank-separated compiler options of an experiment variable
@@ -219,12 +227,19 @@ inline int compile_module(const char *src, const char *fname, const std::vector<
     if (co->lowered.size() != names.size())
         return fail(SPCIES_HIP_EHIP, "cached code object of %s has %zu kernels, %zu expected", fname, co->lowered.size(), names.size());
     // loading is per device (the caller has made its device current) and needs no lock
-    SPCIES_HIP_CHECK(hipModuleLoadData(module, co->code.data()));
-    {
+    {   // load and pin under the lock unload_module takes (see there)
         std::lock_guard<std::mutex> lk(pins_mutex());
+        SPCIES_HIP_CHECK(hipModuleLoadData(module, co->code.data()));
         module_pins()[*module] = co;
     }
-    for (size_t i = 0; i < co->lowered.size(); i++) SPCIES_HIP_CHECK(hipModuleGetFunction(&fns[i], *module, co->lowered[i].c_str()));
+    for (size_t i = 0; i < co->lowered.size(); i++) {
+        const hipError_t err = hipModuleGetFunction(&fns[i], *module, co->lowered[i].c_str());
+        if (err != hipSuccess) {  // a loaded module must not outlive a failed look-up (nobody would unload it)
+            unload_module(*module);
+            *module = nullptr;
+            return fail(SPCIES_HIP_EHIP, "hipModuleGetFunction(%s): %s", co->lowered[i].c_str(), hipGetErrorString(err));
+        }
+    }
     return 0;
 }
 

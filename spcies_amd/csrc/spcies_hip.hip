@@ -7,7 +7,6 @@
 #include "admm_mfma4.hpp"
 #include "mfma4_rtc.hpp"
 #include "admm_stream.hpp"
-#include "admm_tvw.hpp"
 #include "admm_tvr.hpp"
 #include "fista_stream.hpp"
 #include "fista_mfma4g.hpp"
@@ -120,6 +119,7 @@ struct Solver {
     g4::Plan g4plan;  // MFMA4G (FISTA, EADMM)
     hgemm::Plan hgemm;             // GEMM (HMPC split, NON_SPARSE path)
     unsigned long long *d_hist = nullptr;  // spcies_hip_k_histogram_device's bins and counters
+    int num_cu = 256;                      // compute units of the handle's device (hipGetDeviceProperties once, at create time)
     tvr::Plan tvrp;                        // time-varying ADMM, MFMA4R: one wavefront per instance, factors in registers (admm_tvr.hpp)
     std::string build_failures;    // the subset of `notes` that are failed builds (SPCIES_HIP_STRICT)
     std::string notes;             // which faster (run-time specialised) variants AUTO could not use, and why (spcies_hip_get_notes)
@@ -760,18 +760,6 @@ static int ensure_mfma4_rtc(Solver &s) {
     return 0;
 }
 
-// Time-varying lax/equ ADMM, variant TILE (admm_tvw.hpp: one wavefront per instance, the instance's factors in LDS): wavefronts
-// (instances) per workgroup the LDS holds, 0 when the variant does not apply
-static int tvw_waves(const Solver &s) {
-    if (!s.tv || s.method != SPCIES_ADMM) return 0;
-    const int n = s.host.n, m = s.host.m, N = s.host.N;
-    if (!((n == 6 || n == 12) && m == 2) || N < 2 || N + 1 > 32) return 0;
-    if (const char *ev = getenv("SPCIES_TVW_DISABLE"))
-        if (ev[0] == '1') return 0;
-    const long per = 8L * tvw::lds_doubles_per_wave(n, m, N);
-    return (int)std::min<long>(4, (160 * 1024) / per);
-}
-
 // Time-varying lax/equ ADMM, variant MFMA4R (admm_tvr.hpp: one wavefront per instance, the instance's factors in its registers): the
 // plan is built at create time (hiprtc for horizons without a build-time kernel); SPCIES_HIP_TVR=0 switches the variant off
 static bool tvr_ok(const Solver &s) { return s.tv && (s.method == SPCIES_ADMM || s.method == SPCIES_FISTA) && s.tvrp.ok; }
@@ -779,13 +767,16 @@ static bool tvr_ok(const Solver &s) { return s.tv && (s.method == SPCIES_ADMM ||
 static int resolve_variant(const Solver &s) {
     if (s.variant != SPCIES_VARIANT_AUTO) return s.variant;
     if (s.host.ellip) return s.bsp.ok ? SPCIES_VARIANT_BSP : SPCIES_VARIANT_STREAM;
-    // (time-varying ADMM: MFMA4R - one wavefront per instance, factors in registers, admm_tvr.hpp - where its kernel is built; TILE - the
-    // same with the factors in LDS and the reference's recurrences, admm_tvw.hpp - on request only: 0.157 M solves/s against STREAM's 0.28 M)
+    // (time-varying ADMM / FISTA: MFMA4R - factors in registers, admm_tvr.hpp - where its kernel is built.  The north star's sketch - one
+    // wavefront per instance, factors in LDS, the reference's recurrences - was built in round 3, measured at 0.157 M solves/s against STREAM's
+    // 0.28 M and removed in round 5: DESIGN.md 4.2f keeps the numbers.)
     if (s.tv) return tvr_ok(s) ? SPCIES_VARIANT_MFMA4R : SPCIES_VARIANT_STREAM;
-    if (s.is_hdense()) return s.hfused.ok ? SPCIES_VARIANT_FUSED : SPCIES_VARIANT_GEMM;
+    // (HMPC, split or not: the hand-written FUSED kernel, else the reference-order kernels of the library itself - TILE / STREAM.  The
+    // rocBLAS variant GEMM is a cross-check that runs only when asked for by name: AUTO never hands a product to a library, never
+    // loads librocblas and stays asynchronous / graph-capturable on every path.)
+    if (s.is_hdense()) return s.hfused.ok ? SPCIES_VARIANT_FUSED : SPCIES_VARIANT_STREAM;
     if (s.is_cs()) return s.csf.ok ? SPCIES_VARIANT_FUSED : (s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM);
     if (s.is_hmpc() && s.hfused.ok) return SPCIES_VARIANT_FUSED;
-    if (s.is_hmpc() && s.hgemm.ok) return SPCIES_VARIANT_GEMM;
     if (s.is_soc() && !s.is_hmpc() && s.bsp.ok) return SPCIES_VARIANT_BSP;
     if (s.is_soc()) return s.tdev.lpi ? SPCIES_VARIANT_TILE : SPCIES_VARIANT_STREAM;
     if (s.method == SPCIES_FISTA && s.frplan.ok) return SPCIES_VARIANT_MFMA4R;
@@ -916,12 +907,7 @@ static int launch_fista_tv_nm(Solver &s, const double *x0, const double *xr, con
     if (chunk > B) chunk = (B + 63) / 64 * 64;
     int rc = ensure_scratch(s, (rows_stream + rows_tv) * (size_t)chunk * sizeof(double));
     if (rc) return rc;
-    int num_cu = 256;
-    if (regs) {
-        hipDeviceProp_t prop;
-        SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, s.device));
-        if (prop.multiProcessorCount > 0) num_cu = prop.multiProcessorCount;
-    }
+    const int num_cu = s.num_cu;  // (queried once at create time)
     for (long b0 = 0; b0 < B; b0 += chunk) {
         const long Bc = std::min(chunk, B - b0), Bp = (Bc + 63) / 64 * 64;
         double *Y = s.d_scratch, *LAM = Y + Nn * Bp, *DL = LAM + Nn * Bp;
@@ -1027,20 +1013,14 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
     const TvLayout tl = tv_layout(n, m, N);
     const bool want_sol = (z || v || lam);
     const size_t dim = (size_t)s.host.dim();
-    const int nw = resolve_variant(s) == SPCIES_VARIANT_TILE ? tvw_waves(s) : 0;  // TILE: one wavefront per instance (admm_tvw.hpp)
     const bool regs = resolve_variant(s) == SPCIES_VARIANT_MFMA4R;               // MFMA4R: one wavefront per instance, factors in registers (admm_tvr.hpp)
-    const size_t rows_stream = (nw || regs) ? 0 : 2 * dim + (size_t)N * n + (want_sol ? dim : 0);
+    const size_t rows_stream = regs ? 0 : 2 * dim + (size_t)N * n + (want_sol ? dim : 0);
     const size_t rows_tv = regs ? (size_t)tl.rows_all : (size_t)tl.rows;  // (MFMA4R: the explicit inverses behind the factors)
     long chunk = (long)((3900ull << 20) / (rows_tv * 8)) / 64 * 64;
     if (chunk > B) chunk = (B + 63) / 64 * 64;
     int rc = ensure_scratch(s, (rows_stream + rows_tv) * (size_t)chunk * sizeof(double));
     if (rc) return rc;
-    int num_cu = 256;
-    if (regs) {
-        hipDeviceProp_t prop;
-        SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, s.device));
-        if (prop.multiProcessorCount > 0) num_cu = prop.multiProcessorCount;
-    }
+    const int num_cu = s.num_cu;  // (queried once at create time)
     for (long b0 = 0; b0 < B; b0 += chunk) {
         const long Bc = std::min(chunk, B - b0), Bp = (Bc + 63) / 64 * 64;
         double *V = s.d_scratch, *LAM = V + dim * Bp, *Y = LAM + dim * Bp;
@@ -1056,43 +1036,6 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
             rc = tvr::launch(s.tvrp, want_sol, ta, s.d_consts + s.dev.Hi_N, s.d_consts + s.dev.T, TVS, x0 + b0 * n, xrc, urc, u + b0 * m,
                              k + b0, e + b0, z ? z + b0 * dim : nullptr, v ? v + b0 * dim : nullptr, lam ? lam + b0 * dim : nullptr, num_cu, st);
             if (rc) return rc;
-            continue;
-        }
-        if (nw) {  // update phase as before (the reference's operation order, one lane per instance), then one wavefront per instance
-            if (s.host.terminal)
-                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, true>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
-                                   (long)model_stride, Bc, Bp, TVS);
-            else
-                hipLaunchKernelGGL((admm_tv_update_kernel<n, m, false>), grid, block, 0, st, N, s.host.rho, s.d_consts + s.dev.Hi_N, mc,
-                                   (long)model_stride, Bc, Bp, TVS);
-            SPCIES_HIP_CHECK(hipGetLastError());
-            tvw::Args ta{N, s.host.k_max, ref_stride, s.host.rho, s.host.rho_i, s.host.tol, Bc, Bp};
-            const size_t shmem = (size_t)nw * tvw::lds_doubles_per_wave(n, m, N) * sizeof(double);
-            hipDeviceProp_t prop;
-            SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, s.device));
-            const long wgs = std::min<long>((Bc + nw - 1) / nw, (long)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256));
-            const double *hin = s.d_consts + s.dev.Hi_N, *tt = s.d_consts + s.dev.T;
-            double *zo = z ? z + b0 * dim : nullptr, *vo = v ? v + b0 * dim : nullptr, *lo = lam ? lam + b0 * dim : nullptr;
-#define SPCIES_TVW_LAUNCH(TT, RR)                                                                                                        \
-    do {                                                                                                                                 \
-        if (shmem > 64 * 1024)                                                                                                           \
-            SPCIES_HIP_CHECK(hipFuncSetAttribute((const void *)tvw::admm_tvw_kernel<n, m, TT, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                 (int)shmem));                                                                           \
-        hipLaunchKernelGGL((tvw::admm_tvw_kernel<n, m, TT, RR>), dim3((unsigned)wgs), dim3(64 * nw), shmem, st, ta, hin, tt, TVS, x0 + b0 * n, xrc, \
-                           urc, u + b0 * m, k + b0, e + b0, zo, vo, lo);                                                                 \
-    } while (0)
-#define SPCIES_TVW_CASE(RR)                                 \
-    case RR:                                                \
-        if (s.host.terminal) SPCIES_TVW_LAUNCH(true, RR);   \
-        else SPCIES_TVW_LAUNCH(false, RR);                  \
-        break;
-            switch ((N + 4) / 4) {
-                SPCIES_TVW_CASE(1) SPCIES_TVW_CASE(2) SPCIES_TVW_CASE(3) SPCIES_TVW_CASE(4) SPCIES_TVW_CASE(5) SPCIES_TVW_CASE(6) SPCIES_TVW_CASE(7) SPCIES_TVW_CASE(8)
-                default: return fail(SPCIES_HIP_ENOSUP, "time-varying TILE variant: N + 1 > 32");
-            }
-#undef SPCIES_TVW_CASE
-#undef SPCIES_TVW_LAUNCH
-            SPCIES_HIP_CHECK(hipGetLastError());
             continue;
         }
         if (s.host.terminal) {
@@ -1263,9 +1206,7 @@ static int launch_tv_rtc(Solver &s, const double *x0, const double *xr, const do
     if (chunk > B) chunk = (B + 63) / 64 * 64;
     int rc = ensure_scratch(s, rows_tv * (size_t)chunk * sizeof(double));
     if (rc) return rc;
-    hipDeviceProp_t prop;
-    SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, s.device));
-    const int num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int num_cu = s.num_cu;  // (queried once at create time)
     for (long b0 = 0; b0 < B; b0 += chunk) {
         const long Bc = std::min(chunk, B - b0), Bp = (Bc + 63) / 64 * 64;
         double *TVS = s.d_scratch;
@@ -1500,14 +1441,15 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
                                hipStream_t st) {
     if (B <= 0) return 0;
     // "a NULL entry skips that output" (include/spcies_hip.h) holds for every variant: the register-resident kernels (MFMA,
-    // MFMA4, BSP) write the whole record or nothing, so the fields the caller left out land in handle-owned scratch.
+    // MFMA4, BSP, and every MFMA4R form: lax / equ ADMM, FISTA, MPCT EADMM and the time-varying pair) write the whole record
+    // or nothing, so the fields the caller left out land in handle-owned scratch.
     double *f[6] = {f_in[0], f_in[1], f_in[2], f_in[3], f_in[4], f_in[5]};
     {
         const int nf = s.n_fields();
         bool any = false, all = true;
         for (int i = 0; i < nf; i++) { any |= f[i] != nullptr; all &= f[i] != nullptr; }
         const int var = resolve_variant(s);
-        if (any && !all && (var == SPCIES_VARIANT_MFMA || var == SPCIES_VARIANT_MFMA4 || var == SPCIES_VARIANT_BSP)) {
+        if (any && !all && (var == SPCIES_VARIANT_MFMA || var == SPCIES_VARIANT_MFMA4 || var == SPCIES_VARIANT_BSP || var == SPCIES_VARIANT_MFMA4R)) {
             size_t need = 0;
             for (int i = 0; i < nf; i++)
                 if (!f[i]) need += (size_t)B * s.field_dim(i) * sizeof(double);
@@ -1551,7 +1493,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
             return fail(SPCIES_HIP_ENOSUP, "HMPC without the splitting: variants FUSED, GEMM and STREAM are built");
         hdense::Dev &hd = s.hd_plan.dev;
         hd.k_max = s.hd_host.k_max; hd.tol_p = s.hd_host.tol_p; hd.tol_d = s.hd_host.tol_d;  // set_exit overrides
-        const bool stream = s.variant == SPCIES_VARIANT_STREAM;
+        const bool stream = resolve_variant(s) == SPCIES_VARIANT_STREAM;
         int rc = ensure_scratch(s, stream ? hdense::stream_scratch_bytes(hd, B) : hdense::scratch_bytes(hd, B));
         if (rc) return rc;
         if (stream) return hdense::launch_stream(s.hd_plan, x0, xr, ur, ref_stride, B, s.d_scratch, u, k, e, f, st);
@@ -1655,10 +1597,8 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (!extra) return fail(SPCIES_HIP_EINVAL, "time-varying solvers take A, B, Q, R, LB, UB with every call (extra): Spcies:laxMPC:nrhs:number");
         if (extra_stride != 0 && extra_stride != s.tv_model_size())
             return fail(SPCIES_HIP_EINVAL, "time-varying: extra_stride must be 0 (shared model) or %d", s.tv_model_size());
-        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM && !(s.variant == SPCIES_VARIANT_TILE && tvw_waves(s) > 0) &&
-            !(s.variant == SPCIES_VARIANT_MFMA4R && tvr_ok(s)))
-            return fail(SPCIES_HIP_ENOSUP, "time-varying ADMM: variants STREAM, MFMA4R (factors in registers: the shapes built in admm_tvr.hpp) and TILE "
-                                          "(one wavefront per instance, when the factors fit the LDS) are built");
+        if (s.variant != SPCIES_VARIANT_AUTO && s.variant != SPCIES_VARIANT_STREAM && !(s.variant == SPCIES_VARIANT_MFMA4R && tvr_ok(s)))
+            return fail(SPCIES_HIP_ENOSUP, "time-varying ADMM: variants STREAM and MFMA4R (factors in registers: admm_tvr.hpp) are built");
         if (!s.tvrp.update_builtin && tvr_ok(s) && resolve_variant(s) == SPCIES_VARIANT_MFMA4R)  // any other (n, m): everything run-time specialised
             return launch_tv_rtc(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         if (s.host.n == 6 && s.host.m == 2) return launch_tv_nm<6, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
@@ -1822,6 +1762,11 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
     s->device = device;
     SPCIES_HIP_CHECK(hipSetDevice(device));
     s->device_bound = true;
+    {
+        hipDeviceProp_t prop;
+        SPCIES_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        if (prop.multiProcessorCount > 0) s->num_cu = prop.multiProcessorCount;
+    }
     SPCIES_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     rc = upload_consts(*s);
     if (rc) return rc;
@@ -2048,7 +1993,7 @@ int spcies_hip_rtc_cache_selftest(const char *text, int work_ms, int drop_memory
         if (work_ms < 0) return fail(SPCIES_HIP_EHIP, "selftest: the stand-in compiler was told to fail");
         usleep((useconds_t)work_ms * 1000);
         const size_t len = strlen(text);
-        out.code.resize(4096);
+        out.code.resize(std::max<size_t>(4096, len));  // (grows with the text: the size-cap test writes big ones)
         for (size_t i = 0; i < out.code.size(); i++) out.code[i] = (char)(text[i % (len ? len : 1)] ^ (char)(i * 31));
         out.lowered = {std::string("lowered_") + std::to_string(len)};
         return 0;
@@ -2158,10 +2103,6 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (s->is_cs()) {
         if (variant != SPCIES_VARIANT_AUTO && variant != SPCIES_VARIANT_STREAM && !(variant == SPCIES_VARIANT_TILE && s->tdev.lpi))
             return fail(SPCIES_HIP_ENOSUP, "MPCT ADMM cs: variants STREAM and TILE (when the right-hand side fits the LDS) are built");
-        s->variant = variant;
-        return 0;
-    }
-    if (variant == SPCIES_VARIANT_TILE && s->tv && tvw_waves(*s) > 0) {  // time-varying ADMM: one wavefront per instance (admm_tvw.hpp)
         s->variant = variant;
         return 0;
     }

@@ -1629,6 +1629,46 @@ def test_partial_record_through_the_c_abi(cfg_name, variant):
     s.close()
 
 
+@pytest.mark.parametrize("cfg_name,tv", [("C1_lax", True), ("C1_lax_FISTA", True), ("C1_MPCT", False), ("C1_MPCT_nd", False), ("C1_equ_FISTA", False),
+                                         ("C2_lax_N30", False)])
+def test_partial_record_on_every_mfma4r_form(cfg_name, tv):
+    """"A NULL entry skips that output" on AUTO = MFMA4R too (round-4 advisor finding: the time-varying pair and MPCT EADMM rejected
+    {z, NULL, NULL} with EINVAL once AUTO moved them to MFMA4R): every single field, and every field but one, through
+    spcies_hip_solve_batch_ex; what is returned equals the full record's field bit for bit."""
+    import ctypes as C
+    from spcies_amd import _lib, benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = benchmarks.config(cfg_name)
+    v = benchmarks.ingredients(cfg, time_varying=True) if tv else benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    assert s.variant == "mfma4r"
+    B = 37
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    extra_in = ()
+    if tv:
+        sysm, prm = cfg.sys, cfg.param
+        extra_in = (sysm.A, sysm.B, np.diag(prm.Q), np.diag(prm.R), np.concatenate([np.ravel(sysm.LBx), np.ravel(sysm.LBu)]),
+                    np.concatenate([np.ravel(sysm.UBx), np.ravel(sysm.UBu)]))
+    u, k, e, sol = s(x0, xr, ur, *extra_in)
+    full = [getattr(sol, "lam" if name == "lambda" else name) for name, _ in s.sol_fields]
+    extra, extra_stride = (s._pack_model(extra_in, B) if tv else (None, 0))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    nf = len(s.sol_fields)
+    picks = [tuple(int(i == j) for i in range(nf)) for j in range(nf)] + [tuple(int(i != j) for i in range(nf)) for j in range(nf)]
+    for pick in picks:
+        bufs = [np.full((B, d), np.nan) if p else None for p, (_, d) in zip(pick, s.sol_fields)]
+        ptrs = (C.POINTER(C.c_double) * nf)(*[dp(b) if b is not None else None for b in bufs])
+        u2, k2, e2 = np.zeros((B, s.m)), np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        _lib.check(s._lib.spcies_hip_solve_batch_ex(s._h, dp(x0), dp(xr), dp(ur), 1, dp(extra) if extra is not None else None,
+                                                    C.c_int(int(extra_stride)), C.c_long(B), dp(u2), ip(k2), ip(e2), ptrs, nf, None))
+        assert np.array_equal(u2, u) and np.array_equal(k2, k) and np.array_equal(e2, e), pick
+        for b, ref in zip(bufs, full):
+            if b is not None:
+                assert np.array_equal(b, ref), pick
+    s.close()
+
+
 # ----------------------------------------------------------------------------------------------
 # One process, several device handles (spcies_hip_create_multi): contiguous shards, one host thread per handle
 # ----------------------------------------------------------------------------------------------

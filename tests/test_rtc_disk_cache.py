@@ -118,3 +118,34 @@ def test_memory_cache_is_bounded(tmp_path, monkeypatch):
     _call("bounded c", 0)
     assert _stats()["evictions"] - e0 == 2
     assert _call("bounded c", 0)[1] == 0 and _call("bounded a", 0)[1] == 2
+
+
+def test_disk_cache_is_capped_and_leaves_no_lock_files(tmp_path, monkeypatch):
+    """SPCIES_HIP_DISK_CACHE_MB: the directory does not grow without bound (round-4 advisor finding) - the least recently USED code
+    objects go first - and a digest's lock file is gone once its code object is written."""
+    monkeypatch.setenv("SPCIES_HIP_CACHE_DIR", str(tmp_path))
+    monkeypatch.delenv("SPCIES_HIP_DISK_CACHE", raising=False)
+    monkeypatch.setenv("SPCIES_HIP_DISK_CACHE_MB", "1")
+    tag = f"{os.getpid()} {time.time()}"
+    big = "x" * 300_000  # the stand-in compiler's code object grows with the text
+    texts = [f"prune {tag} {i} {big}" for i in range(6)]
+    rc, src, chk0 = _call(texts[0], 0, 1)
+    assert rc == 0 and src == 2
+    size = max(os.path.getsize(tmp_path / f) for f in os.listdir(tmp_path) if f.endswith(".hsaco"))
+    if size * 6 < (1 << 20):
+        pytest.skip(f"stand-in code objects are {size} B: six of them stay under the 1 MB cap")
+    time.sleep(1.1)  # mtime resolution
+    for t in texts[1:3]:
+        assert _call(t, 0, 1)[0] == 0
+        time.sleep(0.02)
+    time.sleep(1.1)
+    assert _call(texts[0], 0, 1)[1] == 1  # a disk hit: text 0 is now the most recently used
+    time.sleep(1.1)
+    assert _call(texts[3], 0, 1)[0] == 0  # the fourth file crosses the cap: the two least recently used (1, 2) go, 80 % of the cap is left
+    files = os.listdir(tmp_path)
+    total = sum(os.path.getsize(tmp_path / f) for f in files if f.endswith(".hsaco"))
+    assert total <= (1 << 20), total
+    assert not [f for f in files if f.endswith(".lock") and f != ".prune.lock"], files
+    rc, src, chk = _call(texts[0], 0, 1)
+    assert (rc, src, chk) == (0, 1, chk0)  # the recently used one survived the pruning
+    assert _call(texts[1], 0, 1)[1] == 2   # the oldest one did not: compiled again

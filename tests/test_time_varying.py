@@ -98,9 +98,8 @@ def _compare_tv(variant, got, O, vt, x0, xr, ur, model, per):
 
 
 @pytest.mark.gpu
-# tile: one wavefront per instance, the factors in LDS, the reference's recurrences (admm_tvw.hpp) - bit-exact too; mfma4r: one wavefront per
-# instance, the factors in REGISTERS, explicit inverses on the matrix pipe (admm_tvr.hpp) - 1e-10, AUTO's choice where its kernel is built
-@pytest.mark.parametrize("variant", ["stream", "tile", "mfma4r"])
+# mfma4r: the factors in REGISTERS, explicit inverses on the matrix pipe (admm_tvr.hpp) - 1e-10, AUTO's choice where its kernel is built
+@pytest.mark.parametrize("variant", ["stream", "mfma4r"])
 @pytest.mark.parametrize("name,B,overrides", [("C1_lax", 70, {}), ("C1_equ", 40, {}), ("C2_lax", 130, {}),
                                               ("C2_lax", 50, dict(tol=1e-6, k_max=3000)), ("C2_equ", 45, {})])
 def test_hip_time_varying_vs_oracle(name, B, overrides, variant):
@@ -110,7 +109,7 @@ def test_hip_time_varying_vs_oracle(name, B, overrides, variant):
     cfg, v, vt, design = _setup(name)
     vt = benchmarks.ingredients(cfg, time_varying=True, **overrides)
     s = HipSolver(vt)
-    assert s.time_varying and s.variant == "mfma4r"  # AUTO (TILE is the slowest of the three: DESIGN.md 4.2f)
+    assert s.time_varying and s.variant == "mfma4r"  # AUTO
     s.set_variant(variant)
     assert s.variant == variant
     x0, xr, ur = benchmarks.sample_batch(cfg, B)

@@ -11,6 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 variant = sys.argv[2] if len(sys.argv) > 2 else "auto"
 cfg = benchmarks.config(sys.argv[4] if len(sys.argv) > 4 else "C2_lax")
 vt = benchmarks.ingredients(cfg, time_varying=True)
+torch.cuda.init()  # torch's bundled ROCm user space first, the library's second (tests/conftest.py: the other order loses torch its GPU)
 s = HipSolver(vt)
 if variant != "auto":
     s.set_variant(variant)
