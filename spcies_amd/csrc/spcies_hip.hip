@@ -216,7 +216,7 @@ static int parse_soc(const uint8_t *blob, size_t bytes, const spcies_blob_header
     AdmmHost &a = s.host;
     a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max; a.terminal = true;
     a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
-    if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0) || !(h.reserved[0] > 0))
+    if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.m > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0) || !(h.reserved[0] > 0))
         return fail(SPCIES_HIP_EINVAL, "bad n/m/N/k_max/rho/sigma");
     const int n = a.n, m = a.m, N = a.N, nm = n + m;
     SocDev &d = s.sdev;
@@ -293,7 +293,7 @@ static int parse_hmpc(const uint8_t *blob, size_t bytes, const spcies_blob_heade
     AdmmHost &a = s.host;
     a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max; a.terminal = true;
     a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
-    if (h.n == 0 || h.m == 0 || h.N < 3 || h.n > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0) || !(h.reserved[0] > 0))
+    if (h.n == 0 || h.m == 0 || h.N < 3 || h.n > 4096 || h.m > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0) || !(h.reserved[0] > 0))
         return fail(SPCIES_HIP_EINVAL, "bad n/m/N/k_max/rho/sigma");
     const int n = a.n, m = a.m, N = a.N, nm = n + m;
     HmpcDev &d = s.hdev;
@@ -378,7 +378,7 @@ static int parse_mpct_cs(const uint8_t *blob, size_t bytes, const spcies_blob_he
     AdmmHost &a = s.host;
     a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max; a.terminal = true;
     a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
-    if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0))
+    if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.m > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0))
         return fail(SPCIES_HIP_EINVAL, "bad n/m/N/k_max/rho");
     const int n = a.n, m = a.m, N = a.N, dnm = 2 * (n + m);
     CsDev &d = s.cdev;
@@ -459,7 +459,7 @@ static int parse_hmpc_dense(const uint8_t *blob, size_t bytes, const spcies_blob
     AdmmHost &a = s.host;
     a.n = (int)h.n; a.m = (int)h.m; a.N = (int)h.N; a.k_max = (int)h.k_max; a.terminal = true;
     a.tol = h.tol; a.rho = h.rho; a.rho_i = h.rho_i;
-    if (h.n == 0 || h.m == 0 || h.N < 3 || h.n > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0))
+    if (h.n == 0 || h.m == 0 || h.N < 3 || h.n > 4096 || h.m > 4096 || h.N > 100000 || a.k_max <= 0 || !(a.rho > 0))
         return fail(SPCIES_HIP_EINVAL, "bad n/m/N/k_max/rho");
     const int n = a.n, m = a.m, N = a.N, nm = n + m;
     hdense::Host &d = s.hd_host;
@@ -547,7 +547,7 @@ static int parse_blob(const void *blobv, size_t bytes, Solver &s) {
         !(ellip_admm && !var_b))  // ellipMPC ADMM: vector rho (cons_ellipMPC_ADMM_C.m:111-117); its bounds are stage-wise already
         return fail(SPCIES_HIP_ENOSUP, "vector rho / stage-wise bounds are built for the lax/equ/ellip MPC ADMM solvers only");
     if ((vec_rho || var_b) && (h.flags & 4u)) return fail(SPCIES_HIP_EINVAL, "time-varying solvers take a scalar rho and constant bounds");
-    if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.N > 100000) return fail(SPCIES_HIP_EINVAL, "bad n/m/N");
+    if (h.n == 0 || h.m == 0 || h.N < 2 || h.n > 4096 || h.m > 4096 || h.N > 100000) return fail(SPCIES_HIP_EINVAL, "bad n/m/N");
     s.formulation = (int)h.formulation;
     s.method = (int)h.method;
     s.submethod = (int)h.submethod;

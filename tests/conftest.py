@@ -15,6 +15,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: the long tail of the GPU suite (tests/_slow.py): deselected unless -m names `slow` or SPCIES_RUN_SLOW=1")
 
 
 @pytest.fixture(scope="session")
@@ -26,6 +27,17 @@ def pytest_collection_modifyitems(config, items):
     """A GPU session initialises torch's HIP runtime BEFORE the library's first call: the PyTorch wheel bundles its own ROCm user space,
     and initialised second (after libspcies_hip.so has brought up the installed one) it reports "No HIP GPUs are available" - the tests
     that hand torch device buffers to the C-ABI would then depend on which test ran before them."""
+    import _slow
+    for item in items:
+        if _slow.is_slow(item.nodeid):
+            item.add_marker(pytest.mark.slow)
+    if "slow" not in (config.getoption("-m") or "") and os.environ.get("SPCIES_RUN_SLOW", "0") != "1":
+        keep, drop = [], []
+        for item in items:
+            (drop if item.get_closest_marker("slow") else keep).append(item)
+        if drop:
+            config.hook.pytest_deselected(items=drop)
+            items[:] = keep
     if any(item.get_closest_marker("gpu") for item in items):
         try:
             import torch
