@@ -123,7 +123,53 @@ int pack(Plan &p, const AdmmHost &a, std::vector<double> &tab) {
     for (int t = 2; t < N; t++)
         for (int j = 0; j < nm; j++)
             if (a.Hi[(size_t)(t - 1) * nm + j] != a.Hi[j]) { p.why = "MFMA4R (ADMM): stage-wise Hi"; return 0; }
+    // ---- unit-box coordinates (admm_r_kernel.inc, UNIT): D = ub - lb per kind of stage when every real row has a finite box that contains
+    // 0 (w = 0, the cold start, is then a state of the scaled iteration) and is not wider than 1e5 (absolute rounding of w = D w' stays
+    // below 1e-11); D = 1, lb = 0 on rows that do not exist.  SPCIES_AR_UNIT=0 keeps the plain coordinates.
+    std::vector<double> D0(4 * KS, 1.0), DM_(4 * KS, 1.0), DT(4 * KS, 1.0), L0(4 * KS, 0.0), LM(4 * KS, 0.0), LT(4 * KS, 0.0);
+    bool unit = true;
+    {
+        auto take = [&](int j, std::vector<double> &D, std::vector<double> &L) {
+            const double lo = a.LB[j], hi = a.UB[j];
+            if (!(std::isfinite(lo) && std::isfinite(hi)) || !(lo <= 0.0 && hi >= 0.0) || !(hi - lo > 1e-9) || hi - lo > 1e5) { unit = false; return; }
+            D[j] = hi - lo;
+            L[j] = lo;
+        };
+        for (int j = 0; j < nm; j++) take(j, DM_, LM);
+        for (int j = n; j < nm; j++) take(j, D0, L0);
+        if (TERMINAL)
+            for (int j = 0; j < n; j++) take(j, DT, LT);
+        if (const char *ev = getenv("SPCIES_AR_UNIT"))
+            if (ev[0] == '0') unit = false;
+        if (!(a.rho > 0)) unit = false;
+    }
+    p.unit = unit;
+    auto rhoD = [&](const std::vector<double> &D, int cnt) { std::vector<double> v(cnt); for (int j = 0; j < cnt; j++) v[j] = unit ? a.rho * D[j] : 1.0; return v; };
+    auto invD = [&](const std::vector<double> &D, int cnt) { std::vector<double> v(cnt); for (int j = 0; j < cnt; j++) v[j] = unit ? 1.0 / D[j] : 1.0; return v; };
+    auto Dst = [&](int t) -> const std::vector<double> & { return t == 0 ? D0 : (t == N ? DT : DM_); };  // stage t's scaling
     auto rc = [&](int which) { return tab.data() + (size_t)which * LY::RC; };
+    if (unit) {
+        for (int j = n; j < nm; j++) {  // stage 0: the u rows
+            const double hd = a.Hi_0[j - n];
+            rc(LY::C_IQ0)[j] = 1.0 / (a.rho * D0[j]); rc(LY::C_A30)[j] = L0[j] / D0[j]; rc(LY::C_A10)[j] = a.rho * hd;
+        }
+        for (int j = 0; j < 4 * KS; j++) {
+            rc(LY::C_B10)[j] = 1.0 - rc(LY::C_A10)[j];
+            rc(LY::C_D0)[j] = D0[j];
+            rc(LY::C_DM)[j] = DM_[j];
+            rc(LY::C_DT)[j] = DT[j];
+        }
+        for (int j = 0; j < nm; j++) {
+            const double hd = a.Hi[j];
+            rc(LY::C_IQM)[j] = 1.0 / (a.rho * DM_[j]); rc(LY::C_A3M)[j] = LM[j] / DM_[j]; rc(LY::C_A1M)[j] = a.rho * hd;
+            if (j < n) rc(LY::C_A2M)[j] = hd / DM_[j];
+        }
+        for (int j = 0; j < 4 * KS; j++) rc(LY::C_B1M)[j] = 1.0 - rc(LY::C_A1M)[j];
+        if (TERMINAL)
+            for (int j = 0; j < n; j++) {
+                rc(LY::C_IQT)[j] = 1.0 / (a.rho * DT[j]); rc(LY::C_A3T)[j] = LT[j] / DT[j]; rc(LY::C_RDT)[j] = a.rho * DT[j];
+            }
+    }
     for (int j = 0; j < m; j++) {
         rc(LY::C_HD0)[n + j] = a.Hi_0[j];
         rc(LY::C_LB0)[n + j] = a.LB[n + j];
@@ -152,7 +198,7 @@ int pack(Plan &p, const AdmmHost &a, std::vector<double> &tab) {
     bool ok = true;
     {
         BlockWriter w(tab.data() + LY::Z0_OFF, false);
-        w.emit(neg(scale_rows(ABt, Hd(0))), KS, KX, DENSE);  // Z_0 = -Hd_0 AB'
+        w.emit(scale_rows(neg(scale_rows(ABt, Hd(0))), invD(D0, nm)), KS, KX, DENSE);  // Z_0 = -Hd_0 AB' (unit-box: rows / D_0)
         ok = ok && w.structure_ok && w.cursor == KS * KX;
         BlockWriter w0(tab.data() + LY::S_C0, false), wt(tab.data() + LY::S_T, false), wn(tab.data() + LY::S_CN, false);
         w0.emit(mul(tr(Bi[0]), A), KX, KX, DENSE);  // c_0 = Bi_0' A x0
@@ -165,14 +211,14 @@ int pack(Plan &p, const AdmmHost &a, std::vector<double> &tab) {
         if (s < N) {  // forward chunk of block l: F2, F3, F1
             const int l = s;
             const DM BiT = tr(Bi[l]);
-            w.emit(neg(mul(BiT, scale_cols(AB, Hd(l)))), KX, KS, DENSE);
+            w.emit(scale_cols(neg(mul(BiT, scale_cols(AB, Hd(l)))), rhoD(Dst(l), nm)), KX, KS, DENSE);  // F2 (unit-box: columns x rho D_l)
             w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
             if (l + 1 < N) {
                 std::vector<double> dx = Hd(l + 1);
                 dx.resize(n);
-                w.emit(scale_cols(BiT, dx), KX, KX, LOWER);
+                w.emit(scale_cols(scale_cols(BiT, dx), rhoD(Dst(l + 1), n)), KX, KX, LOWER);  // F1 (unit-box: columns x rho D_{l+1})
             } else if (TERMINAL) {
-                w.emit(mul(BiT, HiN), KX, KX, DENSE);
+                w.emit(scale_cols(mul(BiT, HiN), rhoD(DT, n)), KX, KX, DENSE);
             } else {
                 w.emit(Zero, KX, KX, LOWER);
             }
@@ -180,8 +226,8 @@ int pack(Plan &p, const AdmmHost &a, std::vector<double> &tab) {
         } else {  // backward chunk of block l = 2N-1-s: B1, B2 (block N - 1: Hi_N), Z_{l+1}
             const int l = 2 * N - 1 - s;
             w.emit(Bi[l], KX, KX, UPPER);
-            w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : (TERMINAL ? HiN : Zero), KX, KX, DENSE);
-            w.emit(l < N - 1 ? neg(scale_rows(ABt, Hd(l + 1))) : ZeroZ, KS, KX, DENSE);
+            w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : (TERMINAL ? scale_rows(HiN, invD(DT, n)) : Zero), KX, KX, DENSE);  // (unit-box: Hi_N rows / D_N)
+            w.emit(l < N - 1 ? scale_rows(neg(scale_rows(ABt, Hd(l + 1))), invD(DM_, nm)) : ZeroZ, KS, KX, DENSE);         // Z_{l+1} (unit-box: rows / D)
             ok = ok && w.structure_ok && w.cursor == LY::NTB;
         }
     }
@@ -259,8 +305,8 @@ int plan_build(Plan &p, const AdmmHost &a) {
     std::vector<std::string> nm;
     for (int s = 0; s < 2; s++) {
         char name[160];
-        snprintf(name, sizeof(name), "spcies::ar::admm_r_kernel<%d, %d, %d, %s, %s, %d, %d>", a.N, KX, KS, a.terminal ? "true" : "false",
-                 s ? "true" : "false", p.NW, p.NLDS);
+        snprintf(name, sizeof(name), "spcies::ar::admm_r_kernel<%d, %d, %d, %s, %s, %d, %d, %s>", a.N, KX, KS, a.terminal ? "true" : "false",
+                 s ? "true" : "false", p.NW, p.NLDS, p.unit ? "true" : "false");
         nm.push_back(name);
     }
     std::vector<std::string> extra = {"-DSPCIES_AR_PD=" + std::to_string(p.PD), std::string("-DSPCIES_AR_KREG=") + (KS <= 4 ? "1" : "0"),
@@ -273,7 +319,7 @@ int plan_build(Plan &p, const AdmmHost &a) {
     if (getenv("SPCIES_AR_VERBOSE")) {
         int scratch = 0;
         if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fns[0]) != hipSuccess) scratch = 0;
-        fprintf(stderr, "[spcies admm_r] N=%d KX=%d KS=%d NW=%d NLDS=%d of %d scratch=%d B per lane\n", a.N, KX, KS, p.NW, p.NLDS, (a.N + 1) * KS, scratch);
+        fprintf(stderr, "[spcies admm_r] N=%d KX=%d KS=%d NW=%d NLDS=%d of %d unit=%d scratch=%d B per lane\n", a.N, KX, KS, p.NW, p.NLDS, (a.N + 1) * KS, (int)p.unit, scratch);
     }
     p.module = mod;
     p.fn[0] = fns[0];

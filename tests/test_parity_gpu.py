@@ -617,6 +617,55 @@ def test_soc_vs_reference_template_fixture(variant, tag, golden_dir):
 
 # ----------------------------------------------------------------------------------------------
 # HMPC ADMM / SADMM split (KKT CSC-LDL + proj_SOC3): STREAM variant -> bit-exact
+@pytest.mark.parametrize("cfg_name,B,overrides", [("C2_lax_N30", 48, {}), ("C2_equ_N30", 40, {}), ("C1_lax", 33, dict(tol=1e-6, k_max=3000))])
+def test_admm_r_plain_and_unit_box_coordinates(cfg_name, B, overrides, monkeypatch):
+    """admm_r (MFMA4R, lax / equ ADMM) runs in unit-box coordinates when every real row has a finite box around 0 (round 5); the plain
+    form stays for every other controller and behind SPCIES_AR_UNIT=0: both against the oracle, and against each other far inside the bar."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    got = {}
+    for unit in ("1", "0"):
+        monkeypatch.setenv("SPCIES_AR_UNIT", unit)
+        cfg, v, s = _solver(cfg_name, "mfma4r", **overrides)
+        x0, xr, ur = benchmarks.sample_batch(cfg, B)
+        ref = oracle.admm_banded_batch(v, x0, xr, ur)
+        got[unit] = s(x0, xr, ur)
+        _compare("mfma4r", got[unit], ref, v, rerun=_rerun_admm(v, x0, xr, ur))
+        nosol = s(x0[:21], xr[:21], ur[:21], want_sol=False)
+        assert np.array_equal(nosol[0], got[unit][0][:21]) and np.array_equal(nosol[1], got[unit][1][:21])
+        s.close()
+    assert np.array_equal(got["1"][1], got["0"][1]) and np.abs(got["1"][0] - got["0"][0]).max() <= 1e-11
+
+
+@pytest.mark.parametrize("n,m,N,formulation", [(9, 3, 8, "laxMPC"), (5, 3, 6, "equMPC"), (13, 2, 17, "laxMPC")])
+def test_admm_r_with_boxes_that_do_not_contain_zero(n, m, N, formulation):
+    """Boxes that exclude the origin (the cold start v = lambda = 0 is then not a point of the scaled state): admm_r keeps its plain
+    coordinates for such a controller - same instances as the MFMA4 test above, variant MFMA4R."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=700 + n)
+    cfg.formulation = formulation
+    rng = np.random.default_rng(31 * n + m)
+    cfg.sys.LBu = np.where(rng.random(m) < 0.5, 0.05 + 0.1 * rng.random(m), -0.4 - rng.random(m))
+    cfg.sys.UBu = cfg.sys.LBu + 0.3 + rng.random(m)
+    cfg.sys.LBx = -0.3 - 2.0 * rng.random(n)
+    cfg.sys.UBx = 0.2 + 3.0 * rng.random(n)
+    if formulation == "laxMPC":
+        k = int(rng.integers(n))
+        cfg.sys.LBx[k], cfg.sys.UBx[k] = 0.02, 1.5
+    cfg.solver_options = dict(rho=6.0, tol=1e-6, k_max=2000)
+    v = benchmarks.ingredients(cfg)
+    s = HipSolver(v)
+    s.set_variant("mfma4r")
+    B = 60
+    x0 = 0.5 * rng.standard_normal((B, n))
+    xr = 0.2 * rng.standard_normal((B, n)) + 0.1
+    ur = 0.1 * rng.standard_normal((B, m)) + 0.2
+    _compare("mfma4r", s(x0, xr, ur), oracle.admm_banded_batch(v, x0, xr, ur), v, rerun=_rerun_admm(v, x0, xr, ur))
+    s.close()
+
+
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg_name,B,overrides", [
     ("C1_HMPC", 40, {}), ("C1_HMPC_SADMM", 70, {}), ("C1_HMPC_soc", 33, {}), ("C1_HMPC_SADMM_soc", 20, {}),

@@ -21,7 +21,6 @@ JOBS=${JOBS:-6}
 blobs() {  # a few controllers' blobs as files for the stress driver
     python3 - "$1" <<'PY'
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), ".."))
 sys.path.insert(0, os.environ["SPCIES_ROOT"])
 from spcies_amd import benchmarks, blob
 for name in ("C1", "C1_lax_gen", "C1_MPCT", "C1_soc", "C1_HMPC_SADMM", "C1_MPCT_cs", "C1_lax_FISTA"):
@@ -38,7 +37,7 @@ build_lib() {  # $1 = mode name, $2 = sanitizer list
 run_stress() {  # $1 = mode, $2 = sanitizer list
     local T=$(mktemp -d /tmp/spcies_san.XXXXXX)
     mkdir -p $T/cache $T/blobs
-    SPCIES_ROOT=$R blobs $T/blobs/x || return 1
+    SPCIES_ROOT=$R blobs $T/blobs || return 1
     $CLANG -O1 -g -std=c++17 -fsanitize=$2 -fno-omit-frame-pointer -o $T/stress $R/tools/sanitize_stress.cpp -ldl -lpthread || return 1
     $T/stress $R/spcies_amd/libspcies_hip_$1.so $T/cache ${STRESS_THREADS:-8} ${STRESS_ROUNDS:-150} $T/blobs/*.blob
     local rc=$?
