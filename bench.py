@@ -47,6 +47,10 @@ EXTRA_CONFIGS = {
     # 112) - the MFMA4R variant of admm_r.hpp (w on the chip, blocks streamed); flop per iteration scales with the horizon (2 x C2's 27 498)
     "C2_N30": dict(name="C2_lax_N30", B=65536, flop=2 * 27498.0 * 200, io=232,
                    what="laxMPC-ADMM, C2 plant (n=12, m=2) at N=30, 200 iterations, batch=65536: past MFMA4's register file"),
+    # ... and with vector rho + stage-wise bounds (code_laxMPC_ADMM_C.c:323-348, 490-568: no SCALAR_RHO, VAR_BOUNDS): the block program (BSP) does not fit
+    # the LDS at this horizon; round 5: MFMA4R with the middle stages' row constants in the chunk stream (MFMA4G before: state through HBM)
+    "C2_N30_gen": dict(name="C2_lax_N30_gen", B=65536, flop=2 * 27498.0 * 200, io=232,
+                       what="laxMPC-ADMM with vector rho and VAR_BOUNDS, C2 plant (n=12, m=2) at N=30, 200 iterations, batch=65536"),
     "C5_soc": dict(name="C5_soc", B=65536, flop=23.4e3 * 200, io=240,
                    what="configs[4]a: ellipMPC-ADMM-soc, 12-state, N=15, 200 iterations, 1/8 shard (65536) of batch=524288"),
     "C5_hmpc": dict(name="C5_HMPC_SADMM", B=65536, flop=2.0 * 282 * 282 * 200, io=232,

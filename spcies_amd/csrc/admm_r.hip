@@ -96,9 +96,9 @@ struct BlockWriter {
     }
 };
 
-template <int KX, int KS, bool TERMINAL>
+template <int KX, int KS, bool TERMINAL, bool GEN>
 int pack(Plan &p, const AdmmHost &a, std::vector<double> &tab) {
-    using LY = Layout<KX, KS, TERMINAL>;
+    using LY = Layout<KX, KS, TERMINAL, GEN>;
     const int n = a.n, m = a.m, N = a.N, nm = n + m;
     tab.assign((size_t)LY::table_doubles(N), 0.0);
     DM AB(n, nm), A(n, n), HiN(n, n), T(n, n);
@@ -119,73 +119,91 @@ int pack(Plan &p, const AdmmHost &a, std::vector<double> &tab) {
             for (int j = 0; j < nm; j++) d[j] = a.Hi[(size_t)(t - 1) * nm + j];
         return d;
     };
-    // the middle stages share their row constants (scalar rho, constant bounds: Hi{l} is the same vector for l = 1 .. N - 1)
-    for (int t = 2; t < N; t++)
-        for (int j = 0; j < nm; j++)
-            if (a.Hi[(size_t)(t - 1) * nm + j] != a.Hi[j]) { p.why = "MFMA4R (ADMM): stage-wise Hi"; return 0; }
-    // ---- unit-box coordinates (admm_r_kernel.inc, UNIT): D = ub - lb per kind of stage when every real row has a finite box that contains
-    // 0 (w = 0, the cold start, is then a state of the scaled iteration) and is not wider than 1e5 (absolute rounding of w = D w' stays
-    // below 1e-11); D = 1, lb = 0 on rows that do not exist.  SPCIES_AR_UNIT=0 keeps the plain coordinates.
-    std::vector<double> D0(4 * KS, 1.0), DM_(4 * KS, 1.0), DT(4 * KS, 1.0), L0(4 * KS, 0.0), LM(4 * KS, 0.0), LT(4 * KS, 0.0);
-    bool unit = true;
-    {
-        auto take = [&](int j, std::vector<double> &D, std::vector<double> &L) {
-            const double lo = a.LB[j], hi = a.UB[j];
-            if (!(std::isfinite(lo) && std::isfinite(hi)) || !(lo <= 0.0 && hi >= 0.0) || !(hi - lo > 1e-9) || hi - lo > 1e5) { unit = false; return; }
-            D[j] = hi - lo;
-            L[j] = lo;
-        };
-        for (int j = 0; j < nm; j++) take(j, DM_, LM);
-        for (int j = n; j < nm; j++) take(j, D0, L0);
-        if (TERMINAL)
-            for (int j = 0; j < n; j++) take(j, DT, LT);
-        if (const char *ev = getenv("SPCIES_AR_UNIT"))
-            if (ev[0] == '0') unit = false;
-        if (!(a.rho > 0)) unit = false;
+    // rho and the bounds of row j of stage t = 0 .. N (stage 0: u rows, stage N: x rows); scalar rho / constant bounds unless `gen`
+    // (vector rho, VAR_BOUNDS: code_laxMPC_ADMM_C.c:323-348, 490-568 - rho_0 / rho_v / rho_N and LBu0 / LBz / LBN of AdmmHost)
+    auto has = [&](int t, int j) { return t == 0 ? (j >= n && j < nm) : (t == N ? (TERMINAL && j < n) : j < nm); };
+    auto rho_of = [&](int t, int j) -> double {
+        if (!a.gen) return a.rho;
+        return t == 0 ? a.rho_0[j - n] : (t == N ? a.rho_N[j] : a.rho_v[(size_t)(t - 1) * nm + j]);
+    };
+    auto lb_of = [&](int t, int j) -> double {
+        if (!a.gen) return a.LB[j];
+        return t == 0 ? a.LBu0[j - n] : (t == N ? a.LBN[j] : a.LBz[(size_t)(t - 1) * nm + j]);
+    };
+    auto ub_of = [&](int t, int j) -> double {
+        if (!a.gen) return a.UB[j];
+        return t == 0 ? a.UBu0[j - n] : (t == N ? a.UBN[j] : a.UBz[(size_t)(t - 1) * nm + j]);
+    };
+    if (!GEN) {  // the middle stages share their row constants (scalar rho, constant bounds: Hi{l} is the same vector for l = 1 .. N - 1)
+        for (int t = 2; t < N; t++)
+            for (int j = 0; j < nm; j++)
+                if (a.Hi[(size_t)(t - 1) * nm + j] != a.Hi[j]) { p.why = "MFMA4R (ADMM): stage-wise Hi"; return 0; }
     }
+    // ---- unit-box coordinates (admm_r_kernel.inc, UNIT): D = ub - lb per row and stage when every real row has a finite box that contains
+    // 0 (w = 0, the cold start, is then a state of the scaled iteration) and is not wider than 1e5 (absolute rounding of w = D w' stays
+    // below 1e-11); D = 1, lb = 0 on rows that do not exist.  SPCIES_AR_UNIT=0 keeps the plain coordinates (not with GEN).
+    bool unit = a.rho > 0 || a.gen;
+    for (int t = 0; t <= N && unit; t++)
+        for (int j = 0; j < nm && unit; j++) {
+            if (!has(t, j)) continue;
+            const double lo = lb_of(t, j), hi = ub_of(t, j), r = rho_of(t, j);
+            if (!(std::isfinite(lo) && std::isfinite(hi)) || !(lo <= 0.0 && hi >= 0.0) || !(hi - lo > 1e-9) || hi - lo > 1e5 || !(r > 0)) unit = false;
+        }
+    if (const char *ev = getenv("SPCIES_AR_UNIT"))
+        if (ev[0] == '0') unit = false;
+    if (GEN && !unit) { p.why = "MFMA4R (ADMM): vector rho / stage-wise bounds need a finite box around 0 on every row (unit-box coordinates)"; return 0; }
     p.unit = unit;
-    auto rhoD = [&](const std::vector<double> &D, int cnt) { std::vector<double> v(cnt); for (int j = 0; j < cnt; j++) v[j] = unit ? a.rho * D[j] : 1.0; return v; };
-    auto invD = [&](const std::vector<double> &D, int cnt) { std::vector<double> v(cnt); for (int j = 0; j < cnt; j++) v[j] = unit ? 1.0 / D[j] : 1.0; return v; };
-    auto Dst = [&](int t) -> const std::vector<double> & { return t == 0 ? D0 : (t == N ? DT : DM_); };  // stage t's scaling
+    auto Dof = [&](int t) { std::vector<double> v(4 * KS, 1.0); for (int j = 0; j < nm; j++) if (unit && has(t, j)) v[j] = ub_of(t, j) - lb_of(t, j); return v; };
+    auto Lof = [&](int t) { std::vector<double> v(4 * KS, 0.0); for (int j = 0; j < nm; j++) if (unit && has(t, j)) v[j] = lb_of(t, j); return v; };
+    auto rhoD = [&](int t, int cnt) {  // column scaling of the blocks that multiply s_t (q_hat = rho D s)
+        std::vector<double> v(cnt, 1.0), D = Dof(t);
+        for (int j = 0; j < cnt; j++) v[j] = (unit && has(t, j)) ? rho_of(t, j) * D[j] : 1.0;
+        return v;
+    };
+    auto invD = [&](int t, int cnt) {  // row scaling of the blocks that produce z_t
+        std::vector<double> v(cnt, 1.0), D = Dof(t);
+        for (int j = 0; j < cnt; j++) v[j] = unit ? 1.0 / D[j] : 1.0;
+        return v;
+    };
     auto rc = [&](int which) { return tab.data() + (size_t)which * LY::RC; };
-    if (unit) {
-        for (int j = n; j < nm; j++) {  // stage 0: the u rows
-            const double hd = a.Hi_0[j - n];
-            rc(LY::C_IQ0)[j] = 1.0 / (a.rho * D0[j]); rc(LY::C_A30)[j] = L0[j] / D0[j]; rc(LY::C_A10)[j] = a.rho * hd;
-        }
+    // the eight row constants of stage t in unit-box coordinates (Layout::G_*), rows that do not exist: IQ = A3 = A1 = A2 = LB = RD = 0, B1 = D = 1
+    auto unit_consts = [&](int t, double *iq, double *a3, double *a1, double *b1, double *a2, double *dd, double *lbv, double *rd) {
+        const std::vector<double> D = Dof(t), L = Lof(t), hd = t < N ? Hd(t) : std::vector<double>(nm, 0.0);
         for (int j = 0; j < 4 * KS; j++) {
-            rc(LY::C_B10)[j] = 1.0 - rc(LY::C_A10)[j];
-            rc(LY::C_D0)[j] = D0[j];
-            rc(LY::C_DM)[j] = DM_[j];
-            rc(LY::C_DT)[j] = DT[j];
+            const bool h = j < nm && has(t, j);
+            const double r = h ? rho_of(t, j) : 0.0;
+            if (iq) iq[j] = h ? 1.0 / (r * D[j]) : 0.0;
+            if (a3) a3[j] = h ? L[j] / D[j] : 0.0;
+            if (a1) a1[j] = (h && t < N) ? r * hd[j] : 0.0;
+            if (b1) b1[j] = 1.0 - ((h && t < N) ? r * hd[j] : 0.0);
+            if (a2) a2[j] = (h && t > 0 && t < N && j < n) ? hd[j] / D[j] : 0.0;
+            if (dd) dd[j] = D[j];
+            if (lbv) lbv[j] = L[j];
+            if (rd) rd[j] = h ? r * D[j] : 0.0;
         }
-        for (int j = 0; j < nm; j++) {
-            const double hd = a.Hi[j];
-            rc(LY::C_IQM)[j] = 1.0 / (a.rho * DM_[j]); rc(LY::C_A3M)[j] = LM[j] / DM_[j]; rc(LY::C_A1M)[j] = a.rho * hd;
-            if (j < n) rc(LY::C_A2M)[j] = hd / DM_[j];
-        }
-        for (int j = 0; j < 4 * KS; j++) rc(LY::C_B1M)[j] = 1.0 - rc(LY::C_A1M)[j];
-        if (TERMINAL)
-            for (int j = 0; j < n; j++) {
-                rc(LY::C_IQT)[j] = 1.0 / (a.rho * DT[j]); rc(LY::C_A3T)[j] = LT[j] / DT[j]; rc(LY::C_RDT)[j] = a.rho * DT[j];
-            }
+    };
+    if (unit) {
+        unit_consts(0, rc(LY::C_IQ0), rc(LY::C_A30), rc(LY::C_A10), rc(LY::C_B10), nullptr, rc(LY::C_D0), nullptr, rc(LY::C_RD0));
+        if (!GEN) unit_consts(1, rc(LY::C_IQM), rc(LY::C_A3M), rc(LY::C_A1M), rc(LY::C_B1M), rc(LY::C_A2M), rc(LY::C_DM), nullptr, rc(LY::C_RDM));
+        if (TERMINAL) unit_consts(N, rc(LY::C_IQT), rc(LY::C_A3T), nullptr, nullptr, nullptr, rc(LY::C_DT), nullptr, rc(LY::C_RDT));
+        else for (int j = 0; j < 4 * KS; j++) rc(LY::C_DT)[j] = 1.0;
     }
     for (int j = 0; j < m; j++) {
         rc(LY::C_HD0)[n + j] = a.Hi_0[j];
-        rc(LY::C_LB0)[n + j] = a.LB[n + j];
-        rc(LY::C_UB0)[n + j] = a.UB[n + j];
+        rc(LY::C_LB0)[n + j] = lb_of(0, n + j);
+        rc(LY::C_UB0)[n + j] = ub_of(0, n + j);
         rc(LY::C_QR)[n + j] = a.R[j];
     }
     for (int j = 0; j < n; j++) rc(LY::C_QR)[j] = a.Q[j];
     for (int j = 0; j < nm; j++) {
         rc(LY::C_HDM)[j] = a.Hi[j];
-        rc(LY::C_LBM)[j] = a.LB[j];
-        rc(LY::C_UBM)[j] = a.UB[j];
+        rc(LY::C_LBM)[j] = lb_of(1, j);
+        rc(LY::C_UBM)[j] = ub_of(1, j);
     }
     if (TERMINAL)
         for (int j = 0; j < n; j++) {
-            rc(LY::C_LBT)[j] = a.LB[j];
-            rc(LY::C_UBT)[j] = a.UB[j];
+            rc(LY::C_LBT)[j] = lb_of(N, j);
+            rc(LY::C_UBT)[j] = ub_of(N, j);
         }
     std::vector<DM> Bi(N), Al(N - 1);
     for (int l = 0; l < N; l++) Bi[l] = beta_inverse(a.Beta.data() + (size_t)l * n * n, n);
@@ -198,7 +216,7 @@ int pack(Plan &p, const AdmmHost &a, std::vector<double> &tab) {
     bool ok = true;
     {
         BlockWriter w(tab.data() + LY::Z0_OFF, false);
-        w.emit(scale_rows(neg(scale_rows(ABt, Hd(0))), invD(D0, nm)), KS, KX, DENSE);  // Z_0 = -Hd_0 AB' (unit-box: rows / D_0)
+        w.emit(scale_rows(neg(scale_rows(ABt, Hd(0))), invD(0, nm)), KS, KX, DENSE);  // Z_0 = -Hd_0 AB' (unit-box: rows / D_0)
         ok = ok && w.structure_ok && w.cursor == KS * KX;
         BlockWriter w0(tab.data() + LY::S_C0, false), wt(tab.data() + LY::S_T, false), wn(tab.data() + LY::S_CN, false);
         w0.emit(mul(tr(Bi[0]), A), KX, KX, DENSE);  // c_0 = Bi_0' A x0
@@ -207,28 +225,35 @@ int pack(Plan &p, const AdmmHost &a, std::vector<double> &tab) {
         ok = ok && w0.structure_ok && wt.structure_ok && wn.structure_ok;
     }
     for (int s = 0; s < 2 * N; s++) {
-        BlockWriter w(tab.data() + LY::chunk_off(s, N), true);
+        double *chunk = tab.data() + LY::chunk_off(s, N);
+        BlockWriter w(chunk, true);
         if (s < N) {  // forward chunk of block l: F2, F3, F1
             const int l = s;
             const DM BiT = tr(Bi[l]);
-            w.emit(scale_cols(neg(mul(BiT, scale_cols(AB, Hd(l)))), rhoD(Dst(l), nm)), KX, KS, DENSE);  // F2 (unit-box: columns x rho D_l)
+            w.emit(scale_cols(neg(mul(BiT, scale_cols(AB, Hd(l)))), rhoD(l, nm)), KX, KS, DENSE);  // F2 (unit-box: columns x rho D_l)
             w.emit(l >= 1 ? neg(mul(BiT, tr(Al[l - 1]))) : Zero, KX, KX, DENSE);
             if (l + 1 < N) {
                 std::vector<double> dx = Hd(l + 1);
                 dx.resize(n);
-                w.emit(scale_cols(scale_cols(BiT, dx), rhoD(Dst(l + 1), n)), KX, KX, LOWER);  // F1 (unit-box: columns x rho D_{l+1})
+                w.emit(scale_cols(scale_cols(BiT, dx), rhoD(l + 1, n)), KX, KX, LOWER);  // F1 (unit-box: columns x rho D_{l+1})
             } else if (TERMINAL) {
-                w.emit(scale_cols(mul(BiT, HiN), rhoD(DT, n)), KX, KX, DENSE);
+                w.emit(scale_cols(mul(BiT, HiN), rhoD(N, n)), KX, KX, DENSE);
             } else {
                 w.emit(Zero, KX, KX, LOWER);
             }
             ok = ok && w.structure_ok && w.cursor == LY::ntf(l, N);
+            if (GEN && l + 1 < N) unit_consts(l + 1, chunk + LY::GF_OFF, chunk + LY::GF_OFF + LY::RC, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         } else {  // backward chunk of block l = 2N-1-s: B1, B2 (block N - 1: Hi_N), Z_{l+1}
             const int l = 2 * N - 1 - s;
             w.emit(Bi[l], KX, KX, UPPER);
-            w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : (TERMINAL ? scale_rows(HiN, invD(DT, n)) : Zero), KX, KX, DENSE);  // (unit-box: Hi_N rows / D_N)
-            w.emit(l < N - 1 ? scale_rows(neg(scale_rows(ABt, Hd(l + 1))), invD(DM_, nm)) : ZeroZ, KS, KX, DENSE);         // Z_{l+1} (unit-box: rows / D)
+            w.emit(l < N - 1 ? neg(mul(Bi[l], Al[l])) : (TERMINAL ? scale_rows(HiN, invD(N, n)) : Zero), KX, KX, DENSE);  // (unit-box: Hi_N rows / D_N)
+            w.emit(l < N - 1 ? scale_rows(neg(scale_rows(ABt, Hd(l + 1))), invD(l + 1, nm)) : ZeroZ, KS, KX, DENSE);       // Z_{l+1} (unit-box: rows / D_{l+1})
             ok = ok && w.structure_ok && w.cursor == LY::NTB;
+            if (GEN && l + 1 < N) {
+                double *g = chunk + LY::GB_OFF;
+                unit_consts(l + 1, g + LY::G_IQ * LY::RC, g + LY::G_A3 * LY::RC, g + LY::G_A1 * LY::RC, g + LY::G_B1 * LY::RC, g + LY::G_A2 * LY::RC,
+                            g + LY::G_D * LY::RC, g + LY::G_LB * LY::RC, g + LY::G_RD * LY::RC);
+            }
         }
     }
     if (!ok) { p.why = "MFMA4R (ADMM) packer: block structure mismatch"; return 0; }
@@ -277,7 +302,8 @@ int plan_build(Plan &p, const AdmmHost &a) {
     p.ok = false;
     p.n = a.n; p.m = a.m; p.N = a.N; p.terminal = a.terminal; p.rho = a.rho;
     if (a.N < 2) { p.why = "N < 2"; return 0; }
-    if (a.gen || a.ellip) { p.why = "vector rho / stage-wise bounds / ellipMPC: the block programs (BSP) carry those"; return 0; }
+    if (a.ellip) { p.why = "ellipMPC: the block program (BSP) carries it"; return 0; }
+    p.gen = a.gen;  // vector rho / stage-wise bounds: the middle stages' row constants ride in the chunk stream (unit-box coordinates only)
     if (const char *ev = getenv("SPCIES_AR_DISABLE"))
         if (ev[0] == '1') { p.why = "disabled (SPCIES_AR_DISABLE=1)"; return 0; }
     {
@@ -287,8 +313,10 @@ int plan_build(Plan &p, const AdmmHost &a) {
     const int KX = (a.n + 3) / 4, KS = (a.n + a.m + 3) / 4;
     std::vector<double> tab;
     int got = -1;
-#define X(KKX, KKS) \
-    if (KX == KKX && KS == KKS) got = a.terminal ? pack<KKX, KKS, true>(p, a, tab) : pack<KKX, KKS, false>(p, a, tab);
+#define X(KKX, KKS)                                                                                                          \
+    if (KX == KKX && KS == KKS)                                                                                              \
+        got = a.gen ? (a.terminal ? pack<KKX, KKS, true, true>(p, a, tab) : pack<KKX, KKS, false, true>(p, a, tab))          \
+                    : (a.terminal ? pack<KKX, KKS, true, false>(p, a, tab) : pack<KKX, KKS, false, false>(p, a, tab));
     SPCIES_AR_SHAPES(X)
 #undef X
     if (got < 0) { p.why = "MFMA4R (ADMM): (ceil(n/4), ceil((n+m)/4)) outside the packer's shapes"; return 0; }
@@ -305,8 +333,8 @@ int plan_build(Plan &p, const AdmmHost &a) {
     std::vector<std::string> nm;
     for (int s = 0; s < 2; s++) {
         char name[160];
-        snprintf(name, sizeof(name), "spcies::ar::admm_r_kernel<%d, %d, %d, %s, %s, %d, %d, %s>", a.N, KX, KS, a.terminal ? "true" : "false",
-                 s ? "true" : "false", p.NW, p.NLDS, p.unit ? "true" : "false");
+        snprintf(name, sizeof(name), "spcies::ar::admm_r_kernel<%d, %d, %d, %s, %s, %d, %d, %s, %s>", a.N, KX, KS, a.terminal ? "true" : "false",
+                 s ? "true" : "false", p.NW, p.NLDS, p.unit ? "true" : "false", p.gen ? "true" : "false");
         nm.push_back(name);
     }
     std::vector<std::string> extra = {"-DSPCIES_AR_PD=" + std::to_string(p.PD), std::string("-DSPCIES_AR_KREG=") + (KS <= 4 ? "1" : "0"),

@@ -14,6 +14,7 @@ struct Plan {
     bool build_failed = false;  // the variant applies to this controller but its run-time specialisation failed: what SPCIES_HIP_STRICT reacts to
     int n = 0, m = 0, N = 0, KX = 0, KS = 0, NW = 0, NLDS = 0, PD = 3;
     bool terminal = false;
+    bool gen = false;   // vector rho / stage-wise bounds (row constants of the middle stages in the chunk stream)
     bool unit = false;  // unit-box coordinates (admm_r_kernel.inc, UNIT): every real row has a finite box around 0
     double rho = 0;
     double *d_table = nullptr;  // + a dump word for masked-off stores

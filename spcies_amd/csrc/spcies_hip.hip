@@ -1855,7 +1855,8 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         }
         // MFMA4R: where neither MFMA4 nor MFMA holds the controller (more than 112 slab registers, n + m > 16, blocks past the LDS) - or on
         // request (SPCIES_AR_ALWAYS=1: tests and comparisons at shapes MFMA4 serves).  A failure is not an error: AUTO then runs MFMA4G.
-        if (!s->tv && !s->host.gen && !s->host.ellip && ((!s->mfma4.ok && !s->mfma.ok) || getenv("SPCIES_AR_ALWAYS"))) {
+        // (vector rho / stage-wise bounds: where the block program - BSP, the faster one while its table fits the LDS - is not available)
+        if (!s->tv && !s->host.ellip && ((!s->mfma4.ok && !s->mfma.ok && !(s->host.gen && s->bsp.ok)) || getenv("SPCIES_AR_ALWAYS"))) {
             rc = ar::plan_build(s->arplan, s->host);
             if (rc) return rc;
         } else {
@@ -2116,7 +2117,7 @@ int spcies_hip_set_variant(spcies_hip_handle h, int variant) {
     if (variant == SPCIES_VARIANT_MFMA4R && s->method == SPCIES_EADMM && !s->erplan.ok)
         return fail(SPCIES_HIP_ENOSUP, "MFMA4R variant not available for this solver: %s", s->erplan.why.c_str());
     if (variant == SPCIES_VARIANT_MFMA4R && s->method == SPCIES_ADMM) {  // lax / equ ADMM: built on request where MFMA4 serves the controller (admm_r.hpp)
-        if (!s->arplan.ok && !s->host.gen && !s->host.ellip && (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC)) {
+        if (!s->arplan.ok && !s->host.ellip && (s->formulation == SPCIES_LAXMPC || s->formulation == SPCIES_EQUMPC)) {
             SPCIES_HIP_CHECK(hipSetDevice(s->device));
             int rc = ar::plan_build(s->arplan, s->host);
             if (rc) return rc;

@@ -1566,7 +1566,7 @@ def test_mfma4_unit_box_with_boxes_that_do_not_contain_zero(n, m, N, formulation
 # ----------------------------------------------------------------------------------------------
 # lax/equ MPC ADMM with vector rho and stage-wise bounds (no SCALAR_RHO, VAR_BOUNDS)
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["stream", "mfma4g"])
+@pytest.mark.parametrize("variant", ["stream", "mfma4g", "mfma4r"])  # mfma4r (round 5): the middle stages' row constants ride in admm_r's chunk stream
 @pytest.mark.parametrize("cfg_name,B,overrides", [("C1_lax_gen", 60, {}), ("C1_equ_gen", 40, dict(k_max=3000)), ("C2_lax_gen", 100, {}),
                                                   ("C2_lax_gen", 40, dict(tol=1e-6, k_max=3000))])
 def test_vector_rho_and_var_bounds_vs_oracle(variant, cfg_name, B, overrides):
@@ -1578,6 +1578,28 @@ def test_vector_rho_and_var_bounds_vs_oracle(variant, cfg_name, B, overrides):
     _compare(variant, s(x0, xr, ur), oracle.admm_banded_batch(v, x0, xr, ur), v, rerun=_rerun_admm(v, x0, xr, ur))
     with pytest.raises(Exception):
         s.set_variant("mfma4")  # the register-resident kernels take a scalar rho and constant bounds
+
+
+@pytest.mark.parametrize("cfg_name,B,overrides", [("C2_lax_N30_gen", 64, {}), ("C2_equ_N30_gen", 48, {}), ("C4_lax_ADMM_gen", 48, {}),
+                                                  ("C2_lax_N30_gen", 24, dict(tol=1e-6, k_max=3000))])
+def test_vector_rho_and_var_bounds_past_the_block_programs(cfg_name, B, overrides):
+    """Vector rho / VAR_BOUNDS (code_laxMPC_ADMM_C.c:323-348, 490-568) at shapes whose block program does not fit the LDS (n = 12 at N = 30,
+    n = 20 at N = 20): AUTO used to fall to MFMA4G (state through HBM); round 5: MFMA4R - admm_r in unit-box coordinates with the middle
+    stages' row constants riding in the chunk stream - is AUTO there.  Both against the oracle; the record-free run returns the same (u, k)."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    cfg, v, s = _solver(cfg_name, "auto", **overrides)
+    assert not v["rho_is_scalar"] and v["var_bounds"]
+    assert s.variant == "mfma4r", (s.variant, s.notes)
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    ref = oracle.admm_banded_batch(v, x0, xr, ur)
+    for variant in ("mfma4r", "mfma4g"):
+        s.set_variant(variant)
+        got = s(x0, xr, ur)
+        _compare(variant, got, ref, v, rerun=_rerun_admm(v, x0, xr, ur))
+        nosol = s(x0[:21], xr[:21], ur[:21], want_sol=False)
+        assert np.array_equal(nosol[0], got[0][:21]) and np.array_equal(nosol[1], got[1][:21])
+    s.close()
 
 
 @pytest.mark.parametrize("which", ["rho", "bounds"])

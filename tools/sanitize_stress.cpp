@@ -17,15 +17,15 @@
 #include <thread>
 #include <vector>
 
-typedef void *handle_t;
-static int (*p_selftest)(const char *, int, int, int *, unsigned long long *);
-static int (*p_stats)(long *, int);
-static int (*p_create)(const void *, size_t, int, handle_t *);
-static int (*p_destroy)(handle_t);
-static int (*p_create_multi)(const void *, size_t, const int *, int, handle_t *);
-static int (*p_multi_destroy)(handle_t);
-static int (*p_shard)(long, int, int, long *, long *);
-static const char *(*p_last_error)();
+#include "../include/spcies_hip.h"  // the prototypes only: every entry point is bound with dlsym (the sanitizer build is not the linked one)
+static decltype(&spcies_hip_rtc_cache_selftest) p_selftest;
+static decltype(&spcies_hip_rtc_cache_stats_ex) p_stats;
+static decltype(&spcies_hip_create) p_create;
+static decltype(&spcies_hip_destroy) p_destroy;
+static decltype(&spcies_hip_create_multi) p_create_multi;
+static decltype(&spcies_hip_multi_destroy) p_multi_destroy;
+static decltype(&spcies_hip_shard_range) p_shard;
+static decltype(&spcies_hip_last_error) p_last_error;
 
 template <class F>
 static void bind(void *lib, const char *name, F &f) {
@@ -82,7 +82,7 @@ int main(int argc, char **argv) {
                 // (b) the parser and the host packers behind create / create_multi (ENODEV = -2 after a clean parse; anything but a crash for a mutant)
                 if (!blobs.empty()) {
                     const std::string &b = blobs[rnd() % blobs.size()];
-                    handle_t h = nullptr;
+                    spcies_hip_handle h = nullptr;
                     int rc2 = p_create(b.data(), b.size(), 0, &h);
                     if (rc2 == 0) p_destroy(h);
                     else if (rc2 != -2) bad++;
@@ -92,7 +92,7 @@ int main(int argc, char **argv) {
                     rc2 = p_create(m.data(), m.size(), 0, &h);
                     if (rc2 == 0) p_destroy(h);
                     const int ids[2] = {0, 0};
-                    handle_t mh = nullptr;
+                    spcies_hip_multi_handle mh = nullptr;
                     rc2 = p_create_multi(b.data(), b.size(), ids, 2, &mh);
                     if (rc2 == 0) p_multi_destroy(mh);
                     creates += 3;
