@@ -699,10 +699,14 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
         const double *x0 = x0g + ii * n;
         const double *xr = p.ref_stride ? xrg + ii * n : xrg;
         const double *ur = p.ref_stride ? urg + ii * m : urg;
+        // (gs: the lane's row group laundered per group of instances - the set-up's row addresses into A, Q, R, T depend on the lane only and
+        // would otherwise be formed once in front of this loop and parked in scratch memory, soc_bsp.hpp)
+        int gs = g;
+        asm volatile("" : "+v"(gs));
         double bh[NBH_];
 #pragma unroll
         for (int I = 0; I < NBH_; I++) {
-            const int row = 4 * I + g;
+            const int row = 4 * I + gs;
             double v = 0.0;
             if (row < n)
                 for (int i = 0; i < n; i++) v -= cA[row * n + i] * x0[i];
@@ -712,14 +716,14 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
         double bt[NBT_];  // equMPC: b = xr in the last n rows
 #pragma unroll
         for (int I = 0; I < NBT_; I++) {
-            const int row = 4 * (BT_FIRST_ + I) + g - BT_ROW0_;
+            const int row = 4 * (BT_FIRST_ + I) + gs - BT_ROW0_;
             bt[I] = (row >= 0 && row < n) ? xr[row] : 0.0;
         }
 #endif
         double qv[NQ_], qTv[TSA_];
 #pragma unroll
         for (int u = 0; u < NQ_; u++) {
-            const int j = QROW_[u] + g;
+            const int j = QROW_[u] + gs;
             double v = 0.0;
             if (j < m) {
                 for (int i = 0; i < m; i++) v += cR[j * m + i] * ur[i];
@@ -735,7 +739,7 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
         }
 #pragma unroll
         for (int k = 0; k < TS_; k++) {
-            const int e = 4 * k + g;
+            const int e = 4 * k + gs;
             double v = 0.0;
             if (e < n)
                 for (int i = 0; i < n; i++) v += cT[e * n + i] * xr[i];

@@ -107,7 +107,6 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
             Dinv[j] = Dv[j];
         }
     }
-    const BlockList bG = blocks_of(G, RR, PR_), bHG = blocks_of(HG, PR_, RR), bH = blocks_of(H, PR_, PR_), bL = blocks_of(L, RR, RR);
     // ---- table + program text
     // scheduling fences every SEG_EVERY block rows / columns: without them the compiler hoists the LDS reads of whole phases
     // ring depth: measured at C5 with the split tail (ms, scratch B per lane): 4: 11.51 / 236, 8: 11.13 / 300, 12: 10.71 / 356, 16: 10.36 / 412,
@@ -185,9 +184,74 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
             bnd_of[J] = it->second;
         }
     }
+    // ---- q: slabs with the same row pattern share one register
+    std::map<std::vector<int>, int> sig_index;
+    std::vector<int> qi(ZS), qrow;
+    auto row_type = [&](int r) {  // 0: zero; 1 + j: (R ur)_j; 1000 + j: (Q xr)_j; 2000 + j: (T xr)_j
+        if (r >= dim) return 0;
+        if (r < m) return 1 + r;
+        if (r < m + (N - 1) * nm) { const int e = (r - m) % nm; return e < n ? 1000 + e : 1 + (e - n); }
+        if (r < m + (N - 1) * nm + n) return 2000 + (r - m - (N - 1) * nm);
+        return 0;
+    };
+    for (int J = 0; J < ZS; J++) {
+        std::vector<int> sig = {row_type(4 * J), row_type(4 * J + 1), row_type(4 * J + 2), row_type(4 * J + 3)};
+        auto it = sig_index.find(sig);
+        if (it == sig_index.end()) {
+            it = sig_index.emplace(sig, (int)qrow.size()).first;
+            qrow.push_back(4 * J);
+        }
+        qi[J] = it->second;
+    }
     int bnd_regs_max = 16;
     if (const char *ev = getenv("SPCIES_BSP_BND_REGS")) bnd_regs_max = atoi(ev);
     const bool bnd_in_regs = use_sched && (int)bnd_slab.size() <= bnd_regs_max;
+    // ---- unit-box coordinates for the z slabs whose four rows have a finite box around 0 (admm_mfma4u.hpp's algebra, round 5): per row
+    // D = ub - lb, w' = (w - lb) / D, state w^ = w' + kappa, kappa = q / (sigma D) - lb / D:  c' = clamp01(w^ - kappa) (the hardware's [0, 1]
+    // output modifier), s = w^ - 2 c', q_hat = sigma D s - sigma D folded into the columns of G and H, 1 / D into the rows of H and HG, -lb / D
+    // seeds the row's accumulator - and w^+ = z_hat' + (w^ - c'): 6 vector instructions per slab and iteration instead of 10.  The other z
+    // slabs (free terminal rows, pads, mixed slabs) and the cone slabs keep the plain form.  Scheduled programs only; SPCIES_BSP_UNIT=0: off.
+    std::vector<char> unit(ZS, 0);
+    const bool unit_on = !p.legacy_order && !(getenv("SPCIES_BSP_SCHED") && getenv("SPCIES_BSP_SCHED")[0] == '0') &&
+                         !(getenv("SPCIES_BSP_UNIT") && getenv("SPCIES_BSP_UNIT")[0] == '0');
+    int n_unit = 0;
+    for (int J = 0; J < ZS && unit_on && bnd_in_regs; J++) {
+        bool ok = true;
+        for (int r = 4 * J; r < 4 * J + 4; r++) {
+            if (r >= dim - n - 1) { ok = false; break; }
+            const double lo = F[c.LB + r], hi = F[c.UB + r];
+            if (!(std::isfinite(lo) && std::isfinite(hi)) || !(lo <= 0.0 && hi >= 0.0) || !(hi - lo > 1e-9) || hi - lo > 1e5) { ok = false; break; }
+        }
+        unit[J] = ok;
+        n_unit += ok;
+    }
+    for (int J = 0; J < ZS; J++)
+        if (unit[J])
+            for (int r = 4 * J; r < 4 * J + 4; r++) {
+                const double D = F[c.UB + r] - F[c.LB + r], sD = c.sigma * D;
+                for (int i = 0; i < RR; i++) G[(size_t)i * PR_ + r] *= sD;
+                for (int i = 0; i < PR_; i++) H[(size_t)i * PR_ + r] *= sD;
+            }
+    for (int J = 0; J < ZS; J++)
+        if (unit[J])
+            for (int r = 4 * J; r < 4 * J + 4; r++) {
+                const double D = F[c.UB + r] - F[c.LB + r];
+                for (int j = 0; j < PR_; j++) H[(size_t)r * PR_ + j] /= D;
+                for (int j = 0; j < RR; j++) HG[(size_t)r * RR + j] /= D;
+            }
+    const BlockList bG = blocks_of(G, RR, PR_), bHG = blocks_of(HG, PR_, RR), bH = blocks_of(H, PR_, PR_), bL = blocks_of(L, RR, RR);
+    // (unit-box) kappa is per instance and per (q pattern, bound pattern) of a slab: one register per distinct combination
+    std::vector<int> kap_of(ZS, -1), kap_q, kap_b;
+    {
+        std::map<std::pair<int, int>, int> combo;
+        for (int J = 0; J < ZS; J++) {
+            if (!unit[J]) continue;
+            auto key = std::make_pair(qi[J], bnd_of[J]);
+            auto it = combo.find(key);
+            if (it == combo.end()) { it = combo.emplace(key, (int)kap_q.size()).first; kap_q.push_back(qi[J]); kap_b.push_back(bnd_of[J]); }
+            kap_of[J] = it->second;
+        }
+    }
     std::vector<double> kreg_blocks;  // (scheduled program) the register-resident blocks, 16 doubles each in A-operand order
     std::vector<int> bh_slabs;  // slabs of the right-hand side that hold a row of bh: -A x0, r, -PhiP xr (:97-131)
     std::map<int, int> saved;   // (row-order program) slab -> index into sv[]
@@ -243,6 +307,11 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
                     P.stmt(sched::K_VALU, F_("double wp_%d = w[%d]; asm volatile(\"\" : \"+v\"(wp_%d));", J, J, J), "", {w}, {wx}, 0, false);
                 }
                 const std::string wv = prim ? wx : w;
+                if (unit[J]) {  // c' = clamp01(w^ - kappa) (v_add_f64 ... clamp), s = w^ - 2 c': the operand of the column-scaled blocks
+                    P.stmt(sched::K_VALU, F_("const double %s = fmin(fmax(%s - kapv[%d], 0.0), 1.0);", cc.c_str(), wx.c_str(), kap_of[J]), "", {wv}, {cc}, 1);
+                    P.stmt(sched::K_VALU, F_("const double %s = __builtin_fma(-2.0, %s, %s);", q.c_str(), cc.c_str(), wx.c_str()), "", {cc, wv}, {q}, 1);
+                    return;
+                }
                 if (bnd_in_regs) {  // (plain aliases: no instruction)
                     P.stmt(sched::K_VALU, F_("const double %s = lbv[%d], %s = ubv[%d];", lb.c_str(), bnd_of[J], ub.c_str(), bnd_of[J]), "", {}, {lb, ub}, 0, false);
                 } else {
@@ -345,6 +414,10 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
         auto prim_row = [&](int Ib, const std::string &acc) {
             bool first = true;
             for (int J : bH.by_row[Ib]) need_qp(J);
+            if (Ib < ZS && unit[Ib]) {  // z_hat' = (z_hat - lb) / D: the row's accumulator starts at -lb / D (no instruction: the first product's C operand)
+                P.stmt(sched::K_VALU, F_("double %s = na3v[%d];", acc.c_str(), bnd_of[Ib]), "", {}, {acc}, 0, false);
+                first = false;
+            }
             for (int J : bH.by_row[Ib]) {
                 double blk[16];
                 block_of(H, PR_, Ib, J, blk);
@@ -376,6 +449,24 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
             const std::string full =
                 F_("{ const double wn_ = ph_%d + dp_%d, z_ = fmin(fmax(wn_, lbp_%d), ubp_%d); w[%d] = wn_; rd_ = fmax(rd_, fabs(cp_%d - z_)); "
                    "rp_ = fmax(rp_, fabs(z_ - ph_%d)); asm volatile(\"\" : \"+v\"(rd_), \"+v\"(rp_)); }", Ib, Ib, Ib, Ib, Ib, Ib, Ib) + store;
+            if (unit[Ib]) {  // residuals in the caller's coordinates (x D); the record's z_hat = lb + D z_hat'
+                const std::string ustore = F_(" if (WANT_SOL) *(zhp + 4 * %d) = __builtin_fma(dv[%d], ph_%d, lbv[%d]);", Ib, bnd_of[Ib], Ib, bnd_of[Ib]);
+                const std::string ulight = F_("w[%d] = ph_%d + dp_%d;", Ib, Ib, Ib) + ustore;
+                const std::string ufull0 =
+                    F_("{ const double wn_ = ph_%d + dp_%d, z_ = fmin(fmax(wn_ - kapv[%d], 0.0), 1.0), D_ = dv[%d]; w[%d] = wn_; "
+                       "res |= (fabs(cp_%d - z_) * D_ > tol_d) | (fabs(z_ - ph_%d) * D_ > tol_p); }", Ib, Ib, kap_of[Ib], bnd_of[Ib], Ib, Ib, Ib) + ustore;
+                const std::string ufull =
+                    F_("{ const double wn_ = ph_%d + dp_%d, z_ = fmin(fmax(wn_ - kapv[%d], 0.0), 1.0), D_ = dv[%d]; w[%d] = wn_; "
+                       "rd_ = fmax(rd_, fabs(cp_%d - z_) * D_); rp_ = fmax(rp_, fabs(z_ - ph_%d) * D_); asm volatile(\"\" : \"+v\"(rd_), \"+v\"(rp_)); }",
+                       Ib, Ib, kap_of[Ib], bnd_of[Ib], Ib, Ib, Ib) + ustore;
+                if (Ib == 0) {
+                    P.stmt(sched::K_VALU, ufull0, "", {ph, dd, cc}, {w, "res"}, 8);
+                    P.mark = P.stmt(sched::K_MARK, "", "", {"res"}, {"branch"}, 2, false);
+                } else {
+                    P.stmt(sched::K_VALU, ulight, ufull, {ph, dd, cc, "branch"}, {w}, 1);
+                }
+                return;
+            }
             if (Ib == 0) {
                 P.stmt(sched::K_VALU, full0, "", {ph, dd, cc, lb, ub}, {w, "res"}, 8);
                 // one wave-uniform branch: once the first slab's check has put every instance of the wavefront above its tolerance no
@@ -808,25 +899,6 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     if (lds_bytes > 160 * 1024 - 1024 || p.n_blocks > 1536) { p.why = "block table exceeds the LDS"; return 0; }
     if (p.n_blocks <= PF) { p.why = "fewer blocks than the prefetch ring"; return 0; }
     if (NR + ZS + 2 * SS > 190) { p.why = "state does not fit the register file"; return 0; }
-    // ---- q: slabs with the same row pattern share one register
-    std::map<std::vector<int>, int> sig_index;
-    std::vector<int> qi(ZS), qrow;
-    auto row_type = [&](int r) {  // 0: zero; 1 + j: (R ur)_j; 1000 + j: (Q xr)_j; 2000 + j: (T xr)_j
-        if (r >= dim) return 0;
-        if (r < m) return 1 + r;
-        if (r < m + (N - 1) * nm) { const int e = (r - m) % nm; return e < n ? 1000 + e : 1 + (e - n); }
-        if (r < m + (N - 1) * nm + n) return 2000 + (r - m - (N - 1) * nm);
-        return 0;
-    };
-    for (int J = 0; J < ZS; J++) {
-        std::vector<int> sig = {row_type(4 * J), row_type(4 * J + 1), row_type(4 * J + 2), row_type(4 * J + 3)};
-        auto it = sig_index.find(sig);
-        if (it == sig_index.end()) {
-            it = sig_index.emplace(sig, (int)qrow.size()).first;
-            qrow.push_back(4 * J);
-        }
-        qi[J] = it->second;
-    }
     // ---- source
     std::string s;
     auto def = [&](const char *name, long v) { snprintf(line, sizeof(line), "#define %s %ld\n", name, v); s += line; };
@@ -850,6 +922,19 @@ inline int build_soc(Plan &p, const SocDev &c, const double *F, const int *I, in
     def("BND_IN_REGS_", bnd_in_regs ? 1 : 0);
     s += "static __device__ const int BNDSLAB_[NBND_] = {";
     for (size_t i = 0; i < (bnd_in_regs ? bnd_slab.size() : (size_t)1); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", bnd_slab[i]); s += line; }
+    s += "};\n";
+    def("NKAP_", (long)kap_q.size());
+    if (!kap_q.empty()) {
+        s += "static __device__ const int KAPQ_[NKAP_] = {";
+        for (size_t i = 0; i < kap_q.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", kap_q[i]); s += line; }
+        s += "};\nstatic __device__ const int KAPB_[NKAP_] = {";
+        for (size_t i = 0; i < kap_b.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", kap_b[i]); s += line; }
+        s += "};\n";
+    }
+    s += "static __device__ const int KIA_[ZS_] = {";  // slab -> its kappa register (-1: plain coordinates)
+    for (int J = 0; J < ZS; J++) { snprintf(line, sizeof(line), "%s%d", J ? ", " : "", kap_of[J]); s += line; }
+    s += "};\nstatic __device__ const int BIA_[ZS_] = {";  // slab -> its bound pattern
+    for (int J = 0; J < ZS; J++) { snprintf(line, sizeof(line), "%s%d", J ? ", " : "", bnd_in_regs ? bnd_of[J] : 0); s += line; }
     s += "};\n";
     def("NBH_", (long)bh_slabs.size());
     s += "static __device__ const int BHSLAB_[NBH_] = {";
@@ -927,11 +1012,15 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
         const double *xr = p.ref_stride ? xrg + ii * n : xrg;
         const double *ur = p.ref_stride ? urg + ii * m : urg;
         const double r_ellip = rg[p.r_stride ? ii : 0];
-        // per-instance constants: bh (rows of the right-hand side), q (one register per distinct slab pattern)
+        // per-instance constants: bh (rows of the right-hand side), q (one register per distinct slab pattern).  (gs: the lane's row group,
+        // laundered per group of instances - the rows' addresses into A, Q, R, T, PhiP depend on the lane only, and left alone the compiler
+        // forms all ~60 of them once in front of this loop and parks them in scratch memory for the whole launch: 488 B per lane)
+        int gs = g;
+        asm volatile("" : "+v"(gs));
         double bh[NBH_];
 #pragma unroll
         for (int I = 0; I < NBH_; I++) {
-            const int row = 4 * BHSLAB_[I] + g;
+            const int row = 4 * BHSLAB_[I] + gs;
             double v = 0.0;
             if (row < n) {
                 for (int i = 0; i < n; i++) v -= cA[row * n + i] * x0[i];
@@ -946,7 +1035,7 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
         double qv[NQ_];
 #pragma unroll
         for (int u = 0; u < NQ_; u++) {
-            const int j = QROW_[u] + g;
+            const int j = QROW_[u] + gs;
             double v = 0.0;
             if (j < m) {
                 for (int i = 0; i < m; i++) v += cR[j * m + i] * ur[i];
@@ -980,6 +1069,31 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
             lbv[u] = ldsr[4 * BNDSLAB_[u] + g];
             ubv[u] = ldsr[4 * ZS_ + 4 * BNDSLAB_[u] + g];
         }
+#endif
+#if NKAP_ > 0  // unit-box slabs: kappa = q / (sigma D) - lb / D per (q pattern, bound pattern), -lb / D per bound pattern; w = 0 is w^ = kappa - lb / D
+        double kapv[NKAP_], na3v[NBND_], dv[NBND_];  // (dv: the checked path's residuals and the record, in the caller's coordinates)
+#pragma unroll
+        for (int u = 0; u < NBND_; u++) {
+            const double D_ = ubv[u] - lbv[u];
+            dv[u] = D_;
+            na3v[u] = (D_ > 0.0 && D_ < 1e6) ? -lbv[u] / D_ : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NKAP_; u++) {
+            const double D_ = ubv[KAPB_[u]] - lbv[KAPB_[u]];
+            kapv[u] = qv[KAPQ_[u]] / (sigma * D_) + na3v[KAPB_[u]];
+        }
+#pragma unroll
+        for (int I = 0; I < ZS_; I++)
+            if (KIA_[I] >= 0) w[I] = kapv[KIA_[I]] + na3v[BIA_[I]];
+#endif
+        // z of slab I and w - z (= lambda / sigma) in the caller's coordinates from the state (exit, record: cold)
+#if NKAP_ > 0
+#define ZOF_(I) (KIA_[I] >= 0 ? __builtin_fma(UBR(I) - LBR(I), fmin(fmax(w[I] - kapv[KIA_[I] >= 0 ? KIA_[I] : 0], 0.0), 1.0), LBR(I)) : fmin(fmax(w[I], LBR(I)), UBR(I)))
+#define WOF_(I) (KIA_[I] >= 0 ? __builtin_fma(UBR(I) - LBR(I), w[I] - kapv[KIA_[I] >= 0 ? KIA_[I] : 0], LBR(I)) : w[I])
+#else
+#define ZOF_(I) fmin(fmax(w[I], LBR(I)), UBR(I))
+#define WOF_(I) w[I]
 #endif
 #ifdef EARLY_BOUNDS_  // the slab's bounds were read at the top of its block (lbx, ubx)
 #define BND_LB(I) lbx
@@ -1093,16 +1207,16 @@ __device__ __forceinline__ void soc_bsp_body(const Args &p, const double *__rest
                         k_out[inst] = kk;
                         e_out[inst] = res_inst ? -1 : 1;
                     }
-                    if (g < m) u_out[inst * m + g] = fmin(fmax(w[0], LBR(0)), UBR(0));  // u = z[0 .. m)  (m <= 4: inside slab 0)
+                    if (g < m) u_out[inst * m + g] = ZOF_(0);  // u = z[0 .. m)  (m <= 4: inside slab 0)
                     if (WANT_SOL) {
                         double *zp = f0 + inst * dim + g, *lp = f4 + inst * dim + g, *sp = f1 + inst * n_s + g, *mp = f5 + inst * n_s + g;
 #pragma unroll
                         for (int I = 0; I < ZS_; I++)
                         {
                             const bool in_ = 4 * I + 3 < DIM_ || 4 * I + g < DIM_;
-                            const double z_ = fmin(fmax(w[I], LBR(I)), UBR(I));
+                            const double z_ = ZOF_(I);
                             *(in_ ? zp + 4 * I : dump) = z_;
-                            *(in_ ? lp + 4 * I : dump) = sigma * (w[I] - z_);
+                            *(in_ ? lp + 4 * I : dump) = sigma * (WOF_(I) - z_);
                         }
 #pragma unroll
                         for (int k = 0; k < SS_; k++)

@@ -178,7 +178,10 @@ def test_admm_r_kernels_compile_with_the_flags_the_library_uses(tmp_path):
     src = open(os.path.join(here, "spcies_amd", "csrc", "admm_r_kernel.inc")).read()
     sig = "(Args, const double *, const double *, const double *, const double *, double *, int *, int *, double *, double *, double *, double *, double *)"
     src += "\nnamespace spcies { namespace ar {\n"
-    for targs in ("30, 3, 4, false, true, 4, 70", "20, 5, 6, false, false, 4, 56"):
+    # <N, KX, KS, TERMINAL, WANT_SOL, NW, NLDS, UNIT, GEN>: the two round-4 instantiations in plain coordinates, and the round-5 forms (unit-box
+    # coordinates; vector rho / stage-wise bounds with the row constants in the chunk stream)
+    for targs in ("30, 3, 4, false, true, 4, 69, false, false", "20, 5, 6, false, false, 4, 55, false, false",
+                  "30, 3, 4, true, true, 4, 69, true, false", "20, 5, 6, true, false, 4, 53, true, true"):
         src += f"template __global__ void admm_r_kernel<{targs}>{sig};\n"
     src += "}}\n"
     p = tmp_path / "admm_r_check.hip"
@@ -190,7 +193,7 @@ def test_admm_r_kernels_compile_with_the_flags_the_library_uses(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     notes = subprocess.run([READELF, "--notes", str(co)], capture_output=True, text=True).stdout
     lds = [int(x) for x in re.findall(r"\.group_segment_fixed_size:\s+(\d+)", notes)]
-    assert len(lds) == 2 and max(lds) <= 160 * 1024
+    assert len(lds) == 4 and max(lds) <= 160 * 1024
 
 
 @pytest.mark.parametrize("family,inst", [("admm", "admm_stream_kernel<7, 3, true, true>"), ("fista", "fista_stream_kernel<7, 3, false, true>"),

@@ -64,7 +64,7 @@ int main(int argc, char **argv) {
                 // (a) the cache: a handful of keys shared by all threads, some big (eviction / pruning), some slow (in-flight sharing)
                 const int keyid = (int)(rnd() % 12);
                 std::string text = "stress key " + std::to_string(keyid) + " ";
-                if (keyid % 3 == 0) text.append(200000, (char)('a' + keyid));
+                if (keyid % 3 == 0) text.append(400000, (char)('a' + keyid));
                 int src = -1;
                 unsigned long long chk = 0;
                 const int rc = p_selftest(text.c_str(), keyid % 4 == 1 ? 3 : 0, (int)(rnd() % 7 == 0), &src, &chk);
