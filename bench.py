@@ -71,7 +71,7 @@ def traffic_from_profile(variant):
     profiles/rNN_<variant>_pmc_summary.txt: separate FETCH_SIZE / WRITE_SIZE runs of this same command), corrected as
     MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE x 2 on gfx950, values in KB.  Returns (bytes, file) -
     a constant read from the repository, NOT a measurement of the run that prints it (`traffic_source` says so)."""
-    for stem in (f"r04_C2_{variant}", f"r03_C2_{variant}", f"r02_C2_{variant}", f"r02_{variant}", f"r01_{variant}"):
+    for stem in (f"r05_C2_{variant}", f"r04_C2_{variant}", f"r03_C2_{variant}", f"r02_C2_{variant}", f"r02_{variant}", f"r01_{variant}"):
         path = os.path.join(ROOT, "profiles", f"{stem}_pmc_summary.txt")
         if not os.path.exists(path):
             continue
@@ -89,14 +89,15 @@ def traffic_from_profile(variant):
     return None, None
 
 
-_PROFILE_TAG = {"C3": "C3", "C4": "C4", "C5_soc": "C5soc", "C5_hmpc": "C5hmpc", "C2_tv": "C2tv", "C2_tv_fista": "C2tvfista"}
+_PROFILE_TAG = {"C3": "C3", "C4": "C4", "C4_nd": "C4nd", "C2_N30": "C2N30", "C2_N30_gen": "C2N30gen", "C5_soc": "C5soc", "C5_hmpc": "C5hmpc", "C2_tv": "C2tv",
+                "C2_tv_fista": "C2tvfista"}
 
 
 def design_traffic(key, variant):
     """HBM bytes per launch of a configuration's kernel from its committed rocprofv3 PMC passes (profiles/rNN_<config>_<variant>_pmc_summary.txt,
     newest round first; FETCH_SIZE x 2 + WRITE_SIZE, KB) - the DESIGN traffic, a constant read from the repository like `roofline.traffic`
     above.  Only a profile of the SAME variant counts."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{_PROFILE_TAG.get(key, key)}_{variant}_pmc_summary.txt")
         if not os.path.exists(path):
             continue

@@ -23,9 +23,15 @@ SLOW = {
     "test_mpct_general_qr_seeded_batch_vs_oracle[C4_nd-40-overrides2-stream]": 18.0,
     "test_mpct_seeded_batch_vs_oracle[stream-C4-70-overrides2]": 15.3,
     "test_hip_time_varying_fista_vs_oracle[C2_equ_FISTA-50-overrides3-stream]": 9.1,
+    "test_mpct_general_qr_seeded_batch_vs_oracle[C4_nd-90-overrides1-stream]": 7.4,
+    "test_hmpc_coupled_split_vs_oracle[stream-C1_HMPCcc_soc-33]": 6.8,
+    "test_hmpc_coupled_split_vs_oracle[stream-C1_HMPCcc-40]": 6.5,
+    "test_mpct_cs_seeded_batch_vs_oracle[stream-C1_MPCT_cs_vec-40-overrides1]": 5.6,
+    "test_vector_rho_and_var_bounds_past_the_block_programs[C2_lax_N30_gen-24-overrides3]": 10.0,
     "test_admm_past_the_register_file_vs_oracle[C2_equ_N30-40-overrides1]": 8.8,
     # arbitrary-shape sweeps: the largest shape of each (a fresh hiprtc specialisation of 5-10 s); the other shapes stay
     "test_time_varying_any_plant_size[13-3-5-laxMPC-ADMM]": 12.6,
+    "test_time_varying_any_plant_size[10-4-7-laxMPC-FISTA]": 6.1,
     "test_mfma4r_plants_with_many_inputs_or_up_to_32_rows[26-3-5-admm]": 8.0,
     "test_admm_r_arbitrary_shapes[18-3-9-laxMPC]": 7.9,
     "test_mfma4r_plants_with_many_inputs_or_up_to_32_rows[26-3-5-fista]": 5.7,
