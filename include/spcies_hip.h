@@ -317,6 +317,11 @@ int spcies_hip_rtc_cache_stats_ex(long *out, int n);
  * (work_ms < 0: fails) and returns bytes that depend on `text` only.  *source: 0 memory, 1 disk, 2 compiled; *checksum of the
  * code object handed back; drop_memory != 0 empties the in-memory cache first.  tests/test_rtc_disk_cache.py. */
 int spcies_hip_rtc_cache_selftest(const char *text, int work_ms, int drop_memory, int *source, unsigned long long *checksum);
+/* Test hook of the compiler process (spcies_amd/spcies_rtc_helper, rtc_helper.cpp: since round 5 hiprtc runs in a process of its own,
+ * so that a compiler crash fails one build instead of taking the caller down; SPCIES_HIP_RTC_ISOLATE=0 compiles in-process).  Compiles
+ * `src` - which must define `extern "C" __global__ void selftest_kernel(...)` - for gfx950 in the helper, bypassing both caches, without
+ * loading the result (no device needed).  *isolated = 1 when the helper did it, 0 when no helper is available (then SPCIES_HIP_ENOSUP). */
+int spcies_hip_rtc_compile_selftest(const char *src, int *isolated, unsigned long *code_bytes);
 
 /* Batch statistics of a solve (the batch counterpart of the dense MATLAB solvers' genHist record,
  * platforms/Matlab/spcies_laxMPC_ADMM_solver.m:253-261): k, e_flag are DEVICE arrays [B] as a device solve left them;

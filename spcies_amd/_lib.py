@@ -17,7 +17,7 @@ EXPORTS = (
     "spcies_hip_get_sol_layout", "spcies_hip_solve_batch_ex", "spcies_hip_solve_batch_device_ex",
     "spcies_hip_closed_loop",
     "spcies_hip_shard_range", "spcies_hip_create_multi", "spcies_hip_multi_destroy", "spcies_hip_multi_count", "spcies_hip_multi_get",
-    "spcies_hip_get_extra_width", "spcies_hip_host_alloc", "spcies_hip_host_free", "spcies_hip_rtc_cache_stats", "spcies_hip_rtc_cache_stats_ex", "spcies_hip_rtc_cache_selftest", "spcies_hip_residual_trace",
+    "spcies_hip_get_extra_width", "spcies_hip_host_alloc", "spcies_hip_host_free", "spcies_hip_rtc_cache_stats", "spcies_hip_rtc_cache_stats_ex", "spcies_hip_rtc_cache_selftest", "spcies_hip_rtc_compile_selftest", "spcies_hip_residual_trace",
     "spcies_hip_k_histogram_device",
     "spcies_hip_get_notes", "spcies_hip_multi_set_variant", "spcies_hip_multi_set_exit", "spcies_hip_multi_solve_batch", "spcies_hip_multi_solve_batch_ex",
 )
@@ -83,6 +83,7 @@ def load():
     lib.spcies_hip_residual_trace.argtypes = [vp, dp, dp, dp, C.c_int, C.c_long, C.c_int, dp, dp, ip]
     lib.spcies_hip_rtc_cache_stats_ex.argtypes = [lp, C.c_int]
     lib.spcies_hip_rtc_cache_selftest.argtypes = [C.c_char_p, C.c_int, C.c_int, ip, C.POINTER(C.c_ulonglong)]
+    lib.spcies_hip_rtc_compile_selftest.argtypes = [C.c_char_p, ip, C.POINTER(C.c_ulong)]
     lib.spcies_hip_k_histogram_device.argtypes = [vp, vp, vp, C.c_long, C.c_int, lp, lp, vp]
     lib.spcies_hip_shard_range.argtypes = [C.c_long, C.c_int, C.c_int, lp, lp]
     lib.spcies_hip_create_multi.argtypes = [C.c_char_p, C.c_size_t, ip, C.c_int, C.POINTER(vp)]

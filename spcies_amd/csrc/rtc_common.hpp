@@ -4,6 +4,10 @@
 #include <dlfcn.h>
 #include <limits.h>
 #include <link.h>
+#include <poll.h>
+#include <signal.h>
+#include <spawn.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <functional>
@@ -13,6 +17,7 @@
 
 #include <sys/stat.h>
 
+#include "../../include/spcies_hip.h"
 #include "code_cache.hpp"
 #include "common.hpp"
 
@@ -170,6 +175,177 @@ inline std::vector<std::string> split_flags(const char *ev) {  // blank-separate
     return out;
 }
 
+// ---- the compiler in a process of its own (rtc_helper.cpp; SPCIES_HIP_RTC_ISOLATE=0: in-process as before) -----------------------------
+// One helper per process, started at the first compilation that misses both caches and kept until the library is unloaded (its stdin
+// closes: it exits).  Requests are serialised by rtc_mutex().  A helper that dies mid-request (compiler crash) fails THAT build - the caller's
+// process goes on, AUTO falls back - and the next request starts a fresh one.  No helper binary next to the library: in-process.
+struct HelperProc {
+    pid_t pid = -1;
+    int to = -1, from = -1;
+    bool looked = false;
+    std::string path;
+    ~HelperProc() { stop(); }
+    void stop() {
+        if (to >= 0) close(to);
+        if (from >= 0) close(from);
+        to = from = -1;
+        if (pid > 0) {
+            int st = 0;
+            for (int i = 0; i < 200 && waitpid(pid, &st, WNOHANG) == 0; i++) usleep(5000);  // (stdin closed: it leaves by itself)
+            if (waitpid(pid, &st, WNOHANG) == 0) { kill(pid, SIGKILL); waitpid(pid, &st, 0); }
+        }
+        pid = -1;
+    }
+    bool find() {
+        if (looked) return !path.empty();
+        looked = true;
+        if (const char *ev = getenv("SPCIES_HIP_RTC_ISOLATE"))
+            if (ev[0] == '0') return false;
+        if (const char *ev = getenv("SPCIES_HIP_RTC_HELPER")) {
+            if (access(ev, X_OK) == 0) path = ev;
+            return !path.empty();
+        }
+        Dl_info info;
+        if (!dladdr((void *)&spcies_hip_abi_version, &info) || !info.dli_fname) return false;
+        char real[PATH_MAX];
+        const std::string lib = realpath(info.dli_fname, real) ? real : info.dli_fname;
+        const std::string cand = lib.substr(0, lib.rfind('/') + 1) + "spcies_rtc_helper";
+        if (access(cand.c_str(), X_OK) == 0) path = cand;
+        return !path.empty();
+    }
+    bool start() {
+        if (pid > 0) return true;
+        int a[2], b[2];
+        if (pipe2(a, O_CLOEXEC) != 0) return false;
+        if (pipe2(b, O_CLOEXEC) != 0) { close(a[0]); close(a[1]); return false; }
+        posix_spawn_file_actions_t fa;
+        posix_spawn_file_actions_init(&fa);
+        posix_spawn_file_actions_adddup2(&fa, a[0], 0);  // (dup2 clears O_CLOEXEC on the new descriptor; every other one closes at exec)
+        posix_spawn_file_actions_adddup2(&fa, b[1], 1);
+        char *argv[] = {const_cast<char *>(path.c_str()), nullptr};
+        pid_t child = -1;
+        const int rc = posix_spawn(&child, path.c_str(), &fa, nullptr, argv, environ);
+        posix_spawn_file_actions_destroy(&fa);
+        close(a[0]);
+        close(b[1]);
+        if (rc != 0) { close(a[1]); close(b[0]); return false; }
+        pid = child;
+        to = a[1];
+        from = b[0];
+        return true;
+    }
+    static bool wr(int fd, const void *p, size_t n) {
+        const char *c = static_cast<const char *>(p);
+        while (n) {
+            const ssize_t r = write(fd, c, n);
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) return false;
+            c += r;
+            n -= (size_t)r;
+        }
+        return true;
+    }
+    static bool rd(int fd, void *p, size_t n, int timeout_s) {
+        char *c = static_cast<char *>(p);
+        while (n) {
+            struct pollfd pf{fd, POLLIN, 0};
+            const int pr = poll(&pf, 1, timeout_s * 1000);
+            if (pr < 0 && errno == EINTR) continue;
+            if (pr <= 0) return false;
+            const ssize_t r = read(fd, c, n);
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) return false;
+            c += r;
+            n -= (size_t)r;
+        }
+        return true;
+    }
+};
+inline HelperProc &helper_proc() {
+    static HelperProc h;
+    return h;
+}
+// 1: compiled by the helper (out filled); 0: no helper - compile in-process; -1: failed (g_last_error set)
+inline int compile_in_helper(const std::string &hiprtc_path, const char *src, const char *fname, const std::vector<std::string> &names,
+                             const std::vector<std::string> &opts, bool names_are_symbols, CodeObject &out) {
+    HelperProc &h = helper_proc();
+    if (!h.find() || hiprtc_path.empty()) return 0;
+    struct sigaction ign{}, old{};
+    ign.sa_handler = SIG_IGN;  // a helper that died must not kill the caller with SIGPIPE when the next request is written
+    sigaction(SIGPIPE, &ign, &old);
+    struct Restore { struct sigaction *o; ~Restore() { sigaction(SIGPIPE, o, nullptr); } } restore{&old};
+    if (!h.start()) return 0;
+    std::vector<char> req;
+    auto u32 = [&](uint32_t v) { req.insert(req.end(), (char *)&v, (char *)&v + 4); };
+    auto u64 = [&](uint64_t v) { req.insert(req.end(), (char *)&v, (char *)&v + 8); };
+    auto str = [&](const std::string &s) { u64(s.size()); req.insert(req.end(), s.begin(), s.end()); };
+    req.insert(req.end(), "SPCSRQ01", "SPCSRQ01" + 8);
+    str(hiprtc_path);
+    str(fname);
+    u32((uint32_t)opts.size());
+    for (const std::string &o : opts) str(o);
+    u32((uint32_t)names.size());
+    for (const std::string &n : names) str(n);
+    u32(names_are_symbols ? 1u : 0u);
+    str(src);
+    const uint64_t bytes = req.size();
+    uint64_t rb = 0;
+    std::vector<char> resp;
+    int timeout_s = 900;
+    if (const char *ev = getenv("SPCIES_HIP_RTC_TIMEOUT_S")) timeout_s = std::max(1, atoi(ev));
+    bool ok = HelperProc::wr(h.to, &bytes, 8) && HelperProc::wr(h.to, req.data(), req.size()) && HelperProc::rd(h.from, &rb, 8, timeout_s);
+    if (ok && rb >= 8 && rb < (1ull << 31)) {
+        resp.resize((size_t)rb);
+        ok = HelperProc::rd(h.from, resp.data(), resp.size(), timeout_s);
+    } else {
+        ok = false;
+    }
+    if (!ok) {  // the compiler process died (or hung past the limit): this build fails, the caller lives
+        int st = 0;
+        const pid_t pid = h.pid;
+        if (pid > 0 && waitpid(pid, &st, WNOHANG) == 0) { kill(pid, SIGKILL); waitpid(pid, &st, 0); }
+        h.pid = -1;
+        h.stop();
+        if (WIFSIGNALED(st))
+            return fail(SPCIES_HIP_EHIP, "hiprtc: the compiler process died with signal %d while compiling %s (the caller's process is unharmed; "
+                                         "this variant counts as a failed build)", WTERMSIG(st), fname), -1;
+        return fail(SPCIES_HIP_EHIP, "hiprtc: the compiler process ended (status %d) or did not answer within %d s while compiling %s", st, timeout_s, fname), -1;
+    }
+    size_t at = 0;
+    auto g32 = [&]() { uint32_t v = 0; if (at + 4 <= resp.size()) memcpy(&v, resp.data() + at, 4); at += 4; return v; };
+    auto gstr = [&]() {
+        uint64_t n = 0;
+        if (at + 8 <= resp.size()) memcpy(&n, resp.data() + at, 8);
+        at += 8;
+        std::string s;
+        if (at + n <= resp.size()) s.assign(resp.data() + at, (size_t)n);
+        at += (size_t)n;
+        return s;
+    };
+    if (resp.size() < 8 || memcmp(resp.data(), "SPCSRS01", 8) != 0) return fail(SPCIES_HIP_EHIP, "hiprtc helper: malformed response"), -1;
+    at = 8;
+    const uint32_t rc = g32();
+    const std::string log = gstr();
+    if (rc != 0) return fail(SPCIES_HIP_EHIP, "%.460s", log.c_str()), -1;
+    const uint32_t nl = g32();
+    out.lowered.clear();
+    for (uint32_t i = 0; i < nl; i++) out.lowered.push_back(gstr());
+    const std::string code = gstr();
+    if (at > resp.size() || code.empty()) return fail(SPCIES_HIP_EHIP, "hiprtc helper: truncated response"), -1;
+    out.code.assign(code.begin(), code.end());
+    return 1;
+}
+// path of the libhiprtc the binding resolved (what the helper is told to load)
+inline std::string hiprtc_library_path() {
+    Hiprtc &rt = hiprtc();
+    Dl_info info;
+    if (rt.create && dladdr((void *)rt.create, &info) && info.dli_fname) {
+        char real[PATH_MAX];
+        return realpath(info.dli_fname, real) ? real : info.dli_fname;
+    }
+    return "";
+}
+
 // Compile `src` for gfx950 - or take the code object from the process's cache or the on-disk cache (code_cache.hpp) - and load it
 // on the current device: `names` are name expressions (template instantiations) resolved to functions
 inline int compile_module(const char *src, const char *fname, const std::vector<std::string> &names, const std::vector<std::string> &extra_opts,
@@ -188,6 +364,11 @@ inline int compile_module(const char *src, const char *fname, const std::vector<
     auto compile = [&](CodeObject &out) -> int {
         std::lock_guard<std::mutex> lk(rtc_mutex());
         Hiprtc &rt = hiprtc();
+        {   // the compiler process first (rtc_helper.cpp): 1 = done there, -1 = failed there (not retried in-process: a crash must stay out)
+            const int hr = compile_in_helper(hiprtc_library_path(), src, fname, names, opts, names_are_symbols, out);
+            if (hr == 1) return 0;
+            if (hr < 0) return SPCIES_HIP_EHIP;
+        }
         rt.sync_env();
         void *prog = nullptr;
         if (rt.create(&prog, src, fname, 0, nullptr, nullptr) != 0) return fail(SPCIES_HIP_EHIP, "hiprtcCreateProgram failed");

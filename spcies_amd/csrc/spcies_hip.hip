@@ -2008,6 +2008,23 @@ int spcies_hip_rtc_cache_selftest(const char *text, int work_ms, int drop_memory
     return 0;
 }
 
+int spcies_hip_rtc_compile_selftest(const char *src, int *isolated, unsigned long *code_bytes) {
+    if (!src) return fail(SPCIES_HIP_EINVAL, "NULL argument");
+    if (isolated) *isolated = 0;
+    if (code_bytes) *code_bytes = 0;
+    std::lock_guard<std::mutex> lk(rtc::rtc_mutex());
+    int rc = rtc::hiprtc().open();
+    if (rc) return rc;
+    rtc::CodeObject co;
+    const int hr = rtc::compile_in_helper(rtc::hiprtc_library_path(), src, "selftest.hip", {"selftest_kernel"},
+                                          {"--offload-arch=gfx950", "-O3", "-std=c++17"}, true, co);
+    if (hr == 0) return fail(SPCIES_HIP_ENOSUP, "no compiler process (spcies_rtc_helper not found next to the library, or SPCIES_HIP_RTC_ISOLATE=0)");
+    if (isolated) *isolated = 1;
+    if (hr < 0) return SPCIES_HIP_EHIP;
+    if (code_bytes) *code_bytes = (unsigned long)co.code.size();
+    return 0;
+}
+
 int spcies_hip_k_histogram_device(spcies_hip_handle h, const int *k, const int *e_flag, long B, int n_bins, long *hist, long *counts,
                                   void *stream) {
     if (!h || !hist || !counts) return fail(SPCIES_HIP_EINVAL, "NULL argument");
