@@ -180,7 +180,7 @@ inline std::vector<std::string> split_flags(const char *ev) {  // blank-separate
 // closes: it exits).  Requests are serialised by rtc_mutex().  A helper that dies mid-request (compiler crash) fails THAT build - the caller's
 // process goes on, AUTO falls back - and the next request starts a fresh one.  No helper binary next to the library: in-process.
 struct HelperProc {
-    pid_t pid = -1;
+    pid_t pid = -1, owner = -1;  // owner: the process that started it (a fork()ed copy of this object must not share the parent's pipe)
     int to = -1, from = -1;
     bool looked = false;
     std::string path;
@@ -189,7 +189,7 @@ struct HelperProc {
         if (to >= 0) close(to);
         if (from >= 0) close(from);
         to = from = -1;
-        if (pid > 0) {
+        if (pid > 0 && owner == getpid()) {
             int st = 0;
             for (int i = 0; i < 200 && waitpid(pid, &st, WNOHANG) == 0; i++) usleep(5000);  // (stdin closed: it leaves by itself)
             if (waitpid(pid, &st, WNOHANG) == 0) { kill(pid, SIGKILL); waitpid(pid, &st, 0); }
@@ -214,6 +214,12 @@ struct HelperProc {
         return !path.empty();
     }
     bool start() {
+        if (pid > 0 && owner != getpid()) {  // we are a fork()ed child of the process that owns this helper: leave it alone, get our own
+            if (to >= 0) close(to);
+            if (from >= 0) close(from);
+            to = from = -1;
+            pid = -1;
+        }
         if (pid > 0) return true;
         int a[2], b[2];
         if (pipe2(a, O_CLOEXEC) != 0) return false;
@@ -230,6 +236,7 @@ struct HelperProc {
         close(b[1]);
         if (rc != 0) { close(a[1]); close(b[0]); return false; }
         pid = child;
+        owner = getpid();
         to = a[1];
         from = b[0];
         return true;
