@@ -748,7 +748,7 @@ def run_rank(args):
             # against their teardown), the leg runs in a FRESH child process (this one keeps its idle context on GPU 0 and is
             # never replaced), bounded by a timeout; its failure is reported inside `multi_launch`, the line survives.
             # Self-launched runs do this in the parent instead (launch_ranks).
-            if world > 1 and not dry and not args.no_multi_leg and not os.environ.get("SPCIES_BENCH_SELF_LAUNCHED"):
+            if use_dist and not dry and not args.no_multi_leg and not os.environ.get("SPCIES_BENCH_SELF_LAUNCHED"):
                 time.sleep(2.0)
                 try:
                     out["multi_launch"] = run_multi_leg_child(args)

@@ -40,9 +40,9 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
         if (a.AB != b.AB || a.Alpha != b.Alpha || a.Beta != b.Beta || a.Hi != b.Hi || a.Q != b.Q || a.R != b.R || a.LB != b.LB || a.UB != b.UB || a.Bi != b.Bi)
             return fail(SPCIES_HIP_EINVAL, "MFMA4R (time-varying): row layout mismatch between admm_stream.hpp and admm_tvr_kernel.inc");
     }
-    // registers: Bi and Bi' (2 N KX doubles per lane), the Alpha blocks the LDS does not hold, the state (2 N + 1; FISTA: 3 N), constants and temporaries
+    // registers: S_l (N KX doubles per lane; rounds 3-4: Bi and Bi', 2 N KX), the Alpha blocks the LDS does not hold, the state (2 N + 1; FISTA: 3 N), constants and temporaries
     const int KX = (n + 3) / 4, NL = std::min(N - 1, 80 / (2 * KX));
-    const int doubles = 2 * N * KX + 2 * (N - 1 - NL) * KX + 16 + (fista ? 3 * N : 2 * N + 1) + 40;
+    const int doubles = N * KX + 2 * (N - 1 - NL) * KX + 16 + (fista ? 3 * N : 2 * N + 1) + 40;  // (L D L' form since round 5: S_l = S_l', one image)
     if (2 * doubles > 500) { p.why = "MFMA4R (time-varying): the instance's factors do not fit the wavefront's registers (use STREAM)"; return 0; }
     p.builtin = shape_built(n, m, N);
     if (!p.builtin || !p.update_builtin) {
@@ -54,6 +54,8 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
             snprintf(name, sizeof(name), "spcies::tvr::%s_tvr_kernel<%d, %d, %d, %s, %s>", fista ? "fista" : "admm", n, m, N, terminal ? "true" : "false", s ? "true" : "false");
             nm.push_back(name);
         }
+        snprintf(name, sizeof(name), "spcies::tvr::tv_ms_kernel<%d>", n);
+        nm.push_back(name);
         if (!p.update_builtin) {  // an (n, m) without a build-time update phase: the same text as admm_stream.hpp compiles, specialised here
             snprintf(name, sizeof(name), "spcies::%s_tv_update_kernel<%d, %d, %s, true>", fista ? "fista" : "admm", n, m, terminal ? "true" : "false");
             nm.push_back(name);
@@ -67,7 +69,8 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
         if (rc) { p.why = std::string("MFMA4R (time-varying): run-time specialisation failed: ") + spcies_hip_last_error(); p.build_failed = true; return 0; }
         p.module = mod;
         p.fn[0] = nullptr; p.fn[1] = fns[0]; p.fn[2] = fns[1];  // (fn[0]: the inverses' kernel of rounds 3-4; the update phase writes them now)
-        p.fn_update = p.update_builtin ? nullptr : (void *)fns[2];
+        p.fn_ms = (void *)fns[2];
+        p.fn_update = p.update_builtin ? nullptr : (void *)fns[3];
         p.builtin = false;  // (a build-time horizon of an (n, m) whose update phase is not: everything from the module)
     }
     p.ok = true;
@@ -158,12 +161,29 @@ static void launch_update_builtin(const Plan &p, double c0, const double *Tc, co
     }
 }
 
+// the update phase's rows -> the block L D L' form the solve kernels consume (tv_ms_kernel: Alpha_l <- Bi_l Alpha_l, Bi_l <- Bi_l Bi_l', in place)
+static int launch_ms(const Plan &p, long B, long Bp, double *TVS, hipStream_t st) {
+    int N = p.N, row_bi = p.fista ? frows_of(p.n, p.m, p.N).Bi : rows_of(p.n, p.m, p.N).Bi;
+    int row_alpha = p.fista ? frows_of(p.n, p.m, p.N).Alpha : rows_of(p.n, p.m, p.N).Alpha;
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    if (p.fn_ms) {
+        void *params[] = {&N, &row_bi, &row_alpha, &B, &Bp, &TVS};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_ms, grid, 1, 1, 64, 1, 1, 0, st, params, nullptr));
+        return 0;
+    }
+    if (p.n == 6) hipLaunchKernelGGL((tv_ms_kernel<6>), dim3(grid), dim3(64), 0, st, N, row_bi, row_alpha, B, Bp, TVS);
+    else if (p.n == 12) hipLaunchKernelGGL((tv_ms_kernel<12>), dim3(grid), dim3(64), 0, st, N, row_bi, row_alpha, B, Bp, TVS);
+    else return fail(SPCIES_HIP_ENOSUP, "time-varying update phase: no L D L' transform for n=%d", p.n);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_update(const Plan &p, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp, double *TVS, hipStream_t st) {
     if (p.ok && p.update_builtin) {
         if (p.n == 6 && p.m == 2) launch_update_builtin<6, 2>(p, c0, Tc, model, model_stride, B, Bp, TVS, st);
         else launch_update_builtin<12, 2>(p, c0, Tc, model, model_stride, B, Bp, TVS, st);
         SPCIES_HIP_CHECK(hipGetLastError());
-        return 0;
+        return launch_ms(p, B, Bp, TVS, st);
     }
     if (!p.ok || !p.fn_update) return fail(SPCIES_HIP_ENOSUP, "time-varying update phase: no run-time specialised kernel for n=%d m=%d", p.n, p.m);
     int N = p.N;
@@ -174,7 +194,7 @@ int launch_update(const Plan &p, double c0, const double *Tc, const double *mode
         void *params[] = {&N, &c0, &Tc, &model, &model_stride, &B, &Bp, &TVS};
         SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_update, (unsigned)(Bp / 64), 1, 1, 64, 1, 1, 0, st, params, nullptr));
     }
-    return 0;
+    return launch_ms(p, B, Bp, TVS, st);
 }
 
 }  // namespace tvr

@@ -53,6 +53,7 @@ struct Plan {
     bool terminal = true, builtin = false, fista = false;
     void *module = nullptr;            // hipModule_t of a run-time specialised kernel
     void *fn[3] = {nullptr, nullptr, nullptr};  // (unused), iteration without / with the record
+    void *fn_ms = nullptr;                      // (run-time specialised path) tv_ms_kernel<n>: the update phase's rows -> the L D L' form's M, S
     void *fn_update = nullptr;                  // the update-phase kernel of an (n, m) without a build-time instantiation (tv_update_kernel.inc)
     bool update_builtin = false;                // (n, m) = (6, 2), (12, 2): admm_stream.hpp's instantiations, launched by the caller
 };

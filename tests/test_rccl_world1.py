@@ -87,3 +87,20 @@ def test_bench_runs_its_rccl_leg_on_one_gpu():
     assert out["n_gpus"] == 1 and out["config"]["all_k_200_eflag_-1"] is True and out["value"] > 0
     assert "teardown_error" not in out
     assert out["multi_launch"].get("last_shard_equals_single_device") is True, out["multi_launch"]
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_with_one_rank():
+    """The driver's N > 1 launch line - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...` - with N = 1 and --force-dist on the one GPU here: the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    TORCHELASTIC_RUN_ID), the `nccl` rendezvous through the launcher's store, every collective of the N > 1 path, the teardown, and rank 0's
+    one-process `multi_launch` leg in a fresh child."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--batch", "8192", "--force-dist", "--no-cpu-baseline", "--no-configs", "--no-pcie"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=_env())
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["process_group"] == "nccl" and out["config"]["launch"] == "torchrun" and out["rccl_ranks_seen"] == 1
+    assert out["n_gpus"] == 1 and out["config"]["all_k_200_eflag_-1"] is True and "teardown_error" not in out
+    assert out["multi_launch"].get("last_shard_equals_single_device") is True, out["multi_launch"]
