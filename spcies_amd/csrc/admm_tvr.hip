@@ -41,10 +41,12 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
             return fail(SPCIES_HIP_EINVAL, "MFMA4R (time-varying): row layout mismatch between admm_stream.hpp and admm_tvr_kernel.inc");
     }
     // registers: S_l (N KX doubles per lane; rounds 3-4: Bi and Bi', 2 N KX), the Alpha blocks the LDS does not hold, the state (2 N + 1; FISTA: 3 N), constants and temporaries
-    const int KX = (n + 3) / 4, NL = std::min(N - 1, 80 / (2 * KX));
+    const int KX = (n + 3) / 4, NL = nl_of(N, KX);
     const int doubles = N * KX + 2 * (N - 1 - NL) * KX + 16 + (fista ? 3 * N : 2 * N + 1) + 40;  // (L D L' form since round 5: S_l = S_l', one image)
     if (2 * doubles > 500) { p.why = "MFMA4R (time-varying): the instance's factors do not fit the wavefront's registers (use STREAM)"; return 0; }
     p.builtin = shape_built(n, m, N);
+    if (const char *ev = getenv("SPCIES_TVR_RTC"))  // kernel experiments: re-specialise a built-in shape (with SPCIES_TVR_RTC_FLAGS)
+        if (ev[0] == '1') p.builtin = false;
     if (!p.builtin || !p.update_builtin) {
         const char *ev = getenv("SPCIES_HIP_RTC");
         if (ev && ev[0] == '0') { p.why = "horizon not instantiated at build time and SPCIES_HIP_RTC=0"; return 0; }
