@@ -780,7 +780,7 @@ def main(argv=None):
                          "--gpus devices through spcies_hip_create_multi from page-locked host buffers")
     ap.add_argument("--no-multi-leg", action="store_true", help="N > 1: skip the one-process create_multi leg reported as `multi_launch`")
     ap.add_argument("--launch-timeout", type=float, default=540.0, help="self-launched ranks: overall limit in seconds before the parent stops them")
-    ap.add_argument("--init-timeout", type=float, default=120.0, help="torch.distributed rendezvous / collective timeout in seconds")
+    ap.add_argument("--init-timeout", type=float, default=300.0, help="torch.distributed rendezvous / collective timeout in seconds")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl = RCCL; gloo with --dry-run) and run every "
                     "collective of the N > 1 path also at --gpus 1")
     ap.add_argument("--self-launch", action="store_true", help="go through the self-launcher (fresh rank processes, watchdog) also at --gpus 1; implies --force-dist")
