@@ -137,6 +137,52 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         for (int j = 0; j < i; j++) L[(size_t)i * RR + j] = Ln[(size_t)i * nr + j];
         Dinv[i] = Dn[i];
     }
+    // ---- unit-box coordinates for the z slabs (round 5; soc_bsp.hpp has the algebra): scalar rho, the grouped program with the bound patterns in
+    // registers, every row of the slab with a finite box around 0.  kappa = q / (rho D) - lb / D per instance and (q pattern, bound pattern);
+    // c' = clamp01(w^ - kappa), s = w^ - 2 c'; rho D folded into the columns of -G H^-1 and -H^-1, 1 / D into the rows of -H^-1 and -H^-1 G',
+    // -lb / D seeds the row's accumulator.  The terminal slabs (P-coordinates / the lax box) keep their form.  SPCIES_BSP_UNIT=0: off.
+    std::vector<char> unit(ZS, 0);
+    {
+        // (measured at the C2 shape, 40 launches each, median: the lax program 7.40 -> 7.20 ms; the ellipMPC program 7.62 -> 7.69 - its terminal
+        // P-coordinate phase reschedules worse - so the ellipsoid mode keeps the plain form unless SPCIES_BSP_UNIT=1 asks)
+        const char *uev = getenv("SPCIES_BSP_UNIT");
+        bool on = !a.gen && ((lax || equ) ? !(uev && uev[0] == '0') : (uev && uev[0] == '1')) &&
+                  !(getenv("SPCIES_BSP_GROUP") && getenv("SPCIES_BSP_GROUP")[0] == '0') && !getenv("SPCIES_BSP_BND_REGS");
+        std::map<std::vector<double>, int> pat;
+        for (int J = 0; J < ZS; J++) {
+            std::vector<double> key;
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * J + r;
+                key.push_back(row < dz ? lb_row[row] : 0.0);
+                key.push_back(row < dz ? ub_row[row] : 0.0);
+            }
+            pat.emplace(key, (int)pat.size());
+        }
+        if (pat.size() > 24) on = false;  // (the patterns must live in registers)
+        for (int J = 0; J < ZS && on; J++) {
+            bool ok = true;
+            for (int r = 4 * J; r < 4 * J + 4; r++) {
+                if (r >= dz) { ok = false; break; }
+                const double lo = lb_row[r], hi = ub_row[r];
+                if (!(std::isfinite(lo) && std::isfinite(hi)) || !(lo <= 0.0 && hi >= 0.0) || !(hi - lo > 1e-9) || hi - lo > 1e5) { ok = false; break; }
+            }
+            unit[J] = ok;
+        }
+        for (int J = 0; J < ZS; J++)
+            if (unit[J])
+                for (int r = 4 * J; r < 4 * J + 4; r++) {  // (z rows keep their index in the internal layout)
+                    const double D = ub_row[r] - lb_row[r], sD = a.rho * D;
+                    for (int i = 0; i < RR; i++) Gm[(size_t)i * PR_ + ip(r)] *= sD;
+                    for (int i = 0; i < PR_; i++) H[(size_t)i * PR_ + ip(r)] *= sD;
+                }
+        for (int J = 0; J < ZS; J++)
+            if (unit[J])
+                for (int r = 4 * J; r < 4 * J + 4; r++) {
+                    const double D = ub_row[r] - lb_row[r];
+                    for (int j = 0; j < PR_; j++) H[(size_t)ip(r) * PR_ + j] /= D;
+                    for (int j = 0; j < RR; j++) HG[(size_t)ip(r) * RR + j] /= D;
+                }
+    }
     const BlockList bG = blocks_of(Gm, RR, PR_), bHG = blocks_of(HG, PR_, RR), bH = blocks_of(H, PR_, PR_), bL = blocks_of(L, RR, RR);
     // ring depth: measured at the C2 shape (ms, scratch B per lane): 8: 10.5 / 0, 12: 9.94 / 116, 16: 9.77 / 148, 20: 9.58 / 156, 24: 9.29 / 280
     // (the laxMPC programs do not care: 12.5 ms and no scratch at any depth)
@@ -272,7 +318,8 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         for (int J = J0; J < J1 && group_qhat; J++) {
             if (bG.by_col[J].empty()) continue;
             char e[160];
-            if (prefetch_bounds && J < ZS) snprintf(e, sizeof(e), "(qv[QI_%d] + rhg_%d * (w[%d] - 2.0 * fmin(fmax(w[%d], lbg_%d), ubg_%d)))", J, J, J, J, J, J);
+            if (J < ZS && unit[J]) snprintf(e, sizeof(e), "QHZU(%d)", J);
+            else if (prefetch_bounds && J < ZS) snprintf(e, sizeof(e), "(qv[QI_%d] + rhg_%d * (w[%d] - 2.0 * fmin(fmax(w[%d], lbg_%d), ubg_%d)))", J, J, J, J, J, J);
             else qhat_expr(J, e, sizeof(e));
             snprintf(line, sizeof(line), "              const double qh_%d = %s;\n", J, e);
             body += line;
@@ -450,6 +497,9 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
             if (prefetch_bounds)
                 snprintf(line, sizeof(line), "              double ph_%d = 0.0; double wl_%d = w[%d]; asm volatile(\"\" : \"+v\"(wl_%d)); const double qp_%d = qv[QI_%d] + rhp_%d * "
                          "(wl_%d - 2.0 * fmin(fmax(wl_%d, lbp_%d), ubp_%d));\n", Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib);
+            else if (unit[Ib])
+                snprintf(line, sizeof(line), "              double ph_%d = na3v[BI_%d]; double wl_%d = w[%d]; asm volatile(\"\" : \"+v\"(wl_%d)); const double cp_%d = "
+                         "fmin(fmax(wl_%d - kapv[KI_%d], 0.0), 1.0); const double qp_%d = __builtin_fma(-2.0, cp_%d, wl_%d);\n", Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib, Ib);
             else snprintf(line, sizeof(line), "              double ph_%d = 0.0; const double qp_%d = QHZP(%d);\n", Ib, Ib, Ib);
             body += line;
         }
@@ -462,6 +512,7 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         body += "              SEG;\n";
         for (int Ib = I0; Ib < I1; Ib++) {
             if (prefetch_bounds) snprintf(line, sizeof(line), "              ZUPD2(%d, ph_%d, lbp_%d, ubp_%d);\n", Ib, Ib, Ib, Ib);
+            else if (unit[Ib]) snprintf(line, sizeof(line), "              ZUPDU(%d, ph_%d, cp_%d, wl_%d);\n", Ib, Ib, Ib, Ib);
             else snprintf(line, sizeof(line), "              LAUNDER; ZUPD(%d, ph_%d);\n", Ib, Ib);
             body += line;
         }
@@ -632,6 +683,31 @@ inline int build_ellip(Plan &p, const AdmmHost &a, int pf_request = 0) {
         s += "static __device__ const int BROW_[NBND_] = {";
         for (size_t i = 0; i < brow.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", brow[i]); s += line; }
         s += "};\n";
+        // (unit-box slabs) one kappa register per (q pattern, bound pattern)
+        if (!in_regs) std::fill(unit.begin(), unit.end(), 0);  // (cannot happen: the unit decision asked for <= 24 patterns)
+        std::map<std::pair<int, int>, int> combo;
+        std::vector<int> kq, kb, ki(ZS, -1);
+        for (int J = 0; J < ZS; J++) {
+            if (!unit[J]) continue;
+            auto key = std::make_pair(qi[J], bi[J]);
+            auto it = combo.find(key);
+            if (it == combo.end()) { it = combo.emplace(key, (int)kq.size()).first; kq.push_back(qi[J]); kb.push_back(bi[J]); }
+            ki[J] = it->second;
+        }
+        def("NKAP_", (long)kq.size());
+        for (int J = 0; J < ZS; J++) { snprintf(line, sizeof(line), "#define KI_%d %d\n", J, ki[J] < 0 ? 0 : ki[J]); s += line; }
+        if (!kq.empty()) {
+            s += "static __device__ const int KAPQ_[NKAP_] = {";
+            for (size_t i = 0; i < kq.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", kq[i]); s += line; }
+            s += "};\nstatic __device__ const int KAPB_[NKAP_] = {";
+            for (size_t i = 0; i < kb.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", kb[i]); s += line; }
+            s += "};\n";
+        }
+        s += "static __device__ const int KIA_[ZS_] = {";
+        for (int J = 0; J < ZS; J++) { snprintf(line, sizeof(line), "%s%d", J ? ", " : "", ki[J]); s += line; }
+        s += "};\nstatic __device__ const int BIA_[ZS_] = {";
+        for (int J = 0; J < ZS; J++) { snprintf(line, sizeof(line), "%s%d", J ? ", " : "", bi[J]); s += line; }
+        s += "};\n";
     }
     s += "static __device__ const int QROW_[NQ_] = {";
     for (size_t i = 0; i < qrow.size(); i++) { snprintf(line, sizeof(line), "%s%d", i ? ", " : "", qrow[i]); s += line; }
@@ -781,6 +857,27 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
 #define UBR(I) UBL(I)
 #define RHOR(I) RHOL(I)
 #endif
+#if NKAP_ > 0  // unit-box slabs (scalar rho, patterns in registers): kappa, -lb / D, D; w = 0 is w^ = kappa - lb / D
+        double kapv[NKAP_], na3v[NBND_], dv[NBND_];
+#pragma unroll
+        for (int u = 0; u < NBND_; u++) {
+            const double D_ = ubv[u] - lbv[u];
+            dv[u] = D_;
+            na3v[u] = (D_ > 0.0 && D_ < 1e6) ? -lbv[u] / D_ : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NKAP_; u++) kapv[u] = qv[KAPQ_[u]] / (rho * (ubv[KAPB_[u]] - lbv[KAPB_[u]])) + na3v[KAPB_[u]];
+#pragma unroll
+        for (int I = 0; I < ZS_; I++)
+            if (KIA_[I] >= 0) w[I] = kapv[KIA_[I]] + na3v[BIA_[I]];
+#define QHZU(J) ({ const double c_ = fmin(fmax(w[J] - kapv[KI_##J], 0.0), 1.0); __builtin_fma(-2.0, c_, w[J]); })
+        // v (= clamp(w)) and w in the caller's coordinates from the state (exit, record: cold)
+#define VOF_(I) (KIA_[I] >= 0 ? __builtin_fma(UBL(I) - LBL(I), fmin(fmax(w[I] - kapv[KIA_[I] >= 0 ? KIA_[I] : 0], 0.0), 1.0), LBL(I)) : fmin(fmax(w[I], LBL(I)), UBL(I)))
+#define WOF_(I) (KIA_[I] >= 0 ? __builtin_fma(UBL(I) - LBL(I), w[I] - kapv[KIA_[I] >= 0 ? KIA_[I] : 0], LBL(I)) : w[I])
+#else
+#define VOF_(I) fmin(fmax(w[I], LBL(I)), UBL(I))
+#define WOF_(I) w[I]
+#endif
 #define CE(k) ldsr[8 * ZS_ + 4 * (k) + go]
 #define LBT(k) ldsr[8 * ZS_ + 4 * (k) + go]
 #define UBT(k) ldsr[8 * ZS_ + 4 * TS_ + 4 * (k) + go]
@@ -804,6 +901,14 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
         w[I] = wn_;                                                                              \
         res |= (fabs(vo_ - v_) > tol) | (fabs((zh) - v_) > tol);                                 \
         if (WANT_SOL) *((4 * (I) + 3 < DZ_ || 4 * (I) + g < DZ_) ? zp + 4 * (I) : dump) = (zh); \
+    } while (0)
+        // the same in unit-box coordinates: zh is (z_hat - lb) / D, cp the clamp of the old state, wl the old state; residuals x D
+#define ZUPDU(I, zh, cp, wl)                                                                     \
+    do {                                                                                         \
+        const double wn_ = (zh) + ((wl) - (cp)), v_ = fmin(fmax(wn_ - kapv[KI_##I], 0.0), 1.0), D_ = dv[BI_##I]; \
+        w[I] = wn_;                                                                              \
+        res |= (fabs((cp) - v_) * D_ > tol) | (fabs((zh) - v_) * D_ > tol);                      \
+        if (WANT_SOL) *(zp + 4 * (I)) = __builtin_fma(D_, (zh), lbv[BI_##I]);                    \
     } while (0)
         // lax: the terminal slabs are boxes like the others
 #define ZUPDT(k, zh)                                                                             \
@@ -857,15 +962,15 @@ __device__ __forceinline__ void ellip_bsp_body(const EArgs &p, const double *__r
                         k_out[inst] = kk;
                         e_out[inst] = res_inst ? -1 : 1;
                     }
-                    if (g < m) u_out[inst * m + g] = fmin(fmax(w[0], LBL(0)), UBL(0));  // u = v_0
+                    if (g < m) u_out[inst * m + g] = VOF_(0);  // u = v_0
                     if (WANT_SOL) {
                         double *vp = f1 + inst * dim + g, *lp = f2 + inst * dim + g;
 #pragma unroll
                         for (int I = 0; I < ZS_; I++) {
                             const bool in_ = 4 * I + 3 < DZ_ || 4 * I + g < DZ_;
-                            const double v_ = fmin(fmax(w[I], LBL(I)), UBL(I));
+                            const double v_ = VOF_(I);
                             *(in_ ? vp + 4 * I : dump) = v_;
-                            *(in_ ? lp + 4 * I : dump) = RHOL(I) * (w[I] - v_);
+                            *(in_ ? lp + 4 * I : dump) = RHOL(I) * (WOF_(I) - v_);
                         }
 #pragma unroll
                         for (int k = 0; k < TS_; k++) {
