@@ -342,7 +342,28 @@ int plan_build(Plan &p, const AdmmHost &a) {
     for (const std::string &e : rtc::split_flags(getenv("SPCIES_AR_RTC_FLAGS"))) extra.push_back(e);
     hipModule_t mod = nullptr;
     hipFunction_t fns[2] = {nullptr, nullptr};
-    int rc = rtc::compile_module(kSource, "spcies_admm_r_rtc.hip", nm, extra, &mod, fns);
+    int rc = -1;
+    // Accumulators in VGPR form (762 -> 198 accumulator moves per iteration at n = 12, N = 30: 18.0 -> 17.3 ms) where the compiler takes it: ROCm
+    // 7.2's "Rewrite AGPR-Copy-MFMA" pass crashes on some of these kernels when the allocator spills (n = 20 laxMPC) - survivable since the compiler runs in
+    // a process of its own (rtc_helper.cpp), and remembered per machine (<digest>.crashed) - so: unit-box kernels up to 16 rows, only with the helper,
+    // the plain options on any failure.  SPCIES_AR_VGPR_FORM=0: never; =1: for every shape.
+    {
+        const char *ev = getenv("SPCIES_AR_VGPR_FORM");
+        const bool want = ev ? ev[0] == '1' : (p.unit && KS <= 4);
+        bool have_helper = false;
+        if (want) {
+            std::lock_guard<std::mutex> lk(rtc::rtc_mutex());
+            have_helper = rtc::helper_proc().find();
+        }
+        if (want && have_helper) {
+            std::vector<std::string> extra_vf = extra;
+            extra_vf.push_back("-mllvm");
+            extra_vf.push_back("-amdgpu-mfma-vgpr-form");
+            rc = rtc::compile_module(kSource, "spcies_admm_r_rtc.hip", nm, extra_vf, &mod, fns);
+            if (rc) mod = nullptr;
+        }
+    }
+    if (rc) rc = rtc::compile_module(kSource, "spcies_admm_r_rtc.hip", nm, extra, &mod, fns);
     if (rc) { p.why = std::string("MFMA4R (ADMM): run-time specialisation failed: ") + spcies_hip_last_error(); p.build_failed = true; return 0; }
     if (getenv("SPCIES_AR_VERBOSE")) {
         int scratch = 0;

@@ -239,6 +239,9 @@ class CodeCache {
         bytes_ = 0;
     }
 
+    // return codes a compile callback / get() may use next to the caller's own: the compiler process died on this program (the callback says so;
+    // the disk cache then remembers it), and "it did before" (get() says so without compiling)
+    static constexpr int RC_COMPILER_DIED = -7001, RC_KNOWN_CRASH = -7002;
     // directory of the disk cache ("" = off); created on first use
     static std::string disk_dir() {
         const char *sw = getenv("SPCIES_HIP_DISK_CACHE");
@@ -443,6 +446,10 @@ class CodeCache {
             return 0;
         }
         const std::string path = dir + "/" + key.digest + ".hsaco", lock_path = dir + "/" + key.digest + ".lock";
+        // a program that killed the compiler process on this machine before (same compiler identity, options and text: the digest) is not
+        // tried again - <digest>.crashed marks it; delete the file to retry
+        const std::string crashed = dir + "/" + key.digest + ".crashed";
+        if (access(crashed.c_str(), F_OK) == 0) return RC_KNOWN_CRASH;
         if (read_file(path, key, *fresh)) {  // the common warm case takes no lock: a file is complete once it has its name
             (void)utimensat(AT_FDCWD, path.c_str(), nullptr, 0);  // "used now": prune_disk deletes the least recently used first
             std::lock_guard<std::mutex> lk(mu_);
@@ -471,6 +478,10 @@ class CodeCache {
         } else {
             *fresh = CodeObject();  // (a failed read may have filled part of it)
             rc = compile(*fresh);
+            if (rc == RC_COMPILER_DIED) {
+                const int fd = open(crashed.c_str(), O_CREAT | O_WRONLY | O_CLOEXEC, 0600);
+                if (fd >= 0) close(fd);
+            }
             if (rc == 0) {
                 wrote = write_file(dir, path, key, *fresh);
                 std::lock_guard<std::mutex> lk(mu_);

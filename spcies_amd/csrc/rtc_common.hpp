@@ -315,7 +315,7 @@ inline int compile_in_helper(const std::string &hiprtc_path, const char *src, co
         h.stop();
         if (WIFSIGNALED(st))
             return fail(SPCIES_HIP_EHIP, "hiprtc: the compiler process died with signal %d while compiling %s (the caller's process is unharmed; "
-                                         "this variant counts as a failed build)", WTERMSIG(st), fname), -1;
+                                         "this variant counts as a failed build)", WTERMSIG(st), fname), -2;
         return fail(SPCIES_HIP_EHIP, "hiprtc: the compiler process ended (status %d) or did not answer within %d s while compiling %s", st, timeout_s, fname), -1;
     }
     size_t at = 0;
@@ -374,6 +374,7 @@ inline int compile_module(const char *src, const char *fname, const std::vector<
         {   // the compiler process first (rtc_helper.cpp): 1 = done there, -1 = failed there (not retried in-process: a crash must stay out)
             const int hr = compile_in_helper(hiprtc_library_path(), src, fname, names, opts, names_are_symbols, out);
             if (hr == 1) return 0;
+            if (hr == -2) return CodeCache::RC_COMPILER_DIED;  // (the disk cache marks the program: not tried again on this machine)
             if (hr < 0) return SPCIES_HIP_EHIP;
         }
         rt.sync_env();
@@ -411,6 +412,10 @@ inline int compile_module(const char *src, const char *fname, const std::vector<
     };
     std::shared_ptr<const CodeObject> co;
     const int rc = CodeCache::instance().get(key, compile, &co);
+    if (rc == CodeCache::RC_COMPILER_DIED) return SPCIES_HIP_EHIP;  // (the message is the helper client's)
+    if (rc == CodeCache::RC_KNOWN_CRASH)
+        return fail(SPCIES_HIP_EHIP, "hiprtc: %s with these options killed the compiler process on this machine before (%s/%s.crashed marks it; delete the file to try again)",
+                    fname, CodeCache::disk_dir().c_str(), key.digest.c_str());
     if (rc) return rc;
     if (co->lowered.size() != names.size())
         return fail(SPCIES_HIP_EHIP, "cached code object of %s has %zu kernels, %zu expected", fname, co->lowered.size(), names.size());

@@ -1991,6 +1991,7 @@ int spcies_hip_rtc_cache_selftest(const char *text, int work_ms, int drop_memory
     const rtc::CacheKey key = rtc::make_key("selftest compiler", "selftest.hip", {"kernel"}, {"-O3"}, text);
     // the stand-in compiler: takes work_ms, returns bytes that depend on the text only
     auto compile = [&](rtc::CodeObject &out) -> int {
+        if (work_ms == -2) { fail(SPCIES_HIP_EHIP, "selftest: the stand-in compiler process died"); return rtc::CodeCache::RC_COMPILER_DIED; }
         if (work_ms < 0) return fail(SPCIES_HIP_EHIP, "selftest: the stand-in compiler was told to fail");
         usleep((useconds_t)work_ms * 1000);
         const size_t len = strlen(text);

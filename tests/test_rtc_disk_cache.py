@@ -149,3 +149,21 @@ def test_disk_cache_is_capped_and_leaves_no_lock_files(tmp_path, monkeypatch):
     rc, src, chk = _call(texts[0], 0, 1)
     assert (rc, src, chk) == (0, 1, chk0)  # the recently used one survived the pruning
     assert _call(texts[1], 0, 1)[1] == 2   # the oldest one did not: compiled again
+
+
+def test_a_program_that_killed_the_compiler_is_not_tried_again(tmp_path, monkeypatch):
+    """Round 5: hiprtc runs in a helper process, and a program that kills it (ROCm 7.2 has such kernels) fails ONE build.  The disk cache marks
+    the digest (<digest>.crashed), so the next process - every later MATLAB session - skips the attempt instead of crashing the helper again."""
+    monkeypatch.setenv("SPCIES_HIP_CACHE_DIR", str(tmp_path))
+    monkeypatch.delenv("SPCIES_HIP_DISK_CACHE", raising=False)
+    text = f"crasher {os.getpid()} {time.time()}"
+    rc1, _, _ = _call(text, -2, 1)
+    assert rc1 == -7001 and [f for f in os.listdir(tmp_path) if f.endswith(".crashed")]
+    s0 = _stats()
+    rc2, _, _ = _call(text, 0, 1)  # (work_ms = 0 would compile fine: the marker answers before the compiler is asked)
+    assert rc2 == -7002 and _stats()["compiles"] == s0["compiles"]
+    for f in os.listdir(tmp_path):
+        if f.endswith(".crashed"):
+            os.unlink(tmp_path / f)
+    rc3, src, _ = _call(text, 0, 1)
+    assert rc3 == 0 and src == 2
