@@ -101,6 +101,10 @@ int main() {
     const int in = 0, out = dup(1);
     if (out < 0) return 2;
     dup2(2, 1);  // whatever the compiler prints to stdout must not corrupt the response stream
+    // the library's process may hold GPU device files and sockets open without O_CLOEXEC: this process compiles, it must not keep them alive (nor
+    // count as a user of the GPU)
+    for (int fd = 3; fd < 4096; fd++)
+        if (fd != out) close(fd);
     for (;;) {
         uint64_t bytes = 0;
         if (!read_all(in, &bytes, 8)) return 0;  // the library closed the pipe: done
