@@ -131,6 +131,7 @@ struct Solver {
         std::string why;
         hipModule_t mod = nullptr;
         hipFunction_t fn = nullptr;
+        hipFunction_t fn_update = nullptr;  // time-varying solvers: the update phase of the same (n, m)
     } srtc;
     hfused::Plan hfused;           // FUSED (HMPC split NON_SPARSE path: product + projections in one MFMA kernel)
     std::vector<double> h_M1, h_M2, h_bh_nat;
@@ -1065,9 +1066,12 @@ static int launch_tv_nm(Solver &s, const double *x0, const double *xr, const dou
 // their STREAM kernel - the bit-exact variant - exists for EVERY plant size: the build-time instantiations for the benchmark shapes, hiprtc for
 // any other (admm_stream_kernel.inc / fista_stream_kernel.inc / eadmm_stream_kernel.inc are the text of both).
 static bool stream_rtc_applies(const Solver &s) {
-    if (s.tv || s.host.gen || s.host.ellip || s.is_soc() || s.is_cs() || s.is_hmpc() || s.is_hdense()) return false;
-    if (s.method == SPCIES_ADMM) return s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC;
-    if (s.method == SPCIES_FISTA) return s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC;
+    if (s.is_soc() || s.is_cs() || s.is_hmpc() || s.is_hdense()) return false;
+    // (round 5: the template's other switches too - time-varying model with its update phase, vector rho / stage-wise bounds, the ellipMPC
+    // terminal block: every option of the banded ADMM / FISTA solvers has its bit-exact kernel at any plant size)
+    if (s.method == SPCIES_ADMM) return s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC || s.host.ellip;
+    if (s.method == SPCIES_FISTA) return !s.host.gen && !s.host.ellip && (s.formulation == SPCIES_LAXMPC || s.formulation == SPCIES_EQUMPC);
+    if (s.tv || s.host.gen || s.host.ellip) return false;
     if (s.method == SPCIES_EADMM) return true;  // (general Q, R: that branch's STREAM kernel is always the run-time specialised one)
     return false;
 }
@@ -1080,13 +1084,20 @@ static int ensure_stream_rtc(Solver &s) {
             s.srtc.why = "no build-time kernel for this (n, m) and SPCIES_HIP_RTC=0";
             return fail(SPCIES_HIP_ENOSUP, "STREAM variant unavailable: %s", s.srtc.why.c_str());
         }
-    char name[160];
+    char name[200], uname[200] = "";
     std::string src = std::string(kAdmmDevSrc) + "\n" + kTvUpdateSrc + "\n" + kAdmmStreamSrc;
     const char *fname = "spcies_admm_stream_rtc.hip";
+    const char *term = s.host.terminal ? "true" : "false", *tvs = s.tv ? "true" : "false";
     if (s.method == SPCIES_FISTA) {
-        snprintf(name, sizeof(name), "spcies::fista_stream_kernel<%d, %d, %s, true>", s.host.n, s.host.m, s.host.terminal ? "true" : "false");
+        snprintf(name, sizeof(name), "spcies::fista_stream_kernel<%d, %d, %s, true, %s>", s.host.n, s.host.m, term, tvs);
+        if (s.tv) snprintf(uname, sizeof(uname), "spcies::fista_tv_update_kernel<%d, %d, %s>", s.host.n, s.host.m, term);
         src += std::string("\n") + kFistaStreamSrc;
         fname = "spcies_fista_stream_rtc.hip";
+    } else if (s.method == SPCIES_ADMM && (s.tv || s.host.gen || s.host.ellip)) {
+        // <n, m, TERMINAL, EXACT, TV, ELLIP, GEN>: the instantiations launch_stream_nm / launch_tv_nm pick at build time
+        snprintf(name, sizeof(name), "spcies::admm_stream_kernel<%d, %d, %s, true, %s, %s, %s>", s.host.n, s.host.m, s.host.ellip ? "true" : term, tvs,
+                 s.host.ellip ? "true" : "false", s.host.gen ? "true" : "false");
+        if (s.tv) snprintf(uname, sizeof(uname), "spcies::admm_tv_update_kernel<%d, %d, %s>", s.host.n, s.host.m, term);
     } else if (s.method == SPCIES_EADMM) {
         snprintf(name, sizeof(name), "spcies::eadmm_stream_kernel<%d, %d, %s>", s.host.n, s.host.m, s.e_general ? "true" : "false");
         src += std::string("\n") + kEadmmStreamSrc;
@@ -1095,14 +1106,17 @@ static int ensure_stream_rtc(Solver &s) {
         snprintf(name, sizeof(name), "spcies::admm_stream_kernel<%d, %d, %s, true>", s.host.n, s.host.m, s.host.terminal ? "true" : "false");
     }
     hipModule_t mod = nullptr;
-    hipFunction_t fn = nullptr;
-    int rc = rtc::compile_module(src.c_str(), fname, {std::string(name)}, {}, &mod, &fn);
+    hipFunction_t fns[2] = {nullptr, nullptr};
+    std::vector<std::string> names = {std::string(name)};
+    if (uname[0]) names.push_back(uname);
+    int rc = rtc::compile_module(src.c_str(), fname, names, {}, &mod, fns);
     if (rc) {
         s.srtc.why = spcies_hip_last_error();
         return rc;
     }
     s.srtc.mod = mod;
-    s.srtc.fn = fn;
+    s.srtc.fn = fns[0];
+    s.srtc.fn_update = fns[1];
     s.srtc.ok = true;
     return 0;
 }
@@ -1226,6 +1240,77 @@ static int launch_tv_rtc(Solver &s, const double *x0, const double *xr, const do
                              z ? z + b0 * dim : nullptr, v ? v + b0 * dim : nullptr, lam ? lam + b0 * dim : nullptr, num_cu, st);
         }
         if (rc) return rc;
+    }
+    return 0;
+}
+
+// Time-varying lax / equ ADMM and FISTA on STREAM at an (n, m) without build-time kernels: launch_tv_nm / launch_fista_tv_nm's buffers, the
+// update phase and the iteration of ensure_stream_rtc's module (bit-exact like the build-time pair; plants past n = 16 take the rolled update
+// phase of tv_update_kernel.inc).  AUTO lands here when the register-resident solver does not hold the controller (n + m > 16, or a horizon
+// past the register file); STREAM by name lands here for any plant size.  z, v, lam: ADMM's record; FISTA passes z and lam (v = NULL).
+static int launch_tv_stream_rtc(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, const double *model, int model_stride,
+                                long B, double *u, int *k, int *e, double *z, double *v, double *lam, hipStream_t st) {
+    int rc = ensure_stream_rtc(s);
+    if (rc) return rc;
+    const int n = s.host.n, m = s.host.m, N = s.host.N;
+    const bool fista = s.method == SPCIES_FISTA;
+    const bool want_sol = (z || v || lam);
+    const size_t dim = (size_t)s.host.dim(), Nn = (size_t)N * n;
+    const size_t rows_stream = fista ? 3 * Nn + (want_sol ? dim : 0) : 2 * dim + Nn + (want_sol ? dim : 0);
+    const size_t rows_tv = fista ? (size_t)fista_tv_layout(n, m, N).rows : (size_t)tv_layout(n, m, N).rows;
+    long chunk = (long)((3900ull << 20) / (rows_tv * 8)) / 64 * 64;  // one launch's rows stay below the 4 GB a buffer resource addresses
+    if (chunk < 64) return fail(SPCIES_HIP_ENOSUP, "time-varying STREAM: one wavefront's factors exceed a buffer resource (n=%d N=%d)", n, N);
+    if (chunk > B) chunk = (B + 63) / 64 * 64;
+    rc = ensure_scratch(s, (rows_stream + rows_tv) * (size_t)chunk * sizeof(double));
+    if (rc) return rc;
+    for (long b0 = 0; b0 < B; b0 += chunk) {
+        long Bc = std::min(chunk, B - b0), Bp = (Bc + 63) / 64 * 64;
+        double *TVS = s.d_scratch + rows_stream * Bp;
+        const double *x0c = x0 + b0 * n, *xrc = ref_stride ? xr + b0 * n : xr, *urc = ref_stride ? ur + b0 * m : ur;
+        const double *mc = model_stride ? model + b0 * (long)model_stride : model;
+        long mstride = model_stride;
+        double *uc = u + b0 * m;
+        int *kc = k + b0, *ec = e + b0;
+        const double *C = s.d_consts;
+        int Nv = N;
+        const unsigned grid = (unsigned)(Bp / 64);
+        if (fista) {
+            const double *Ti = s.d_consts + s.fdev.Ti;
+            void *up[] = {&Nv, &Ti, &mc, &mstride, &Bc, &Bp, &TVS};
+            SPCIES_HIP_CHECK(hipModuleLaunchKernel(s.srtc.fn_update, grid, 1, 1, 64, 1, 1, 0, st, up, nullptr));
+            double *Y = s.d_scratch, *LAM = Y + Nn * Bp, *DL = LAM + Nn * Bp;
+            double *ZS = want_sol ? DL + Nn * Bp : nullptr;
+            const double *TVSc = TVS;
+            FistaDev dev = s.fdev;
+            void *params[] = {&dev, &C, &x0c, &xrc, &urc, &ref_stride, &Bc, &Bp, &Y, &LAM, &DL, &ZS, &uc, &kc, &ec, &TVSc};
+            SPCIES_HIP_CHECK(hipModuleLaunchKernel(s.srtc.fn, grid, 1, 1, 64, 1, 1, 0, st, params, nullptr));
+            if (z) {
+                dim3 tg((unsigned)(Bp / 64), (unsigned)((dim + 63) / 64));
+                hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, ZS, Bp, Bc, (int)dim, z + b0 * dim);
+            }
+            if (lam) {
+                dim3 tg((unsigned)(Bp / 64), (unsigned)((Nn + 63) / 64));
+                hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, Y, Bp, Bc, (int)Nn, lam + b0 * Nn);
+            }
+        } else {
+            double rho = s.host.rho;
+            const double *HiN = s.d_consts + s.dev.Hi_N;
+            void *up[] = {&Nv, &rho, &HiN, &mc, &mstride, &Bc, &Bp, &TVS};
+            SPCIES_HIP_CHECK(hipModuleLaunchKernel(s.srtc.fn_update, grid, 1, 1, 64, 1, 1, 0, st, up, nullptr));
+            double *V = s.d_scratch, *LAM = V + dim * Bp, *Y = LAM + dim * Bp;
+            double *ZS = want_sol ? Y + Nn * Bp : nullptr;
+            const double *TVSc = TVS;
+            AdmmDev dev = s.dev;
+            void *params[] = {&dev, &C, &x0c, &xrc, &urc, &ref_stride, &Bc, &Bp, &V, &LAM, &Y, &ZS, &uc, &kc, &ec, &TVSc};
+            SPCIES_HIP_CHECK(hipModuleLaunchKernel(s.srtc.fn, grid, 1, 1, 64, 1, 1, 0, st, params, nullptr));
+            if (want_sol) {
+                dim3 tg((unsigned)(Bp / 64), (unsigned)((dim + 63) / 64));
+                if (z) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, ZS, Bp, Bc, (int)dim, z + b0 * dim);
+                if (v) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, V, Bp, Bc, (int)dim, v + b0 * dim);
+                if (lam) hipLaunchKernelGGL(soa_to_aos_kernel, tg, dim3(256), 0, st, LAM, Bp, Bc, (int)dim, lam + b0 * dim);
+            }
+        }
+        SPCIES_HIP_CHECK(hipGetLastError());
     }
     return 0;
 }
@@ -1408,6 +1493,21 @@ __global__ __launch_bounds__(256) void eng_out_kernel(double *__restrict__ u, lo
     u[i] = u[i] * sc[j] + op[j];
 }
 
+// time-varying solvers: the model's LB / UB columns arrive in engineering units too (code_laxMPC_ADMM_C.c:91-100); A, B, Q, R pass as they are
+__global__ __launch_bounds__(256) void eng_tv_model_kernel(const double *__restrict__ in, long rows, int w, int off_lb, int n, int nm,
+                                                           const double *__restrict__ scx, const double *__restrict__ opx,
+                                                           const double *__restrict__ scu, const double *__restrict__ opu, double *__restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * w) return;
+    const int j = (int)(i % w);
+    double x = in[i];
+    if (j >= off_lb) {
+        const int r = (j - off_lb) % nm;
+        x = (r < n) ? scx[r] * (x - opx[r]) : scu[r - n] * (x - opu[r - n]);
+    }
+    out[i] = x;
+}
+
 // Option in_engineering wraps every solver: scale the arguments, solve, un-scale the control action.
 static int solve_device(Solver &s, const double *x0, const double *xr, const double *ur, int ref_stride, long B,
                         double *u, int *k, int *e, double *const *f, const double *extra, int extra_stride,
@@ -1415,7 +1515,8 @@ static int solve_device(Solver &s, const double *x0, const double *xr, const dou
     if (B <= 0) return 0;
     if (!s.eng) return solve_device_scaled(s, x0, xr, ur, ref_stride, B, u, k, e, f, extra, extra_stride, st);
     const long n = s.host.n, m = s.host.m, nref = ref_stride ? B : 1;
-    const size_t need = (size_t)(B * n + nref * (n + m)) * sizeof(double);
+    const long msz = s.tv ? s.tv_model_size() : 0, mrows = (s.tv && extra) ? (extra_stride ? B : 1) : 0;
+    const size_t need = (size_t)(B * n + nref * (n + m) + mrows * msz) * sizeof(double);
     if (need > s.eng_in_bytes) {
         if (s.d_eng_in) SPCIES_HIP_CHECK(hipFree(s.d_eng_in));
         s.d_eng_in = nullptr; s.eng_in_bytes = 0;
@@ -1428,6 +1529,12 @@ static int solve_device(Solver &s, const double *x0, const double *xr, const dou
     hipLaunchKernelGGL(eng_in_kernel, blocks(B * n), dim3(256), 0, st, x0, B, (int)n, scx, opx, sx0);
     hipLaunchKernelGGL(eng_in_kernel, blocks(nref * n), dim3(256), 0, st, xr, nref, (int)n, scx, opx, sxr);
     hipLaunchKernelGGL(eng_in_kernel, blocks(nref * m), dim3(256), 0, st, ur, nref, (int)m, scu, opu, sur);
+    if (mrows) {  // time-varying: the bounds of every instance's model in scaled units (the model layout: A, B, Q, R, LB, UB)
+        double *sm = sur + nref * m;
+        hipLaunchKernelGGL(eng_tv_model_kernel, blocks(mrows * msz), dim3(256), 0, st, extra, mrows, (int)msz, (int)(n * n + n * m + n + m), (int)n,
+                           (int)(n + m), scx, opx, scu, opu, sm);
+        extra = sm;
+    }
     SPCIES_HIP_CHECK(hipGetLastError());
     int rc = solve_device_scaled(s, sx0, sxr, sur, ref_stride, B, u, k, e, f, extra, extra_stride, st);
     if (rc) return rc;
@@ -1565,7 +1672,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
             return launch_tv_rtc(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, nullptr, lam, st);
         if (s.host.n == 6 && s.host.m == 2) return launch_fista_tv_nm<6, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, lam, st);
         if (s.host.n == 12 && s.host.m == 2) return launch_fista_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, lam, st);
-        return fail(SPCIES_HIP_ENOSUP, "time-varying solvers: STREAM is instantiated for (n, m) = (6, 2), (12, 2); MFMA4R for any n + m <= 16 within the register file (n=%d m=%d: %s)", s.host.n, s.host.m, s.tvrp.ok ? "ask for MFMA4R or AUTO" : s.tvrp.why.c_str());
+        return launch_tv_stream_rtc(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, nullptr, lam, st);  // STREAM at any other plant size
     }
     if (s.method == SPCIES_FISTA) {
         const int fv = resolve_variant(s);
@@ -1603,7 +1710,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
             return launch_tv_rtc(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         if (s.host.n == 6 && s.host.m == 2) return launch_tv_nm<6, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
         if (s.host.n == 12 && s.host.m == 2) return launch_tv_nm<12, 2>(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);
-        return fail(SPCIES_HIP_ENOSUP, "time-varying solvers: STREAM is instantiated for (n, m) = (6, 2), (12, 2); MFMA4R for any n + m <= 16 within the register file (n=%d m=%d: %s)", s.host.n, s.host.m, s.tvrp.ok ? "ask for MFMA4R or AUTO" : s.tvrp.why.c_str());
+        return launch_tv_stream_rtc(s, x0, xr, ur, ref_stride, extra, extra_stride, B, u, k, e, z, v, lam, st);  // STREAM at any other plant size
     }
     if (!s.is_soc() && s.bsp.ok && resolve_variant(s) == SPCIES_VARIANT_BSP)
         return bsp::launch_ellip(s.bsp, s.host, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
@@ -1614,7 +1721,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (rc) return rc;
         if (s.host.n == 6 && s.host.m == 2) return launch_stream_nm<6, 2, true>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
         if (s.host.n == 12 && s.host.m == 2) return launch_stream_nm<12, 2, true>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
-        return fail(SPCIES_HIP_ENOSUP, "ellipMPC ADMM STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
+        return launch_stream_rtc(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);  // any other plant size: the ELLIP instantiation through hiprtc
     }
     const int variant = resolve_variant(s);
     if (variant == SPCIES_VARIANT_MFMA4) {
@@ -1649,7 +1756,7 @@ static int solve_device_scaled(Solver &s, const double *x0, const double *xr, co
         if (rc) return rc;
         if (s.host.n == 6 && s.host.m == 2) return launch_stream_nm<6, 2, false, true>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
         if (s.host.n == 12 && s.host.m == 2) return launch_stream_nm<12, 2, false, true>(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);
-        return fail(SPCIES_HIP_ENOSUP, "STREAM variant with vector rho / stage-wise bounds not instantiated for n=%d m=%d", s.host.n, s.host.m);
+        return launch_stream_rtc(s, x0, xr, ur, ref_stride, B, u, k, e, z, v, lam, st);  // any other plant size: the GEN instantiation through hiprtc
     }
     if (!stream_shape_built(s.host.n, s.host.m) && !stream_rtc_applies(s))
         return fail(SPCIES_HIP_ENOSUP, "STREAM variant not instantiated for n=%d m=%d", s.host.n, s.host.m);
@@ -1832,7 +1939,6 @@ int spcies_hip_create(const void *blob, size_t bytes, int device, spcies_hip_han
         if (!(ev && ev[0] == '0') && bsp::finish_ellip(s->bsp, s->host) != 0) s->bsp.why = g_last_error, s->bsp.build_failed = true;
     }
     if (s->eng) {
-        if (s->tv) return fail(SPCIES_HIP_ENOSUP, "in_engineering with time_varying is not built");
         SPCIES_HIP_CHECK(hipMalloc((void **)&s->d_eng, s->eng_v.size() * sizeof(double)));
         SPCIES_HIP_CHECK(hipMemcpy(s->d_eng, s->eng_v.data(), s->eng_v.size() * sizeof(double), hipMemcpyHostToDevice));
     }

@@ -197,7 +197,13 @@ def test_admm_r_kernels_compile_with_the_flags_the_library_uses(tmp_path):
 
 
 @pytest.mark.parametrize("family,inst", [("admm", "admm_stream_kernel<7, 3, true, true>"), ("fista", "fista_stream_kernel<7, 3, false, true>"),
-                                         ("eadmm", "eadmm_stream_kernel<7, 3, true>"), ("tv", "admm_tv_update_kernel<7, 3, true, true>")])
+                                         ("eadmm", "eadmm_stream_kernel<7, 3, true>"), ("tv", "admm_tv_update_kernel<7, 3, true, true>"),
+                                         # round 5: the other switches of the template at any plant size (ensure_stream_rtc) - time-varying
+                                         # (with the ROLLED update phase past n = 16: the register form does not compile at n = 20), GEN, ELLIP
+                                         ("tv", "admm_tv_update_kernel<20, 4, true>"), ("fista", "fista_tv_update_kernel<17, 3, false>"),
+                                         ("admm", "admm_stream_kernel<9, 2, true, true, true>"), ("fista", "fista_stream_kernel<7, 3, false, true, true>"),
+                                         ("admm", "admm_stream_kernel<7, 3, false, true, false, false, true>"),
+                                         ("admm", "admm_stream_kernel<7, 3, true, true, false, true, true>")])
 def test_run_time_specialised_stream_sources_compile(family, inst, tmp_path):
     """The kernel texts the library hands to hiprtc for plant sizes without a build-time instantiation (spcies_hip.hip ensure_stream_rtc,
     admm_tvr.hip) are the concatenation of .inc files that are also #included at build time: here the concatenation itself is compiled,
@@ -211,7 +217,7 @@ def test_run_time_specialised_stream_sources_compile(family, inst, tmp_path):
     src = "\n".join(open(os.path.join(here, f)).read() for f in parts)
     # the signature is taken from the template itself: an explicit instantiation through a function pointer of the deduced type
     src += f"\nnamespace spcies {{ __device__ void *spcies_keep_ = (void *)&{inst}; }}\n"
-    p = tmp_path / f"stream_{family}.hip"
+    p = tmp_path / f"stream_{family}.hip"  # (tmp_path is per test case)
     p.write_text(src)
     import sys
     co = tmp_path / f"stream_{family}.co"

@@ -12,6 +12,7 @@ import os
 
 import numpy as np
 import pytest
+from types import SimpleNamespace
 
 import _margins
 
@@ -1400,6 +1401,45 @@ def test_mfma4g_fista_arbitrary_shapes(n, m, N, formulation, variant):
     x0, xr, ur = 0.6 * rng.standard_normal((B, n)), 0.2 * rng.standard_normal((B, n)), 0.1 * rng.standard_normal((B, m))
     _compare_fista(variant, s(x0, xr, ur), oracle.fista_banded_batch(v, x0, xr, ur), rerun=_rerun_with(oracle.fista_banded_batch, v, x0, xr, ur))
     s.close()
+
+
+@pytest.mark.parametrize("n,m,N,kind", [(7, 3, 6, "lax_gen"), (9, 2, 5, "equ_gen"), (7, 2, 6, "ellip"), (5, 3, 7, "ellip_vec"), (34, 3, 4, "lax_gen")])
+def test_stream_with_every_switch_at_any_plant_size(n, m, N, kind):
+    """STREAM - the bit-exact variant - with the template's other switches at plant sizes without a build-time kernel (round 5: the run-time
+    specialised kernel takes GEN - vector rho / stage-wise bounds, code_laxMPC_ADMM_C.c:323-348, 490-568 - and ELLIP - the ellipMPC terminal
+    block, code_ellipMPC_ADMM_C.c:318-352 - too; 'not instantiated' before): bit for bit against the oracle.  (34, 3): past every matrix-pipe
+    variant's 32 rows - AUTO itself is STREAM there."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _random_cfg(n, m, N, seed=1600 + n)
+    rng = np.random.default_rng(23 * n + m)
+    if kind.startswith("ellip"):
+        M = rng.standard_normal((n, n))
+        cfg.formulation, cfg.method, cfg.submethod = "ellipMPC", "ADMM", ""
+        cfg.param.P, cfg.param.c, cfg.param.r = np.eye(n) + 0.05 * (M @ M.T), 0.05 * rng.standard_normal(n), 0.25
+        cfg.solver_options = dict(rho=8.0, tol=1e-6, k_max=400)
+        if kind == "ellip_vec":
+            cfg.solver_options["rho"] = 8.0 * (0.5 + rng.random(N * (n + m)))
+    else:
+        cfg.formulation = "laxMPC" if kind.startswith("lax") else "equMPC"
+        sysd = dict(vars(cfg.sys))
+        wide = lambda a, sc: np.tile(np.ravel(a)[:, None], (1, N + 1)) * (1.0 + sc * rng.random((np.size(a), N + 1)))
+        sysd.update(LBx=wide(cfg.sys.LBx, 0.2), UBx=wide(cfg.sys.UBx, 0.2), LBu=wide(cfg.sys.LBu, 0.3), UBu=wide(cfg.sys.UBu, 0.3))
+        cfg.sys = SimpleNamespace(**sysd)
+        dim = N * (n + m) - (0 if cfg.formulation == "laxMPC" else n)
+        cfg.solver_options = dict(cfg.solver_options, rho=8.0 * (0.5 + rng.random(dim)))
+    v = benchmarks.ingredients(cfg)
+    B = 70
+    x0, xr, ur = 0.4 * rng.standard_normal((B, n)), 0.1 * rng.standard_normal((B, n)), 0.05 * rng.standard_normal((B, m))
+    with HipSolver(v) as s:
+        if n + m > 32:
+            assert s.variant == "stream", (s.variant, s.notes)
+        s.set_variant("stream")
+        got = s(x0, xr, ur)
+        _compare("stream", got, oracle.admm_banded_batch(v, x0, xr, ur), v)
+        nosol = s(x0[:9], xr[:9], ur[:9], want_sol=False)
+        assert np.array_equal(nosol[0], got[0][:9]) and np.array_equal(nosol[1], got[1][:9])
 
 
 @pytest.mark.parametrize("family", ["admm", "fista", "eadmm"])

@@ -171,7 +171,7 @@ def test_time_varying_mfma4r_other_horizons(name, N):
 def test_time_varying_any_plant_size(n, m, N, formulation, method):
     """The 9-input solvers of a plant whose (n, m) has no build-time kernel: the whole MFMA4R path - update phase (tv_update_kernel.inc,
     the text the build-time instantiations compile), inverses, solve - is specialised with hiprtc at create time; one model per
-    instance against the oracle; STREAM (build-time kernels for (6, 2) and (12, 2) only) refuses by name."""
+    instance against the oracle; STREAM by name runs the bit-exact pair specialised for the same (n, m)."""
     from oracle import oracle
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
@@ -203,8 +203,55 @@ def test_time_varying_any_plant_size(n, m, N, formulation, method):
             _compare_tv("mfma4r", s(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
         nosol = s(x0[:7], xr[:7], ur[:7], *[a[:7] for a in models], want_sol=False)
         assert np.abs(nosol[0] - O[0][:7]).max() <= 1e-9 and np.abs(nosol[1].astype(int) - O[1][:7].astype(int)).max() <= 1
-        with pytest.raises(Exception, match="STREAM variant not instantiated"):
-            s.set_variant("stream")
+        # STREAM by name: the bit-exact pair (update phase + iteration) specialised for this (n, m) as well (round 5; refused before)
+        s.set_variant("stream")
+        assert s.variant == "stream"
+        if method == "FISTA":
+            _compare_tv_fista("stream", s(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
+        else:
+            _compare_tv("stream", s(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,N,formulation,method", [(20, 4, 6, "laxMPC", "ADMM"), (12, 6, 5, "equMPC", "ADMM"), (17, 3, 6, "equMPC", "FISTA"),
+                                                      (20, 2, 5, "laxMPC", "FISTA")])
+def test_time_varying_plants_past_the_register_file(n, m, N, formulation, method):
+    """The 9-input solvers of plants the register-resident solver does not hold (n + m > 16: the 20-state plant of configs[3] among them): AUTO is
+    STREAM - update phase and iteration specialised with hiprtc for this (n, m), the update phase in its rolled form past n = 16
+    (tv_band_factor_rolled) - bit for bit against the oracle, one model per instance and one shared model.  Rounds 2-4 answered ENOSUP here."""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    from _cases import random_cfg
+    cfg = random_cfg(n, m, N, seed=1400 + n)
+    cfg.formulation, cfg.method = formulation, method
+    cfg.param.T = np.diag(np.diag(cfg.param.T))
+    if method == "FISTA":
+        cfg.solver_options = dict(tol=1e-6, k_max=400)
+    vt = benchmarks.ingredients(cfg, time_varying=True)
+    sysm, prm = cfg.sys, cfg.param
+    LB = np.concatenate([np.ravel(sysm.LBx), np.ravel(sysm.LBu)])
+    UB = np.concatenate([np.ravel(sysm.UBx), np.ravel(sysm.UBu)])
+    design = (np.asarray(sysm.A, float), np.asarray(sysm.B, float), np.diag(prm.Q).copy(), np.diag(prm.R).copy(), LB, UB)
+    rng = np.random.default_rng(19 * n + m)
+    B = 70  # (two wavefronts, the second partly filled)
+    x0 = (0.6 if method == "FISTA" else 0.4) * rng.standard_normal((B, n))
+    xr = 0.1 * rng.standard_normal((B, n))
+    ur = 0.05 * rng.standard_normal((B, m))
+    models = _perturbed_models(design, B)
+    model, per = oracle.pack_tv_model(*models)
+    fn, cmp = (oracle.fista_tv_batch, _compare_tv_fista) if method == "FISTA" else (oracle.admm_tv_batch, _compare_tv)
+    with HipSolver(vt) as s:
+        assert s.time_varying and s.variant == "stream", (s.variant, s.notes)
+        O = fn(vt, x0, xr, ur, model, per)
+        cmp("stream", s(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
+        nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)
+        assert np.array_equal(nosol[0], O[0][:9]) and np.array_equal(nosol[1], O[1][:9])
+        shared, per1 = oracle.pack_tv_model(*design)
+        O1 = fn(vt, x0, xr, ur, shared, per1)
+        cmp("stream", s(x0, xr, ur, *design), O1, vt, x0, xr, ur, shared, per1)
+        with pytest.raises(Exception, match="MFMA4R"):
+            s.set_variant("mfma4r")
 
 
 @pytest.mark.gpu
@@ -385,6 +432,45 @@ def test_hip_in_engineering_sparse_solvers_vs_oracle(name, B):
         s.set_variant("stream")
         u, k, e, sol = s(x0, xr, ur, *extra)
         assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0]) and np.array_equal(sol.z, O[3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,variant", [("C1_lax", "stream"), ("C1_lax", "mfma4r"), ("C1_equ", "stream"), ("C1_lax_FISTA", "stream"), ("C1_lax_FISTA", "mfma4r")])
+def test_hip_time_varying_in_engineering_vs_oracle(name, variant):
+    """Both options at once (code_laxMPC_ADMM_C.c:83-100: with TIME_VARYING == 1 the model's LB / UB arrive in engineering units too and are
+    scaled like x0 / xr / ur; A, B, Q, R pass as they are): the oracle in scaled units wrapped by that scaling, one model per instance.
+    (Refused with ENOSUP before round 5.)"""
+    from oracle import oracle
+    from spcies_amd import benchmarks
+    from spcies_amd.solver import HipSolver
+    cfg = _eng_cfg(name)
+    vt = benchmarks.ingredients(cfg, time_varying=True, in_engineering=True)
+    assert vt["time_varying"] and vt["in_engineering"]
+    n, m = cfg.sys.n, cfg.sys.m
+    sysm, prm = cfg.sys, cfg.param
+    LB = np.concatenate([np.ravel(sysm.LBx), np.ravel(sysm.LBu)])
+    UB = np.concatenate([np.ravel(sysm.UBx), np.ravel(sysm.UBu)])
+    design = (np.asarray(sysm.A, float), np.asarray(sysm.B, float), np.diag(prm.Q).copy(), np.diag(prm.R).copy(), LB, UB)
+    B = 45
+    A, Bm, Q, R, LBs, UBs = _perturbed_models(design, B)
+    sc = np.concatenate([vt["scaling_x"], vt["scaling_u"]])
+    op = np.concatenate([vt["OpPoint_x"], vt["OpPoint_u"]])
+    LB_in, UB_in = LBs / sc + op, UBs / sc + op          # what the caller hands over: engineering units
+    model, per = oracle.pack_tv_model(A, Bm, Q, R, sc * (LB_in - op), sc * (UB_in - op))  # what the solver iterates on
+    x0, xr, ur = benchmarks.sample_batch(cfg, B)
+    x0, xr, ur = x0 / vt["scaling_x"] + vt["OpPoint_x"], xr / vt["scaling_x"] + vt["OpPoint_x"], ur / vt["scaling_u"] + vt["OpPoint_u"]
+    fista = cfg.method == "FISTA"
+    fn = oracle.fista_tv_batch if fista else oracle.admm_tv_batch
+    O = _oracle_eng(fn, vt, x0, xr, ur, model=model, per_instance=per)
+    with HipSolver(vt) as s:
+        s.set_variant(variant)
+        u, k, e, sol = s(x0, xr, ur, A, Bm, Q, R, LB_in, UB_in)
+        if variant == "stream":
+            assert np.array_equal(k, O[1]) and np.array_equal(e, O[2]) and np.array_equal(u, O[0])
+            assert np.array_equal(sol.z, O[3])  # the record stays in scaled units, as the reference's
+        else:
+            assert np.array_equal(e, O[2]) and np.abs(k.astype(int) - O[1]).max() <= 1
+            assert np.abs(u - O[0]).max() <= 1e-10 and np.abs(sol.z - O[3]).max() <= 1e-10
 
 
 @pytest.mark.gpu
