@@ -38,6 +38,11 @@ SLOW = {
     "test_mfma4r_plants_with_many_inputs_or_up_to_32_rows[26-3-5-admm]": 8.0,
     "test_admm_r_arbitrary_shapes[18-3-9-laxMPC]": 7.9,
     "test_mfma4r_plants_with_many_inputs_or_up_to_32_rows[26-3-5-fista]": 5.7,
+    # later in round 5 (fast tier 423 s with the any-plant-size STREAM cases added): duplicates of shapes the fast tier keeps
+    "test_vector_rho_and_var_bounds_past_the_block_programs[C2_equ_N30_gen-48-overrides1]": 9.0,   # lax at the same shape stays
+    "test_admm_r_plain_and_unit_box_coordinates[C2_lax_N30-48-overrides0]": 7.9,                  # C1_lax stays; C2_lax_N30 runs in test_admm_past_the_register_file
+    "test_time_varying_any_plant_size[10-4-7-equMPC-ADMM]": 8.7,                                  # (9, 2) lax and (8, 3) equ FISTA stay
+    "test_time_varying_plants_past_the_register_file[12-6-5-equMPC-ADMM]": 8.8,                   # (20, 4) lax ADMM, (17, 3) equ FISTA, (20, 2) lax FISTA stay
 }
 
 
