@@ -5,6 +5,7 @@
 #include "admm_stream.hpp"   // tv_layout: the rows the update phase writes
 #include "fista_stream.hpp"  // fista_tv_layout
 #include "admm_tvr_kernel.inc"
+#include "admm_tvl_kernel.inc"  // (tvl_image_doubles; the kernels themselves are always run-time specialised)
 #include "rtc_common.hpp"
 
 namespace spcies {
@@ -15,6 +16,9 @@ static const char *const kSourceSolve =
     ;
 static const char *const kSourceUpdate =
 #include "tv_update_src.inc"
+    ;
+static const char *const kSourceLds =
+#include "admm_tvl_src.inc"
     ;
 
 void plan_free(Plan &p) {
@@ -27,8 +31,25 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
     p.ok = false;
     p.n = n; p.m = m; p.N = N; p.terminal = terminal; p.fista = fista;
     p.update_builtin = (n == 6 && m == 2) || (n == 12 && m == 2);  // admm_stream.hpp / fista_stream.hpp instantiate the update phase for these
-    if (n + m > 16 || n < 1 || m < 1) { p.why = "MFMA4R (time-varying): n + m <= 16 (a vector is one register in the D layout)"; return 0; }
+    p.lds = false;
+    if (n < 1 || m < 1) { p.why = "MFMA4R (time-varying): n, m >= 1"; return 0; }
     if (N < 2) { p.why = "N < 2"; return 0; }
+    {   // do the instance's factors fit the wavefront's registers?  Otherwise: the LDS form (admm_tvl_kernel.inc)
+        const int KXr = (n + 3) / 4, NLr = nl_of(N, KXr);
+        const int need = N * KXr + 2 * (N - 1 - NLr) * KXr + 16 + (fista ? 3 * N : 2 * N + 1) + 40;
+        if (n + m > 16 || 2 * need > 500) {
+            const char *ev = getenv("SPCIES_HIP_TVL");
+            if (ev && ev[0] == '0') { p.why = "MFMA4R (time-varying): the instance's factors do not fit the wavefront's registers and SPCIES_HIP_TVL=0 (use STREAM)"; return 0; }
+            if (fista) { p.why = "MFMA4R (time-varying FISTA): n + m <= 16 within the register file (the LDS form is built for ADMM; use STREAM)"; return 0; }
+            if (n + m > 32) { p.why = "MFMA4R (time-varying): n + m <= 32 (a stage vector is at most two registers in the D layout; use STREAM)"; return 0; }
+            const long bytes = 8L * tvl_image_doubles(n, m, N, terminal);
+            if (bytes > 160 * 1024) { p.why = "MFMA4R (time-varying): the instance's factors do not fit the CU's LDS (use STREAM)"; return 0; }
+            if (4 * ((n + m + 15) / 16) * (2 * N + 1) > 400) { p.why = "MFMA4R (time-varying, LDS form): the iteration state does not fit the registers (use STREAM)"; return 0; }
+            p.lds = true;
+            p.lds_per_cu = (int)std::min<long>(8, (160 * 1024) / bytes);
+            p.update_builtin = false;  // (everything from one module: update phase - rolled past n = 16 -, inverses, solve)
+        }
+    }
     if (fista) {   // the kernel's restatement of the update phase's row layout must be the layout
         const FistaTvLayout a = fista_tv_layout(n, m, N);
         const FRows b = frows_of(n, m, N);
@@ -40,10 +61,38 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
         if (a.AB != b.AB || a.Alpha != b.Alpha || a.Beta != b.Beta || a.Hi != b.Hi || a.Q != b.Q || a.R != b.R || a.LB != b.LB || a.UB != b.UB || a.Bi != b.Bi)
             return fail(SPCIES_HIP_EINVAL, "MFMA4R (time-varying): row layout mismatch between admm_stream.hpp and admm_tvr_kernel.inc");
     }
-    // registers: S_l (N KX doubles per lane; rounds 3-4: Bi and Bi', 2 N KX), the Alpha blocks the LDS does not hold, the state (2 N + 1; FISTA: 3 N), constants and temporaries
-    const int KX = (n + 3) / 4, NL = nl_of(N, KX);
-    const int doubles = N * KX + 2 * (N - 1 - NL) * KX + 16 + (fista ? 3 * N : 2 * N + 1) + 40;  // (L D L' form since round 5: S_l = S_l', one image)
-    if (2 * doubles > 500) { p.why = "MFMA4R (time-varying): the instance's factors do not fit the wavefront's registers (use STREAM)"; return 0; }
+    if (p.lds) {
+        const char *ev = getenv("SPCIES_HIP_RTC");
+        if (ev && ev[0] == '0') { p.why = "the LDS form is run-time specialised and SPCIES_HIP_RTC=0"; return 0; }
+        std::vector<std::string> nm;
+        char name[160];
+        for (int s = 0; s < 2; s++) {
+            snprintf(name, sizeof(name), "spcies::tvr::admm_tvl_kernel<%d, %d, %d, %s, %s>", n, m, N, terminal ? "true" : "false", s ? "true" : "false");
+            nm.push_back(name);
+        }
+        snprintf(name, sizeof(name), "spcies::tvr::tv_bi_rolled_kernel<%d>", n);
+        nm.push_back(name);
+        snprintf(name, sizeof(name), "spcies::admm_tv_update_kernel<%d, %d, %s, false>", n, m, terminal ? "true" : "false");
+        nm.push_back(name);
+        const std::string source = std::string(kSourceUpdate) + "\n" + kSourceSolve + "\n" + kSourceLds;
+        std::vector<std::string> extra = {"-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form"};
+        for (const std::string &e : rtc::split_flags(getenv("SPCIES_TVR_RTC_FLAGS"))) extra.push_back(e);
+        hipModule_t mod = nullptr;
+        hipFunction_t fns[4] = {nullptr, nullptr, nullptr, nullptr};
+        int rc = rtc::compile_module(source.c_str(), "spcies_admm_tvl_rtc.hip", nm, extra, &mod, fns);
+        if (rc) { p.why = std::string("MFMA4R (time-varying, LDS form): run-time specialisation failed: ") + spcies_hip_last_error(); p.build_failed = true; p.lds = false; return 0; }
+        p.module = mod;
+        p.fn[0] = nullptr; p.fn[1] = fns[0]; p.fn[2] = fns[1];
+        p.fn_bi = (void *)fns[2];
+        p.fn_update = (void *)fns[3];
+        p.fn_ms = nullptr;
+        p.builtin = false;
+        p.ok = true;
+        p.why.clear();
+        return 0;
+    }
+    // (registers: S_l - N KX doubles per lane; rounds 3-4: Bi and Bi', 2 N KX -, the Alpha blocks the LDS does not hold, the state - 2 N + 1; FISTA: 3 N -, constants
+    // and temporaries: checked above)
     p.builtin = shape_built(n, m, N);
     if (const char *ev = getenv("SPCIES_TVR_RTC"))  // kernel experiments: re-specialise a built-in shape (with SPCIES_TVR_RTC_FLAGS)
         if (ev[0] == '1') p.builtin = false;
@@ -99,6 +148,13 @@ int launch(const Plan &p, bool want_sol, const Args &a, const double *TRI, const
            const double *ur, double *u, int *k, int *e, double *z, double *v, double *lam, int num_cu, hipStream_t st) {
     if (!p.ok) return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying) unavailable: %s", p.why.c_str());
     if (want_sol && !(z && v && lam)) return fail(SPCIES_HIP_EINVAL, "MFMA4R (time-varying): pass all of z, v, lambda or none");
+    if (p.lds) {  // one 64-lane workgroup per instance, as many per CU as its LDS holds
+        const unsigned g = (unsigned)std::min<long>(a.B, (long)num_cu * p.lds_per_cu);
+        Args aa = a;
+        void *params[] = {&aa, &TRI, &T, &TVS, &x0, &xr, &ur, &u, &k, &e, &z, &v, &lam};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 2 : 1], g, 1, 1, 64, 1, 1, 0, st, params, nullptr));
+        return 0;
+    }
     const long groups = (a.B + 3) / 4;
     const unsigned grid = (unsigned)std::min<long>(groups, (long)num_cu);
     if (p.builtin) {
@@ -181,6 +237,14 @@ static int launch_ms(const Plan &p, long B, long Bp, double *TVS, hipStream_t st
 }
 
 int launch_update(const Plan &p, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp, double *TVS, hipStream_t st) {
+    if (p.ok && p.lds) {  // update phase without the inverses (rolled past n = 16), then the inverses by the rolled kernel: Alpha / Beta / Bi rows, no L D L' transform
+        int N = p.N, row_beta = rows_of(p.n, p.m, p.N).Beta, row_bi = rows_of(p.n, p.m, p.N).Bi;
+        void *up[] = {&N, &c0, &Tc, &model, &model_stride, &B, &Bp, &TVS};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_update, (unsigned)(Bp / 64), 1, 1, 64, 1, 1, 0, st, up, nullptr));
+        void *bp[] = {&N, &row_beta, &row_bi, &B, &Bp, &TVS};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_bi, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, st, bp, nullptr));
+        return 0;
+    }
     if (p.ok && p.update_builtin) {
         if (p.n == 6 && p.m == 2) launch_update_builtin<6, 2>(p, c0, Tc, model, model_stride, B, Bp, TVS, st);
         else launch_update_builtin<12, 2>(p, c0, Tc, model, model_stride, B, Bp, TVS, st);

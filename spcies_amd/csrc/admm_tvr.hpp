@@ -56,8 +56,14 @@ struct Plan {
     void *fn_ms = nullptr;                      // (run-time specialised path) tv_ms_kernel<n>: the update phase's rows -> the L D L' form's M, S
     void *fn_update = nullptr;                  // the update-phase kernel of an (n, m) without a build-time instantiation (tv_update_kernel.inc)
     bool update_builtin = false;                // (n, m) = (6, 2), (12, 2): admm_stream.hpp's instantiations, launched by the caller
+    // plants past the register file (n + m > 16, or a horizon whose factors the registers do not hold): the same iteration with the instance's
+    // factors in the LDS - admm_tvl_kernel.inc, ADMM only, n + m <= 32, N n^2 + (N - 1) n^2 + n (n + m) (+ n^2) doubles within 160 KB; always run-time
+    // specialised, with the update phase (rolled past n = 16) and the explicit inverses (tv_bi_rolled_kernel) of the same module
+    bool lds = false;
+    int lds_per_cu = 1;                         // workgroups (= instances) a CU's LDS holds at once
+    void *fn_bi = nullptr;
 };
-// decides whether the variant applies (n + m <= 16, the state within the register file) and, for a shape without build-time kernels, compiles
+// decides whether the variant applies (n + m <= 16 and the state within the register file; past it the LDS form, see Plan::lds) and, for a shape without build-time kernels, compiles
 // them (hiprtc; code-object cache) - the update phase included, so that ANY plant size within those limits has a time-varying path
 int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista = false);
 void plan_free(Plan &p);
