@@ -44,7 +44,7 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
             if (n + m > 32) { p.why = "MFMA4R (time-varying): n + m <= 32 (a stage vector is at most two registers in the D layout; use STREAM)"; return 0; }
             const long bytes = 8L * tvl_image_doubles(n, m, N, terminal);
             if (bytes > 160 * 1024) { p.why = "MFMA4R (time-varying): the instance's factors do not fit the CU's LDS (use STREAM)"; return 0; }
-            if (2 * ((n + m + 15) / 16) * (2 * N + 1) > 400)  // (w and mu: (2 N + 1) vectors of one or two registers of doubles) { p.why = "MFMA4R (time-varying, LDS form): the iteration state does not fit the registers (use STREAM)"; return 0; }
+            if (2 * ((n + m + 15) / 16) * (2 * N + 1) > 400) /* w and mu: (2 N + 1) vectors of one or two registers of doubles */ { p.why = "MFMA4R (time-varying, LDS form): the iteration state does not fit the registers (use STREAM)"; return 0; }
             p.lds = true;
             p.lds_per_cu = (int)std::min<long>(8, (160 * 1024) / bytes);
             p.update_builtin = false;  // (everything from one module: update phase - rolled past n = 16 -, inverses, solve)

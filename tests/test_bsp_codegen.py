@@ -196,6 +196,28 @@ def test_admm_r_kernels_compile_with_the_flags_the_library_uses(tmp_path):
     assert len(lds) == 4 and max(lds) <= 160 * 1024
 
 
+@pytest.mark.parametrize("inst", ["tvr::admm_tvl_kernel<20, 4, 20, true, false>", "tvr::admm_tvl_kernel<18, 3, 7, false, true>", "tvr::tv_bi_rolled_kernel<20>"])
+def test_time_varying_lds_form_compiles_within_the_lds_and_without_scratch(inst, tmp_path):
+    """admm_tvl_kernel.inc (time-varying ADMM for plants past the register file: the instance's factors in the LDS) is always run-time specialised,
+    as the concatenation admm_tvr.hip hands to hiprtc: compiled here out of process with the library's options - the 20-state plant of BASELINE
+    configs[3] at N = 20 must fit the CU's 160 KB of LDS, and the iteration must not touch scratch memory (the first version hoisted its LDS reads
+    into registers and spilled 1 KB per lane)."""
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spcies_amd", "csrc")
+    src = "\n".join(open(os.path.join(here, f)).read() for f in ("tv_update_kernel.inc", "admm_tvr_kernel.inc", "admm_tvl_kernel.inc"))
+    src += f"\nnamespace spcies {{ __device__ void *spcies_keep_ = (void *)&{inst}; }}\n"
+    p = tmp_path / "tvl.hip"
+    p.write_text(src)
+    import sys
+    co = tmp_path / "tvl.co"
+    r = subprocess.run([sys.executable, "-c", _COMPILE, HIPRTC, str(p), str(co), "-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    notes = subprocess.run([READELF, "--notes", str(co)], capture_output=True, text=True).stdout
+    lds = [int(x) for x in re.findall(r"\.group_segment_fixed_size:\s+(\d+)", notes)]
+    scratch = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+    assert len(lds) == 1 and lds[0] <= 160 * 1024 and scratch == [0], (lds, scratch)
+
+
 @pytest.mark.parametrize("family,inst", [("admm", "admm_stream_kernel<7, 3, true, true>"), ("fista", "fista_stream_kernel<7, 3, false, true>"),
                                          ("eadmm", "eadmm_stream_kernel<7, 3, true>"), ("tv", "admm_tv_update_kernel<7, 3, true, true>"),
                                          # round 5: the other switches of the template at any plant size (ensure_stream_rtc) - time-varying
