@@ -93,6 +93,12 @@ def config(name):
         if name == "C3":
             c.param.N, c.B, c.seed = 30, 262144, 1203
         return c
+    if name in ("C4_lax_FISTA", "C4_equ_FISTA"):  # the 20-state plant of configs[3] at N = 20 under FISTA, 100 fixed iterations (time-varying runs past the register file)
+        c = config("C4_lax_ADMM" if "lax" in name else "C4_equ_ADMM")
+        c.name, c.method = name, "FISTA"
+        c.param.T = np.diag(np.diag(c.param.T))
+        c.solver_options = dict(k_max=100, tol=0.0)
+        return c
     if name in ("C1_MPCT", "C4"):  # tests/test_MPCT_EADMM.m:6-17; C4: 20-state, N = 20, 200 fixed iterations
         sys = sp_utils.oscillating_masses_sys(3 if name == "C1_MPCT" else 10)
         Q, R, _ = _weights(sys, "diag")

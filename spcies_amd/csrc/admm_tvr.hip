@@ -40,11 +40,10 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
         if (n + m > 16 || 2 * need > 500) {
             const char *ev = getenv("SPCIES_HIP_TVL");
             if (ev && ev[0] == '0') { p.why = "MFMA4R (time-varying): the instance's factors do not fit the wavefront's registers and SPCIES_HIP_TVL=0 (use STREAM)"; return 0; }
-            if (fista) { p.why = "MFMA4R (time-varying FISTA): n + m <= 16 within the register file (the LDS form is built for ADMM; use STREAM)"; return 0; }
             if (n + m > 32) { p.why = "MFMA4R (time-varying): n + m <= 32 (a stage vector is at most two registers in the D layout; use STREAM)"; return 0; }
-            const long bytes = 8L * tvl_image_doubles(n, m, N, terminal);
+            const long bytes = 8L * (fista ? ftvl_image_doubles(n, m, N) : tvl_image_doubles(n, m, N, terminal));
             if (bytes > 160 * 1024) { p.why = "MFMA4R (time-varying): the instance's factors do not fit the CU's LDS (use STREAM)"; return 0; }
-            if (2 * ((n + m + 15) / 16) * (2 * N + 1) > 400) /* w and mu: (2 N + 1) vectors of one or two registers of doubles */ { p.why = "MFMA4R (time-varying, LDS form): the iteration state does not fit the registers (use STREAM)"; return 0; }
+            if (2 * ((n + m + 15) / 16) * (fista ? 3 * N : 2 * N + 1) > 400) /* w and mu (FISTA: y, lambda, d): 2 N + 1 (3 N) vectors of one or two registers of doubles */ { p.why = "MFMA4R (time-varying, LDS form): the iteration state does not fit the registers (use STREAM)"; return 0; }
             p.lds = true;
             p.lds_per_cu = (int)std::min<long>(8, (160 * 1024) / bytes);
             p.update_builtin = false;  // (everything from one module: update phase - rolled past n = 16 -, inverses, solve)
@@ -67,12 +66,12 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
         std::vector<std::string> nm;
         char name[160];
         for (int s = 0; s < 2; s++) {
-            snprintf(name, sizeof(name), "spcies::tvr::admm_tvl_kernel<%d, %d, %d, %s, %s>", n, m, N, terminal ? "true" : "false", s ? "true" : "false");
+            snprintf(name, sizeof(name), "spcies::tvr::%s_tvl_kernel<%d, %d, %d, %s, %s>", fista ? "fista" : "admm", n, m, N, terminal ? "true" : "false", s ? "true" : "false");
             nm.push_back(name);
         }
         snprintf(name, sizeof(name), "spcies::tvr::tv_bi_rolled_kernel<%d>", n);
         nm.push_back(name);
-        snprintf(name, sizeof(name), "spcies::admm_tv_update_kernel<%d, %d, %s, false>", n, m, terminal ? "true" : "false");
+        snprintf(name, sizeof(name), "spcies::%s_tv_update_kernel<%d, %d, %s, false>", fista ? "fista" : "admm", n, m, terminal ? "true" : "false");
         nm.push_back(name);
         const std::string source = std::string(kSourceUpdate) + "\n" + kSourceSolve + "\n" + kSourceLds;
         std::vector<std::string> extra = {"-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form"};
@@ -189,6 +188,13 @@ int launch_fista(const Plan &p, bool want_sol, const Args &a, const double *T, c
                  const double *ur, double *u, int *k, int *e, double *z, double *lam, int num_cu, hipStream_t st) {
     if (!p.ok || !p.fista) return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying FISTA) unavailable: %s", p.why.c_str());
     if (want_sol && !(z && lam)) return fail(SPCIES_HIP_EINVAL, "MFMA4R (time-varying FISTA): pass both z and lambda or neither");
+    if (p.lds) {  // one 64-lane workgroup per instance, as many per CU as its LDS holds
+        const unsigned g = (unsigned)std::min<long>(a.B, (long)num_cu * p.lds_per_cu);
+        Args aa = a;
+        void *params[] = {&aa, &T, &Ti, &TVS, &x0, &xr, &ur, &u, &k, &e, &z, &lam};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 2 : 1], g, 1, 1, 64, 1, 1, 0, st, params, nullptr));
+        return 0;
+    }
     const long groups = (a.B + 3) / 4;
     const unsigned grid = (unsigned)std::min<long>(groups, (long)num_cu);
     if (p.builtin) {
@@ -238,9 +244,15 @@ static int launch_ms(const Plan &p, long B, long Bp, double *TVS, hipStream_t st
 
 int launch_update(const Plan &p, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp, double *TVS, hipStream_t st) {
     if (p.ok && p.lds) {  // update phase without the inverses (rolled past n = 16), then the inverses by the rolled kernel: Alpha / Beta / Bi rows, no L D L' transform
-        int N = p.N, row_beta = rows_of(p.n, p.m, p.N).Beta, row_bi = rows_of(p.n, p.m, p.N).Bi;
-        void *up[] = {&N, &c0, &Tc, &model, &model_stride, &B, &Bp, &TVS};
-        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_update, (unsigned)(Bp / 64), 1, 1, 64, 1, 1, 0, st, up, nullptr));
+        int N = p.N, row_beta = p.fista ? frows_of(p.n, p.m, p.N).Beta : rows_of(p.n, p.m, p.N).Beta;
+        int row_bi = p.fista ? frows_of(p.n, p.m, p.N).Bi : rows_of(p.n, p.m, p.N).Bi;
+        if (p.fista) {
+            void *up[] = {&N, &Tc, &model, &model_stride, &B, &Bp, &TVS};
+            SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_update, (unsigned)(Bp / 64), 1, 1, 64, 1, 1, 0, st, up, nullptr));
+        } else {
+            void *up[] = {&N, &c0, &Tc, &model, &model_stride, &B, &Bp, &TVS};
+            SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_update, (unsigned)(Bp / 64), 1, 1, 64, 1, 1, 0, st, up, nullptr));
+        }
         void *bp[] = {&N, &row_beta, &row_bi, &B, &Bp, &TVS};
         SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_bi, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, st, bp, nullptr));
         return 0;

@@ -57,7 +57,7 @@ struct Plan {
     void *fn_update = nullptr;                  // the update-phase kernel of an (n, m) without a build-time instantiation (tv_update_kernel.inc)
     bool update_builtin = false;                // (n, m) = (6, 2), (12, 2): admm_stream.hpp's instantiations, launched by the caller
     // plants past the register file (n + m > 16, or a horizon whose factors the registers do not hold): the same iteration with the instance's
-    // factors in the LDS - admm_tvl_kernel.inc, ADMM only, n + m <= 32, N n^2 + (N - 1) n^2 + n (n + m) (+ n^2) doubles within 160 KB; always run-time
+    // factors in the LDS - admm_tvl_kernel.inc (ADMM and FISTA), n + m <= 32, N n^2 + (N - 1) n^2 + n (n + m) (+ n^2) doubles within 160 KB; always run-time
     // specialised, with the update phase (rolled past n = 16) and the explicit inverses (tv_bi_rolled_kernel) of the same module
     bool lds = false;
     int lds_per_cu = 1;                         // workgroups (= instances) a CU's LDS holds at once

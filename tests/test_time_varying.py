@@ -220,8 +220,8 @@ def test_time_varying_any_plant_size(n, m, N, formulation, method):
 def test_time_varying_plants_past_the_register_file(n, m, N, formulation, method):
     """The 9-input solvers of plants the register-resident solver does not hold (n + m > 16: the 20-state plant of configs[3] among them).  Rounds 2-4
     answered ENOSUP here.  STREAM - update phase and iteration specialised with hiprtc for this (n, m), the update phase in its rolled form past
-    n = 16 (tv_band_factor_rolled) - bit for bit against the oracle, one model per instance and one shared model; it is AUTO for FISTA.  ADMM: AUTO is
-    MFMA4R in its LDS form (admm_tvl_kernel.inc: one wavefront per instance, the instance's factors in the LDS, stage vectors of two registers), 1e-10."""
+    n = 16 (tv_band_factor_rolled) - bit for bit against the oracle, one model per instance and one shared model.  AUTO is MFMA4R in its LDS form
+    (admm_tvl_kernel.inc: one wavefront per instance, the instance's factors in the LDS, stage vectors of two registers; ADMM and FISTA), 1e-10."""
     from oracle import oracle
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
@@ -245,19 +245,16 @@ def test_time_varying_plants_past_the_register_file(n, m, N, formulation, method
     model, per = oracle.pack_tv_model(*models)
     fn, cmp = (oracle.fista_tv_batch, _compare_tv_fista) if method == "FISTA" else (oracle.admm_tv_batch, _compare_tv)
     with HipSolver(vt) as s:
-        auto = "stream" if method == "FISTA" else "mfma4r"
+        auto = "mfma4r"  # the LDS form, ADMM and FISTA
         assert s.time_varying and s.variant == auto, (s.variant, s.notes)
         O = fn(vt, x0, xr, ur, model, per)
         shared, per1 = oracle.pack_tv_model(*design)
         O1 = fn(vt, x0, xr, ur, shared, per1)
-        if auto == "mfma4r":  # the LDS form
-            cmp("mfma4r", s(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
-            nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)
-            assert np.abs(nosol[0] - O[0][:9]).max() <= 1e-9 and np.abs(nosol[1].astype(int) - O[1][:9].astype(int)).max() <= 1
-            cmp("mfma4r", s(x0, xr, ur, *design), O1, vt, x0, xr, ur, shared, per1)
-        else:
-            with pytest.raises(Exception, match="MFMA4R"):
-                s.set_variant("mfma4r")
+        full = s(x0, xr, ur, *models)
+        cmp("mfma4r", full, O, vt, x0, xr, ur, model, per)
+        nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)  # the record-free instantiation: the same bits (no contraction in either)
+        assert np.array_equal(nosol[0], full[0][:9]) and np.array_equal(nosol[1], full[1][:9])
+        cmp("mfma4r", s(x0, xr, ur, *design), O1, vt, x0, xr, ur, shared, per1)
         s.set_variant("stream")
         cmp("stream", s(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
         nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)
