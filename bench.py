@@ -97,7 +97,7 @@ def traffic_from_profile(variant):
 
 
 _PROFILE_TAG = {"C3": "C3", "C4": "C4", "C4_nd": "C4nd", "C2_N30": "C2N30", "C2_N30_gen": "C2N30gen", "C5_soc": "C5soc", "C5_hmpc": "C5hmpc", "C2_tv": "C2tv",
-                "C2_tv_fista": "C2tvfista"}
+                "C2_tv_fista": "C2tvfista", "C4_tv": "C4tv", "C4_tv_fista": "C4tvfista"}
 
 
 def design_traffic(key, variant):
