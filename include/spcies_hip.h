@@ -220,7 +220,8 @@ typedef struct spcies_hip_solver_s *spcies_hip_handle;
                                  * (AUTO's choice there with vector rho or stage-wise bounds, on request otherwise) */
 #define SPCIES_VARIANT_FUSED 8  /* HMPC dense paths and MPCT ADMM cs: product, projections, duals and exit test in one v_mfma_f64_4x4x4 kernel */
 #define SPCIES_VARIANT_MFMA4R 9 /* FISTA, MPCT EADMM, lax / equ ADMM (AUTO past MFMA4's register file), time-varying ADMM / FISTA:
-                                   v_mfma_f64_4x4x4, unrolled on the horizon, iteration state in registers + LDS  */
+                                   v_mfma_f64_4x4x4, unrolled on the horizon, iteration state in registers + LDS.  Time-varying: one wavefront per
+                                   instance, its factors in registers (n + m <= 16) or - past the register file, n + m <= 32 - in the LDS */
 /* Integer outputs.  STREAM runs the reference's operation order and returns its k / e_flag bit for bit.  The other variants
  * re-associate sums (1e-10 on the iterates): an exit test decided within rounding may fire one iteration apart on < 0.1 % of
  * instances.  tol = 0 is the reference tests' fixed-iteration setting (k = k_max, e_flag = -1): MPCT ADMM cs FUSED, whose
