@@ -73,17 +73,24 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
         nm.push_back(name);
         snprintf(name, sizeof(name), "spcies::%s_tv_update_kernel<%d, %d, %s, false>", fista ? "fista" : "admm", n, m, terminal ? "true" : "false");
         nm.push_back(name);
+        snprintf(name, sizeof(name), "spcies::tvr::tv_update_coop_kernel<%d, %d, %s, %s>", n, m, terminal ? "true" : "false", fista ? "true" : "false");
+        nm.push_back(name);
         const std::string source = std::string(kSourceUpdate) + "\n" + kSourceSolve + "\n" + kSourceLds;
         std::vector<std::string> extra = {"-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form"};
         for (const std::string &e : rtc::split_flags(getenv("SPCIES_TVR_RTC_FLAGS"))) extra.push_back(e);
         hipModule_t mod = nullptr;
-        hipFunction_t fns[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipFunction_t fns[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         int rc = rtc::compile_module(source.c_str(), "spcies_admm_tvl_rtc.hip", nm, extra, &mod, fns);
         if (rc) { p.why = std::string("MFMA4R (time-varying, LDS form): run-time specialisation failed: ") + spcies_hip_last_error(); p.build_failed = true; p.lds = false; return 0; }
         p.module = mod;
         p.fn[0] = nullptr; p.fn[1] = fns[0]; p.fn[2] = fns[1];
         p.fn_bi = (void *)fns[2];
         p.fn_update = (void *)fns[3];
+        p.fn_coop = (void *)fns[4];
+        {   // SPCIES_TVL_COOP=0: the one-lane-per-instance update phase and inverses (the cross-check of the cooperative kernel: the same bits)
+            const char *cv = getenv("SPCIES_TVL_COOP");
+            p.coop = !(cv && cv[0] == '0');
+        }
         p.fn_ms = nullptr;
         p.builtin = false;
         p.ok = true;
@@ -243,7 +250,14 @@ static int launch_ms(const Plan &p, long B, long Bp, double *TVS, hipStream_t st
 }
 
 int launch_update(const Plan &p, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp, double *TVS, hipStream_t st) {
-    if (p.ok && p.lds) {  // update phase without the inverses (rolled past n = 16), then the inverses by the rolled kernel: Alpha / Beta / Bi rows, no L D L' transform
+    if (p.ok && p.lds && p.coop) {  // the cooperative update phase (tv_update_coop_kernel): 8 / 16 / 32 lanes per instance, the small rows and the packed triangles of the Bi_l out
+        int N = p.N;
+        const int lpi = p.n <= 8 ? 8 : (p.n <= 16 ? 16 : 32), g = 64 / lpi;
+        void *up[] = {&N, &c0, &Tc, &model, &model_stride, &B, &Bp, &TVS};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_coop, (unsigned)((B + g - 1) / g), 1, 1, 64, 1, 1, 0, st, up, nullptr));
+        return 0;
+    }
+    if (p.ok && p.lds) {  // cross-check path: update phase without the inverses (rolled past n = 16), then the inverses by the rolled kernel (packed triangles)
         int N = p.N, row_beta = p.fista ? frows_of(p.n, p.m, p.N).Beta : rows_of(p.n, p.m, p.N).Beta;
         int row_bi = p.fista ? frows_of(p.n, p.m, p.N).Bi : rows_of(p.n, p.m, p.N).Bi;
         if (p.fista) {

@@ -62,6 +62,8 @@ struct Plan {
     bool lds = false;
     int lds_per_cu = 1;                         // workgroups (= instances) a CU's LDS holds at once
     void *fn_bi = nullptr;
+    void *fn_coop = nullptr;                    // tv_update_coop_kernel: the LDS form's update phase, several lanes per instance (the product path)
+    bool coop = true;                           // (SPCIES_TVL_COOP=0: fn_update + fn_bi instead - one lane per instance, the same bits)
 };
 // decides whether the variant applies (n + m <= 16 and the state within the register file; past it the LDS form, see Plan::lds) and, for a shape without build-time kernels, compiles
 // them (hiprtc; code-object cache) - the update phase included, so that ANY plant size within those limits has a time-varying path

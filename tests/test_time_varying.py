@@ -217,7 +217,7 @@ def test_time_varying_any_plant_size(n, m, N, formulation, method):
                                                       (20, 2, 5, "laxMPC", "FISTA"),
                                                       (6, 2, 40, "laxMPC", "ADMM"),    # n + m <= 16 but 40 blocks of factors: past the registers, 35 KB of LDS
                                                       (18, 3, 7, "equMPC", "ADMM")])   # n, n + m not multiples of 4: the masked last k-slab, two ragged row groups
-def test_time_varying_plants_past_the_register_file(n, m, N, formulation, method):
+def test_time_varying_plants_past_the_register_file(n, m, N, formulation, method, monkeypatch):
     """The 9-input solvers of plants the register-resident solver does not hold (n + m > 16: the 20-state plant of configs[3] among them).  Rounds 2-4
     answered ENOSUP here.  STREAM - update phase and iteration specialised with hiprtc for this (n, m), the update phase in its rolled form past
     n = 16 (tv_band_factor_rolled) - bit for bit against the oracle, one model per instance and one shared model.  AUTO is MFMA4R in its LDS form
@@ -260,6 +260,14 @@ def test_time_varying_plants_past_the_register_file(n, m, N, formulation, method
         nosol = s(x0[:9], xr[:9], ur[:9], *[a[:9] for a in models], want_sol=False)
         assert np.array_equal(nosol[0], O[0][:9]) and np.array_equal(nosol[1], O[1][:9])
         cmp("stream", s(x0, xr, ur, *design), O1, vt, x0, xr, ur, shared, per1)
+    # the update phase of the LDS form is cooperative (tv_update_coop_kernel: a lane per column, several instances per wavefront); every entry of its
+    # factors is the sum the one-lane-per-instance kernels form, in their order - SPCIES_TVL_COOP=0 runs those instead: the same bits out of the solve
+    monkeypatch.setenv("SPCIES_TVL_COOP", "0")
+    with HipSolver(vt) as s1:
+        assert s1.variant == "mfma4r", (s1.variant, s1.notes)
+        one = s1(x0, xr, ur, *models)
+    assert all(np.array_equal(a, b) for a, b in zip(full[:3], one[:3]))
+    assert np.array_equal(full[3].z, one[3].z) and np.array_equal(full[3].lam, one[3].lam)
 
 
 @pytest.mark.gpu
