@@ -5,7 +5,6 @@
 #include "admm_stream.hpp"   // tv_layout: the rows the update phase writes
 #include "fista_stream.hpp"  // fista_tv_layout
 #include "admm_tvr_kernel.inc"
-#include "admm_tvl_kernel.inc"  // (tvl_image_doubles; the kernels themselves are always run-time specialised)
 #include "rtc_common.hpp"
 
 namespace spcies {
@@ -16,9 +15,6 @@ static const char *const kSourceSolve =
     ;
 static const char *const kSourceUpdate =
 #include "tv_update_src.inc"
-    ;
-static const char *const kSourceLds =
-#include "admm_tvl_src.inc"
     ;
 
 void plan_free(Plan &p) {
@@ -41,7 +37,7 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
             const char *ev = getenv("SPCIES_HIP_TVL");
             if (ev && ev[0] == '0') { p.why = "MFMA4R (time-varying): the instance's factors do not fit the wavefront's registers and SPCIES_HIP_TVL=0 (use STREAM)"; return 0; }
             if (n + m > 32) { p.why = "MFMA4R (time-varying): n + m <= 32 (a stage vector is at most two registers in the D layout; use STREAM)"; return 0; }
-            const long bytes = 8L * (fista ? ftvl_image_doubles(n, m, N) : tvl_image_doubles(n, m, N, terminal));
+            const long bytes = tvl_lds_bytes(n, m, N, terminal, fista);  // (admm_tvl.hip)
             if (bytes > 160 * 1024) { p.why = "MFMA4R (time-varying): the instance's factors do not fit the CU's LDS (use STREAM)"; return 0; }
             if (2 * ((n + m + 15) / 16) * (fista ? 3 * N : 2 * N + 1) > 400) /* w and mu (FISTA: y, lambda, d): 2 N + 1 (3 N) vectors of one or two registers of doubles */ { p.why = "MFMA4R (time-varying, LDS form): the iteration state does not fit the registers (use STREAM)"; return 0; }
             p.lds = true;
@@ -75,7 +71,7 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
         nm.push_back(name);
         snprintf(name, sizeof(name), "spcies::tvr::tv_update_coop_kernel<%d, %d, %s, %s>", n, m, terminal ? "true" : "false", fista ? "true" : "false");
         nm.push_back(name);
-        const std::string source = std::string(kSourceUpdate) + "\n" + kSourceSolve + "\n" + kSourceLds;
+        const std::string source = std::string(kSourceUpdate) + "\n" + kSourceSolve + "\n" + tvl_source();
         std::vector<std::string> extra = {"-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form"};
         for (const std::string &e : rtc::split_flags(getenv("SPCIES_TVR_RTC_FLAGS"))) extra.push_back(e);
         hipModule_t mod = nullptr;

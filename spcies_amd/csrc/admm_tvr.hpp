@@ -68,6 +68,9 @@ struct Plan {
 // decides whether the variant applies (n + m <= 16 and the state within the register file; past it the LDS form, see Plan::lds) and, for a shape without build-time kernels, compiles
 // them (hiprtc; code-object cache) - the update phase included, so that ANY plant size within those limits has a time-varying path
 int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista = false);
+// (admm_tvl.hip) the LDS form: the text of admm_tvl_kernel.inc for hiprtc, and the bytes of LDS one instance's images take
+const char *tvl_source();
+long tvl_lds_bytes(int n, int m, int N, bool terminal, bool fista);
 void plan_free(Plan &p);
 // the solve of one chunk; pointers are device memory, TVS as admm_tv_update_kernel<n, m, TERMINAL, BI = true> left it (factors AND the explicit
 // inverses Bi: tv_update_kernel.inc)

@@ -42,9 +42,14 @@ def main():
         i = args.index("--isa")
         isa = args[i + 1]
         del args[i:i + 2]
+    inc = os.path.join(HERE, "admm_tvl_kernel.inc")
+    if "--inc" in args:  # a working copy of admm_tvl_kernel.inc
+        i = args.index("--inc")
+        inc = args[i + 1]
+        del args[i:i + 2]
     insts = [a for a in args if not a.startswith("-")]
     flags = [a for a in args if a.startswith("-")]
-    src = "\n".join(open(os.path.join(HERE, f)).read() for f in ("tv_update_kernel.inc", "admm_tvr_kernel.inc", "admm_tvl_kernel.inc"))
+    src = "\n".join(open(f).read() for f in (os.path.join(HERE, "tv_update_kernel.inc"), os.path.join(HERE, "admm_tvr_kernel.inc"), inc))
     src += "\nnamespace spcies { __device__ void *spcies_keep_[] = {" + ", ".join(f"(void *)&{i}" for i in insts) + "}; }\n"
     d = isa or tempfile.mkdtemp()
     os.makedirs(d, exist_ok=True)
