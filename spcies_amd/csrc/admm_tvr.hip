@@ -33,7 +33,9 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
     {   // do the instance's factors fit the wavefront's registers?  Otherwise: the LDS form (admm_tvl_kernel.inc)
         const int KXr = (n + 3) / 4, NLr = nl_of(N, KXr);
         const int need = N * KXr + 2 * (N - 1 - NLr) * KXr + 16 + (fista ? 3 * N : 2 * N + 1) + 40;
-        if (n + m > 16 || 2 * need > 500) {
+        const char *pv = getenv("SPCIES_HIP_TVL");
+        const bool prefer_lds = pv && pv[0] == '2';  // (experiments: the LDS form also where the registers would hold the factors)
+        if (n + m > 16 || 2 * need > 500 || prefer_lds) {
             const char *ev = getenv("SPCIES_HIP_TVL");
             if (ev && ev[0] == '0') { p.why = "MFMA4R (time-varying): the instance's factors do not fit the wavefront's registers and SPCIES_HIP_TVL=0 (use STREAM)"; return 0; }
             if (n + m > 32) { p.why = "MFMA4R (time-varying): n + m <= 32 (a stage vector is at most two registers in the D layout; use STREAM)"; return 0; }
@@ -42,6 +44,7 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
             if (2 * ((n + m + 15) / 16) * (fista ? 3 * N : 2 * N + 1) > 400) /* w and mu (FISTA: y, lambda, d): 2 N + 1 (3 N) vectors of one or two registers of doubles */ { p.why = "MFMA4R (time-varying, LDS form): the iteration state does not fit the registers (use STREAM)"; return 0; }
             p.lds = true;
             p.lds_per_cu = (int)std::min<long>(8, (160 * 1024) / bytes);
+            if (const char *cv = getenv("SPCIES_TVL_PER_CU")) p.lds_per_cu = std::max(1, std::min(atoi(cv), (int)((160 * 1024) / bytes)));
             p.update_builtin = false;  // (everything from one module: update phase - rolled past n = 16 -, inverses, solve)
         }
     }
