@@ -63,9 +63,9 @@ EXTRA_CONFIGS = {
     # ... and its FISTA twin (code_laxMPC_FISTA_C.c with TIME_VARYING == 1): 100 iterations
     "C2_tv_fista": dict(name="C2_lax_FISTA", tv=True, B=65536, flop=23.8e3 * 100 + 95e3, io=232 + 232 * 8,
                         what="SURVEY 8f rank 1: time-varying laxMPC-FISTA, C2 shape (n=12, m=2, N=15), one model per instance, 100 iterations, batch=65536"),
-    # ... at the plant of configs[3] (n = 20, m = 2, N = 20): past the register file - round 5: MFMA4R in its LDS form (admm_tvl_kernel.inc: the instance's
-    # 129 KB of factors in the LDS, one instance per CU); STREAM (27 k / 15 k solves/s) before, and no path at all before round 5.  flop: 2 (2 n (n + m) +
-    # 3 n^2) + elementwise per stage and iteration, plus the on-line factorisation
+    # ... at the plant of configs[3] (n = 20, m = 2, N = 20): past the register file - round 5: MFMA4R in its LDS form (admm_tvl_kernel.inc: the packed
+    # triangles of S_l = Bi_l Bi_l' in the LDS, 34 KB per instance, one instance per SIMD); STREAM (27 k / 15 k solves/s) before, and no path at all before
+    # round 5.  flop: 2 (2 n (n + m) + 3 n^2) + elementwise per stage and iteration (the reference's count), plus the on-line factorisation
     "C4_tv": dict(name="C4_lax_ADMM", tv=True, B=16384, flop=90e3 * 200 + 350e3, io=(20 + 20 + 2 + 2) * 8 + 506 * 8,
                   what="SURVEY 8f rank 1 at the configs[3] plant: time-varying laxMPC-ADMM, n=20, m=2, N=20, one model per instance, 200 iterations, batch=16384"),
     "C4_tv_fista": dict(name="C4_lax_FISTA", tv=True, B=16384, flop=78e3 * 100 + 350e3, io=(20 + 20 + 2 + 2) * 8 + 506 * 8,
