@@ -16,6 +16,26 @@ const char *tvl_source() {
     return text;
 }
 
+// the cooperative update phase in its instance-major form (FORM 1) for the (n, m) of the build-time register-resident kernels
+template <int n, int m>
+static void coop_go(bool terminal, bool fista, unsigned grid, hipStream_t st, int N, double c0, const double *Tc, const double *model, long model_stride, long B,
+                    long Bp, double *TVS) {
+#define SPCIES_GO(TT, FF) hipLaunchKernelGGL((tv_update_coop_kernel<n, m, TT, FF, 1>), dim3(grid), dim3(64), 0, st, N, c0, Tc, model, model_stride, B, Bp, TVS)
+    if (terminal) { if (fista) SPCIES_GO(true, true); else SPCIES_GO(true, false); }
+    else { if (fista) SPCIES_GO(false, true); else SPCIES_GO(false, false); }
+#undef SPCIES_GO
+}
+int launch_coop_builtin(int n, int m, int N, bool terminal, bool fista, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp,
+                        double *TVS, hipStream_t st) {
+    const int lpi = n <= 8 ? 8 : (n <= 16 ? 16 : 32), g = 64 / lpi;
+    const unsigned grid = (unsigned)((B + g - 1) / g);
+    if (n == 6 && m == 2) coop_go<6, 2>(terminal, fista, grid, st, N, c0, Tc, model, model_stride, B, Bp, TVS);
+    else if (n == 12 && m == 2) coop_go<12, 2>(terminal, fista, grid, st, N, c0, Tc, model, model_stride, B, Bp, TVS);
+    else return fail(SPCIES_HIP_ENOSUP, "cooperative update phase: no build-time kernel for n=%d m=%d", n, m);
+    SPCIES_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 long tvl_lds_bytes(int n, int m, int N, bool terminal, bool fista) {
     return 8L * (fista ? ftvl_image_doubles(n, m, N) : tvl_image_doubles(n, m, N, terminal));
 }

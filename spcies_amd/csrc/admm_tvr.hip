@@ -48,6 +48,11 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
             p.update_builtin = false;  // (everything from one module: update phase - rolled past n = 16 -, inverses, solve)
         }
     }
+    p.rows_all = (fista ? (long)frows_of(n, m, N).Bi : (long)rows_of(n, m, N).Bi) + (long)N * n * n;
+    {   // the register-resident form takes its images from the cooperative update phase, instance-major (SPCIES_TVR_COOP=0: one lane per instance + tv_ms_kernel)
+        const char *cv = getenv("SPCIES_TVR_COOP");
+        p.coop_im = !p.lds && !(cv && cv[0] == '0');
+    }
     if (fista) {   // the kernel's restatement of the update phase's row layout must be the layout
         const FistaTvLayout a = fista_tv_layout(n, m, N);
         const FRows b = frows_of(n, m, N);
@@ -115,18 +120,21 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista) {
         if (!p.update_builtin) {  // an (n, m) without a build-time update phase: the same text as admm_stream.hpp compiles, specialised here
             snprintf(name, sizeof(name), "spcies::%s_tv_update_kernel<%d, %d, %s, true>", fista ? "fista" : "admm", n, m, terminal ? "true" : "false");
             nm.push_back(name);
+            snprintf(name, sizeof(name), "spcies::tvr::tv_update_coop_kernel<%d, %d, %s, %s, 1>", n, m, terminal ? "true" : "false", fista ? "true" : "false");
+            nm.push_back(name);
         }
-        const std::string source = std::string(kSourceUpdate) + "\n" + kSourceSolve;
+        const std::string source = std::string(kSourceUpdate) + "\n" + kSourceSolve + (p.update_builtin ? "" : std::string("\n") + tvl_source());
         std::vector<std::string> extra = {"-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form"};
         for (const std::string &e : rtc::split_flags(getenv("SPCIES_TVR_RTC_FLAGS"))) extra.push_back(e);
         hipModule_t mod = nullptr;
-        hipFunction_t fns[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipFunction_t fns[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         int rc = rtc::compile_module(source.c_str(), "spcies_admm_tvr_rtc.hip", nm, extra, &mod, fns);
         if (rc) { p.why = std::string("MFMA4R (time-varying): run-time specialisation failed: ") + spcies_hip_last_error(); p.build_failed = true; return 0; }
         p.module = mod;
         p.fn[0] = nullptr; p.fn[1] = fns[0]; p.fn[2] = fns[1];  // (fn[0]: the inverses' kernel of rounds 3-4; the update phase writes them now)
         p.fn_ms = (void *)fns[2];
         p.fn_update = p.update_builtin ? nullptr : (void *)fns[3];
+        p.fn_coop = p.update_builtin ? nullptr : (void *)fns[4];
         p.builtin = false;  // (a build-time horizon of an (n, m) whose update phase is not: everything from the module)
     }
     p.ok = true;
@@ -162,14 +170,15 @@ int launch(const Plan &p, bool want_sol, const Args &a, const double *TRI, const
     }
     const long groups = (a.B + 3) / 4;
     const unsigned grid = (unsigned)std::min<long>(groups, (long)num_cu);
+    Args aa = a;
+    aa.RA = p.coop_im ? p.rows_all : 0;
     if (p.builtin) {
 #define X(nn, mm, NN) \
-    if (p.n == nn && p.m == mm && p.N == NN) return launch_shape<nn, mm, NN>(p.terminal, want_sol, a, TRI, T, TVS, x0, xr, ur, u, k, e, z, v, lam, grid, st);
+    if (p.n == nn && p.m == mm && p.N == NN) return launch_shape<nn, mm, NN>(p.terminal, want_sol, aa, TRI, T, TVS, x0, xr, ur, u, k, e, z, v, lam, grid, st);
         SPCIES_TVR_SHAPES(X)
 #undef X
         return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying): bad build-time shape");
     }
-    Args aa = a;
     void *params[] = {&aa, &TRI, &T, &TVS, &x0, &xr, &ur, &u, &k, &e, &z, &v, &lam};
     SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 2 : 1], grid, 1, 1, 256, 1, 1, 0, st, params, nullptr));
     return 0;
@@ -203,14 +212,15 @@ int launch_fista(const Plan &p, bool want_sol, const Args &a, const double *T, c
     }
     const long groups = (a.B + 3) / 4;
     const unsigned grid = (unsigned)std::min<long>(groups, (long)num_cu);
+    Args aa = a;
+    aa.RA = p.coop_im ? p.rows_all : 0;
     if (p.builtin) {
 #define X(nn, mm, NN) \
-    if (p.n == nn && p.m == mm && p.N == NN) return launch_fista_shape<nn, mm, NN>(p.terminal, want_sol, a, T, Ti, TVS, x0, xr, ur, u, k, e, z, lam, grid, st);
+    if (p.n == nn && p.m == mm && p.N == NN) return launch_fista_shape<nn, mm, NN>(p.terminal, want_sol, aa, T, Ti, TVS, x0, xr, ur, u, k, e, z, lam, grid, st);
         SPCIES_TVR_SHAPES(X)
 #undef X
         return fail(SPCIES_HIP_ENOSUP, "MFMA4R (time-varying FISTA): bad build-time shape");
     }
-    Args aa = a;
     void *params[] = {&aa, &T, &Ti, &TVS, &x0, &xr, &ur, &u, &k, &e, &z, &lam};
     SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn[want_sol ? 2 : 1], grid, 1, 1, 256, 1, 1, 0, st, params, nullptr));
     return 0;
@@ -268,6 +278,15 @@ int launch_update(const Plan &p, double c0, const double *Tc, const double *mode
         }
         void *bp[] = {&N, &row_beta, &row_bi, &B, &Bp, &TVS};
         SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_bi, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, st, bp, nullptr));
+        return 0;
+    }
+    if (p.ok && p.coop_im) {  // the register form's images from the cooperative update phase, instance-major (FORM 1): S_l and M_l rows, no transform kernel
+        if (p.update_builtin) return launch_coop_builtin(p.n, p.m, p.N, p.terminal, p.fista, c0, Tc, model, model_stride, B, Bp, TVS, st);
+        if (!p.fn_coop) return fail(SPCIES_HIP_ENOSUP, "time-varying update phase: no cooperative kernel for n=%d m=%d", p.n, p.m);
+        int N = p.N;
+        const int lpi = p.n <= 8 ? 8 : (p.n <= 16 ? 16 : 32), g = 64 / lpi;
+        void *up[] = {&N, &c0, &Tc, &model, &model_stride, &B, &Bp, &TVS};
+        SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_coop, (unsigned)((B + g - 1) / g), 1, 1, 64, 1, 1, 0, st, up, nullptr));
         return 0;
     }
     if (p.ok && p.update_builtin) {

@@ -32,6 +32,7 @@ struct Args {
     int k_max, ref_stride;
     double rho, tol;
     long B, Bp;
+    long RA;  // 0: the scratch is [row][Bp]; > 0: instance-major, RA rows per instance (tv_update_coop_kernel, FORM 1)
 };
 #define SPCIES_TVR_ARGS_DEFINED 1
 
@@ -64,6 +65,10 @@ struct Plan {
     void *fn_bi = nullptr;
     void *fn_coop = nullptr;                    // tv_update_coop_kernel: the LDS form's update phase, several lanes per instance (the product path)
     bool coop = true;                           // (SPCIES_TVL_COOP=0: fn_update + fn_bi instead - one lane per instance, the same bits)
+    // the register-resident form (not lds): coop_im = the cooperative update phase in its instance-major form (FORM 1: S_l / M_l rows, no L D L' transform
+    // kernel); SPCIES_TVR_COOP=0: the one-lane update phase + tv_ms_kernel, [row][Bp] scratch
+    bool coop_im = false;
+    long rows_all = 0;                          // rows per instance of the scratch (Bi + N n^2)
 };
 // decides whether the variant applies (n + m <= 16 and the state within the register file; past it the LDS form, see Plan::lds) and, for a shape without build-time kernels, compiles
 // them (hiprtc; code-object cache) - the update phase included, so that ANY plant size within those limits has a time-varying path
@@ -71,6 +76,8 @@ int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista = false);
 // (admm_tvl.hip) the LDS form: the text of admm_tvl_kernel.inc for hiprtc, and the bytes of LDS one instance's images take
 const char *tvl_source();
 long tvl_lds_bytes(int n, int m, int N, bool terminal, bool fista);
+int launch_coop_builtin(int n, int m, int N, bool terminal, bool fista, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp,
+                        double *TVS, hipStream_t st);
 void plan_free(Plan &p);
 // the solve of one chunk; pointers are device memory, TVS as admm_tv_update_kernel<n, m, TERMINAL, BI = true> left it (factors AND the explicit
 // inverses Bi: tv_update_kernel.inc)

@@ -271,6 +271,31 @@ def test_time_varying_plants_past_the_register_file(n, m, N, formulation, method
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["C2_lax", "C1_equ", "C2_lax_FISTA"])
+def test_time_varying_register_form_takes_its_images_from_the_cooperative_update_phase(name, monkeypatch):
+    """The register-resident MFMA4R kernels read S_l and M_l = S_l E from an instance-major scratch written by tv_update_coop_kernel (FORM 1: several lanes
+    per instance, the reference's sums for Beta / Alpha, S and M formed in the LDS).  SPCIES_TVR_COOP=0 is the path of rounds 4-5 - one lane per instance,
+    then tv_ms_kernel, [row][Bp] scratch: the same factors with M and S summed in another order, so the solves agree to rounding (and both sit inside the
+    oracle's bar: test_hip_time_varying_vs_oracle runs the default)."""
+    from spcies_amd.solver import HipSolver
+    cfg, v, vt, design = _setup(name)
+    B = 150
+    rng = np.random.default_rng(77)
+    n, m = cfg.sys.n, cfg.sys.m
+    x0 = 0.4 * rng.standard_normal((B, n)); xr = 0.1 * rng.standard_normal((B, n)); ur = 0.05 * rng.standard_normal((B, m))
+    models = _perturbed_models(design, B)
+    with HipSolver(vt) as s:
+        assert s.variant == "mfma4r", (s.variant, s.notes)
+        coop = s(x0, xr, ur, *models)
+    monkeypatch.setenv("SPCIES_TVR_COOP", "0")
+    with HipSolver(vt) as s:
+        assert s.variant == "mfma4r", (s.variant, s.notes)
+        lane = s(x0, xr, ur, *models)
+    assert np.abs(coop[0] - lane[0]).max() <= 1e-10 and np.abs(coop[3].z - lane[3].z).max() <= 1e-9  # (equMPC: multipliers of 1e3 - the scaled bar of _cases.py)
+    assert (np.abs(coop[1].astype(int) - lane[1].astype(int)) <= 1).all() and (coop[1] != lane[1]).mean() <= 0.01
+
+
+@pytest.mark.gpu
 def test_time_varying_mfma4r_is_switched_off_by_the_environment(monkeypatch):
     from spcies_amd import benchmarks
     from spcies_amd.solver import HipSolver
