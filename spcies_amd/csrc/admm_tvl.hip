@@ -27,7 +27,7 @@ static void coop_go(bool terminal, bool fista, unsigned grid, hipStream_t st, in
 }
 int launch_coop_builtin(int n, int m, int N, bool terminal, bool fista, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp,
                         double *TVS, hipStream_t st) {
-    const int lpi = n <= 8 ? 8 : (n <= 16 ? 16 : 32), g = 64 / lpi;
+    const int g = coop_instances_per_wavefront(n);
     const unsigned grid = (unsigned)((B + g - 1) / g);
     if (n == 6 && m == 2) coop_go<6, 2>(terminal, fista, grid, st, N, c0, Tc, model, model_stride, B, Bp, TVS);
     else if (n == 12 && m == 2) coop_go<12, 2>(terminal, fista, grid, st, N, c0, Tc, model, model_stride, B, Bp, TVS);

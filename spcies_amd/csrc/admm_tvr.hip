@@ -261,7 +261,7 @@ static int launch_ms(const Plan &p, long B, long Bp, double *TVS, hipStream_t st
 int launch_update(const Plan &p, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp, double *TVS, hipStream_t st) {
     if (p.ok && p.lds && p.coop) {  // the cooperative update phase (tv_update_coop_kernel): 8 / 16 / 32 lanes per instance, the small rows and the packed triangles of the Bi_l out
         int N = p.N;
-        const int lpi = p.n <= 8 ? 8 : (p.n <= 16 ? 16 : 32), g = 64 / lpi;
+        const int g = coop_instances_per_wavefront(p.n);
         void *up[] = {&N, &c0, &Tc, &model, &model_stride, &B, &Bp, &TVS};
         SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_coop, (unsigned)((B + g - 1) / g), 1, 1, 64, 1, 1, 0, st, up, nullptr));
         return 0;
@@ -284,7 +284,7 @@ int launch_update(const Plan &p, double c0, const double *Tc, const double *mode
         if (p.update_builtin) return launch_coop_builtin(p.n, p.m, p.N, p.terminal, p.fista, c0, Tc, model, model_stride, B, Bp, TVS, st);
         if (!p.fn_coop) return fail(SPCIES_HIP_ENOSUP, "time-varying update phase: no cooperative kernel for n=%d m=%d", p.n, p.m);
         int N = p.N;
-        const int lpi = p.n <= 8 ? 8 : (p.n <= 16 ? 16 : 32), g = 64 / lpi;
+        const int g = coop_instances_per_wavefront(p.n);
         void *up[] = {&N, &c0, &Tc, &model, &model_stride, &B, &Bp, &TVS};
         SPCIES_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)p.fn_coop, (unsigned)((B + g - 1) / g), 1, 1, 64, 1, 1, 0, st, up, nullptr));
         return 0;
