@@ -9,6 +9,14 @@
 namespace spcies {
 namespace tvr {
 
+// the host's grid arithmetic (admm_tvr.hpp) and the kernel's lane layout must agree for every plant size
+template <int n>
+constexpr bool coop_layouts_agree() {
+    if constexpr (n == 0) return true;
+    else return 64 / tvl_coop_lpi(n) == coop_instances_per_wavefront(n) && coop_layouts_agree<n - 1>();
+}
+static_assert(coop_layouts_agree<32>(), "coop_instances_per_wavefront (admm_tvr.hpp) != 64 / tvl_coop_lpi (admm_tvl_kernel.inc)");
+
 const char *tvl_source() {
     static const char *const text =
 #include "admm_tvl_src.inc"

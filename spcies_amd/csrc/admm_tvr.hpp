@@ -74,7 +74,7 @@ struct Plan {
 // them (hiprtc; code-object cache) - the update phase included, so that ANY plant size within those limits has a time-varying path
 int plan_build(Plan &p, int n, int m, int N, bool terminal, bool fista = false);
 // (admm_tvl.hip) the LDS form: the text of admm_tvl_kernel.inc for hiprtc, and the bytes of LDS one instance's images take
-inline int coop_instances_per_wavefront(int n) { return 64 / (n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 21 ? 21 : 32))); }  // (tvl_coop_lpi of admm_tvl_kernel.inc)
+constexpr int coop_instances_per_wavefront(int n) { return 64 / (n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 21 ? 21 : 32))); }  // (tvl_coop_lpi of admm_tvl_kernel.inc)
 const char *tvl_source();
 long tvl_lds_bytes(int n, int m, int N, bool terminal, bool fista);
 int launch_coop_builtin(int n, int m, int N, bool terminal, bool fista, double c0, const double *Tc, const double *model, long model_stride, long B, long Bp,
