@@ -1,3 +1,6 @@
+"""GPU: the LDS form of the time-varying MFMA4R path on a few plant shapes against the oracle, under each of its switches - default (cooperative update
+phase, S form), SPCIES_TVL_COOP=0 (one-lane update phase), -DSPCIES_TVL_SFORM=0 (triangles of Bi_l): max |du|, k differences, instances off by more than 1e-8.
+The bisection that found the S form's first bug (the switch was defined below the kernels that test it).  usage: python tools/tvl_debug.py"""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
