@@ -216,7 +216,8 @@ def test_time_varying_any_plant_size(n, m, N, formulation, method):
 @pytest.mark.parametrize("n,m,N,formulation,method", [(20, 4, 6, "laxMPC", "ADMM"), (12, 6, 5, "equMPC", "ADMM"), (17, 3, 6, "equMPC", "FISTA"),
                                                       (20, 2, 5, "laxMPC", "FISTA"),
                                                       (6, 2, 40, "laxMPC", "ADMM"),    # n + m <= 16 but 40 blocks of factors: past the registers, 35 KB of LDS
-                                                      (18, 3, 7, "equMPC", "ADMM")])   # n, n + m not multiples of 4: the masked last k-slab, two ragged row groups
+                                                      (18, 3, 7, "equMPC", "ADMM"),    # n, n + m not multiples of 4: the masked last k-slab, two ragged row groups
+                                                      (21, 3, 4, "laxMPC", "ADMM")])   # 21 lanes per instance in the cooperative update phase, all of them columns; n past the merged-tile form
 def test_time_varying_plants_past_the_register_file(n, m, N, formulation, method, monkeypatch):
     """The 9-input solvers of plants the register-resident solver does not hold (n + m > 16: the 20-state plant of configs[3] among them).  Rounds 2-4
     answered ENOSUP here.  STREAM - update phase and iteration specialised with hiprtc for this (n, m), the update phase in its rolled form past
