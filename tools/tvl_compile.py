@@ -47,6 +47,10 @@ def main():
         i = args.index("--inc")
         inc = args[i + 1]
         del args[i:i + 2]
+    vgpr_form = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+    if "--no-vgpr-form" in args:  # (experiment: MFMA results in the accumulation registers)
+        args.remove("--no-vgpr-form")
+        vgpr_form = []
     insts = [a for a in args if not a.startswith("-")]
     flags = [a for a in args if a.startswith("-")]
     src = "\n".join(open(f).read() for f in (os.path.join(HERE, "tv_update_kernel.inc"), os.path.join(HERE, "admm_tvr_kernel.inc"), inc))
@@ -55,7 +59,7 @@ def main():
     os.makedirs(d, exist_ok=True)
     p, co = os.path.join(d, "tvl.hip"), os.path.join(d, "tvl.co")
     open(p, "w").write(src)
-    r = subprocess.run([sys.executable, "-c", _COMPILE, HIPRTC, p, co, "-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form", *flags],
+    r = subprocess.run([sys.executable, "-c", _COMPILE, HIPRTC, p, co, "-mllvm", "-pragma-unroll-threshold=1000000", *vgpr_form, *flags],
                        capture_output=True, text=True)
     if r.returncode:
         sys.exit(r.stderr[-4000:])
