@@ -269,6 +269,12 @@ def test_time_varying_plants_past_the_register_file(n, m, N, formulation, method
         one = s1(x0, xr, ur, *models)
     assert all(np.array_equal(a, b) for a, b in zip(full[:3], one[:3]))
     assert np.array_equal(full[3].z, one[3].z) and np.array_equal(full[3].lam, one[3].lam)
+    if (n, m, N) == (20, 4, 6):  # the triangles of Bi_l instead of S_l (the chain with six products per stage pair): the documented switch stays alive
+        monkeypatch.delenv("SPCIES_TVL_COOP")
+        monkeypatch.setenv("SPCIES_TVR_RTC_FLAGS", "-DSPCIES_TVL_SFORM=0")
+        with HipSolver(vt) as s2:
+            assert s2.variant == "mfma4r", (s2.variant, s2.notes)
+            cmp("mfma4r", s2(x0, xr, ur, *models), O, vt, x0, xr, ur, model, per)
 
 
 @pytest.mark.gpu
